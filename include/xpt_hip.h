@@ -1,0 +1,122 @@
+/* xpt_hip.h -- C ABI of libxpt_hip.so: the MI355X (gfx950) kernels of the
+ * self-supervised depth/pose training hot path of goodgodgd/xpt-mde-2021.
+ *
+ * The reference has NO plugin / operator / FFI interface for this path: it is pure
+ * Python on TensorFlow ops.  Each entry point below therefore cites the
+ * reference Python callable (file:line, relative to the reference checkout) whose
+ * arithmetic it replaces; INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer to contiguous float32 owned by the caller
+ *     (PyTorch's allocator in the shipped host code); nothing is allocated here,
+ *     no global state, re-entrant;
+ *   - images use the reference's axis order: [batch, numsrc, height, width, C]
+ *     (channels last), depth [batch, height, width(,1)], pixel order row-major;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it and
+ *     capturable into a hipGraph (no sync / malloc inside);
+ *   - return value: 0 on success, XPT_ERR_* (< 0) on a bad argument or launch error;
+ *     never throws;
+ *   - reductions are deterministic: per-workgroup partial sums go to a caller-provided
+ *     workspace and are summed in a fixed order (no float atomics).
+ */
+#ifndef XPT_HIP_H_
+#define XPT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XPT_OK 0
+#define XPT_ERR_NULL (-1)      /* a required pointer is NULL            */
+#define XPT_ERR_SHAPE (-2)     /* non-positive or inconsistent dimension */
+#define XPT_ERR_ARG (-3)       /* bad enum / flag value                  */
+#define XPT_ERR_WORKSPACE (-4) /* workspace too small                    */
+#define XPT_ERR_LAUNCH (-5)    /* hipGetLastError() != hipSuccess        */
+
+/* photometric methods: model/loss_and_metric/loss_util.py:6 (L1), :29 (L2), :52 (SSIM) */
+#define XPT_PHOTO_L1 0
+#define XPT_PHOTO_L2 1
+#define XPT_PHOTO_SSIM 2
+
+/* library / ABI version and the gfx target the code objects were built for */
+int xpt_abi_version(void);
+const char* xpt_build_arch(void);
+
+/* ------------------------------------------------------------------ K0: pose algebra
+ * replaces utils/convert_pose.py:32-71 pose_rvec2matr_batch_tf (negated-skew Rodrigues).
+ * pose [M,6] (tx,ty,tz,u1,u2,u3) -> T [M,4,4].  bwd: dT [M,4,4] -> dpose [M,6]. */
+int xpt_pose_rvec2matr_fwd(const float* pose, float* T, int M, void* stream);
+int xpt_pose_rvec2matr_bwd(const float* pose, const float* dT, float* dpose, int M, void* stream);
+
+/* ------------------------------------------------------------------ K1 / a15: image pyramid
+ * replaces tf.image.resize(bilinear, half-pixel centres, no antialias) at an exact integer
+ * down-scale factor (synthesize_base.py:74-85 resize_source_images, util_funcs.py:163-175
+ * multi_scale_like_depth).  img [M,H,W,C] -> out [M,H/scale,W/scale,C]; scale in {1,2,4,8,..}. */
+int xpt_resize_down_fwd(const float* img, float* out, int M, int H, int W, int C, int scale, void* stream);
+
+/* ------------------------------------------------------------------ K2+K3: view synthesis
+ * replaces SynthesizeSingleScale.synthesize_batch_view (synthesize_base.py:88-178:
+ * pixel_meshgrid, pixel2cam, transform_to_source, cam2pixel) fused with
+ * BilinearInterpolation.__call__ (bilinear_interp.py:7-147).
+ *   src   [B,N,h,w,3]  source images already resized to this scale
+ *   depth [B,h,w]      target depth at this scale (0 = invalid pixel)
+ *   T     [B,N,4,4]    target->source pose matrices
+ *   K     [B,3,3]      UNSCALED intrinsic; rows 0,1 are divided by `scale` inside
+ *                      (scale_intrinsic, synthesize_base.py:66-71)
+ *   synth [B,N,h,w,3]  out
+ * bwd: dsynth [B,N,h,w,3] -> ddepth [B,h,w], dT [B,N,4,4] (last row 0).
+ *   workspace: xpt_warp_bwd_workspace_floats(B,N,h,w) floats. */
+int xpt_warp_fwd(const float* src, const float* depth, const float* T, const float* K, float* synth,
+                 int B, int N, int h, int w, float scale, void* stream);
+size_t xpt_warp_bwd_workspace_floats(int B, int N, int h, int w);
+int xpt_warp_bwd(const float* src, const float* depth, const float* T, const float* K, const float* dsynth,
+                 float* ddepth, float* dT, float* workspace, size_t workspace_floats,
+                 int B, int N, int h, int w, float scale, void* stream);
+
+/* ------------------------------------------------------------------ K3 alone: bilinear sampler
+ * replaces BilinearInterpolation.__call__(image, pixel_coords, valid_mask)
+ * (bilinear_interp.py:7-32), also the sampler of FlowBilinearInterpolation (:166-181).
+ *   image  [B,N,h,w,C], coords [B,N,ncoord,h*w] rows (u,v[,1]), ncoord in {2,3}
+ *   valid_mask [B,h*w] or NULL (zero = invalid), out [B,N,h,w,C].
+ * bwd: dout -> dcoords [B,N,ncoord,h*w] (row 2, if present, is zero).  C <= 16. */
+int xpt_bilinear_fwd(const float* image, const float* coords, const float* valid_mask, float* out,
+                     int B, int N, int h, int w, int C, int ncoord, void* stream);
+int xpt_bilinear_bwd(const float* image, const float* coords, const float* valid_mask, const float* dout,
+                     float* dcoords, int B, int N, int h, int w, int C, int ncoord, void* stream);
+
+/* ------------------------------------------------------------------ K4/K5: photometric losses
+ * replaces photometric_loss_l1 / _l2 / _ssim (loss_util.py:6-25, 29-48, 52-96).
+ *   synth [B,N,h,w,3], target [B,h,w,3]
+ *   map   [B,N,h,w,3] or NULL : per-pixel loss (the reduce=False result)
+ *   loss  [B] or NULL         : mean over (N,h,w,3)  (the reduce=True result)
+ *   workspace: xpt_photo_workspace_floats(B,N,h,w) floats (needed when loss != NULL).
+ * bwd: exactly one of gloss [B] (grad of the reduce=True result) / gmap [B,N,h,w,3]
+ *   (grad of the per-pixel map) is non-NULL -> dsynth [B,N,h,w,3].
+ *   SSIM bwd needs workspace of xpt_photo_workspace_floats(B,N,h,w) floats. */
+size_t xpt_photo_workspace_floats(int B, int N, int h, int w);
+int xpt_photo_fwd(int method, const float* synth, const float* target, float* map, float* loss,
+                  float* workspace, size_t workspace_floats, int B, int N, int h, int w, void* stream);
+int xpt_photo_bwd(int method, const float* synth, const float* target, const float* gloss, const float* gmap,
+                  float* dsynth, float* workspace, size_t workspace_floats, int B, int N, int h, int w,
+                  void* stream);
+
+/* ------------------------------------------------------------------ K6 (+a4): edge-aware smoothness
+ * replaces SmoothenessLossMultiScale.smootheness_loss (losses.py:409-440) for one scale
+ * (the caller divides by the scale, losses.py:401-402).
+ *   disp [B,h,w] (or depth when input_is_depth != 0: disp = (1/d)*[d>1e-5],
+ *   util_funcs.py:157-160, fused), image [B,h,w,3] -> loss [B].
+ *   grad_factor = opts.IMAGE_GRADIENT_FACTOR (config-example.py:67).
+ * bwd: gloss [B] -> dinput [B,h,w] (w.r.t. disp, or depth when input_is_depth). */
+size_t xpt_smooth_workspace_floats(int B, int h, int w);
+int xpt_smooth_fwd(const float* disp, const float* image, float* loss, float* workspace, size_t workspace_floats,
+                   int B, int h, int w, float grad_factor, int input_is_depth, void* stream);
+int xpt_smooth_bwd(const float* disp, const float* image, const float* gloss, float* dinput,
+                   int B, int h, int w, float grad_factor, int input_is_depth, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XPT_HIP_H_ */

@@ -1,0 +1,70 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/xpt_hip.h declares,
+and rejects bad arguments before touching the GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "xpt_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    from xpt_mde_2021_amd.hip import lib as xl
+    if not os.path.isfile(xl.LIB_PATH):
+        ge.build()
+    return xl.load()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(xpt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from xpt_mde_2021_amd.hip import lib as xl
+    syms = declared_symbols()
+    assert len(syms) >= 16
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in xpt_hip.h but not exported"
+        assert name in xl.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(xl.SIGNATURES) == set(syms)
+
+
+def test_version_and_arch(lib):
+    assert lib.xpt_abi_version() >= 1
+    assert lib.xpt_build_arch() == b"gfx950"
+
+
+def test_bad_arguments_are_rejected_without_gpu(lib):
+    null = None
+    one = ctypes.c_void_p(16)   # never dereferenced: argument checks fail first
+    assert lib.xpt_pose_rvec2matr_fwd(null, one, 4, null) == -1
+    assert lib.xpt_pose_rvec2matr_fwd(one, one, 0, null) == -2
+    assert lib.xpt_warp_fwd(one, one, one, one, null, 1, 1, 4, 4, 1.0, null) == -1
+    assert lib.xpt_warp_fwd(one, one, one, one, one, 1, 0, 4, 4, 1.0, null) == -2
+    assert lib.xpt_warp_fwd(one, one, one, one, one, 1, 1, 4, 4, 0.0, null) == -2
+    assert lib.xpt_resize_down_fwd(one, one, 1, 6, 8, 3, 4, null) == -2      # 6 % 4 != 0
+    assert lib.xpt_bilinear_fwd(one, one, null, one, 1, 1, 4, 4, 3, 4, null) == -3
+    assert lib.xpt_photo_fwd(7, one, one, one, null, null, 0, 1, 1, 4, 4, null) == -3
+    assert lib.xpt_photo_fwd(0, one, one, null, null, null, 0, 1, 1, 4, 4, null) == -1
+    assert lib.xpt_photo_fwd(0, one, one, null, one, one, 0, 1, 1, 4, 4, null) == -4
+    assert lib.xpt_photo_bwd(2, one, one, one, one, one, one, 10 ** 9, 1, 1, 4, 4, null) == -3   # both grads given
+    assert lib.xpt_smooth_fwd(one, one, one, one, 100, 1, 1, 8, 4.0, 0, null) == -2           # h < 2
+    assert lib.xpt_warp_bwd(one, one, one, one, one, one, one, one, 1, 2, 4, 64, 64, 1.0, null) == -4
+    assert lib.xpt_warp_bwd_workspace_floats(2, 4, 64, 64) == 2 * 4 * 16 * 12
+    assert lib.xpt_photo_workspace_floats(2, 4, 8, 8) == 2 * 4 * 64 * 9
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    import torch
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.hip.lib import XptHipError
+    with pytest.raises(XptHipError):
+        ops.pose_rvec2matr(torch.zeros(2, 4, 6))
+    with pytest.raises(XptHipError):
+        ops.photometric("L1", torch.zeros(1, 1, 4, 4, 3), torch.zeros(1, 4, 4, 3))

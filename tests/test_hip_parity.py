@@ -1,0 +1,187 @@
+"""GPU parity: every entry point of libxpt_hip.so (through the ctypes C ABI) against the oracle.
+
+Tolerance: 1e-4 absolute in fp32 (BASELINE.json north_star) on values in [-1,1]; gradients are compared
+with 1e-4 * max|ref| + 1e-3 relative.  Bilinear validity / floor() flips at exact-integer coordinates are
+allowed for a <=1e-4 fraction of elements (fp32 rounding of the projection differs between devices)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_loss, ref_pose, ref_synthesize as rs
+from tests.util import frac_close
+from xpt_mde_2021_amd.utils import synthetic_data as sd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(gpu_device):
+    from xpt_mde_2021_amd.hip import ops as _ops
+    return _ops
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def warp_inputs(B, N, h, w, seed, scale=1):
+    g = gen(seed)
+    src = torch.stack([sd.smooth_noise((B, h, w, 3), g) for _ in range(N)], dim=1).contiguous()
+    depth = sd.smooth_depth(B, h, w, g)
+    K = sd.kitti_like_intrinsic(B, h * scale, w * scale)
+    pose = sd.random_poses(B, N, g)
+    return src, depth, K, pose
+
+
+# ------------------------------------------------------------------------------------------------ K0
+def test_pose_fwd_bwd(ops, gpu_device):
+    g = gen(11)
+    pose = torch.rand((8, 4, 6), generator=g) * 2 - 1
+    pose[0, 0, 3:] = 0.0            # exactly-zero rotation: where(|t|<1e-8, I, .) branch
+    pose[0, 1, 3:] = torch.tensor([0., 0., np.pi / 3])
+    dT = torch.randn((8, 4, 4, 4), generator=g)
+    p_ref = pose[:, 1:].clone().double().requires_grad_(True)     # the zero-rotation row is NaN in the reference grad
+    T_ref = ref_pose.pose_rvec2matr_batch(p_ref)
+    T_ref.backward(dT[:, 1:].double())
+    p = pose.to(gpu_device).requires_grad_(True)
+    T = ops.pose_rvec2matr(p)
+    T.backward(dT.to(gpu_device))
+    frac_close(T[:, 1:], T_ref, 1e-5, what="pose T")
+    assert torch.equal(T[0, 0].cpu(), torch.eye(4))
+    c, s = np.cos(np.pi / 3), np.sin(np.pi / 3)
+    assert np.allclose(T[0, 1, :3, :3].detach().cpu().numpy(), [[c, s, 0], [-s, c, 0], [0, 0, 1]], atol=1e-6)
+    frac_close(p.grad[:, 1:], p_ref.grad, 1e-4, rtol=1e-4, what="dpose")
+    assert torch.isfinite(p.grad).all()
+
+
+# ------------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("scale", [2, 4, 8])
+def test_resize_down(ops, gpu_device, scale):
+    g = gen(12)
+    img = torch.rand((3, 32, 48, 3), generator=g) * 2 - 1
+    out = ops.resize_down(img.to(gpu_device), scale)
+    ref = rs.tf_resize_bilinear(img, (32 // scale, 48 // scale))
+    frac_close(out, ref, 1e-6, what=f"resize/{scale}")
+
+
+# ------------------------------------------------------------------------------------------------ K2+K3
+@pytest.mark.parametrize("B,N,h,w,scale", [(4, 4, 128, 416, 1), (2, 4, 32, 104, 4), (2, 1, 16, 52, 8), (1, 3, 5, 7, 1)])
+def test_warp_fwd_bwd(ops, gpu_device, B, N, h, w, scale):
+    src, depth, K, pose = warp_inputs(B, N, h, w, 100 + h, scale)
+    depth[0, 1:3, 2:5] = 0.0                         # invalid depth -> masked pixels
+    pose[0, 0, 0] = 40.0                             # a view that leaves the image almost entirely
+    g = gen(7)
+    dsynth = torch.randn((B, N, h, w, 3), generator=g)
+    # oracle (fp64 keeps the reference gradient free of its own fp32 noise)
+    d_ref = depth.clone().double().requires_grad_(True)
+    T_ref = ref_pose.pose_rvec2matr_batch(pose.double()).requires_grad_(True)
+    K_sc = rs.scale_intrinsic(K.double(), scale)
+    coords = rs.warp_pixel_coords(d_ref, T_ref, K_sc, h, w)
+    synth_ref = rs.bilinear_interpolation(src.double(), coords, d_ref)
+    synth_ref.backward(dsynth.double())
+    # fp32 oracle for the forward value (the bar is the reference's fp32 CPU path)
+    synth_ref32 = rs.bilinear_interpolation(src, rs.warp_pixel_coords(depth, ref_pose.pose_rvec2matr_batch(pose),
+                                                                      rs.scale_intrinsic(K, scale), h, w), depth)
+    d = depth.to(gpu_device).requires_grad_(True)
+    T = ref_pose.pose_rvec2matr_batch(pose).to(gpu_device).requires_grad_(True)
+    synth = ops.warp(src.to(gpu_device), d, T, K.to(gpu_device), scale)
+    synth.backward(dsynth.to(gpu_device))
+    frac_close(synth, synth_ref, 1e-4, max_bad_frac=1e-4, what="synth vs fp64 oracle")
+    frac_close(synth, synth_ref32, 1e-4, max_bad_frac=1e-4, what="synth vs fp32 oracle")
+    gs = d_ref.grad.abs().max().item()
+    frac_close(d.grad, d_ref.grad, 1e-4 * gs, rtol=1e-3, max_bad_frac=2e-4, what="ddepth")
+    ts = T_ref.grad.abs().max().item()
+    frac_close(T.grad, T_ref.grad, 2e-4 * ts, rtol=1e-3, what="dT")
+    assert torch.all(synth[0, :, 1:3, 2:5] == 0)
+
+
+def test_synthesis_known_answer_on_gpu(ops, gpu_device):
+    # the reference's test_reconstruct_bilinear_interp (test_synthesizing.py:258-301) through the HIP sampler
+    batch, numsrc, height, width = 8, 4, 5, 5
+    pc = np.meshgrid(np.arange(0, height), np.arange(0, width))
+    pc = np.stack(pc, axis=0).reshape((1, 1, 2, 5, 5)).astype(np.float32)
+    pc[0, 0, 0] += 1.3
+    pc = np.tile(pc, (batch, numsrc, 1, 1, 1)).reshape((batch, numsrc, 2, height * width))
+    image = np.meshgrid(np.arange(0, height), np.arange(0, width))[0].reshape((1, 1, height, width, 1))
+    image = np.tile(image, (batch, numsrc, 1, 1, 3)).astype(np.float32)
+    depth = np.ones((batch, height, width, 1), dtype=np.float32)
+    recon = ops.bilinear_sample(torch.tensor(image).to(gpu_device), torch.tensor(pc).to(gpu_device),
+                                torch.tensor(depth).to(gpu_device))
+    mask = np.zeros((batch, numsrc, height, width, 1))
+    mask[:, :, :4, :3] = 1
+    assert np.allclose(recon.cpu().numpy(), (image + 1.3) * mask, atol=1e-5)
+
+
+@pytest.mark.parametrize("C,ncoord,use_mask", [(3, 3, True), (2, 2, False), (8, 2, True)])
+def test_bilinear_sampler_fwd_bwd(ops, gpu_device, C, ncoord, use_mask):
+    g = gen(21)
+    B, N, h, w = 2, 3, 12, 20
+    image = torch.rand((B, N, h, w, C), generator=g)
+    coords = torch.rand((B, N, ncoord, h * w), generator=g)
+    coords[:, :, 0] = coords[:, :, 0] * (w + 4) - 2
+    coords[:, :, 1] = coords[:, :, 1] * (h + 4) - 2
+    vm = (torch.rand((B, h, w, 1), generator=g) > 0.2).float() if use_mask else None
+    dout = torch.randn((B, N, h, w, C), generator=g)
+    c_ref = coords.clone().double().requires_grad_(True)
+    out_ref = rs.bilinear_interpolation(image.double(), c_ref, None if vm is None else vm.double())
+    out_ref.backward(dout.double())
+    c = coords.to(gpu_device).requires_grad_(True)
+    out = ops.bilinear_sample(image.to(gpu_device), c, None if vm is None else vm.to(gpu_device))
+    out.backward(dout.to(gpu_device))
+    frac_close(out, out_ref, 1e-5, what="bilinear out")
+    frac_close(c.grad, c_ref.grad, 1e-4, rtol=1e-4, what="dcoords")
+
+
+# ------------------------------------------------------------------------------------------------ K4/K5
+def photo_inputs(B, N, h, w, seed):
+    g = gen(seed)
+    tgt = sd.smooth_noise((B, h, w, 3), g)
+    synth = torch.stack([(tgt + 0.1 * sd.smooth_noise((B, h, w, 3), g)).clamp(-1, 1) for _ in range(N)], dim=1)
+    synth[:, 0, : h // 4] = 0.0                       # black (invalid) band -> gray == 0 mask
+    synth[:, -1, :, w - 3:] = 0.0
+    return synth.contiguous(), tgt.contiguous(), g
+
+
+@pytest.mark.parametrize("method", ["L1", "L2", "SSIM"])
+@pytest.mark.parametrize("B,N,h,w", [(4, 4, 128, 416), (2, 1, 16, 52), (1, 2, 3, 5)])
+def test_photometric_fwd_bwd(ops, gpu_device, method, B, N, h, w):
+    synth, tgt, g = photo_inputs(B, N, h, w, 31 + h)
+    fn = ref_loss.PHOTOMETRIC[method]
+    for reduce in (True, False):
+        s_ref = synth.clone().double().requires_grad_(True)
+        out_ref = fn(s_ref, tgt.double(), reduce)
+        out_ref32 = fn(synth, tgt, reduce)
+        gout = torch.randn(out_ref.shape, generator=g)
+        out_ref.backward(gout.double())
+        s = synth.to(gpu_device).requires_grad_(True)
+        out = ops.photometric(method, s, tgt.to(gpu_device), reduce)
+        out.backward(gout.to(gpu_device))
+        # per-pixel SSIM in fp32 is conditioned by c2 = 9e-4 in flat regions: compare against fp64 with 2e-4
+        atol = 1e-5 if reduce else (2e-4 if method == "SSIM" else 1e-6)
+        frac_close(out, out_ref, atol, what=f"{method} reduce={reduce} vs fp64")
+        frac_close(out, out_ref32, max(atol, 1e-5) * (3 if method == "SSIM" and not reduce else 1),
+                   what=f"{method} reduce={reduce} vs fp32")
+        gs = s_ref.grad.abs().max().item()
+        frac_close(s.grad, s_ref.grad, 2e-4 * gs, rtol=2e-3, max_bad_frac=1e-5, what=f"d{method} reduce={reduce}")
+
+
+# ------------------------------------------------------------------------------------------------ K6
+@pytest.mark.parametrize("B,h,w", [(4, 128, 416), (2, 16, 52), (1, 2, 2)])
+@pytest.mark.parametrize("is_depth", [False, True])
+def test_smoothness_fwd_bwd(ops, gpu_device, B, h, w, is_depth):
+    g = gen(41 + h)
+    img = sd.smooth_noise((B, h, w, 3), g)
+    depth = sd.smooth_depth(B, h, w, g, lo=0.99, hi=100.0)
+    if is_depth:
+        depth[0, 0, 0] = 1e-6                          # below the 1e-5 threshold of safe_reciprocal_number
+    gl = torch.randn((B,), generator=g)
+    d_ref = depth.clone().double().requires_grad_(True)
+    disp_ref = ref_loss.safe_reciprocal_number(d_ref) if is_depth else d_ref
+    loss_ref = ref_loss.smootheness_loss(disp_ref, img.double(), 4)
+    loss_ref.backward(gl.double())
+    d = depth.to(gpu_device).requires_grad_(True)
+    loss = ops.smoothness(d, img.to(gpu_device), 4.0, is_depth)
+    loss.backward(gl.to(gpu_device))
+    frac_close(loss, loss_ref, 1e-6, rtol=1e-5, what="smooth loss")
+    gs = d_ref.grad.abs().max().item()
+    frac_close(d.grad, d_ref.grad, 1e-5 * gs, rtol=1e-4, max_bad_frac=1e-5, what="dsmooth")

@@ -1,0 +1,176 @@
+// xpt_common.h -- device helpers shared by the gfx950 kernels of libxpt_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/xpt_hip.h"
+
+#define XPT_WAVE 64
+
+#define XPT_CHECK_PTR(p) \
+  do {                   \
+    if ((p) == nullptr) return XPT_ERR_NULL; \
+  } while (0)
+
+static inline int xpt_launch_status() { return hipGetLastError() == hipSuccess ? XPT_OK : XPT_ERR_LAUNCH; }
+
+namespace xpt {
+
+// ---------------------------------------------------------------- camera (scaled intrinsic + inverse)
+// scale_intrinsic (synthesize_base.py:66-71): rows 0,1 of K divided by `scale`, row 2 = (0,0,1);
+// pixel2cam (synthesize_base.py:137) inverts the full 3x3 (no zero-skew assumption).
+struct Cam {
+  float k[9];
+  float ki[9];
+};
+
+__device__ inline Cam load_cam(const float* __restrict__ K, float scale) {
+  Cam c;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) c.k[i] = K[i] / scale;
+  c.k[6] = 0.f;
+  c.k[7] = 0.f;
+  c.k[8] = 1.f;
+  const float a = c.k[0], b = c.k[1], cc = c.k[2], d = c.k[3], e = c.k[4], f = c.k[5], g = c.k[6], h = c.k[7],
+              i = c.k[8];
+  const float A = e * i - f * h, Bc = -(d * i - f * g), Cc = d * h - e * g;
+  const float det = a * A + b * Bc + cc * Cc;
+  const float r = 1.0f / det;
+  c.ki[0] = A * r;
+  c.ki[1] = -(b * i - cc * h) * r;
+  c.ki[2] = (b * f - cc * e) * r;
+  c.ki[3] = Bc * r;
+  c.ki[4] = (a * i - cc * g) * r;
+  c.ki[5] = -(a * f - cc * d) * r;
+  c.ki[6] = Cc * r;
+  c.ki[7] = -(a * h - b * g) * r;
+  c.ki[8] = (a * e - b * d) * r;
+  return c;
+}
+
+// rows 0..2 of a 4x4 target->source matrix
+struct Pose {
+  float r[9];
+  float t[3];
+};
+
+__device__ inline Pose load_pose(const float* __restrict__ T) {
+  Pose p;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    p.r[3 * i + 0] = T[4 * i + 0];
+    p.r[3 * i + 1] = T[4 * i + 1];
+    p.r[3 * i + 2] = T[4 * i + 2];
+    p.t[i] = T[4 * i + 3];
+  }
+  return p;
+}
+
+// ---------------------------------------------------------------- projective warp of one target pixel
+// warp_pixel_coords (synthesize_base.py:106-178):
+//   X = d * Kinv (u,v,1)^T ; X' = R X + t ; p = K X' ; (u',v') = p_xy / (p_z + 1e-10)
+struct Warp {
+  float X[3];    // target-frame point
+  float ray[3];  // Kinv (u,v,1)
+  float up, vp;  // projected source pixel
+  float zinv;    // 1 / (p_z + 1e-10)
+};
+
+__device__ inline void backproject(const Cam& c, float u, float v, float d, Warp& w) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    w.ray[i] = c.ki[3 * i + 0] * u + c.ki[3 * i + 1] * v + c.ki[3 * i + 2];
+    w.X[i] = w.ray[i] * d;
+  }
+}
+
+__device__ inline void project(const Cam& c, const Pose& p, Warp& w) {
+  float Xs[3], q[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) Xs[i] = p.r[3 * i + 0] * w.X[0] + p.r[3 * i + 1] * w.X[1] + p.r[3 * i + 2] * w.X[2] + p.t[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = c.k[3 * i + 0] * Xs[0] + c.k[3 * i + 1] * Xs[1] + c.k[3 * i + 2] * Xs[2];
+  const float z = q[2] + 1e-10f;
+  w.zinv = 1.0f / z;
+  w.up = q[0] / z;
+  w.vp = q[1] / z;
+}
+
+// ---------------------------------------------------------------- bilinear neighbourhood
+// BilinearInterpolation (bilinear_interp.py:34-102): clipped floor / floor+1, validity =
+// (uf+1 == uc) & (vf+1 == vc) [& depth != 0], weights (uc-u)(vc-v) ... times the mask.
+struct Taps {
+  int uf, uc, vf, vc;  // clipped integer neighbours
+  float wuf, wuc, wvf, wvc;
+  float mask;  // 1 / 0
+};
+
+__device__ inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+__device__ inline Taps make_taps(float u, float v, int h, int w, bool extra_valid) {
+  Taps t;
+  const float fu = floorf(u), fv = floorf(v);
+  const float ufc = clampf(fu, 0.f, (float)(w - 1));
+  const float ucc = clampf(fu + 1.f, 0.f, (float)(w - 1));
+  const float vfc = clampf(fv, 0.f, (float)(h - 1));
+  const float vcc = clampf(fv + 1.f, 0.f, (float)(h - 1));
+  // NaN coordinates compare false -> invalid (the reference would emit NaN; documented deviation)
+  const bool ok = (ufc + 1.f == ucc) && (vfc + 1.f == vcc) && extra_valid;
+  t.mask = ok ? 1.f : 0.f;
+  t.uf = ok ? (int)ufc : 0;
+  t.uc = ok ? (int)ucc : 0;
+  t.vf = ok ? (int)vfc : 0;
+  t.vc = ok ? (int)vcc : 0;
+  t.wuf = ok ? (ucc - u) : 0.f;
+  t.wuc = ok ? (u - ufc) : 0.f;
+  t.wvf = ok ? (vcc - v) : 0.f;
+  t.wvc = ok ? (v - vfc) : 0.f;
+  return t;
+}
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // valid in lane 0
+}
+
+// sum over a block of up to 1024 threads (blockDim.x multiple of 64); result valid in thread 0.
+// `red` = shared float[16].  Deterministic order.
+__device__ inline float block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = wave_sum(v);
+  __syncthreads();  // protect `red` reuse between consecutive calls
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < nw; ++i) s += red[i];
+  }
+  return s;
+}
+
+// sums NV per-thread values over a block of 256 threads (4 waves); results valid in thread 0.
+// `red` = shared float[4 * NV].  Deterministic order.  Every thread of the block must call it.
+template <int NV>
+__device__ inline void block_sum_n(float (&v)[NV], float* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wid * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float s = 0.f;
+      for (int k = 0; k < nw; ++k) s += red[k * NV + i];
+      v[i] = s;
+    }
+  }
+}
+
+}  // namespace xpt

@@ -1,0 +1,74 @@
+"""ctypes binding of libxpt_hip.so (C ABI: include/xpt_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``csrc/build.py`` with
+``hipcc --offload-arch=gfx950``.  There is deliberately NO fallback: if the shared object is
+missing or does not export a declared symbol, importing the ops raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libxpt_hip.so")
+
+XPT_PHOTO_L1, XPT_PHOTO_L2, XPT_PHOTO_SSIM = 0, 1, 2
+PHOTO_METHODS = {"L1": XPT_PHOTO_L1, "L2": XPT_PHOTO_L2, "SSIM": XPT_PHOTO_SSIM}
+
+_ERRORS = {-1: "XPT_ERR_NULL (required pointer is NULL)", -2: "XPT_ERR_SHAPE (bad dimension)",
+           -3: "XPT_ERR_ARG (bad enum/flag)", -4: "XPT_ERR_WORKSPACE (workspace too small)",
+           -5: "XPT_ERR_LAUNCH (hipGetLastError != hipSuccess)"}
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_z = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/xpt_hip.h declares
+SIGNATURES = {
+    "xpt_abi_version": (_i, []),
+    "xpt_build_arch": (ctypes.c_char_p, []),
+    "xpt_pose_rvec2matr_fwd": (_i, [_p, _p, _i, _p]),
+    "xpt_pose_rvec2matr_bwd": (_i, [_p, _p, _p, _i, _p]),
+    "xpt_resize_down_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "xpt_warp_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
+    "xpt_warp_bwd_workspace_floats": (_z, [_i, _i, _i, _i]),
+    "xpt_warp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _f, _p]),
+    "xpt_bilinear_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "xpt_bilinear_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "xpt_photo_workspace_floats": (_z, [_i, _i, _i, _i]),
+    "xpt_photo_fwd": (_i, [_i, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
+    "xpt_photo_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
+    "xpt_smooth_workspace_floats": (_z, [_i, _i, _i]),
+    "xpt_smooth_fwd": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _f, _i, _p]),
+    "xpt_smooth_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
+}
+
+_lib = None
+
+
+class XptHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libxpt_hip.so and bind every declared entry point (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise XptHipError(f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                          f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback for these ops.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise XptHipError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        raise XptHipError(f"{what} failed: {_ERRORS.get(code, code)}")

@@ -1,0 +1,223 @@
+"""torch.autograd ops over the gfx950 kernels of libxpt_hip.so.
+
+Every op requires contiguous float32 CUDA(HIP) tensors and launches on torch's current stream
+(hipGraph-capturable).  No CPU path exists: a CPU tensor or a missing library raises.
+"""
+import torch
+
+from . import lib as _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.XptHipError(f"{name}: expected a CUDA/HIP tensor (the xpt HIP ops have no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise _lib.XptHipError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------- K0 pose
+class _PoseRvec2Matr(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pose):
+        lib = _lib.load()
+        pose = _dev(pose, "pose")
+        M = pose.numel() // 6
+        T = torch.empty(pose.shape[:-1] + (4, 4), dtype=torch.float32, device=pose.device)
+        _lib.check(lib.xpt_pose_rvec2matr_fwd(_ptr(pose), _ptr(T), M, _stream()), "xpt_pose_rvec2matr_fwd")
+        ctx.save_for_backward(pose)
+        return T
+
+    @staticmethod
+    def backward(ctx, dT):
+        lib = _lib.load()
+        (pose,) = ctx.saved_tensors
+        dT = _dev(dT, "dT")
+        dpose = torch.empty_like(pose)
+        _lib.check(lib.xpt_pose_rvec2matr_bwd(_ptr(pose), _ptr(dT), _ptr(dpose), pose.numel() // 6, _stream()),
+                   "xpt_pose_rvec2matr_bwd")
+        return dpose
+
+
+def pose_rvec2matr(pose):
+    """[..., 6] twist (tx,ty,tz,u1,u2,u3) -> [..., 4, 4]  (utils/convert_pose.py:32-71)."""
+    return _PoseRvec2Matr.apply(pose)
+
+
+# ------------------------------------------------------------------------------- K1 pyramid
+def resize_down(img, scale):
+    """TF2 half-pixel bilinear resize of [M,H,W,C] by an exact integer factor (no gradient: the
+    pyramids are built from input images only, synthesize_base.py:74-85, util_funcs.py:163-175)."""
+    lib = _lib.load()
+    img = _dev(img.detach(), "img")
+    M, H, W, C = img.shape
+    scale = int(scale)
+    if scale == 1:
+        return img
+    out = torch.empty((M, H // scale, W // scale, C), dtype=torch.float32, device=img.device)
+    _lib.check(lib.xpt_resize_down_fwd(_ptr(img), _ptr(out), M, H, W, C, scale, _stream()), "xpt_resize_down_fwd")
+    return out
+
+
+# ------------------------------------------------------------------------------- K2+K3 warp
+class _Warp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, depth, T, K, scale):
+        lib = _lib.load()
+        src, depth, T, K = _dev(src, "src"), _dev(depth, "depth"), _dev(T, "T"), _dev(K, "K")
+        B, N, h, w, C = src.shape
+        if C != 3 or depth.numel() != B * h * w or T.numel() != B * N * 16 or K.numel() != B * 9:
+            raise _lib.XptHipError(f"warp: inconsistent shapes src{tuple(src.shape)} depth{tuple(depth.shape)} "
+                                   f"T{tuple(T.shape)} K{tuple(K.shape)}")
+        synth = torch.empty_like(src)
+        _lib.check(lib.xpt_warp_fwd(_ptr(src), _ptr(depth), _ptr(T), _ptr(K), _ptr(synth), B, N, h, w, float(scale),
+                                    _stream()), "xpt_warp_fwd")
+        ctx.save_for_backward(src, depth, T, K)
+        ctx.scale = float(scale)
+        return synth
+
+    @staticmethod
+    def backward(ctx, dsynth):
+        lib = _lib.load()
+        src, depth, T, K = ctx.saved_tensors
+        dsynth = _dev(dsynth, "dsynth")
+        B, N, h, w, _ = src.shape
+        ddepth = torch.empty_like(depth)
+        dT = torch.empty_like(T)
+        nws = lib.xpt_warp_bwd_workspace_floats(B, N, h, w)
+        ws = torch.empty(nws, dtype=torch.float32, device=src.device)
+        _lib.check(lib.xpt_warp_bwd(_ptr(src), _ptr(depth), _ptr(T), _ptr(K), _ptr(dsynth), _ptr(ddepth), _ptr(dT),
+                                    _ptr(ws), nws, B, N, h, w, ctx.scale, _stream()), "xpt_warp_bwd")
+        return None, ddepth, dT, None, None
+
+
+def warp(src, depth, T, K, scale):
+    """src [B,N,h,w,3] (already at this scale), depth [B,h,w,1], T [B,N,4,4], K [B,3,3] unscaled
+    -> synthesized target views [B,N,h,w,3]; differentiable w.r.t. depth and T."""
+    return _Warp.apply(src, depth, T, K, scale)
+
+
+# ------------------------------------------------------------------------------- K3 sampler
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, coords, valid_mask):
+        lib = _lib.load()
+        image, coords = _dev(image, "image"), _dev(coords, "pixel_coords")
+        vm = None if valid_mask is None else _dev(valid_mask, "valid_mask")
+        B, N, h, w, C = image.shape
+        ncoord = coords.shape[2]
+        if coords.shape[0] != B or coords.shape[1] != N or coords.shape[3] != h * w:
+            raise _lib.XptHipError(f"bilinear: coords {tuple(coords.shape)} do not match image {tuple(image.shape)}")
+        if vm is not None and vm.numel() != B * h * w:
+            raise _lib.XptHipError("bilinear: valid_mask must be [B,h,w,1]")
+        out = torch.empty_like(image)
+        _lib.check(lib.xpt_bilinear_fwd(_ptr(image), _ptr(coords), _ptr(vm), _ptr(out), B, N, h, w, C, ncoord, _stream()),
+                   "xpt_bilinear_fwd")
+        ctx.save_for_backward(image, coords, vm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        image, coords, vm = ctx.saved_tensors
+        dout = _dev(dout, "dout")
+        B, N, h, w, C = image.shape
+        dcoords = torch.empty_like(coords)
+        _lib.check(lib.xpt_bilinear_bwd(_ptr(image), _ptr(coords), _ptr(vm), _ptr(dout), _ptr(dcoords), B, N, h, w, C,
+                                        coords.shape[2], _stream()), "xpt_bilinear_bwd")
+        return None, dcoords, None
+
+
+def bilinear_sample(image, pixel_coords, valid_mask=None):
+    """BilinearInterpolation.__call__ (bilinear_interp.py:7-32); gradient w.r.t. pixel_coords."""
+    return _Bilinear.apply(image, pixel_coords, valid_mask)
+
+
+# ------------------------------------------------------------------------------- K4/K5 photometric
+class _Photo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, synth, target, method, reduce):
+        lib = _lib.load()
+        synth, target = _dev(synth, "synt_target"), _dev(target, "orig_target")
+        B, N, h, w, C = synth.shape
+        if C != 3 or tuple(target.shape) != (B, h, w, 3):
+            raise _lib.XptHipError(f"photometric: synth {tuple(synth.shape)} vs target {tuple(target.shape)}")
+        m = _lib.PHOTO_METHODS[method]
+        if reduce:
+            out = torch.empty((B,), dtype=torch.float32, device=synth.device)
+            nws = B * N * ((h * w + 255) // 256)
+            ws = torch.empty(nws, dtype=torch.float32, device=synth.device)
+            _lib.check(lib.xpt_photo_fwd(m, _ptr(synth), _ptr(target), None, _ptr(out), _ptr(ws), nws, B, N, h, w,
+                                         _stream()), "xpt_photo_fwd")
+        else:
+            out = torch.empty_like(synth)
+            _lib.check(lib.xpt_photo_fwd(m, _ptr(synth), _ptr(target), _ptr(out), None, None, 0, B, N, h, w, _stream()),
+                       "xpt_photo_fwd")
+        ctx.save_for_backward(synth, target)
+        ctx.method, ctx.reduce = m, reduce
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        synth, target = ctx.saved_tensors
+        g = _dev(g, "grad")
+        B, N, h, w, _ = synth.shape
+        dsynth = torch.empty_like(synth)
+        ws, nws = None, 0
+        if ctx.method == _lib.XPT_PHOTO_SSIM:
+            nws = lib.xpt_photo_workspace_floats(B, N, h, w)
+            ws = torch.empty(nws, dtype=torch.float32, device=synth.device)
+        gloss, gmap = (g, None) if ctx.reduce else (None, g)
+        _lib.check(lib.xpt_photo_bwd(ctx.method, _ptr(synth), _ptr(target), _ptr(gloss), _ptr(gmap), _ptr(dsynth),
+                                     _ptr(ws), nws, B, N, h, w, _stream()), "xpt_photo_bwd")
+        return dsynth, None, None, None
+
+
+def photometric(method, synt_target, orig_target, reduce=True):
+    """photometric_loss_l1/_l2/_ssim (loss_util.py:6-96): [B] if reduce else [B,N,h,w,3]."""
+    return _Photo.apply(synt_target, orig_target, method, bool(reduce))
+
+
+# ------------------------------------------------------------------------------- K6 smoothness
+class _Smooth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, image, grad_factor, input_is_depth):
+        lib = _lib.load()
+        disp, image = _dev(disp, "disp"), _dev(image, "image")
+        B, h, w = image.shape[:3]
+        if disp.numel() != B * h * w or image.shape[3] != 3:
+            raise _lib.XptHipError(f"smoothness: disp {tuple(disp.shape)} vs image {tuple(image.shape)}")
+        loss = torch.empty((B,), dtype=torch.float32, device=disp.device)
+        nws = lib.xpt_smooth_workspace_floats(B, h, w)
+        ws = torch.empty(nws, dtype=torch.float32, device=disp.device)
+        _lib.check(lib.xpt_smooth_fwd(_ptr(disp), _ptr(image), _ptr(loss), _ptr(ws), nws, B, h, w, float(grad_factor),
+                                      int(input_is_depth), _stream()), "xpt_smooth_fwd")
+        ctx.save_for_backward(disp, image)
+        ctx.gf, ctx.is_depth = float(grad_factor), int(input_is_depth)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        disp, image = ctx.saved_tensors
+        g = _dev(g, "grad")
+        B, h, w = image.shape[:3]
+        dinput = torch.empty_like(disp)
+        _lib.check(lib.xpt_smooth_bwd(_ptr(disp), _ptr(image), _ptr(g), _ptr(dinput), B, h, w, ctx.gf, ctx.is_depth,
+                                      _stream()), "xpt_smooth_bwd")
+        return dinput, None, None, None
+
+
+def smoothness(disp, image, grad_factor, input_is_depth=False):
+    """smootheness_loss (losses.py:409-440) for one scale -> [B]; gradient w.r.t. disp
+    (or depth when input_is_depth: disp = safe_reciprocal_number(depth) fused, util_funcs.py:157-160)."""
+    return _Smooth.apply(disp, image, grad_factor, input_is_depth)
