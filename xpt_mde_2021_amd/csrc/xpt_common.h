@@ -13,6 +13,9 @@
   } while (0)
 
 static inline int xpt_launch_status() { return hipGetLastError() == hipSuccess ? XPT_OK : XPT_ERR_LAUNCH; }
+// hipGetLastError() is per-thread and shared with the host framework: drop any stale (already handled)
+// error of an earlier runtime call before launching so that the status we return is our own.
+#define XPT_BEGIN_LAUNCH() (void)hipGetLastError()
 
 namespace xpt {
 

@@ -309,6 +309,7 @@ int xpt_photo_fwd(int method, const float* synth, const float* target, float* ma
     part = workspace;
   }
   const dim3 grid(nblk, B * N), block(256);
+  XPT_BEGIN_LAUNCH();
   hipStream_t s = (hipStream_t)stream;
   if (method == XPT_PHOTO_L1) hipLaunchKernelGGL(photo_fwd_kernel<XPT_PHOTO_L1>, grid, block, 0, s, synth, target, map, part, N, h, w);
   else if (method == XPT_PHOTO_L2) hipLaunchKernelGGL(photo_fwd_kernel<XPT_PHOTO_L2>, grid, block, 0, s, synth, target, map, part, N, h, w);
@@ -329,6 +330,7 @@ int xpt_photo_bwd(int method, const float* synth, const float* target, const flo
   const int P = h * w, nblk = (P + 255) / 256;
   const float inv_count = 1.0f / ((float)N * (float)P * 3.0f);
   const dim3 grid(nblk, B * N), block(256);
+  XPT_BEGIN_LAUNCH();
   hipStream_t s = (hipStream_t)stream;
   if (method == XPT_PHOTO_L1) {
     hipLaunchKernelGGL(photo_bwd_pointwise_kernel<XPT_PHOTO_L1>, grid, block, 0, s, synth, target, gloss, gmap, dsynth, N, h, w, inv_count);
@@ -354,6 +356,7 @@ int xpt_smooth_fwd(const float* disp, const float* image, float* loss, float* wo
   if (B <= 0 || h < 2 || w < 2 || B > 65535) return XPT_ERR_SHAPE;
   if (workspace_floats < xpt_smooth_workspace_floats(B, h, w)) return XPT_ERR_WORKSPACE;
   const int P = h * w, nblk = (P + 255) / 256;
+  XPT_BEGIN_LAUNCH();
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nblk, B), dim3(256), 0, s, disp, image, workspace, h, w, grad_factor,
                      input_is_depth);
@@ -367,6 +370,7 @@ int xpt_smooth_bwd(const float* disp, const float* image, const float* gloss, fl
   XPT_CHECK_PTR(disp); XPT_CHECK_PTR(image); XPT_CHECK_PTR(gloss); XPT_CHECK_PTR(dinput);
   if (B <= 0 || h < 2 || w < 2 || B > 65535) return XPT_ERR_SHAPE;
   const int P = h * w, nblk = (P + 255) / 256;
+  XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(smooth_bwd_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, disp, image, gloss, dinput,
                      h, w, grad_factor, input_is_depth, 1.0f / ((float)h * (float)(w - 1)),
                      1.0f / ((float)(h - 1) * (float)w));

@@ -310,6 +310,7 @@ const char* xpt_build_arch(void) { return "gfx950"; }
 int xpt_pose_rvec2matr_fwd(const float* pose, float* T, int M, void* stream) {
   XPT_CHECK_PTR(pose); XPT_CHECK_PTR(T);
   if (M <= 0) return XPT_ERR_SHAPE;
+  XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(pose_fwd_kernel, dim3((M + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, T, M);
   return xpt_launch_status();
 }
@@ -317,6 +318,7 @@ int xpt_pose_rvec2matr_fwd(const float* pose, float* T, int M, void* stream) {
 int xpt_pose_rvec2matr_bwd(const float* pose, const float* dT, float* dpose, int M, void* stream) {
   XPT_CHECK_PTR(pose); XPT_CHECK_PTR(dT); XPT_CHECK_PTR(dpose);
   if (M <= 0) return XPT_ERR_SHAPE;
+  XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(pose_bwd_kernel, dim3((M + 63) / 64), dim3(64), 0, (hipStream_t)stream, pose, dT, dpose, M);
   return xpt_launch_status();
 }
@@ -328,6 +330,7 @@ int xpt_resize_down_fwd(const float* img, float* out, int M, int H, int W, int C
   const long long total = (long long)M * (H / scale) * (W / scale) * C;
   long long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(resize_down_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, out, M, H, W,
                      C, scale);
   return xpt_launch_status();
@@ -338,6 +341,7 @@ int xpt_warp_fwd(const float* src, const float* depth, const float* T, const flo
   XPT_CHECK_PTR(src); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(T); XPT_CHECK_PTR(K); XPT_CHECK_PTR(synth);
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || B > 65535 || !(scale > 0.f)) return XPT_ERR_SHAPE;
   const int P = h * w;
+  XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(warp_fwd_kernel, dim3((P + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, src, depth, T, K,
                      synth, N, h, w, scale);
   return xpt_launch_status();
@@ -358,6 +362,7 @@ int xpt_warp_bwd(const float* src, const float* depth, const float* T, const flo
   if (workspace_floats < xpt_warp_bwd_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
   const int P = h * w;
   const int nblk = (P + 255) / 256;
+  XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(warp_bwd_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, src, depth, T, K, dsynth,
                      ddepth, workspace, N, h, w, scale);
   hipLaunchKernelGGL(warp_bwd_reduce_kernel, dim3((B * N * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
@@ -371,6 +376,7 @@ int xpt_bilinear_fwd(const float* image, const float* coords, const float* valid
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || C <= 0 || (long long)B * N > 65535) return XPT_ERR_SHAPE;
   if (ncoord != 2 && ncoord != 3) return XPT_ERR_ARG;
   const int P = h * w;
+  XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(bilinear_fwd_kernel, dim3((P + 255) / 256, B * N), dim3(256), 0, (hipStream_t)stream, image,
                      coords, valid_mask, out, N, h, w, C, ncoord);
   return xpt_launch_status();
@@ -382,6 +388,7 @@ int xpt_bilinear_bwd(const float* image, const float* coords, const float* valid
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || C <= 0 || (long long)B * N > 65535) return XPT_ERR_SHAPE;
   if (ncoord != 2 && ncoord != 3) return XPT_ERR_ARG;
   const int P = h * w;
+  XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(bilinear_bwd_kernel, dim3((P + 255) / 256, B * N), dim3(256), 0, (hipStream_t)stream, image,
                      coords, valid_mask, dout, dcoords, N, h, w, C, ncoord);
   return xpt_launch_status();

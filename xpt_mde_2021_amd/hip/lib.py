@@ -57,6 +57,9 @@ def load():
     if not os.path.isfile(LIB_PATH):
         raise XptHipError(f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
                           f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback for these ops.")
+    # PyTorch-ROCm bundles its own libamdhip64: it must be the HIP runtime already resident when our
+    # library is dlopen'ed, otherwise two runtimes coexist and launches on torch's streams fail.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         try:
