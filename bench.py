@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""bench.py -- train images/sec of the self-supervised depth/pose training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full training step over one batch of synthetic KITTI-shaped snippets already resident in HBM:
+DepthNet(NASNet-Mobile)+PoseNetImproved forward in bf16 (MIOpen / rocBLAS), view synthesis + multi-scale
+L1 + SSIM + smoothness loss in the gfx950 HIP kernels, backward, [RCCL all-reduce of the flat gradient], fused Adam.
+One "image" = one 5-frame 128x416 snippet (BASELINE.json).  Workload at N=1 = BASELINE.json configs[1]
+(batch 8 per GPU); N>1 keeps 8 snippets per GPU (weak scaling, configs[2]).
+
+Rank 0 prints ONE JSON line; `roofline` prices the warp+photometric HIP kernel of the largest scale against the
+HBM peak with HIP events on the launch stream; `cpu_baseline` times the oracle / CPU port of the same step on the
+host cores (N=1 only).  Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=8, help="snippets per GPU")
+    ap.add_argument("--height", type=int, default=128)
+    ap.add_argument("--width", type=int, default=416)
+    ap.add_argument("--mode", default=None, help="eager | graph | distributed (default: graph at N=1, distributed at N>1)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--stereo", action="store_true", help="stereo feature dict + LOSS_RIGID_T2 (configs[4]-style)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def build_step(args, world):
+    from xpt_mde_2021_amd.config import opts
+    opts.CONV_DTYPE = args.dtype
+    opts.PER_REPLICA_BATCH = args.batch
+    opts.BATCH_SIZE = args.batch * world
+    opts.IMAGE_SIZES["kitti_raw"] = (args.height, args.width)
+    mode = args.mode or ("graph" if world == 1 else "distributed")
+    opts.TRAIN_MODE = mode
+    from xpt_mde_2021_amd.model import model_main as mm
+    from xpt_mde_2021_amd.model import train_val as tv
+    torch.backends.cudnn.benchmark = True
+    name = "synthetic_stereo" if args.stereo else "synthetic"
+    dataset, tfr_config, _ = mm.get_dataset(name, "train", True)
+    loss_weights = opts.LOSS_RIGID_T2 if args.stereo else opts.LOSS_RIGID_T1
+    model, augmenter, loss_object, optimizer = mm.create_training_parts(
+        0, tfr_config, 1e-4, loss_weights, opts.SCALE_WEIGHT_T1, opts.RIGID_NET, ckpt_name="__bench__")
+    trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, opts.STEREO, augmenter, optimizer)
+    return trainer, dataset, mode, loss_object
+
+
+def roofline_leg(args, dataset, repeats=50):
+    """HIP-event timing (on the launch stream) of the dominant hand-written kernel at the step's own shapes:
+    the full-resolution warp + photometric pass.  Returns the `roofline` object."""
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.hip import roofline as rf
+    feats = dataset.batches[0]
+    return rf.measure(ops, feats, repeats, HBM_PEAK_GBS)
+
+
+def cpu_baseline(args, seconds):
+    """The oracle (CPU restatement, "port") of config C1: 4 synthetic 5x128x416 snippets, DepthNet+PoseNet forward,
+    synthesis, L1+SSIM+smoothness, backward -- timed on the host cores with torch's intra-op thread pool."""
+    from oracle import cpu_step
+    return cpu_step.timed_baseline(height=args.height, width=args.width, batch=4, budget_s=seconds)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP ops have no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+
+    trainer, dataset, mode, _ = build_step(args, world)
+    batches = dataset.batches
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.run_a_batch(batches[i % len(batches)])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = trainer.run_a_batch(batches[i % len(batches)])
+    sync()
+    elapsed = time.perf_counter() - t0
+    loss = float(out[1])
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        global_batch = args.batch * world
+        result = {
+            "metric": "train images/sec (5-frame 128x416 snippets)" if (args.height, args.width) == (128, 416)
+            else f"train images/sec (5-frame {args.height}x{args.width} snippets)",
+            "value": round(global_batch * args.steps / elapsed, 3),
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"DepthNet(NASNetMobile)+PoseNetImproved train step, KITTI-raw-shaped "
+                                   f"5x{args.height}x{args.width} snippets, batch {args.batch}/GPU, "
+                                   f"{'stereo LOSS_RIGID_T2' if args.stereo else 'mono L1+SSIM+smoothness'}, 4 scales",
+                       "global_batch": global_batch, "per_gpu_batch": args.batch, "mode": mode,
+                       "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
+        }
+    if rank == 0 and not args.no_roofline:
+        result["roofline"] = roofline_leg(args, dataset)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,15 @@ int xpt_smooth_fwd(const float* disp, const float* image, float* loss, float* wo
 int xpt_smooth_bwd(const float* disp, const float* image, const float* gloss, float* dinput,
                    int B, int h, int w, float grad_factor, int input_is_depth, void* stream);
 
+/* ------------------------------------------------------------------ a14: fused Adam (Keras semantics)
+ * replaces tf.optimizers.Adam(lr).apply_gradients (model/model_util/optimizers.py:7-13,
+ * model/train_val.py:86) over FLAT fp32 buffers of n elements (16-byte aligned):
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m/(sqrt(v)+eps)
+ *   g is first multiplied by grad_scale; `step` is a DEVICE pointer to the float step count t >= 1
+ *   (so the launch can be replayed from a hipGraph); zero_grad != 0 clears g in the same pass. */
+int xpt_adam_step(float* param, float* grad, float* m, float* v, long long n, const float* step, float lr,
+                  float beta1, float beta2, float eps, float grad_scale, int zero_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,61 @@
+"""oracle (test infrastructure): the reference-equivalent CPU path of one training step, timed for bench.py's
+`cpu_baseline`.  Config C1 (BASELINE.json configs[0]): 1 batch of 4 synthetic 5x128x416 snippets,
+DepthNet(NASNet-Mobile)+PoseNetImproved forward, SynthesizeMultiScale, L1 + SSIM + smoothness, backward.
+
+TensorFlow 2.4 (the reference's framework) is not installable here, so this is a "port": PyTorch-CPU fp32 with the
+TF graph's op decomposition (4 gathers + stacked tensor in the sampler, 5 SAME average pools + tiled target in SSIM,
+one call per scale).  The network modules are the same torch modules the product runs on the GPU (they are library
+convolutions either way); synthesis and losses are the oracle restatement.
+"""
+import os
+import time
+
+import torch
+
+from . import ref_loss
+
+
+def build(height, width, batch, seed=20211119):
+    from xpt_mde_2021_amd.config import opts
+    from xpt_mde_2021_amd.model.build_model.model_factory import ModelFactory
+    from xpt_mde_2021_amd.utils import synthetic_data as sd
+    feats = sd.make_features(batch, height, width, 5, seed)
+    cfg = sd.tfr_config_for(feats)
+    prev = opts.CONV_DTYPE
+    opts.CONV_DTYPE = "fp32"
+    try:
+        model = ModelFactory(cfg, global_batch=batch, net_names=opts.RIGID_NET).get_model()
+    finally:
+        opts.CONV_DTYPE = prev
+    weights = {"L1": 0.5, "SSIM": 0.5, "smoothe": 1.0}
+    return model, feats, weights, opts.SCALE_WEIGHT_T1
+
+
+def one_step(model, feats, weights, scale_weights, batch, backward=True):
+    preds = model(feats)
+    preds["disp_ms"] = ref_loss.safe_reciprocal_number_ms(preds["depth_ms"])
+    total, _ = ref_loss.total_loss(preds, feats, weights, scale_weights, stereo=False, batch_size=batch)
+    if backward:
+        for p in model.trainable_weights():
+            p.grad = None
+        total.backward()
+    return float(total.detach())
+
+
+def timed_baseline(height=128, width=416, batch=4, budget_s=20.0):
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    model, feats, weights, sw = build(height, width, batch)
+    one_step(model, feats, weights, sw, batch)                      # warm-up (allocator, thread pool)
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 10 and (time.perf_counter() - t_start < budget_s or len(times) < 2):
+        t0 = time.perf_counter()
+        one_step(model, feats, weights, sw, batch)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(batch / med, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} training steps (fwd+loss+bwd, no optimizer) of config C1: batch {batch} of "
+                      f"5x{height}x{width} snippets, PyTorch-CPU fp32 with the TF graph's op decomposition; "
+                      f"median {med * 1e3:.1f} ms/step; TF 2.4 itself is not installable (reported baseline, not a target)"}

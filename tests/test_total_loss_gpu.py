@@ -1,0 +1,108 @@
+"""GPU parity of the orchestration: TotalLoss (mono LOSS_RIGID_T1 and stereo LOSS_RIGID_T2 sets, 4 scales) through
+the reference-named boundary classes against the oracle's restatement of losses.py, values and gradients."""
+import pytest
+import torch
+
+from oracle import ref_loss
+from tests.util import frac_close
+from xpt_mde_2021_amd.config import opts
+from xpt_mde_2021_amd.utils import synthetic_data as sd
+
+pytestmark = pytest.mark.gpu
+
+
+def fake_predictions(feats, seed, stereo):
+    g = torch.Generator().manual_seed(seed)
+    B, S, H, W, _ = feats["image5d"].shape
+    preds = {}
+    for sfx in ("", "_R") if stereo else ("",):
+        preds["depth_ms" + sfx] = [sd.smooth_depth(B, H // s, W // s, g, lo=1.0, hi=60.0) for s in (1, 2, 4, 8)]
+        preds["pose" + sfx] = sd.random_poses(B, S - 1, g) * 0.3
+    if stereo:
+        preds["pose_LR"] = sd.random_poses(B, S - 1, g) * 0.1
+        preds["pose_RL"] = sd.random_poses(B, S - 1, g) * 0.1
+    return preds
+
+
+def leaves(preds, device, dtype):
+    out = {}
+    for k, v in preds.items():
+        if isinstance(v, list):
+            out[k] = [t.to(device=device, dtype=dtype).requires_grad_(True) for t in v]
+        else:
+            out[k] = v.to(device=device, dtype=dtype).requires_grad_(True)
+    for sfx in ("", "_R"):
+        if "depth_ms" + sfx in out:
+            out["disp_ms" + sfx] = ref_loss.safe_reciprocal_number_ms(out["depth_ms" + sfx])
+    return out
+
+
+@pytest.mark.parametrize("stereo,loss_set", [(False, "LOSS_RIGID_T1"), (True, "LOSS_RIGID_T2")])
+def test_total_loss_matches_oracle(gpu_device, stereo, loss_set):
+    from xpt_mde_2021_amd.model.loss_and_metric.loss_factory import loss_factory
+    B, H, W = 2, 64, 208
+    feats = sd.make_features(B, H, W, 5, 99, stereo)
+    cfg = sd.tfr_config_for(feats)
+    weights = getattr(opts, loss_set)
+    total_loss = loss_factory(cfg, weights, opts.SCALE_WEIGHT_T2, True, None, B)
+    raw = fake_predictions(feats, 5, stereo)
+
+    p_ref = leaves(raw, "cpu", torch.float64)
+    f_ref = {k: v.double() for k, v in feats.items()}
+    w_ref = {k: v for k, v in total_loss.loss_weights.items()}
+    tot_ref, by_ref = ref_loss.total_loss(p_ref, f_ref, w_ref, opts.SCALE_WEIGHT_T2, True, B)
+    tot_ref.backward()
+
+    p = leaves(raw, gpu_device, torch.float32)
+    f = {k: v.to(gpu_device) for k, v in feats.items()}
+    tot, by = total_loss(p, f)
+    tot.backward()
+
+    assert set(by) == set(by_ref)
+    for k in by:
+        frac_close(by[k], by_ref[k], 2e-5, rtol=2e-4, what=f"loss {k}")
+    frac_close(tot, tot_ref, 1e-4, rtol=2e-4, what="total loss")
+    for sfx in ("", "_R") if stereo else ("",):
+        for i, (d, dr) in enumerate(zip(p["depth_ms" + sfx], p_ref["depth_ms" + sfx])):
+            scale = dr.grad.abs().max().item()
+            frac_close(d.grad, dr.grad, 2e-4 * scale, rtol=2e-3, max_bad_frac=5e-4, what=f"d depth_ms{sfx}[{i}]")
+        scale = p_ref["pose" + sfx].grad.abs().max().item()
+        frac_close(p["pose" + sfx].grad, p_ref["pose" + sfx].grad, 1e-2 * scale, rtol=1e-2, what=f"d pose{sfx}")
+    if stereo:
+        for k in ("pose_LR", "pose_RL"):
+            frac_close(p[k].grad, p_ref[k].grad, 1e-6, rtol=1e-4, what=f"d {k}")
+
+
+def test_train_step_runs_and_learns(gpu_device):
+    """Eager and hipGraph trainers: a few steps on one synthetic batch reduce the loss and agree with each other."""
+    from xpt_mde_2021_amd.model import model_main as mm
+    from xpt_mde_2021_amd.model import train_val as tv
+    saved = (opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE, dict(opts.IMAGE_SIZES))
+    opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 2
+    opts.IMAGE_SIZES["kitti_raw"] = (64, 192)
+    try:
+        losses = {}
+        for mode, dtype in (("eager", "fp32"), ("graph", "fp32"), ("graph", "bf16")):
+            opts.CONV_DTYPE = dtype
+            torch.manual_seed(0)
+            dataset, cfg, _ = mm.get_dataset("synthetic", "train", True)
+            model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, opts.LOSS_RIGID_T1,
+                                                                          opts.SCALE_WEIGHT_T1, opts.RIGID_NET,
+                                                                          ckpt_name="__test__")
+            trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, False, aug, optimizer)
+            feats = dataset.batches[0]
+            hist = []
+            for _ in range(8):
+                _, loss, by_type = trainer.run_a_batch(feats)
+                hist.append(float(loss))
+            assert all(torch.isfinite(torch.tensor(hist))), hist
+            assert hist[-1] < hist[0], (mode, dtype, hist)
+            losses[(mode, dtype)] = hist
+        a, b = losses[("eager", "fp32")], losses[("graph", "fp32")]
+        assert abs(a[0] - b[0]) < 1e-5 and abs(a[-1] - b[-1]) < 2e-3 * abs(a[-1]), (a, b)
+        c = losses[("graph", "bf16")]
+        assert abs(a[0] - c[0]) < 5e-2 * abs(a[0]), (a, c)
+    finally:
+        opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
+        opts.IMAGE_SIZES.clear()
+        opts.IMAGE_SIZES.update(saved[3])

@@ -1,0 +1,92 @@
+"""DepthNetPretrained: multi-scale encoder + the reference's U-Net style decoder
+(model/build_model/depth_net.py:76-92 upsample / get_scaled_depth, :101-109 NoResize skip block, :137-167 decode).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..model_util import layer_ops as lo
+from .pretrained_nets import PretrainedModel
+
+
+class UpconvWithSkip(nn.Module):
+    """upconv_with_skip_connection of DepthNetNoResize (depth_net.py:101-109):
+    nearest 2x -> conv3x3 -> concat([., skip][, up-sampled previous prediction]) -> conv3x3."""
+
+    def __init__(self, conv2d, cin, skip_channels, out_channels, upsample_interp="nearest"):
+        super().__init__()
+        self.interp = upsample_interp
+        self.conv1 = conv2d(cin, out_channels, 3)
+        self.conv2 = conv2d(out_channels + skip_channels, out_channels, 3)
+
+    def forward(self, bef_layer, skips):
+        if self.interp == "nearest":
+            up = F.interpolate(bef_layer, scale_factor=2, mode="nearest")        # UpSampling2D(2, "nearest")
+        else:
+            up = F.interpolate(bef_layer, scale_factor=2, mode="bilinear", align_corners=False)
+        up = self.conv1(up)
+        return self.conv2(torch.cat([up] + [s.to(up.dtype) for s in skips], dim=1))
+
+
+class ScaledDepthHead(nn.Module):
+    """get_scaled_depth (depth_net.py:87-92): 3x3 conv to one LINEAR channel, the depth activation on it, and the
+    bilinearly up-sampled raw prediction that feeds the next decoder level.  Runs in fp32 (16..128 -> 1 channels:
+    negligible cost) so that the depth handed to the warp kernels is not quantised to bf16."""
+
+    def __init__(self, conv2d, cin, pred_depth):
+        super().__init__()
+        self.conv = conv2d(cin, 1, 3, activation="linear")
+        self.predict_depth = pred_depth
+
+    def forward(self, src, dst_height, dst_width):
+        with torch.autocast(device_type=src.device.type, enabled=False):
+            conv = self.conv(src.float())
+            depth = self.predict_depth(conv)
+            conv_up = lo.resize_image(conv, dst_height, dst_width)
+        return depth, conv_up, conv
+
+
+class DepthNetPretrained(nn.Module):
+    """depth_net.py:112-167.  forward(image5d [B,S,H,W,3]) -> {"depth_ms": [d0 (1/1), d1 (1/2), d2 (1/4), d3 (1/8)]
+    each [B,h,w,1] fp32, "debug_out": [p0, up0, p3, up3]}.  The target frame is the LAST frame (:131)."""
+
+    def __init__(self, total_shape, global_batch, conv2d, pred_depth, upsample_iterp, net_name, use_pt_weight,
+                 high_res):
+        super().__init__()
+        self.total_shape = tuple(total_shape)
+        self.high_res = high_res
+        self.encoder = PretrainedModel(net_name, use_pt_weight).encoder()
+        c1, c2, c3, c4, c5 = self.encoder.TAP_CHANNELS
+        self.up4 = UpconvWithSkip(conv2d, c5, c4, 256, upsample_iterp)            # 1/16
+        self.up3 = UpconvWithSkip(conv2d, 256, c3, 128, upsample_iterp)           # 1/8
+        self.depth3 = ScaledDepthHead(conv2d, 128, pred_depth)
+        self.up2 = UpconvWithSkip(conv2d, 128, c2 + 1, 64, upsample_iterp)        # 1/4
+        self.depth2 = ScaledDepthHead(conv2d, 64, pred_depth)
+        self.up1 = UpconvWithSkip(conv2d, 64, c1 + 1, 32, upsample_iterp)         # 1/2
+        self.depth1 = ScaledDepthHead(conv2d, 32, pred_depth)
+        self.up0 = UpconvWithSkip(conv2d, 32, 1, 16, upsample_iterp)              # 1/1: the only skip is p1 up-sampled
+        self.depth0 = ScaledDepthHead(conv2d, 16, pred_depth)
+
+    def forward(self, image5d):
+        target = image5d[:, -1].permute(0, 3, 1, 2)                               # [B,3,H,W] view of the NHWC frame
+        height, width = target.shape[2:]
+        conv1, conv2, conv3, conv4, conv5 = self.encoder(target)
+        outputs = self.decode(conv1, conv2, conv3, conv4, conv5, height, width)
+        return outputs
+
+    def decode(self, conv1, conv2, conv3, conv4, conv5, height, width):
+        upconv4 = self.up4(conv5, [conv4])
+        upconv3 = self.up3(upconv4, [conv3])
+        depth3, dpconv2_up, dpconv3 = self.depth3(upconv3, height // 4, width // 4)
+        upconv2 = self.up2(upconv3, [conv2, dpconv2_up])
+        depth2, dpconv1_up, dpconv2 = self.depth2(upconv2, height // 2, width // 2)
+        upconv1 = self.up1(upconv2, [conv1, dpconv1_up])
+        depth1, dpconv0_up, dpconv1 = self.depth1(upconv1, height, width)
+        upconv0 = self.up0(upconv1, [dpconv0_up])
+        depth0, _, dpconv0 = self.depth0(upconv0, height, width)
+
+        def nhwc1(x):      # [B,1,h,w] -> [B,h,w,1]: same memory, the reference's axis order
+            return x.contiguous().reshape(x.shape[0], x.shape[2], x.shape[3], 1)
+
+        return {"depth_ms": [nhwc1(depth0), nhwc1(depth1), nhwc1(depth2), nhwc1(depth3)],
+                "debug_out": [dpconv0, upconv0, dpconv3, upconv3]}

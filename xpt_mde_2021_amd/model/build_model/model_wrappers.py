@@ -1,0 +1,140 @@
+"""ModelWrapper / StereoModelWrapper / StereoPoseModelWrapper with the reference's interface
+(model/build_model/model_wrappers.py:10-177) over torch modules on MI355X."""
+import os.path as op
+
+import numpy as np
+import torch
+
+from ...config import opts
+from ...utils import util_funcs as uf
+
+
+class ModelWrapper:
+    def __init__(self, models):
+        self.models = models                      # {"depthnet": nn.Module, "posenet": nn.Module}
+        self.conv_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[opts.CONV_DTYPE]
+
+    def __call__(self, features):
+        return self.predict_batch(features)
+
+    # ------------------------------------------------------------------ device / format plumbing
+    def to(self, device, channels_last=None):
+        channels_last = opts.CHANNELS_LAST if channels_last is None else channels_last
+        for model in self.models.values():
+            model.to(device)
+            if channels_last:
+                model.to(memory_format=torch.channels_last)
+        return self
+
+    def _run(self, model, image5d):
+        if self.conv_dtype is None or not image5d.is_cuda:
+            return model(image5d)
+        with torch.autocast(device_type="cuda", dtype=self.conv_dtype):
+            return model(image5d)
+
+    # ------------------------------------------------------------------ model_wrappers.py:41-51
+    def predict_batch(self, features, suffix=""):
+        predictions = dict()
+        for netname, model in self.models.items():
+            predictions.update(self._run(model, features["image5d" + suffix]))
+        if "depth_ms" in predictions:
+            predictions["disp_ms"] = uf.safe_reciprocal_number_ms(predictions["depth_ms"])
+        return {key + suffix: value for key, value in predictions.items()}
+
+    def predict_dataset(self, dataset, save_keys, total_steps):
+        """model_wrappers.py:18-31."""
+        outputs = self.init_output_structure(save_keys)
+        with torch.no_grad():
+            for step, features in enumerate(dataset):
+                predictions = self.predict_batch(features)
+                outputs = self.append_outputs(features, predictions, outputs)
+                uf.print_progress_status(f"Progress: {step} / {total_steps}")
+        print("")
+        return {key: np.concatenate(data, axis=0) for key, data in outputs.items() if data}
+
+    def init_output_structure(self, keys):
+        outputs = {"image": []}
+        outputs.update({key: [] for key in keys})
+        outputs.update({key + "_gt": [] for key in keys})
+        if "depth" in keys:
+            outputs["intrinsic"] = []
+        return outputs
+
+    def append_outputs(self, features, predictions, outputs, suffix=""):
+        """model_wrappers.py:53-79: target image (uint8), pose(+gt), full-resolution depth(+gt, intrinsic)."""
+        image = features["image5d" + suffix][:, -1]
+        outputs["image" + suffix].append(uf.to_uint8_image(image).cpu().numpy())
+        if "pose" + suffix in outputs:
+            outputs["pose_gt" + suffix].append(features["pose_gt" + suffix].cpu().numpy())
+            outputs["pose" + suffix].append(predictions["pose" + suffix].float().cpu().numpy())
+        if "depth" + suffix in outputs:
+            outputs["depth_gt" + suffix].append(features["depth_gt" + suffix].cpu().numpy())
+            outputs["depth" + suffix].append(predictions["depth_ms" + suffix][0].float().cpu().numpy())
+            outputs["intrinsic" + suffix].append(features["intrinsic" + suffix].cpu().numpy())
+        return outputs
+
+    def set_trainable(self, name, trainable):
+        for p in self.models[name].parameters():
+            p.requires_grad_(trainable)
+        print(f"[ModelWrapper] set {name} trainable {trainable}")
+
+    def trainable_weights(self):
+        """model_wrappers.py:89-93."""
+        return [p for model in self.models.values() for p in model.parameters() if p.requires_grad]
+
+    def weights_to_regularize(self):
+        return None
+
+    def save_weights(self, ckpt_dir_path, suffix):
+        """model_wrappers.py:101-105 ({netname}_{suffix}; torch state_dict instead of Keras H5)."""
+        for netname, model in self.models.items():
+            save_path = op.join(ckpt_dir_path, f"{netname}_{suffix}.pt")
+            torch.save(model.state_dict(), save_path)
+            print(f"===== {netname} weights are saved to", save_path)
+
+    def load_weights(self, ckpt_dir_path, suffix):
+        """model_wrappers.py:107-117."""
+        for netname, model in self.models.items():
+            ckpt_file = op.join(ckpt_dir_path, f"{netname}_{suffix}.pt")
+            if op.isfile(ckpt_file):
+                model.load_state_dict(torch.load(ckpt_file, map_location="cpu"))
+                print(f"===== {netname} weights loaded from", ckpt_file)
+                print(f"      {netname} num params:", sum(p.numel() for p in model.parameters()))
+            else:
+                print(f"===== Failed to load weights of {netname}, train from scratch ...")
+                print("      tried to load file:", ckpt_file)
+
+    def summary(self, **kwargs):
+        for netname, model in self.models.items():
+            n = sum(p.numel() for p in model.parameters())
+            print(f"{netname}: {n / 1e6:.2f} M parameters")
+
+
+class StereoModelWrapper(ModelWrapper):
+    def __call__(self, features):
+        """model_wrappers.py:141-145."""
+        predictions = self.predict_batch(features)
+        predictions.update(self.predict_batch(features, "_R"))
+        return predictions
+
+
+class StereoPoseModelWrapper(StereoModelWrapper):
+    def __call__(self, features):
+        """model_wrappers.py:152-159."""
+        predictions = self.predict_batch(features)
+        predictions.update(self.predict_batch(features, "_R"))
+        if "posenet" in self.models:
+            predictions.update(self.predict_stereo_pose(features))
+        return predictions
+
+    def predict_stereo_pose(self, features):
+        """model_wrappers.py:161-177: PoseNet on [R,R,R,R,L] -> pose_LR and [L,L,L,L,R] -> pose_RL."""
+        posenet = self.models["posenet"]
+        left_target = features["image5d"][:, -1]
+        right_target = features["image5d_R"][:, -1]
+        numsrc = opts.SNIPPET_LEN - 1
+        lr_input = torch.stack([right_target] * numsrc + [left_target], dim=1)
+        rl_input = torch.stack([left_target] * numsrc + [right_target], dim=1)
+        pose_lr = self._run(posenet, lr_input)
+        pose_rl = self._run(posenet, rl_input)
+        return {"pose_LR": pose_lr["pose"], "pose_RL": pose_rl["pose"]}

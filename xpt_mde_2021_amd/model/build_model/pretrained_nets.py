@@ -1,0 +1,293 @@
+"""Multi-scale encoder behind DepthNetPretrained (reference: model/build_model/pretrained_nets.py:11-117).
+
+The reference takes `tf.keras.applications.NASNetMobile(include_top=False)` from tensorflow==2.4.1 (a
+third-party dependency that is NOT part of the reference checkout) and taps the five layers listed in
+scaled_layers.json ("NASNetMobile": activation_7 / _18 / _77 / _136 / _187 at 1/2 ... 1/32).  This file
+restates the published NASNet-A (4 @ 1056) architecture of that Keras application as torch modules.
+
+PARITY UNPINNED: no golden activations, tap channel counts or ImageNet weights exist offline.  Structural pins
+that tests/test_nets.py checks: (i) creation-order index of the unnamed Activation layers reproduces exactly the
+five tap names above with the spatial sizes scaled_layers.json records; (ii) the parameter count equals Keras'
+published 4,269,716 (include_top=False).
+
+Bug-compatible details kept (SURVEY 7 "Hard parts" h, i):
+  * `preprocess_input` (x/127.5 - 1) is applied to images that are ALREADY in [-1, 1] (pretrained_nets.py:40),
+    then the image is resized to (H+2, W+2) so that the VALID 3x3/2 stem conv yields H/2 x W/2 (:32, :41);
+  * the model is called without training=True (train_val.py:82), so every BatchNormalization uses its moving
+    statistics (never updated) while gamma / beta are trained: FrozenBatchNorm below.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...utils.util_class import WrongInputException
+from ..model_util.layer_ops import same_pad
+
+BN_EPS = 1e-3          # keras_applications nasnet: BatchNormalization(momentum=0.9997, epsilon=1e-3)
+
+
+class FrozenBatchNorm(nn.Module):
+    """Keras BatchNormalization in inference mode with trainable gamma / beta."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("running_mean", torch.zeros(channels))
+        self.register_buffer("running_var", torch.ones(channels))
+
+    def forward(self, x):
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, BN_EPS)
+
+
+def correct_pad(h, w, k):
+    """keras imagenet_utils.correct_pad for a stride-2 VALID conv: ((k//2 - adj_h, k//2), (k//2 - adj_w, k//2))
+    with adj = 1 for an even extent -- identical to TF SAME padding at stride 2."""
+    return same_pad(h, k, 2), same_pad(w, k, 2)
+
+
+def zero_pad(x, pad_hw):
+    (pt, pb), (pl, pr) = pad_hw
+    return F.pad(x, (pl, pr, pt, pb))
+
+
+class SeparableConv(nn.Module):
+    """keras SeparableConv2D(use_bias=False): depthwise k x k (multiplier 1) then pointwise 1x1."""
+
+    def __init__(self, cin, cout, k, stride):
+        super().__init__()
+        self.k, self.stride = k, stride
+        self.depthwise = nn.Conv2d(cin, cin, k, stride, padding=0 if stride == 2 else k // 2, groups=cin, bias=False)
+        self.pointwise = nn.Conv2d(cin, cout, 1, bias=False)
+        nn.init.kaiming_normal_(self.depthwise.weight, mode="fan_in", nonlinearity="relu")
+        nn.init.kaiming_normal_(self.pointwise.weight, mode="fan_in", nonlinearity="relu")
+
+    def forward(self, x):
+        if self.stride == 2:
+            x = zero_pad(x, correct_pad(x.shape[2], x.shape[3], self.k))
+        return self.pointwise(self.depthwise(x))
+
+
+class SepConvBlock(nn.Module):
+    """_separable_conv_block: relu -> sepconv(k, stride) -> BN -> relu -> sepconv(k, 1) -> BN.
+    Creates TWO unnamed Activation layers (counted by the tap bookkeeping)."""
+
+    def __init__(self, net, cin, filters, k=3, stride=1):
+        super().__init__()
+        self.act_id1 = net.new_activation()
+        self.conv1 = SeparableConv(cin, filters, k, stride)
+        self.bn1 = FrozenBatchNorm(filters)
+        self.act_id2 = net.new_activation()
+        self.conv2 = SeparableConv(filters, filters, k, 1)
+        self.bn2 = FrozenBatchNorm(filters)
+
+    def forward(self, x, taps):
+        x = F.relu(x)
+        taps.offer(self.act_id1, x)
+        x = self.bn1(self.conv1(x))
+        x = F.relu(x)
+        taps.offer(self.act_id2, x)
+        return self.bn2(self.conv2(x))
+
+
+class AdjustBlock(nn.Module):
+    """_adjust_block: brings `p` (the cell input of two cells ago) to the spatial size / channel count of the
+    current cell.  The spatial branch uses a NAMED relu (not counted); the projection branch an unnamed one."""
+
+    def __init__(self, net, p_channels, p_reduction, ip_reduction, filters, p_is_none=False):
+        super().__init__()
+        self.mode = "none"
+        if p_is_none:                                   # first cell: `p = ip`, nothing else (if / elif chain)
+            pass
+        elif p_reduction != ip_reduction:
+            self.mode = "spatial"
+            self.conv1 = nn.Conv2d(p_channels, filters // 2, 1, bias=False)
+            self.conv2 = nn.Conv2d(p_channels, filters // 2, 1, bias=False)
+            self.bn = FrozenBatchNorm(2 * (filters // 2))
+        elif p_channels != filters:
+            self.mode = "project"
+            self.act_id = net.new_activation()
+            self.conv = nn.Conv2d(p_channels, filters, 1, bias=False)
+            self.bn = FrozenBatchNorm(filters)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity="relu")
+
+    def forward(self, p, taps):
+        if self.mode == "spatial":
+            p = F.relu(p)
+            p1 = self.conv1(p[:, :, ::2, ::2])                       # AveragePooling2D((1,1), strides 2)
+            p2 = F.pad(p, (0, 1, 0, 1))[:, :, 1:, 1:]                # ZeroPadding2D(((0,1),(0,1))) + Cropping2D(((1,0),(1,0)))
+            p2 = self.conv2(p2[:, :, ::2, ::2])
+            return self.bn(torch.cat([p1, p2], dim=1))
+        if self.mode == "project":
+            p = F.relu(p)
+            taps.offer(self.act_id, p)
+            return self.bn(self.conv(p))
+        return p
+
+
+def avg_pool_same(x):
+    """AveragePooling2D((3,3), strides 1, padding='same'): the divisor excludes the padding."""
+    return F.avg_pool2d(x, 3, 1, 1, count_include_pad=False)
+
+
+class NormalCell(nn.Module):
+    """_normal_a_cell -> concat([p, x1, x2, x3, x4, x5]) = 6 * filters channels."""
+
+    def __init__(self, net, ip_channels, p_channels, ip_reduction, p_reduction, filters, p_is_none=False):
+        super().__init__()
+        self.adjust = AdjustBlock(net, p_channels, p_reduction, ip_reduction, filters, p_is_none)
+        self.act_id = net.new_activation()
+        self.conv = nn.Conv2d(ip_channels, filters, 1, bias=False)
+        nn.init.kaiming_normal_(self.conv.weight, mode="fan_in", nonlinearity="relu")
+        self.bn = FrozenBatchNorm(filters)
+        p_ch = filters if self.adjust.mode != "none" else p_channels
+        self.left1 = SepConvBlock(net, filters, filters, 5)
+        self.right1 = SepConvBlock(net, p_ch, filters, 3)
+        self.left2 = SepConvBlock(net, p_ch, filters, 5)
+        self.right2 = SepConvBlock(net, p_ch, filters, 3)
+        self.left5 = SepConvBlock(net, filters, filters, 3)
+        self.out_channels = p_ch + 5 * filters
+
+    def forward(self, ip, p, taps):
+        p = self.adjust(p, taps)
+        h = F.relu(ip)
+        taps.offer(self.act_id, h)
+        h = self.bn(self.conv(h))
+        x1 = self.left1(h, taps) + self.right1(p, taps)
+        x2 = self.left2(p, taps) + self.right2(p, taps)
+        x3 = avg_pool_same(h) + p
+        x4 = avg_pool_same(p) + avg_pool_same(p)
+        x5 = self.left5(h, taps) + h
+        return torch.cat([p, x1, x2, x3, x4, x5], dim=1), ip
+
+
+class ReductionCell(nn.Module):
+    """_reduction_a_cell -> concat([x2, x3, x4, x5]) = 4 * filters channels at half the resolution."""
+
+    def __init__(self, net, ip_channels, p_channels, ip_reduction, p_reduction, filters, p_is_none=False):
+        super().__init__()
+        self.adjust = AdjustBlock(net, p_channels, p_reduction, ip_reduction, filters, p_is_none)
+        self.act_id = net.new_activation()
+        self.conv = nn.Conv2d(ip_channels, filters, 1, bias=False)
+        nn.init.kaiming_normal_(self.conv.weight, mode="fan_in", nonlinearity="relu")
+        self.bn = FrozenBatchNorm(filters)
+        p_ch = filters if self.adjust.mode != "none" else p_channels
+        self.left1 = SepConvBlock(net, filters, filters, 5, 2)
+        self.right1 = SepConvBlock(net, p_ch, filters, 7, 2)
+        self.right2 = SepConvBlock(net, p_ch, filters, 7, 2)
+        self.right3 = SepConvBlock(net, p_ch, filters, 5, 2)
+        self.left4 = SepConvBlock(net, filters, filters, 3, 1)
+        self.out_channels = 4 * filters
+
+    def forward(self, ip, p, taps):
+        p = self.adjust(p, taps)
+        h = F.relu(ip)
+        taps.offer(self.act_id, h)
+        h = self.bn(self.conv(h))
+        h3 = zero_pad(h, correct_pad(h.shape[2], h.shape[3], 3))
+        x1 = self.left1(h, taps) + self.right1(p, taps)
+        x2 = F.max_pool2d(h3, 3, 2) + self.right2(p, taps)
+        x3 = F.avg_pool2d(h3, 3, 2) + self.right3(p, taps)
+        x4 = x2 + avg_pool_same(x1)
+        x5 = self.left4(x1, taps) + F.max_pool2d(h3, 3, 2)
+        return torch.cat([x2, x3, x4, x5], dim=1), ip
+
+
+class _Taps:
+    def __init__(self, wanted):
+        self.wanted = wanted
+        self.found = {}
+
+    def offer(self, act_id, tensor):
+        if act_id in self.wanted:
+            self.found[act_id] = tensor
+
+
+class NASNetMobileEncoder(nn.Module):
+    """NASNet-A Mobile (penultimate_filters=1056, num_blocks=4, stem_block_filters=32, filter_multiplier=2,
+    skip_reduction=False), include_top=False, with the five taps of scaled_layers.json.
+
+    forward(image NCHW in [-1,1]) -> [c1 (1/2, 32 ch), c2 (1/4, 22), c3 (1/8, 88), c4 (1/16, 176), c5 (1/32, 1056)]."""
+    TAP_ACTIVATIONS = (7, 18, 77, 136, 187)          # scaled_layers.json "NASNetMobile": activation_<k>
+    TAP_CHANNELS = (32, 22, 88, 176, 1056)
+
+    def __init__(self, penultimate_filters=1056, num_blocks=4, stem_block_filters=32, filter_multiplier=2):
+        super().__init__()
+        self._n_act = 0
+        filters = penultimate_filters // 24
+        fm = filter_multiplier
+        self.stem_conv = nn.Conv2d(3, stem_block_filters, 3, 2, 0, bias=False)       # padding="valid"
+        nn.init.kaiming_normal_(self.stem_conv.weight, mode="fan_in", nonlinearity="relu")
+        self.stem_bn = FrozenBatchNorm(stem_block_filters)
+        cells = []
+        # (channels, log2 reduction) of x (current) and p (previous cell input)
+        x_ch, x_red = stem_block_filters, 1
+        p_ch, p_red = None, None
+
+        def add(kind, f):
+            nonlocal x_ch, x_red, p_ch, p_red
+            pc, pr = (x_ch, x_red) if p_ch is None else (p_ch, p_red)
+            cls = ReductionCell if kind == "R" else NormalCell
+            cell = cls(self, x_ch, pc, x_red, pr, f, p_is_none=p_ch is None)
+            cells.append(cell)
+            p_ch, p_red = x_ch, x_red                      # the cell returns (x, ip): p <- ip
+            x_ch = cell.out_channels
+            if kind == "R":
+                x_red += 1
+
+        add("R", filters // (fm ** 2))                     # stem_1
+        add("R", filters // fm)                            # stem_2
+        for _ in range(num_blocks):
+            add("N", filters)
+        add("R", filters * fm)                             # reduce_4  (skip_reduction=False: p <- p0 = its input)
+        for _ in range(num_blocks):
+            add("N", filters * fm)
+        add("R", filters * fm ** 2)                        # reduce_8
+        for _ in range(num_blocks):
+            add("N", filters * fm ** 2)
+        self.cells = nn.ModuleList(cells)
+        self.final_act_id = self.new_activation()
+        self.out_channels = x_ch
+        self.num_activations = self._n_act
+
+    def new_activation(self):
+        """Index this unnamed keras Activation layer would get ('activation', 'activation_1', ...)."""
+        k = self._n_act
+        self._n_act += 1
+        return k
+
+    def preprocess(self, image):
+        """pretrained_nets.py:36-43."""
+        x = image / 127.5 - 1.0
+        h, w = image.shape[2:]
+        return F.interpolate(x, size=(h + 2, w + 2), mode="bilinear", align_corners=False, antialias=False)
+
+    def forward(self, image):
+        taps = _Taps(self.TAP_ACTIVATIONS)
+        x = self.stem_bn(self.stem_conv(self.preprocess(image)))
+        p = None
+        for cell in self.cells:
+            x, p = cell(x, x if p is None else p, taps)
+        x = F.relu(x)
+        taps.offer(self.final_act_id, x)
+        return [taps.found[k] for k in self.TAP_ACTIVATIONS]
+
+
+class PretrainedModel:
+    """pretrained_nets.py:11-117 interface: PretrainedModel(net_name, use_pt_weight).encoder() builds the module
+    whose forward is the reference's `.encode(input_image)`."""
+    SUPPORTED = ("NASNetMobile",)
+
+    def __init__(self, net_name, use_pt_weight):
+        if net_name not in self.SUPPORTED:
+            raise WrongInputException(f"Pretrained backbone '{net_name}' is outside this build's hot path "
+                                      f"(available: {self.SUPPORTED})")
+        if use_pt_weight:
+            raise WrongInputException("ImageNet weights (Keras storage bucket download, pretrained_nets.py:23) are not "
+                                      "obtainable offline; set opts.PRETRAINED_WEIGHT = False")
+        self.net_name = net_name
+
+    def encoder(self):
+        return NASNetMobileEncoder()

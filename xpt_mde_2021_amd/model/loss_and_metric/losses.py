@@ -1,0 +1,201 @@
+"""TotalLoss and the rigid (depth + pose) loss objects with the reference's names and call signatures
+(model/loss_and_metric/losses.py).  All per-pixel arithmetic runs in gfx950 kernels; what is left here is the
+orchestration of losses.py:26-140 (which tensors are synthesized, how scales / types are merged).
+
+In scope: L1, SSIM, smoothe (+ _R), stereoL1, stereoSSIM, stereoPose, and the "next" row
+md2*/moa* min-over-sources variants.  The flow-aided losses (cmb*, flowL2, flow_reg) need FlowNet: out of scope.
+"""
+import numpy as np
+import torch
+
+from ...config import opts
+from ...hip import ops as _ops
+from ...utils import convert_pose as cp
+from ...utils import util_funcs as uf
+from ...utils.util_class import WrongInputException
+from ..synthesize.synthesize_base import SynthesizeMultiScale
+from . import loss_util as lsu
+
+
+class TotalLoss:
+    def __init__(self, loss_objects=None, loss_weights=None, stereo=False, batch_size=1):
+        """
+        :param loss_objects: dict of loss objects
+        :param loss_weights: dict of weights of losses
+        :param batch_size: GLOBAL batch size (losses.py:49: per-example losses are summed and divided by it,
+                           so that data-parallel gradients are SUMMED across replicas)
+        """
+        self.loss_objects = loss_objects
+        self.loss_weights = loss_weights
+        self.stereo = stereo
+        self.batch_size = batch_size
+
+    def __call__(self, predictions, features):
+        """
+        :param predictions: {"depth_ms": .., "disp_ms": .., "pose": ..}
+        :param features: {"image5d": .., "intrinsic": .., ...}
+        :return: (total_loss scalar, {loss name: unweighted per-type mean})     losses.py:26-55
+        """
+        augm_data = self.append_data(features, predictions)
+        if self.stereo and ("image5d_R" in features):
+            augm_data.update(self.append_data(features, predictions, "_R"))
+            augm_data.update(self.synethesize_stereo(features, predictions, augm_data))
+
+        total_loss = None
+        loss_by_type = dict()
+        for loss_name, loss_object in self.loss_objects.items():
+            loss_batch = loss_object(features, predictions, augm_data)
+            loss_mean = torch.sum(loss_batch) / self.batch_size        # tf.nn.compute_average_loss
+            weighted = loss_mean * self.loss_weights[loss_name]
+            total_loss = weighted if total_loss is None else total_loss + weighted
+            loss_by_type[loss_name] = loss_mean
+        return total_loss, loss_by_type
+
+    def append_data(self, features, predictions, suffix=""):
+        """losses.py:57-104: source/target split (TARGET FRAME LAST), multi-scale target, synthesized views."""
+        image5d = features["image5d" + suffix]
+        intrinsic = features["intrinsic" + suffix]
+        source_image = image5d[:, :-1]
+        target_image = image5d[:, -1]
+        augm_data = {"source" + suffix: source_image, "target" + suffix: target_image}
+        if ("depth_ms" + suffix in predictions) and ("pose" + suffix in predictions):
+            pred_depth_ms = predictions["depth_ms" + suffix]
+            pred_pose = predictions["pose" + suffix]
+            augm_data["target_ms" + suffix] = uf.multi_scale_like_depth(target_image, pred_depth_ms)
+            augm_data["synth_target_ms" + suffix] = SynthesizeMultiScale()(source_image, intrinsic,
+                                                                            pred_depth_ms, pred_pose)
+        return augm_data
+
+    def synethesize_stereo(self, features, predictions, augm_data):
+        """losses.py:106-140 (the reference's spelling is kept: logger.py:211-216 calls it by this name)."""
+        synth_stereo = dict()
+        if ("stereo_T_LR" not in features) or ("depth_ms" not in predictions):
+            return synth_stereo
+        # left image from the right image: points move left -> right with inv(T_LR)
+        pose_T_RL = cp.pose_matr2rvec_batch(torch.linalg.inv(features["stereo_T_LR"]).unsqueeze(1))
+        synth_stereo["stereo_synth_ms"] = SynthesizeMultiScale()(
+            augm_data["target_R"].unsqueeze(1), features["intrinsic"], predictions["depth_ms"], pose_T_RL)
+        pose_T_LR = cp.pose_matr2rvec_batch(features["stereo_T_LR"].unsqueeze(1))
+        synth_stereo["stereo_synth_ms_R"] = SynthesizeMultiScale()(
+            augm_data["target"].unsqueeze(1), features["intrinsic"], predictions["depth_ms_R"], pose_T_LR)
+        return synth_stereo
+
+
+class LossBase:
+    scale_weights = None
+
+    def __call__(self, features, predictions, augm_data):
+        raise NotImplementedError()
+
+    def merge_multi_scale_losses(self, losses, name=""):
+        """losses.py:147-154: [scales, batch]^T x scale_weights[scales, 1] -> [batch, 1]."""
+        stacked = torch.stack(list(losses), dim=0)
+        sw = torch.as_tensor(np.asarray(self.scale_weights, dtype=np.float32).reshape(-1, 1), device=stacked.device)
+        return torch.matmul(stacked.t(), sw)
+
+
+class PhotometricLoss(LossBase):
+    def __init__(self, method, scale_weights, key_suffix=""):
+        table = {"L1": lsu.photometric_loss_l1, "L2": lsu.photometric_loss_l2, "SSIM": lsu.photometric_loss_ssim}
+        if method not in table:
+            raise WrongInputException("Wrong photometric loss name: " + method)
+        self.method = method
+        self.photometric_loss = table[method]
+        self.key_suffix = key_suffix
+        self.scale_weights = scale_weights
+
+
+class PhotometricLossMultiScale(PhotometricLoss):
+    def __call__(self, features, predictions, augm_data):
+        """losses.py:179-195 -> photo_loss [batch, 1]"""
+        target_ms = augm_data["target_ms" + self.key_suffix]
+        synth_ms = augm_data["synth_target_ms" + self.key_suffix]
+        losses = [self.photometric_loss(synt, orig) for synt, orig in zip(synth_ms, target_ms)]
+        return self.merge_multi_scale_losses(losses)
+
+
+def resize_bilinear(srcimg, dst_hw):
+    """losses.py:377-383: [B,N,h,w,C] -> [B,N,Hd,Wd,C] (TF2 bilinear; differentiable up-sampling)."""
+    B, N, Hs, Ws, C = srcimg.shape
+    dst = uf.resize_bilinear_tf(srcimg.reshape(B * N, Hs, Ws, C), dst_hw)
+    return dst.reshape(B, N, dst_hw[0], dst_hw[1], C)
+
+
+class MonoDepth2LossMultiScale(PhotometricLoss):
+    """losses.py:198-232: per-pixel loss at full resolution, minimum over the source views."""
+
+    def __call__(self, features, predictions, augm_data):
+        synth_ms = augm_data["synth_target_ms" + self.key_suffix]
+        original_target = augm_data["target" + self.key_suffix]
+        Ho, Wo = original_target.shape[1:3]
+        losses = []
+        for synt in synth_ms:
+            loss = self.photometric_loss(resize_bilinear(synt, (Ho, Wo)), original_target, False)
+            loss = torch.min(loss, dim=1).values
+            losses.append(torch.mean(loss, dim=[1, 2, 3]))
+        return self.merge_multi_scale_losses(losses)
+
+
+class MoALossMultiScale(PhotometricLoss):
+    """losses.py:282-321: minimum over the temporal views and the stereo view."""
+
+    def __call__(self, features, predictions, augm_data):
+        temp_ms = augm_data["synth_target_ms" + self.key_suffix]
+        stro_ms = augm_data["stereo_synth_ms"]                        # losses.py:295 (no suffix, as in the reference)
+        original_target = augm_data["target" + self.key_suffix]
+        Ho, Wo = original_target.shape[1:3]
+        losses = []
+        for temp_target, stro_target in zip(temp_ms, stro_ms):
+            temp_loss = self.photometric_loss(resize_bilinear(temp_target, (Ho, Wo)), original_target, False)
+            stro_loss = self.photometric_loss(resize_bilinear(stro_target, (Ho, Wo)), original_target, False)
+            moa = torch.min(torch.cat([temp_loss, stro_loss], dim=1), dim=1).values
+            losses.append(torch.mean(moa, dim=[1, 2, 3]))
+        return self.merge_multi_scale_losses(losses)
+
+
+class SmoothenessLossMultiScale(LossBase):
+    def __init__(self, scale_weights, key_suffix=""):
+        self.key_suffix = key_suffix
+        self.scale_weights = scale_weights
+
+    def __call__(self, features, predictions, augm_data):
+        """losses.py:391-407: every scale's loss is divided by its scale factor."""
+        disp_ms = predictions["disp_ms" + self.key_suffix]
+        target_ms = augm_data["target_ms" + self.key_suffix]
+        orig_width = target_ms[0].shape[2]
+        losses = []
+        for disp, image in zip(disp_ms, target_ms):
+            scale = orig_width / image.shape[2]
+            losses.append(self.smootheness_loss(disp, image) / scale)
+        return self.merge_multi_scale_losses(losses)
+
+    def smootheness_loss(self, disp, image):
+        """losses.py:409-440 -> [batch]"""
+        return _ops.smoothness(disp, image, float(opts.IMAGE_GRADIENT_FACTOR))
+
+
+class StereoDepthLoss(PhotometricLoss):
+    def __init__(self, method, scale_weights):
+        super().__init__(method, scale_weights)
+
+    def __call__(self, features, predictions, augm_data):
+        """losses.py:447-478: left-from-right + right-from-left photometric loss per scale."""
+        left = self.stereo_photometric_loss(augm_data["stereo_synth_ms"], augm_data["target_ms"])
+        right = self.stereo_photometric_loss(augm_data["stereo_synth_ms_R"], augm_data["target_ms_R"], "_R")
+        return self.merge_multi_scale_losses([l + r for l, r in zip(left, right)])
+
+    def stereo_photometric_loss(self, synth_target_ms, target_ms, suffix=""):
+        return [self.photometric_loss(s, t) for s, t in zip(synth_target_ms, target_ms)]
+
+
+class StereoPoseLoss(LossBase):
+    def __call__(self, features, predictions, augm_data):
+        """losses.py:481-494: MSE between the known stereo extrinsic (as twist) and the PoseNet's
+        left<->right predictions, mean over numsrc -> [batch]"""
+        pose_lr_true_mat = features["stereo_T_LR"].unsqueeze(1)
+        pose_rl_true_mat = torch.linalg.inv(pose_lr_true_mat)
+        pose_lr_true = cp.pose_matr2rvec_batch(pose_lr_true_mat)
+        pose_rl_true = cp.pose_matr2rvec_batch(pose_rl_true_mat)
+        loss = torch.mean(torch.square(pose_lr_true - predictions["pose_LR"]), dim=-1) \
+            + torch.mean(torch.square(pose_rl_true - predictions["pose_RL"]), dim=-1)
+        return torch.mean(loss, dim=1)

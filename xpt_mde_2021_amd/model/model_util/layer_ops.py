@@ -1,0 +1,90 @@
+"""Convolution factory with the reference's defaults (model/model_util/layer_ops.py:5-50):
+Conv2D(padding="same") with TF SAME semantics, LeakyReLU(0.1), TruncatedNormal(0.025) kernels, zero bias.
+
+Tensors are NCHW-indexed torch tensors (stored channels_last for MIOpen when opts.CHANNELS_LAST); the
+convolutions themselves run in MIOpen / rocBLAS (MFMA) through torch.nn.functional.conv2d.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def same_pad(n, k, s):
+    """TF "SAME": total = max((ceil(n/s) - 1) * s + k - n, 0); before = total // 2, after = the rest."""
+    total = max((math.ceil(n / s) - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def make_activation(name, param=None):
+    if name in (None, "linear"):
+        return nn.Identity()
+    if name == "leaky_relu":
+        return nn.LeakyReLU(0.1 if param is None else param)
+    if name == "relu":
+        return nn.ReLU()
+    raise ValueError(f"unknown activation {name}")
+
+
+class Conv2DSame(nn.Module):
+    """keras.layers.Conv2D(filters, k, strides, padding="same", activation=...) on NCHW tensors."""
+
+    def __init__(self, in_channels, filters, kernel_size=3, strides=1, activation="leaky_relu", activation_param=0.1,
+                 kernel_initializer="truncated_normal", kernel_initializer_param=0.025, use_bias=True, groups=1):
+        super().__init__()
+        self.k, self.s = int(kernel_size), int(strides)
+        self.conv = nn.Conv2d(in_channels, filters, self.k, self.s, padding=0, bias=use_bias, groups=groups)
+        self.act = make_activation(activation, activation_param)
+        if kernel_initializer == "truncated_normal":
+            std = kernel_initializer_param
+            nn.init.trunc_normal_(self.conv.weight, mean=0.0, std=std, a=-2 * std, b=2 * std)
+        elif kernel_initializer == "he_normal":
+            nn.init.kaiming_normal_(self.conv.weight, mode="fan_in", nonlinearity="relu")
+        else:
+            nn.init.xavier_uniform_(self.conv.weight)
+        if use_bias:
+            nn.init.zeros_(self.conv.bias)
+
+    def forward(self, x):
+        ph = same_pad(x.shape[2], self.k, self.s)
+        pw = same_pad(x.shape[3], self.k, self.s)
+        if ph[0] == ph[1] and pw[0] == pw[1]:
+            y = F.conv2d(x, self.conv.weight, self.conv.bias, self.s, (ph[0], pw[0]), 1, self.conv.groups)
+        else:  # stride 2 on an even extent: TF pads (k-2)//2 before and (k-1)//2 after
+            y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), self.conv.weight, self.conv.bias, self.s, 0, 1,
+                         self.conv.groups)
+        return self.act(y)
+
+
+class CustomConv2D:
+    """layer_ops.py:5-36: a factory holding default Conv2D arguments; `conv(in_channels, filters, ...)` builds a
+    layer (torch needs the input channel count that Keras infers lazily)."""
+
+    def __init__(self, kernel_size=3, strides=1, activation="relu", activation_param=None,
+                 kernel_initializer="glorot_uniform", kernel_initializer_param=None):
+        self.kernel_size = kernel_size
+        self.strides = strides
+        self.activation = activation
+        self.activation_param = activation_param
+        self.kernel_initializer = kernel_initializer
+        self.kernel_initializer_param = kernel_initializer_param
+
+    def __call__(self, in_channels, filters, kernel_size=None, strides=None, activation=None, name=""):
+        return Conv2DSame(in_channels, filters,
+                          self.kernel_size if kernel_size is None else kernel_size,
+                          self.strides if strides is None else strides,
+                          self.activation if activation is None else activation, self.activation_param,
+                          self.kernel_initializer, self.kernel_initializer_param)
+
+
+def resize_image(src, dst_height, dst_width):
+    """layer_ops.py:43-50: TF2 bilinear resize (half-pixel centres) of NCHW `src`; identity if sizes match."""
+    if src.shape[2] == dst_height and src.shape[3] == dst_width:
+        return src
+    return F.interpolate(src, size=(dst_height, dst_width), mode="bilinear", align_corners=False, antialias=False)
+
+
+def resize_like(src, ref):
+    """layer_ops.py:39-41."""
+    return resize_image(src, ref.shape[2], ref.shape[3])

@@ -1,0 +1,100 @@
+"""optimizer_factory with the reference's signature (model/model_util/optimizers.py:7-13) on flat HBM buffers.
+
+MI355X-first layout: every trainable parameter is a view into ONE flat fp32 buffer, every gradient a view into
+a second one (288 GB of HBM makes the duplication irrelevant).  The flat gradient buffer is at the same time the
+RCCL all-reduce bucket of the data-parallel step, and Adam is one fused gfx950 kernel over the four flat streams
+(xpt_adam_step).  Keras semantics are kept: epsilon = 1e-7 added to the UNcorrected sqrt(v); no weight decay, no
+clipping, constant learning rate; a fresh optimizer state per training-plan row (model_main.py:95).
+"""
+import torch
+
+from ...hip import lib as _lib
+from ...utils.util_class import WrongInputException
+
+
+class FlatParameters:
+    """Re-homes `params` (list of nn.Parameter) into flat data / grad buffers, preserving each parameter's memory
+    format (channels_last conv kernels stay channels_last views)."""
+
+    def __init__(self, params, align=4):
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise WrongInputException("no trainable parameters")
+        self.params = params
+        dev, dtype = params[0].device, torch.float32
+        offsets, total = [], 0
+        for p in params:
+            offsets.append(total)
+            total += (p.numel() + align - 1) // align * align
+        self.numel = total
+        self.data = torch.zeros(total, dtype=dtype, device=dev)
+        self.grad = torch.zeros(total, dtype=dtype, device=dev)
+        for p, off in zip(params, offsets):
+            dview, gview = self._view(self.data, p, off), self._view(self.grad, p, off)
+            dview.copy_(p.data)
+            p.data = dview
+            p.grad = gview
+        self.offsets = offsets
+
+    @staticmethod
+    def _view(flat, p, off):
+        n = p.numel()
+        chunk = flat[off:off + n]
+        if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
+            co, ci, kh, kw = p.shape
+            return chunk.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return chunk.view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def rebind_grads(self):
+        """autograd may replace .grad (e.g. after set_to_none); point every parameter back at its flat view."""
+        for p, off in zip(self.params, self.offsets):
+            g = self._view(self.grad, p, off)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+
+
+class KerasAdam:
+    """tf.optimizers.Adam(learning_rate) over FlatParameters."""
+
+    def __init__(self, learning_rate, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.lr, self.b1, self.b2, self.eps = float(learning_rate), beta_1, beta_2, epsilon
+        self.flat = None
+        self.m = self.v = self.step_count = None
+
+    def bind(self, params):
+        self.flat = params if isinstance(params, FlatParameters) else FlatParameters(list(params))
+        self.m = torch.zeros_like(self.flat.data)
+        self.v = torch.zeros_like(self.flat.data)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=self.flat.data.device)
+        return self.flat
+
+    def apply_gradients(self, grad_scale=1.0, zero_grad=True):
+        """optimizer.apply_gradients (train_val.py:86) on the flat buffers; hipGraph-capturable."""
+        f = self.flat
+        self.step_count += 1
+        if f.data.is_cuda:
+            lib = _lib.load()
+            _lib.check(lib.xpt_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                         f.numel, self.step_count.data_ptr(), self.lr, self.b1, self.b2, self.eps,
+                                         float(grad_scale), int(zero_grad), torch.cuda.current_stream().cuda_stream),
+                       "xpt_adam_step")
+            return
+        # host tensors (CPU-only unit tests of the data-parallel host logic): same arithmetic with tensor ops
+        with torch.no_grad():
+            t = self.step_count
+            lr_t = self.lr * torch.sqrt(1 - self.b2 ** t) / (1 - self.b1 ** t)
+            g = f.grad * grad_scale
+            self.m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+            self.v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            f.data.sub_(lr_t * self.m / (torch.sqrt(self.v) + self.eps))
+            if zero_grad:
+                f.grad.zero_()
+
+
+def optimizer_factory(opt_name, basic_lr, epoch=0):
+    if opt_name == "adam_constant":
+        return KerasAdam(learning_rate=basic_lr)
+    raise WrongInputException(f"{opt_name} is NOT an available optimizer name")

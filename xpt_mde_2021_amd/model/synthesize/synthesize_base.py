@@ -1,0 +1,53 @@
+"""SynthesizeMultiScale / SynthesizeSingleScale with the reference's call signatures
+(model/synthesize/synthesize_base.py:10-58), backed by the gfx950 kernels:
+pose twist -> matrix (K0), source pyramid (K1), projective warp + bilinear sampling (K2+K3)."""
+from ...hip import ops as _ops
+from ...utils.convert_pose import pose_rvec2matr_batch_tf
+
+
+class SynthesizeMultiScale:
+    def __call__(self, source_image, intrinsic, pred_depth_ms, pred_pose):
+        """
+        :param source_image: source images [batch, numsrc, height, width, 3]
+        :param intrinsic: [batch, 3, 3]
+        :param pred_depth_ms: predicted target depth in multi scale, list of [batch, height/scale, width/scale, 1]
+        :param pred_pose: twist poses that transform target points to each source frame [batch, numsrc, 6]
+        :return: reconstructed target view in multi scale, list of [batch, numsrc, height/scale, width/scale, 3]
+        """
+        poses_matr = pose_rvec2matr_batch_tf(pred_pose)
+        return [SynthesizeSingleScale()(source_image, intrinsic, depth_sc, poses_matr) for depth_sc in pred_depth_ms]
+
+
+class SynthesizeSingleScale:
+    def __init__(self, shape=(0, 0, 0), numsrc=0, scale=0):
+        self.batch, self.height_sc, self.width_sc = shape
+        self.numsrc = numsrc
+        self.scale = scale
+
+    def __call__(self, source_image, intrinsic, depth_sc, poses_matr):
+        """source_image [batch, numsrc, height, width, 3] (full resolution), intrinsic [batch, 3, 3] (full
+        resolution; scaled inside the kernel as scale_intrinsic does, :66-71), depth_sc
+        [batch, height/scale, width/scale, 1], poses_matr [batch, numsrc, 4, 4]
+        -> [batch, numsrc, height/scale, width/scale, 3]"""
+        self.read_shape(source_image, depth_sc)
+        source_images_sc = self.resize_source_images(source_image)
+        return _ops.warp(source_images_sc, depth_sc, poses_matr, intrinsic, self.scale)
+
+    def read_shape(self, source_image, depth_sc):
+        _, self.numsrc, height_orig, _, _ = source_image.shape
+        self.batch, self.height_sc, self.width_sc, _ = depth_sc.shape
+        self.scale = int(height_orig // self.height_sc)          # synthesize_base.py:64
+
+    def scale_intrinsic(self, intrinsic, scale):
+        """synthesize_base.py:66-71 (kept for API parity; the warp kernel applies the same scaling itself)."""
+        out = intrinsic.clone()
+        out[:, :2, :] = intrinsic[:, :2, :] / scale
+        out[:, 2, :] = out.new_tensor([0., 0., 1.])
+        return out
+
+    def resize_source_images(self, source_image):
+        """synthesize_base.py:74-85: TF2 bilinear resize of every source to this scale."""
+        batch, numsrc, height, width, ch = source_image.shape
+        flat = source_image.reshape(batch * numsrc, height, width, ch)
+        flat = _ops.resize_down(flat, self.scale)
+        return flat.reshape(batch, numsrc, self.height_sc, self.width_sc, ch)

@@ -1,0 +1,275 @@
+"""Train / validation loop with the reference's public names (model/train_val.py:12-264):
+train_val_factory(mode, model, loss_object, steps_per_epoch, stereo, augmenter, optimizer) -> (trainer, validater),
+`.run_an_epoch(dataset) -> (DataFrame, hours)`, `.run_a_batch(features)`, `.train_a_step(features)`.
+
+MI355X-first differences:
+  * "graph" mode = the whole training step (nets fwd, HIP synthesis + loss kernels, backward, fused Adam) captured
+    ONCE into a hipGraph and replayed on static input buffers -- the counterpart of the reference's @tf.function
+    (train_val.py:100-102) without a tracing compiler;
+  * "distributed" mode = one process per GPU; the flat gradient buffer is all-reduced (SUM) with RCCL between the
+    backward and the optimizer (the reference's implicit MirroredStrategy all-reduce, train_val.py:86,114);
+  * per-step metrics stay on the device and are fetched once per epoch (the reference syncs the host every step in
+    merge_results, train_val.py:157-177).
+"""
+import numpy as np
+import pandas as pd
+import torch
+
+from ..config import opts
+from ..utils import util_class as uc
+from ..utils import util_funcs as uf
+from .model_util.distributer import DistributionStrategy
+from .model_util.optimizers import KerasAdam
+
+
+def train_val_factory(mode_sel, model, loss_object, steps_per_epoch, stereo, augmenter, optimizer):
+    table = {"eager": (ModelTrainer, ModelValidater), "graph": (ModelTrainerGraph, ModelValidaterGraph),
+             "distributed": (ModelTrainerDistrib, ModelValidaterDistrib)}
+    if mode_sel not in table:
+        raise uc.WrongInputException(f"training mode '{mode_sel}' is NOT available")
+    trainer_cls, validater_cls = table[mode_sel]
+    trainer = trainer_cls(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
+    validater = validater_cls(model, loss_object, steps_per_epoch, stereo)
+    return trainer, validater
+
+
+class TrainValBase:
+    def __init__(self, model, loss_object, steps_per_epoch, stereo, augmenter=None, optimizer=None):
+        self.model = model
+        self.augmenter = augmenter
+        self.loss_object = loss_object
+        self.train_val_name = "train_val"
+        self.steps_per_epoch = steps_per_epoch
+        self.stereo = stereo
+        self.optimizer = optimizer
+        self.print_stride = max(int(getattr(opts, "PRINT_STRIDE", 50)), 1)
+
+    def set_name(self, name):
+        self.train_val_name = name
+
+    def run_an_epoch(self, dataset):
+        """train_val.py:43-64 -> (DataFrame of per-step results, hours)."""
+        results = []
+        with uc.DurationTime() as epoch_time:
+            for step, features in enumerate(dataset):
+                preds, loss, loss_by_type = self.run_a_batch(features)
+                results.append(merge_results(features, preds, loss, loss_by_type, self.stereo))
+                if step % self.print_stride == 0:
+                    uf.print_progress_status(f"    {self.train_val_name} {step}/{self.steps_per_epoch} steps, "
+                                             f"loss = {float(results[-1]['loss']):1.4f}...")
+                if self.steps_per_epoch and step + 1 >= self.steps_per_epoch:
+                    break
+        print("")
+        results = pd.DataFrame(fetch_results(results))
+        mean_results = results.mean(axis=0).to_dict()
+        message = f"[{self.train_val_name} Epoch MEAN], result: " + ", ".join(f"{k}={v:1.4f}" for k, v in mean_results.items())
+        print(message, "\n\n")
+        return results, epoch_time.duration / 3600.
+
+    def run_a_batch(self, features):
+        raise NotImplementedError()
+
+
+class ModelTrainer(TrainValBase):
+    def __init__(self, model, loss_object, steps_per_epoch, stereo, augmenter, optimizer):
+        super().__init__(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
+        self.set_name("Train (eager)")
+        if isinstance(optimizer, KerasAdam) and optimizer.flat is None:
+            optimizer.bind(model.trainable_weights())
+
+    def run_a_batch(self, features):
+        return self.train_a_step(features)
+
+    def forward_backward(self, features):
+        if self.augmenter is not None:
+            features = self.augmenter(features)
+        preds = self.model(features)
+        total_loss, loss_by_type = self.loss_object(preds, features)
+        total_loss.backward()
+        return preds, total_loss.detach(), {k: v.detach() for k, v in loss_by_type.items()}
+
+    def reduce_gradients(self):
+        pass
+
+    def train_a_step(self, features):
+        """train_val.py:78-92: augment -> model -> loss -> gradients -> optimizer.apply_gradients."""
+        out = self.forward_backward(features)
+        self.reduce_gradients()
+        self.optimizer.apply_gradients()
+        return out
+
+
+class _StepGraph:
+    """Captures fn(static_features) into a hipGraph; replays it after copying a new batch into the static buffers."""
+
+    def __init__(self, fn, warmup=3):
+        self.fn = fn
+        self.warmup = warmup
+        self.graph = None
+        self.static_in = None
+        self.static_out = None
+        self.signature = None
+
+    @staticmethod
+    def _sig(features):
+        return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in features.items() if torch.is_tensor(v)))
+
+    def __call__(self, features):
+        sig = self._sig(features)
+        if self.graph is None or sig != self.signature:
+            self._capture(features, sig)
+        else:
+            for k, v in self.static_in.items():
+                v.copy_(features[k], non_blocking=True)
+        self.graph.replay()
+        return self.static_out
+
+    def _capture(self, features, sig):
+        self.static_in = {k: v.clone() for k, v in features.items() if torch.is_tensor(v)}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):           # MIOpen find / workspace allocation happens here, not in capture
+                self.fn(self.static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = self.fn(self.static_in)
+        self.signature = sig
+
+
+class ModelTrainerGraph(ModelTrainer):
+    def __init__(self, model, loss_object, steps_per_epoch, stereo, augmenter, optimizer):
+        super().__init__(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
+        self.set_name("Train (graph)")
+        self._graph = _StepGraph(self.train_a_step)
+
+    def run_a_batch(self, features):
+        if not features["image5d"].is_cuda:
+            return self.train_a_step(features)
+        return self._graph(features)
+
+
+class ModelTrainerDistrib(ModelTrainer):
+    """One process per GPU.  forward+backward is a hipGraph; the gradient all-reduce (RCCL) and the fused Adam run
+    behind it on the same stream."""
+
+    def __init__(self, model, loss_object, steps_per_epoch, stereo, augmenter, optimizer):
+        super().__init__(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
+        self.set_name("Train (distributed)")
+        self.strategy = DistributionStrategy.get_strategy()
+        if self.strategy is not None:
+            self.strategy.broadcast_parameters(self.optimizer.flat.data)
+        self._graph = _StepGraph(self.forward_backward) if getattr(opts, "DISTRIB_GRAPH", True) else None
+
+    def reduce_gradients(self):
+        if self.strategy is not None:
+            self.strategy.all_reduce_gradients(self.optimizer.flat.grad)
+
+    def run_a_batch(self, features):
+        if self._graph is not None and features["image5d"].is_cuda:
+            out = self._graph(features)
+        else:
+            out = self.forward_backward(features)
+        self.reduce_gradients()
+        self.optimizer.apply_gradients()
+        return out
+
+
+class ModelValidater(TrainValBase):
+    def __init__(self, model, loss_object, steps_per_epoch, stereo):
+        super().__init__(model, loss_object, steps_per_epoch, stereo)
+        self.set_name("Validate (eager)")
+
+    def run_a_batch(self, features):
+        return self.validate_a_step(features)
+
+    def validate_a_step(self, features):
+        """train_val.py:127-130."""
+        with torch.no_grad():
+            preds = self.model(features)
+            total_loss, loss_by_type = self.loss_object(preds, features)
+        return preds, total_loss, loss_by_type
+
+
+class ModelValidaterGraph(ModelValidater):
+    def __init__(self, model, loss_object, steps_per_epoch, stereo):
+        super().__init__(model, loss_object, steps_per_epoch, stereo)
+        self.set_name("Validate (graph)")
+        self._graph = _StepGraph(self.validate_a_step)
+
+    def run_a_batch(self, features):
+        if not features["image5d"].is_cuda:
+            return self.validate_a_step(features)
+        return self._graph(features)
+
+
+class ModelValidaterDistrib(ModelValidaterGraph):
+    def __init__(self, model, loss_object, steps_per_epoch, stereo):
+        super().__init__(model, loss_object, steps_per_epoch, stereo)
+        self.set_name("Validate (distributed)")
+
+
+# ---------------------------------------------------------------------------------------------- per-step results
+def merge_results(features, preds, loss, loss_by_type, stereo):
+    """train_val.py:157-177, kept on the device: {"loss", "deprel", "gtdepth", "prdepth", <per-type losses>} as
+    0-dim tensors (cloned, so hipGraph replays do not overwrite them); fetch_results() moves a whole epoch to the
+    host at once."""
+    batch_result = {"loss": loss.detach().clone()}
+    if "depth_ms" in preds and "depth_gt" in features:
+        batch_result["deprel"] = get_depth_metric(features, preds)
+        gtdepth, prdepth = get_center_depths(features, preds)
+        batch_result["gtdepth"] = gtdepth[0]
+        batch_result["prdepth"] = prdepth[0]
+    batch_result.update({key: val.detach().clone() for key, val in loss_by_type.items()})
+    return batch_result
+
+
+def fetch_results(results):
+    if not results:
+        return []
+    keys = list(results[0].keys())
+    stacked = torch.stack([torch.stack([torch.as_tensor(r[k], dtype=torch.float32, device=results[0]["loss"].device)
+                                        for k in keys]) for r in results]).cpu().numpy()
+    return [dict(zip(keys, row)) for row in stacked]
+
+
+def get_depth_metric(features, preds):
+    """train_val.py:180-200 + evaluate/eval_utils.py:109-131 (valid_depth_filter: 1e-3 < gt < 80, Garg crop,
+    median scaling, clip) -> mean abs-rel over the batch, computed on the device."""
+    depth_pred = preds["depth_ms"][0].detach()[..., 0].float()
+    depth_true = features["depth_gt"][..., 0]
+    _, h, w = depth_true.shape
+    crop = (np.array([0.40810811 * h, 0.99189189 * h, 0.03594771 * w, 0.96405229 * w])).astype(np.int32)
+    crop_mask = torch.zeros((h, w), dtype=torch.bool, device=depth_true.device)
+    crop_mask[crop[0]:crop[1], crop[2]:crop[3]] = True
+    metrics = []
+    for pr, gt in zip(depth_pred, depth_true):
+        mask = (gt > opts.MIN_DEPTH) & (gt < opts.MAX_DEPTH) & crop_mask
+        big = torch.full_like(gt, float("inf"))
+        cnt = mask.sum()
+        k = torch.clamp((cnt - 1) // 2, min=0)                       # np.median of an even count averages 2; lower one here
+        gt_sorted = torch.sort(torch.where(mask, gt, big).flatten()).values
+        pr_sorted = torch.sort(torch.where(mask, pr, big).flatten()).values
+        k2 = torch.clamp(cnt // 2, min=0)
+        med_gt = 0.5 * (gt_sorted[k] + gt_sorted[k2])
+        med_pr = 0.5 * (pr_sorted[k] + pr_sorted[k2])
+        scaled = torch.clamp(pr * (med_gt / med_pr), opts.MIN_DEPTH, opts.MAX_DEPTH)
+        err = torch.where(mask, torch.abs(gt - scaled) / torch.where(mask, gt, torch.ones_like(gt)), torch.zeros_like(gt))
+        metrics.append(torch.where(cnt > 0, err.sum() / cnt.clamp(min=1), torch.zeros((), device=gt.device)))
+    return torch.stack(metrics).mean()
+
+
+def get_center_depths(features, preds):
+    """train_val.py:213-236: mean true (positive only) / predicted depth in a 20x20 window at 3/4 height."""
+    depth_pred = preds["depth_ms"][0].detach().float()
+    depth_true = features["depth_gt"]
+    _, height, width, _ = depth_pred.shape
+    xs, xe = width // 2 - 10, width // 2 + 10
+    ys, ye = height // 4 * 3 - 10, height // 4 * 3 + 10
+    win = depth_true[:, ys:ye, xs:xe, :]
+    pos = (win > 0).to(win.dtype)
+    mean_true = (win * pos).sum(dim=(1, 2, 3)) / pos.sum(dim=(1, 2, 3)).clamp(min=1)
+    mean_pred = depth_pred[:, ys:ye, xs:xe, :].mean(dim=(1, 2, 3))
+    return mean_true, mean_pred
