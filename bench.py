@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--mode", default=None, help="eager | graph | distributed (default: graph at N=1, distributed at N>1)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--stereo", action="store_true", help="stereo feature dict + LOSS_RIGID_T2 (configs[4]-style)")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (slow first steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
@@ -57,7 +58,7 @@ def build_step(args, world):
     opts.TRAIN_MODE = mode
     from xpt_mde_2021_amd.model import model_main as mm
     from xpt_mde_2021_amd.model import train_val as tv
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)     # exhaustive MIOpen find takes many minutes on NASNet
     name = "synthetic_stereo" if args.stereo else "synthetic"
     dataset, tfr_config, _ = mm.get_dataset(name, "train", True)
     loss_weights = opts.LOSS_RIGID_T2 if args.stereo else opts.LOSS_RIGID_T1
@@ -103,9 +104,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    note(f"mode={mode} world={world} batch/GPU={args.batch} {args.height}x{args.width} dtype={args.dtype}")
     for i in range(args.warmup):
         trainer.run_a_batch(batches[i % len(batches)])
+        if i == 0:
+            torch.cuda.synchronize()
+            note("first step done (graph captured)")
     sync()
+    note("warm-up done")
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = trainer.run_a_batch(batches[i % len(batches)])
@@ -135,8 +145,10 @@ def main():
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "mode": mode,
                        "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
         }
+    note(f"timed region done: {elapsed:.3f} s")
     if rank == 0 and not args.no_roofline:
         result["roofline"] = roofline_leg(args, dataset)
+        note("roofline leg done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
     if rank == 0:

@@ -43,7 +43,11 @@ def one_step(model, feats, weights, scale_weights, batch, backward=True):
 
 
 def timed_baseline(height=128, width=416, batch=4, budget_s=20.0):
-    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, int(os.environ.get("XPT_CPU_BASELINE_THREADS", 16))))   # the GPU box's CPU share
     torch.set_num_threads(threads)
     model, feats, weights, sw = build(height, width, batch)
     one_step(model, feats, weights, sw, batch)                      # warm-up (allocator, thread pool)

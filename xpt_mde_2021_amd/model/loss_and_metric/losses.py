@@ -89,9 +89,12 @@ class LossBase:
 
     def merge_multi_scale_losses(self, losses, name=""):
         """losses.py:147-154: [scales, batch]^T x scale_weights[scales, 1] -> [batch, 1]."""
-        stacked = torch.stack(list(losses), dim=0)
-        sw = torch.as_tensor(np.asarray(self.scale_weights, dtype=np.float32).reshape(-1, 1), device=stacked.device)
-        return torch.matmul(stacked.t(), sw)
+        # the weights are host constants: fold them in as scalars (no H2D copy -> hipGraph-capturable)
+        weights = [float(w) for w in np.asarray(self.scale_weights, dtype=np.float64).reshape(-1)]
+        merged = None
+        for w, loss in zip(weights, losses):
+            merged = loss * w if merged is None else merged + loss * w
+        return merged.unsqueeze(1)
 
 
 class PhotometricLoss(LossBase):

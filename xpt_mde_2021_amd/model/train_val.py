@@ -91,6 +91,10 @@ class ModelTrainer(TrainValBase):
     def reduce_gradients(self):
         pass
 
+    def optimizer_state(self):
+        opt = self.optimizer
+        return [opt.flat.data, opt.flat.grad, opt.m, opt.v, opt.step_count]
+
     def train_a_step(self, features):
         """train_val.py:78-92: augment -> model -> loss -> gradients -> optimizer.apply_gradients."""
         out = self.forward_backward(features)
@@ -102,9 +106,10 @@ class ModelTrainer(TrainValBase):
 class _StepGraph:
     """Captures fn(static_features) into a hipGraph; replays it after copying a new batch into the static buffers."""
 
-    def __init__(self, fn, warmup=3):
+    def __init__(self, fn, warmup=3, state=None):
         self.fn = fn
         self.warmup = warmup
+        self.state = state                     # callable -> list of tensors the warm-up runs must not change
         self.graph = None
         self.static_in = None
         self.static_out = None
@@ -126,6 +131,8 @@ class _StepGraph:
 
     def _capture(self, features, sig):
         self.static_in = {k: v.clone() for k, v in features.items() if torch.is_tensor(v)}
+        state = self.state() if self.state is not None else []
+        saved = [t.clone() for t in state]     # warm-up executes real steps: roll the weights / moments back after it
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -136,6 +143,8 @@ class _StepGraph:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_out = self.fn(self.static_in)
+        for t, s in zip(state, saved):
+            t.copy_(s)
         self.signature = sig
 
 
@@ -143,7 +152,7 @@ class ModelTrainerGraph(ModelTrainer):
     def __init__(self, model, loss_object, steps_per_epoch, stereo, augmenter, optimizer):
         super().__init__(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
         self.set_name("Train (graph)")
-        self._graph = _StepGraph(self.train_a_step)
+        self._graph = _StepGraph(self.train_a_step, state=self.optimizer_state)
 
     def run_a_batch(self, features):
         if not features["image5d"].is_cuda:
@@ -161,7 +170,8 @@ class ModelTrainerDistrib(ModelTrainer):
         self.strategy = DistributionStrategy.get_strategy()
         if self.strategy is not None:
             self.strategy.broadcast_parameters(self.optimizer.flat.data)
-        self._graph = _StepGraph(self.forward_backward) if getattr(opts, "DISTRIB_GRAPH", True) else None
+        self._graph = _StepGraph(self.forward_backward, state=self.optimizer_state) \
+            if getattr(opts, "DISTRIB_GRAPH", True) else None
 
     def reduce_gradients(self):
         if self.strategy is not None:
