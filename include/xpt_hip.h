@@ -125,6 +125,42 @@ int xpt_smooth_bwd(const float* disp, const float* image, const float* gloss, fl
 int xpt_adam_step(float* param, float* grad, float* m, float* v, long long n, const float* step, float lr,
                   float beta1, float beta2, float eps, float grad_scale, int zero_grad, void* stream);
 
+/* ------------------------------------------------------------------ a2: depthwise convolution (NASNet separable convs)
+ * replaces the depthwise half of every keras SeparableConv2D(use_bias=False) inside
+ * tf.keras.applications.NASNetMobile (reference call site model/build_model/pretrained_nets.py:36-44), with the
+ * preceding Activation('relu') of _separable_conv_block optionally fused (relu_in) and the ZeroPadding2D of the
+ * stride-2 blocks folded into (pad_t, pad_l).
+ *   x  [B,H,W,C]   NHWC activations, dtype 0 = float32, 1 = bfloat16 (fp32 accumulation)
+ *   w  [C,k,k]     float32 (k in {3,5,7}), stride in {1,2}
+ *   y  [B,OH,OW,C] = sum_{ky,kx} f(x[b, oy*stride+ky-pad_t, ox*stride+kx-pad_l, c]) w[c,ky,kx], f = relu | id
+ * bwd_data:   dy -> dx [B,H,W,C] (x is only read for the relu mask; may be NULL when relu_in == 0)
+ * bwd_weight: (x, dy) -> dw [C,k,k] float32; workspace xpt_dwconv_bwd_weight_workspace_floats() floats. */
+int xpt_dwconv_fwd(const void* x, const float* w, void* y, int B, int H, int W, int C, int k, int stride, int pad_t,
+                   int pad_l, int OH, int OW, int relu_in, int dtype, void* stream);
+int xpt_dwconv_bwd_data(const void* x, const float* w, const void* dy, void* dx, int B, int H, int W, int C, int k,
+                        int stride, int pad_t, int pad_l, int OH, int OW, int relu_in, int dtype, void* stream);
+size_t xpt_dwconv_bwd_weight_workspace_floats(int B, int OH, int OW, int C, int k);
+int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_floats,
+                          int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW,
+                          int relu_in, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ a2/a3: per-channel conv epilogues on NHWC activations
+ * y = act(f(x) * scale[c] + shift[c]),  scale = gamma*rsqrt(var+eps), shift = beta - mean*scale
+ *   gamma == NULL : bias epilogue of CustomConv2D (model/model_util/layer_ops.py:31-35): scale = 1, shift = beta (the bias),
+ *                   act = LeakyReLU(slope) (config-example.py:56-63) or linear (slope = 1);
+ *   gamma != NULL : keras BatchNormalization in inference mode inside NASNetMobile (called without training=True,
+ *                   model/train_val.py:82), f = relu when relu_in (the Activation('relu') that precedes it is fused).
+ *   x, y [rows, C] (rows = B*H*W pixels of an NHWC tensor), dtype 0 = float32 / 1 = bfloat16; parameters float32.
+ * bwd: dy -> dx (may be NULL), dbeta [C], dgamma [C] (NULL iff gamma is NULL); y is only read when slope != 1;
+ *   workspace xpt_affine_act_bwd_workspace_floats(rows, C) floats; deterministic reduction. */
+int xpt_affine_act_fwd(const void* x, const float* gamma, const float* beta, const float* mean, const float* var,
+                       float eps, void* y, long long rows, int C, float slope, int relu_in, int dtype, void* stream);
+size_t xpt_affine_act_bwd_workspace_floats(long long rows, int C);
+int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
+                       const float* mean, const float* var, float eps, void* dx, float* dbeta, float* dgamma,
+                       float* workspace, size_t workspace_floats, long long rows, int C, float slope, int relu_in,
+                       int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

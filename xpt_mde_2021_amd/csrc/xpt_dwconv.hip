@@ -1,0 +1,283 @@
+// xpt_dwconv.hip -- depthwise k x k convolution (forward, data gradient, weight gradient) on NHWC
+// activations for gfx950.  This is the memory-bound half of every keras SeparableConv2D of the
+// NASNet-A-Mobile encoder behind DepthNetPretrained (reference call site:
+// model/build_model/pretrained_nets.py:36-44 -> tf.keras.applications.NASNetMobile; 10 separable
+// convolutions per cell, ~150 per image).  MIOpen routes the bf16 NHWC depthwise weight gradient to
+// generic grouped-conv / naive kernels (0.5 - 4.5 ms each, 68 % of the training step in
+// profiles/r01_a_*); these kernels are plain streaming stencils instead:
+//   * lanes run along the channel axis (innermost in NHWC) -> every load / store is a contiguous segment;
+//   * each thread keeps OXT neighbouring outputs of one channel in registers and slides the k-wide row window,
+//     so an input row segment is loaded once per ky instead of once per (ky,kx);
+//   * the ReLU that always precedes the convolution in _separable_conv_block is fused into the load
+//     (and its mask into the data gradient), the zero padding of the stride-2 blocks into the bounds test;
+//   * weights / weight gradients stay fp32; activations are fp32 or bf16 with fp32 accumulation;
+//   * the weight gradient is reduced deterministically: per-workgroup partials + a fixed-order sum.
+#include <hip/hip_bf16.h>
+
+#include "xpt_common.h"
+
+namespace {
+
+template <typename T> __device__ inline float ldf(const T* p);
+template <> __device__ inline float ldf<float>(const float* p) { return *p; }
+template <> __device__ inline float ldf<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <typename T> __device__ inline void stf(T* p, float v);
+template <> __device__ inline void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ inline void stf<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+struct DwDims {
+  int B, H, W, C, OH, OW, pad_t, pad_l;
+};
+
+// ---------------------------------------------------------------- forward
+// y[b,oy,ox,c] = sum_{ky,kx} f(x[b, oy*S+ky-pad_t, ox*S+kx-pad_l, c]) * w[c,ky,kx],  f = relu or identity.
+template <typename T, int K, int S, int OXT>
+__global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, DwDims d,
+                              int relu_in) {
+  const int OXG = (d.OW + OXT - 1) / OXT;
+  const long long total = (long long)d.B * d.OH * OXG * d.C;
+  constexpr int IN = (OXT - 1) * S + K;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % d.C);
+    long long r = idx / d.C;
+    const int oxg = (int)(r % OXG); r /= OXG;
+    const int oy = (int)(r % d.OH);
+    const int b = (int)(r / d.OH);
+    const int ox0 = oxg * OXT;
+    const int ix0 = ox0 * S - d.pad_l;
+    float acc[OXT];
+#pragma unroll
+    for (int i = 0; i < OXT; ++i) acc[i] = 0.f;
+    const float* wc = w + (long long)c * K * K;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * S + ky - d.pad_t;
+      if (iy < 0 || iy >= d.H) continue;
+      const T* row = x + (((long long)b * d.H + iy) * d.W) * d.C + c;
+      float in[IN];
+#pragma unroll
+      for (int i = 0; i < IN; ++i) {
+        const int ix = ix0 + i;
+        float v = (ix >= 0 && ix < d.W) ? ldf<T>(row + (long long)ix * d.C) : 0.f;
+        in[i] = relu_in ? fmaxf(v, 0.f) : v;
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const float wv = wc[ky * K + kx];
+#pragma unroll
+        for (int i = 0; i < OXT; ++i) acc[i] += in[i * S + kx] * wv;
+      }
+    }
+    T* out = y + (((long long)b * d.OH + oy) * d.OW + ox0) * d.C + c;
+#pragma unroll
+    for (int i = 0; i < OXT; ++i)
+      if (ox0 + i < d.OW) stf<T>(out + (long long)i * d.C, acc[i]);
+  }
+}
+
+// ---------------------------------------------------------------- data gradient
+// dx[b,iy,ix,c] = [x>0 if relu] * sum_{ky,kx : (iy+pad_t-ky) % S == 0, ...} dy[b,(iy+pad_t-ky)/S,(ix+pad_l-kx)/S,c] * w[c,ky,kx]
+template <typename T, int K, int S>
+__global__ void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy,
+                                   T* __restrict__ dx, DwDims d, int relu_in) {
+  const long long total = (long long)d.B * d.H * d.W * d.C;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % d.C);
+    long long r = idx / d.C;
+    const int ix = (int)(r % d.W); r /= d.W;
+    const int iy = (int)(r % d.H);
+    const int b = (int)(r / d.H);
+    const float* wc = w + (long long)c * K * K;
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int ty = iy + d.pad_t - ky;
+      if (ty < 0 || (S > 1 && (ty % S) != 0)) continue;
+      const int oy = ty / S;
+      if (oy >= d.OH) continue;
+      const T* row = dy + (((long long)b * d.OH + oy) * d.OW) * d.C + c;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int tx = ix + d.pad_l - kx;
+        if (tx < 0 || (S > 1 && (tx % S) != 0)) continue;
+        const int ox = tx / S;
+        if (ox >= d.OW) continue;
+        acc += ldf<T>(row + (long long)ox * d.C) * wc[ky * K + kx];
+      }
+    }
+    if (relu_in && !(ldf<T>(x + idx) > 0.f)) acc = 0.f;
+    stf<T>(dx + idx, acc);
+  }
+}
+
+// ---------------------------------------------------------------- weight gradient
+// dw[c,ky,kx] = sum_{b,oy,ox} dy[b,oy,ox,c] * f(x[b,oy*S+ky-pad_t,ox*S+kx-pad_l,c])
+// grid (channel chunks of 64, pixel chunks of PIX); 4 waves: lane = channel, wave w takes pixels w, w+4, ...
+#define DW_WRW_PIX 64
+template <typename T, int K, int S>
+__global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                                     DwDims d, int relu_in) {
+  __shared__ float red[3][64 * K * K];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const long long npix = (long long)d.B * d.OH * d.OW;
+  const long long p0 = (long long)blockIdx.y * DW_WRW_PIX;
+  float acc[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+  if (c < d.C) {
+    for (int i = wid; i < DW_WRW_PIX; i += 4) {
+      const long long p = p0 + i;
+      if (p >= npix) break;
+      const int ox = (int)(p % d.OW);
+      const long long r = p / d.OW;
+      const int oy = (int)(r % d.OH);
+      const int b = (int)(r / d.OH);
+      const float g = ldf<T>(dy + p * d.C + c);
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * S + ky - d.pad_t;
+        if (iy < 0 || iy >= d.H) continue;
+        const T* row = x + (((long long)b * d.H + iy) * d.W) * d.C + c;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          const int ix = ox * S + kx - d.pad_l;
+          if (ix < 0 || ix >= d.W) continue;
+          float v = ldf<T>(row + (long long)ix * d.C);
+          if (relu_in) v = fmaxf(v, 0.f);
+          acc[ky * K + kx] += g * v;
+        }
+      }
+    }
+  }
+  if (wid > 0) {
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) red[wid - 1][i * 64 + lane] = acc[i];
+  }
+  __syncthreads();
+  if (wid == 0 && c < d.C) {
+    float* out = part + ((long long)blockIdx.y * d.C + c) * (K * K);
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) out[i] = ((acc[i] + red[0][i * 64 + lane]) + red[1][i * 64 + lane]) + red[2][i * 64 + lane];
+  }
+}
+
+__global__ void dw_wrw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int nchunk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[(long long)k * n + i];
+  dw[i] = s;
+}
+
+inline unsigned grid_for(long long total) {
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+template <typename T, int K, int S>
+int launch_fwd(const void* x, const float* w, void* y, const DwDims& d, int relu_in, hipStream_t s) {
+  constexpr int OXT = (S == 1) ? 4 : 2;
+  const long long total = (long long)d.B * d.OH * ((d.OW + OXT - 1) / OXT) * d.C;
+  hipLaunchKernelGGL((dw_fwd_kernel<T, K, S, OXT>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, w, (T*)y, d,
+                     relu_in);
+  return xpt_launch_status();
+}
+
+template <typename T, int K, int S>
+int launch_bwd_data(const void* x, const float* w, const void* dy, void* dx, const DwDims& d, int relu_in,
+                    hipStream_t s) {
+  const long long total = (long long)d.B * d.H * d.W * d.C;
+  hipLaunchKernelGGL((dw_bwd_data_kernel<T, K, S>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, w,
+                     (const T*)dy, (T*)dx, d, relu_in);
+  return xpt_launch_status();
+}
+
+template <typename T, int K, int S>
+int launch_bwd_weight(const void* x, const void* dy, float* dw, float* ws, const DwDims& d, int relu_in,
+                      hipStream_t s) {
+  const long long npix = (long long)d.B * d.OH * d.OW;
+  const int nchunk = (int)((npix + DW_WRW_PIX - 1) / DW_WRW_PIX);
+  hipLaunchKernelGGL((dw_bwd_weight_kernel<T, K, S>), dim3((d.C + 63) / 64, nchunk), dim3(256), 0, s, (const T*)x,
+                     (const T*)dy, ws, d, relu_in);
+  const int n = d.C * K * K;
+  hipLaunchKernelGGL(dw_wrw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, dw, n, nchunk);
+  return xpt_launch_status();
+}
+
+#define DW_DISPATCH(FN, ...)                                                   \
+  do {                                                                         \
+    if (dtype == 0) {                                                          \
+      if (k == 3 && stride == 1) return FN<float, 3, 1>(__VA_ARGS__);          \
+      if (k == 5 && stride == 1) return FN<float, 5, 1>(__VA_ARGS__);          \
+      if (k == 7 && stride == 1) return FN<float, 7, 1>(__VA_ARGS__);          \
+      if (k == 3 && stride == 2) return FN<float, 3, 2>(__VA_ARGS__);          \
+      if (k == 5 && stride == 2) return FN<float, 5, 2>(__VA_ARGS__);          \
+      if (k == 7 && stride == 2) return FN<float, 7, 2>(__VA_ARGS__);          \
+    } else {                                                                   \
+      if (k == 3 && stride == 1) return FN<__hip_bfloat16, 3, 1>(__VA_ARGS__); \
+      if (k == 5 && stride == 1) return FN<__hip_bfloat16, 5, 1>(__VA_ARGS__); \
+      if (k == 7 && stride == 1) return FN<__hip_bfloat16, 7, 1>(__VA_ARGS__); \
+      if (k == 3 && stride == 2) return FN<__hip_bfloat16, 3, 2>(__VA_ARGS__); \
+      if (k == 5 && stride == 2) return FN<__hip_bfloat16, 5, 2>(__VA_ARGS__); \
+      if (k == 7 && stride == 2) return FN<__hip_bfloat16, 7, 2>(__VA_ARGS__); \
+    }                                                                          \
+    return XPT_ERR_ARG;                                                        \
+  } while (0)
+
+int check_dims(int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int dtype) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || pad_t < 0 || pad_l < 0) return XPT_ERR_SHAPE;
+  if ((k != 3 && k != 5 && k != 7) || (stride != 1 && stride != 2) || (dtype != 0 && dtype != 1)) return XPT_ERR_ARG;
+  // every output window must start inside the padded input
+  if ((OH - 1) * stride - pad_t >= H || (OW - 1) * stride - pad_l >= W) return XPT_ERR_SHAPE;
+  return XPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xpt_dwconv_fwd(const void* x, const float* w, void* y, int B, int H, int W, int C, int k, int stride, int pad_t,
+                   int pad_l, int OH, int OW, int relu_in, int dtype, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(y);
+  const int rc = check_dims(B, H, W, C, k, stride, pad_t, pad_l, OH, OW, dtype);
+  if (rc != XPT_OK) return rc;
+  const DwDims d{B, H, W, C, OH, OW, pad_t, pad_l};
+  XPT_BEGIN_LAUNCH();
+  DW_DISPATCH(launch_fwd, x, w, y, d, relu_in, (hipStream_t)stream);
+}
+
+int xpt_dwconv_bwd_data(const void* x, const float* w, const void* dy, void* dx, int B, int H, int W, int C, int k,
+                        int stride, int pad_t, int pad_l, int OH, int OW, int relu_in, int dtype, void* stream) {
+  XPT_CHECK_PTR(w); XPT_CHECK_PTR(dy); XPT_CHECK_PTR(dx);
+  if (relu_in) XPT_CHECK_PTR(x);
+  const int rc = check_dims(B, H, W, C, k, stride, pad_t, pad_l, OH, OW, dtype);
+  if (rc != XPT_OK) return rc;
+  const DwDims d{B, H, W, C, OH, OW, pad_t, pad_l};
+  XPT_BEGIN_LAUNCH();
+  DW_DISPATCH(launch_bwd_data, x, w, dy, dx, d, relu_in, (hipStream_t)stream);
+}
+
+size_t xpt_dwconv_bwd_weight_workspace_floats(int B, int OH, int OW, int C, int k) {
+  if (B <= 0 || OH <= 0 || OW <= 0 || C <= 0 || k <= 0) return 0;
+  const size_t npix = (size_t)B * OH * OW;
+  return ((npix + DW_WRW_PIX - 1) / DW_WRW_PIX) * (size_t)C * k * k;
+}
+
+int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_floats, int B,
+                          int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int relu_in,
+                          int dtype, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(dy); XPT_CHECK_PTR(dw); XPT_CHECK_PTR(workspace);
+  const int rc = check_dims(B, H, W, C, k, stride, pad_t, pad_l, OH, OW, dtype);
+  if (rc != XPT_OK) return rc;
+  if (workspace_floats < xpt_dwconv_bwd_weight_workspace_floats(B, OH, OW, C, k)) return XPT_ERR_WORKSPACE;
+  const DwDims d{B, H, W, C, OH, OW, pad_t, pad_l};
+  XPT_BEGIN_LAUNCH();
+  DW_DISPATCH(launch_bwd_weight, x, dy, dw, workspace, d, relu_in, (hipStream_t)stream);
+}
+
+}  // extern "C"

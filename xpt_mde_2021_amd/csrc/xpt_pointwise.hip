@@ -1,0 +1,252 @@
+// xpt_pointwise.hip -- per-channel epilogues of the convolution layers on NHWC activations for gfx950:
+//   bias + LeakyReLU / linear      (CustomConv2D layers of DepthNet decoder and PoseNet: model/model_util/layer_ops.py:31-35,
+//                                   activation LeakyReLU(0.1) per config-example.py:56-63)
+//   inference-mode BatchNorm affine (+ ReLU on the way in) of the NASNet cells (keras BatchNormalization called without
+//                                   training=True, model/train_val.py:82; reference call site pretrained_nets.py:36-44)
+// Both are one streaming pass forward and one streaming pass backward (dx plus the per-channel parameter gradients
+// reduced deterministically: per-workgroup partials, then a fixed-order sum) instead of the 2-5 library launches per
+// layer (bias add, activation, their backward kernels and a separate reduction) of the generic framework path.
+#include <hip/hip_bf16.h>
+
+#include "xpt_common.h"
+
+namespace {
+
+template <typename T> __device__ inline float ldf(const T* p);
+template <> __device__ inline float ldf<float>(const float* p) { return *p; }
+template <> __device__ inline float ldf<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <typename T> __device__ inline void stf(T* p, float v);
+template <> __device__ inline void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ inline void stf<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+// ---------------------------------------------------------------- y = act(f(x) * scale[c] + shift[c])
+// scale = gamma * rsqrt(var + eps), shift = beta - mean * scale (gamma == nullptr: scale = 1, shift = beta).
+// slope: LeakyReLU negative slope (1 = linear, 0 = ReLU).  relu_in: f(x) = max(x, 0), else f(x) = x.
+struct Affine {
+  const float* gamma;
+  const float* beta;
+  const float* mean;
+  const float* var;
+  float eps;
+};
+
+__device__ inline void affine_coeffs(const Affine& a, int c, float& sc, float& sh, float& rstd, float& mu) {
+  if (a.gamma) {
+    rstd = rsqrtf(a.var[c] + a.eps);
+    mu = a.mean[c];
+    sc = a.gamma[c] * rstd;
+    sh = a.beta[c] - mu * sc;
+  } else {
+    rstd = 1.f; mu = 0.f; sc = 1.f; sh = a.beta[c];
+  }
+}
+
+template <typename T>
+__global__ void affine_act_fwd_kernel(const T* __restrict__ x, Affine a, T* __restrict__ y, long long n, int C,
+                                      float slope, int relu_in) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float sc, sh, rstd, mu;
+    affine_coeffs(a, c, sc, sh, rstd, mu);
+    float v = ldf<T>(x + i);
+    if (relu_in) v = fmaxf(v, 0.f);
+    v = v * sc + sh;
+    v = v > 0.f ? v : v * slope;
+    stf<T>(y + i, v);
+  }
+}
+
+// Backward.  Rows = pixels (n / C), lanes = channels: block (64 channels) x (ROWS pixel rows per block).
+//   g  = dy * act'(y)            (act' from the OUTPUT sign: valid for slope > 0, and for slope == 0 where y == 0 => 0)
+//   dx = g * scale [* (x > 0) if relu_in]
+//   dbeta[c] = sum g ; dgamma[c] = rstd * (sum g f(x) - mean * sum g)
+// part[blk][2][C] partial sums of (g, g f(x)).
+#define PW_ROWS 128
+template <typename T>
+__global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
+                                      Affine a, T* __restrict__ dx, float* __restrict__ part,
+                                      long long rows, int C, float slope, int relu_in, int need_dscale) {
+  __shared__ float red[2][3][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const long long r0 = (long long)blockIdx.y * PW_ROWS;
+  float s_shift = 0.f, s_scale = 0.f;
+  if (c < C) {
+    float sc, sh, rstd, mu;
+    affine_coeffs(a, c, sc, sh, rstd, mu);
+    for (int i = wid; i < PW_ROWS; i += 4) {
+      const long long r = r0 + i;
+      if (r >= rows) break;
+      const long long o = r * C + c;
+      float g = ldf<T>(dy + o);
+      if (slope != 1.f) g = (ldf<T>(y + o) > 0.f) ? g : g * slope;      // y is not read for a linear epilogue
+      float xv = 0.f;
+      if (need_dscale || relu_in) xv = ldf<T>(x + o);
+      float gx = g * sc;
+      if (relu_in) {
+        if (!(xv > 0.f)) gx = 0.f;
+        xv = fmaxf(xv, 0.f);
+      }
+      if (dx) stf<T>(dx + o, gx);
+      s_shift += g;
+      s_scale += g * xv;
+    }
+  }
+  if (wid > 0) {
+    red[0][wid - 1][lane] = s_shift;
+    red[1][wid - 1][lane] = s_scale;
+  }
+  __syncthreads();
+  if (wid == 0 && c < C) {
+    float* p = part + (long long)blockIdx.y * 2 * C;
+    p[c] = ((s_shift + red[0][0][lane]) + red[0][1][lane]) + red[0][2][lane];
+    p[C + c] = ((s_scale + red[1][0][lane]) + red[1][1][lane]) + red[1][2][lane];
+  }
+}
+
+// Few channels (C <= 4, e.g. the 1-channel depth heads): one thread per pixel row keeps the C running sums in
+// registers; the block then reduces them.  Same outputs / partial layout as the kernel above (gridDim.x == 1).
+template <typename T>
+__global__ void affine_act_bwd_smallc_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                             const T* __restrict__ dy, Affine a, T* __restrict__ dx,
+                                             float* __restrict__ part, long long rows, int C, float slope,
+                                             int relu_in, int need_dscale) {
+  __shared__ float red[4 * 8];
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const long long r0 = (long long)blockIdx.y * (PW_ROWS * 8);
+  for (int i = threadIdx.x; i < PW_ROWS * 8; i += blockDim.x) {
+    const long long r = r0 + i;
+    if (r >= rows) break;
+    for (int c = 0; c < C; ++c) {
+      float sc, sh, rstd, mu;
+      affine_coeffs(a, c, sc, sh, rstd, mu);
+      const long long o = r * C + c;
+      float g = ldf<T>(dy + o);
+      if (slope != 1.f) g = (ldf<T>(y + o) > 0.f) ? g : g * slope;
+      float xv = 0.f;
+      if (need_dscale || relu_in) xv = ldf<T>(x + o);
+      float gx = g * sc;
+      if (relu_in) {
+        if (!(xv > 0.f)) gx = 0.f;
+        xv = fmaxf(xv, 0.f);
+      }
+      if (dx) stf<T>(dx + o, gx);
+      acc[c] += g;
+      acc[4 + c] += g * xv;
+    }
+  }
+  xpt::block_sum_n<8>(acc, red);
+  if (threadIdx.x == 0) {
+    float* p = part + (long long)blockIdx.y * 2 * C;
+    for (int c = 0; c < C; ++c) {
+      p[c] = acc[c];
+      p[C + c] = acc[4 + c];
+    }
+  }
+}
+
+// per channel c: S0 = sum_k part[k][0][c], S1 = sum_k part[k][1][c]; 16 threads per channel, fixed tree -> deterministic.
+__global__ void affine_finish_kernel(const float* __restrict__ part, Affine a, float* __restrict__ dbeta,
+                                     float* __restrict__ dgamma, int C, int nblk) {
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int t = threadIdx.x & 15;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C)
+    for (int k = t; k < nblk; k += 16) {
+      s0 += part[(long long)k * 2 * C + c];
+      s1 += part[(long long)k * 2 * C + C + c];
+    }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off, 16);
+    s1 += __shfl_down(s1, off, 16);
+  }
+  if (t == 0 && c < C) {
+    dbeta[c] = s0;
+    if (dgamma) {
+      float sc, sh, rstd, mu;
+      affine_coeffs(a, c, sc, sh, rstd, mu);
+      dgamma[c] = rstd * (s1 - mu * s0);
+    }
+  }
+}
+
+inline unsigned grid_for(long long total) {
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xpt_affine_act_fwd(const void* x, const float* gamma, const float* beta, const float* mean, const float* var,
+                       float eps, void* y, long long rows, int C, float slope, int relu_in, int dtype, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(y);
+  if (gamma && (!mean || !var)) return XPT_ERR_NULL;
+  if (rows <= 0 || C <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  const long long n = rows * C;
+  const Affine a{gamma, beta, mean, var, eps};
+  XPT_BEGIN_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(affine_act_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, a, (float*)y, n, C, slope, relu_in);
+  else
+    hipLaunchKernelGGL(affine_act_fwd_kernel<__hip_bfloat16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)x, a, (__hip_bfloat16*)y, n, C, slope, relu_in);
+  return xpt_launch_status();
+}
+
+size_t xpt_affine_act_bwd_workspace_floats(long long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)((rows + PW_ROWS - 1) / PW_ROWS) * 2 * (size_t)C;
+}
+
+/* dx may be NULL (no data gradient wanted); dgamma must be NULL iff gamma is NULL (bias-only epilogue). */
+int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
+                       const float* mean, const float* var, float eps, void* dx, float* dbeta, float* dgamma,
+                       float* workspace, size_t workspace_floats, long long rows, int C, float slope, int relu_in,
+                       int dtype, void* stream) {
+  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(dbeta); XPT_CHECK_PTR(workspace);
+  if (slope != 1.f) XPT_CHECK_PTR(y);
+  if (rows <= 0 || C <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  if ((gamma == nullptr) != (dgamma == nullptr)) return XPT_ERR_ARG;
+  if (gamma && (!mean || !var)) return XPT_ERR_NULL;
+  if ((dgamma || relu_in) && !x) return XPT_ERR_NULL;
+  if (workspace_floats < xpt_affine_act_bwd_workspace_floats(rows, C)) return XPT_ERR_WORKSPACE;
+  const Affine a{gamma, beta, mean, var, eps};
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+  if (C <= 4) {
+    const int nb = (int)((rows + PW_ROWS * 8 - 1) / (PW_ROWS * 8));
+    const dim3 g1(1, nb);
+    if (dtype == 0)
+      hipLaunchKernelGGL(affine_act_bwd_smallc_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (const float*)y,
+                         (const float*)dy, a, (float*)dx, workspace, rows, C, slope, relu_in, dgamma != nullptr);
+    else
+      hipLaunchKernelGGL(affine_act_bwd_smallc_kernel<__hip_bfloat16>, g1, dim3(256), 0, s, (const __hip_bfloat16*)x,
+                         (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, workspace, rows,
+                         C, slope, relu_in, dgamma != nullptr);
+    hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 15) / 16), dim3(256), 0, s, workspace, a, dbeta, dgamma, C, nb);
+    return xpt_launch_status();
+  }
+  const int nblk = (int)((rows + PW_ROWS - 1) / PW_ROWS);
+  const dim3 grid((C + 63) / 64, nblk);
+  if (dtype == 0)
+    hipLaunchKernelGGL(affine_act_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)y,
+                       (const float*)dy, a, (float*)dx, workspace, rows, C, slope, relu_in, dgamma != nullptr);
+  else
+    hipLaunchKernelGGL(affine_act_bwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, s, (const __hip_bfloat16*)x,
+                       (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, workspace, rows, C,
+                       slope, relu_in, dgamma != nullptr);
+  hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 15) / 16), dim3(256), 0, s, workspace, a, dbeta, dgamma, C, nblk);
+  return xpt_launch_status();
+}
+
+}  // extern "C"

@@ -221,3 +221,116 @@ def smoothness(disp, image, grad_factor, input_is_depth=False):
     """smootheness_loss (losses.py:409-440) for one scale -> [B]; gradient w.r.t. disp
     (or depth when input_is_depth: disp = safe_reciprocal_number(depth) fused, util_funcs.py:157-160)."""
     return _Smooth.apply(disp, image, grad_factor, input_is_depth)
+
+
+# ------------------------------------------------------------------------------- depthwise conv (NASNet separable convs)
+def _nhwc(t, name):
+    if not t.is_cuda:
+        raise _lib.XptHipError(f"{name}: expected a CUDA/HIP tensor (the xpt HIP ops have no CPU fallback)")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.XptHipError(f"{name}: expected float32 or bfloat16, got {t.dtype}")
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+class _DepthwiseConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad_t, pad_b, pad_l, pad_r, relu_in):
+        lib = _lib.load()
+        x = _nhwc(x, "x")
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_cuda:
+            raise _lib.XptHipError("depthwise weight must be a float32 CUDA tensor")
+        w = w.contiguous()
+        B, C, H, W = x.shape
+        k = w.shape[-1]
+        if w.numel() != C * k * k:
+            raise _lib.XptHipError(f"depthwise weight {tuple(w.shape)} does not match {C} channels")
+        OH = (H + pad_t + pad_b - k) // stride + 1
+        OW = (W + pad_l + pad_r - k) // stride + 1
+        y = torch.empty((B, C, OH, OW), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dt = 0 if x.dtype == torch.float32 else 1
+        _lib.check(lib.xpt_dwconv_fwd(_ptr(x), _ptr(w), _ptr(y), B, H, W, C, k, stride, pad_t, pad_l, OH, OW,
+                                      int(relu_in), dt, _stream()), "xpt_dwconv_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad_t, pad_l, OH, OW, int(relu_in), dt, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        stride, pad_t, pad_l, OH, OW, relu_in, dt, wshape = ctx.cfg
+        dy = _nhwc(dy.to(x.dtype), "dy")
+        B, C, H, W = x.shape
+        k = w.shape[-1]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            _lib.check(lib.xpt_dwconv_bwd_data(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), B, H, W, C, k, stride, pad_t,
+                                               pad_l, OH, OW, relu_in, dt, _stream()), "xpt_dwconv_bwd_data")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+            nws = lib.xpt_dwconv_bwd_weight_workspace_floats(B, OH, OW, C, k)
+            ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+            _lib.check(lib.xpt_dwconv_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(ws), nws, B, H, W, C, k, stride,
+                                                 pad_t, pad_l, OH, OW, relu_in, dt, _stream()), "xpt_dwconv_bwd_weight")
+        return dx, dw, None, None, None, None, None, None
+
+
+def depthwise_conv2d(x, weight, stride=1, padding=(0, 0, 0, 0), relu_in=False):
+    """Depthwise k x k convolution of an NCHW-indexed, channels_last-stored tensor.  weight [C,1,k,k] float32;
+    padding = (top, bottom, left, right) zeros; relu_in fuses the preceding ReLU.  x may be float32 or bfloat16
+    (fp32 accumulation); the result has x's dtype.  Differentiable w.r.t. x and weight."""
+    pt, pb, pl, pr = (int(p) for p in padding)
+    return _DepthwiseConv.apply(x, weight, int(stride), pt, pb, pl, pr, bool(relu_in))
+
+
+# ------------------------------------------------------------------------------- per-channel conv epilogues
+class _AffineAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps, slope, relu_in):
+        lib = _lib.load()
+        x = _nhwc(x, "x")
+        B, C, H, W = x.shape
+        rows = B * H * W
+        for name, t in (("gamma", gamma), ("beta", beta), ("mean", mean), ("var", var)):
+            if t is not None and (t.dtype != torch.float32 or not t.is_cuda or t.numel() != C):
+                raise _lib.XptHipError(f"affine_act: {name} must be a float32 CUDA vector of {C} elements")
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        dt = 0 if x.dtype == torch.float32 else 1
+        g_, b_ = (None if gamma is None else gamma.detach().contiguous()), beta.detach().contiguous()
+        _lib.check(lib.xpt_affine_act_fwd(_ptr(x), _ptr(g_), _ptr(b_), _ptr(mean), _ptr(var), float(eps), _ptr(y), rows,
+                                          C, float(slope), int(relu_in), dt, _stream()), "xpt_affine_act_fwd")
+        need_x = (gamma is not None) or relu_in
+        ctx.save_for_backward(x if need_x else None, y if slope != 1.0 else None, g_, b_, mean, var)
+        ctx.cfg = (float(eps), float(slope), int(relu_in), dt, rows, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, y, gamma, beta, mean, var = ctx.saved_tensors
+        eps, slope, relu_in, dt, rows, C = ctx.cfg
+        ref = x if x is not None else y
+        dy = _nhwc(dy if ref is None else dy.to(ref.dtype), "dy")
+        dx = torch.empty_like(dy, memory_format=torch.channels_last) if ctx.needs_input_grad[0] else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=dy.device)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dy.device) if gamma is not None else None
+        nws = lib.xpt_affine_act_bwd_workspace_floats(rows, C)
+        ws = torch.empty(nws, dtype=torch.float32, device=dy.device)
+        _lib.check(lib.xpt_affine_act_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), eps,
+                                          _ptr(dx), _ptr(dbeta), _ptr(dgamma), _ptr(ws), nws, rows, C, slope, relu_in, dt,
+                                          _stream()), "xpt_affine_act_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def bias_act(x, bias, slope=1.0):
+    """y = LeakyReLU_slope(x + bias[c]) on an NCHW-indexed channels_last tensor (slope 1 = linear): the epilogue of
+    CustomConv2D (layer_ops.py:31-35).  x float32 or bfloat16; bias float32; differentiable w.r.t. both."""
+    return _AffineAct.apply(x, None, bias, None, None, 0.0, slope, False)
+
+
+def batchnorm_inference(x, gamma, beta, running_mean, running_var, eps, relu_in=False):
+    """keras BatchNormalization in inference mode (moving statistics, trainable gamma / beta), optionally with the
+    preceding ReLU fused; differentiable w.r.t. x, gamma, beta."""
+    return _AffineAct.apply(x, gamma, beta, running_mean, running_var, eps, 1.0, relu_in)

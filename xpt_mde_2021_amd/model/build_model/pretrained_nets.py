@@ -20,9 +20,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip import ops as _ops
 from ...utils.util_class import WrongInputException
 from ..model_util.layer_ops import same_pad
 
+_DISABLE_HIP_DWCONV = bool(int(__import__("os").environ.get("XPT_DEBUG_MIOPEN_DWCONV", "0")))   # A/B debugging only
 BN_EPS = 1e-3          # keras_applications nasnet: BatchNormalization(momentum=0.9997, epsilon=1e-3)
 
 
@@ -37,7 +39,20 @@ class FrozenBatchNorm(nn.Module):
         self.register_buffer("running_var", torch.ones(channels))
 
     def forward(self, x):
+        if x.is_cuda:      # one gfx950 streaming pass (and one for dx / dgamma / dbeta in the backward)
+            return _ops.batchnorm_inference(x, self.weight, self.bias, self.running_mean, self.running_var, BN_EPS)
         return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, BN_EPS)
+
+
+def conv1x1(x, weight):
+    """1x1 convolution (no bias) of an NCHW-indexed tensor.  On the GPU the channels_last tensor IS a row-major
+    [B*H*W, Cin] matrix, so the convolution is one GEMM (rocBLAS / hipBLASLt on MFMA) on a zero-copy view and its
+    weight gradient one more GEMM -- no MIOpen convolution (nor its zero / cast helper launches) involved."""
+    if not x.is_cuda:
+        return F.conv2d(x, weight)
+    xv = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)            # [B,H,W,Cin] view
+    y = F.linear(xv, weight.reshape(weight.shape[0], weight.shape[1]))                  # [B,H,W,Cout]
+    return y.permute(0, 3, 1, 2)                                                        # NCHW-indexed, channels_last
 
 
 def correct_pad(h, w, k):
@@ -62,7 +77,18 @@ class SeparableConv(nn.Module):
         nn.init.kaiming_normal_(self.depthwise.weight, mode="fan_in", nonlinearity="relu")
         nn.init.kaiming_normal_(self.pointwise.weight, mode="fan_in", nonlinearity="relu")
 
-    def forward(self, x):
+    def forward(self, x, relu_in=False):
+        """relu_in: apply the ReLU that precedes the convolution in _separable_conv_block (fused into the gfx950
+        depthwise kernel on the GPU)."""
+        if x.is_cuda and not _DISABLE_HIP_DWCONV:
+            if self.stride == 2:
+                (pt, pb), (pl, pr) = correct_pad(x.shape[2], x.shape[3], self.k)
+            else:
+                pt = pb = pl = pr = self.k // 2
+            y = _ops.depthwise_conv2d(x, self.depthwise.weight, self.stride, (pt, pb, pl, pr), relu_in)
+            return conv1x1(y, self.pointwise.weight)
+        if relu_in:                       # host tensors (CPU baseline / unit tests): library convolution
+            x = F.relu(x)
         if self.stride == 2:
             x = zero_pad(x, correct_pad(x.shape[2], x.shape[3], self.k))
         return self.pointwise(self.depthwise(x))
@@ -82,12 +108,15 @@ class SepConvBlock(nn.Module):
         self.bn2 = FrozenBatchNorm(filters)
 
     def forward(self, x, taps):
-        x = F.relu(x)
-        taps.offer(self.act_id1, x)
-        x = self.bn1(self.conv1(x))
-        x = F.relu(x)
-        taps.offer(self.act_id2, x)
-        return self.bn2(self.conv2(x))
+        if taps.wants(self.act_id1) or taps.wants(self.act_id2):      # a tapped activation must be materialised
+            x = F.relu(x)
+            taps.offer(self.act_id1, x)
+            x = self.bn1(self.conv1(x))
+            x = F.relu(x)
+            taps.offer(self.act_id2, x)
+            return self.bn2(self.conv2(x))
+        x = self.bn1(self.conv1(x, relu_in=True))
+        return self.bn2(self.conv2(x, relu_in=True))
 
 
 class AdjustBlock(nn.Module):
@@ -116,14 +145,14 @@ class AdjustBlock(nn.Module):
     def forward(self, p, taps):
         if self.mode == "spatial":
             p = F.relu(p)
-            p1 = self.conv1(p[:, :, ::2, ::2])                       # AveragePooling2D((1,1), strides 2)
+            p1 = conv1x1(p[:, :, ::2, ::2], self.conv1.weight)                       # AveragePooling2D((1,1), strides 2)
             p2 = F.pad(p, (0, 1, 0, 1))[:, :, 1:, 1:]                # ZeroPadding2D(((0,1),(0,1))) + Cropping2D(((1,0),(1,0)))
-            p2 = self.conv2(p2[:, :, ::2, ::2])
+            p2 = conv1x1(p2[:, :, ::2, ::2], self.conv2.weight)
             return self.bn(torch.cat([p1, p2], dim=1))
         if self.mode == "project":
             p = F.relu(p)
             taps.offer(self.act_id, p)
-            return self.bn(self.conv(p))
+            return self.bn(conv1x1(p, self.conv.weight))
         return p
 
 
@@ -154,7 +183,7 @@ class NormalCell(nn.Module):
         p = self.adjust(p, taps)
         h = F.relu(ip)
         taps.offer(self.act_id, h)
-        h = self.bn(self.conv(h))
+        h = self.bn(conv1x1(h, self.conv.weight))
         x1 = self.left1(h, taps) + self.right1(p, taps)
         x2 = self.left2(p, taps) + self.right2(p, taps)
         x3 = avg_pool_same(h) + p
@@ -185,7 +214,7 @@ class ReductionCell(nn.Module):
         p = self.adjust(p, taps)
         h = F.relu(ip)
         taps.offer(self.act_id, h)
-        h = self.bn(self.conv(h))
+        h = self.bn(conv1x1(h, self.conv.weight))
         h3 = zero_pad(h, correct_pad(h.shape[2], h.shape[3], 3))
         x1 = self.left1(h, taps) + self.right1(p, taps)
         x2 = F.max_pool2d(h3, 3, 2) + self.right2(p, taps)
@@ -199,6 +228,9 @@ class _Taps:
     def __init__(self, wanted):
         self.wanted = wanted
         self.found = {}
+
+    def wants(self, act_id):
+        return act_id in self.wanted
 
     def offer(self, act_id, tensor):
         if act_id in self.wanted:

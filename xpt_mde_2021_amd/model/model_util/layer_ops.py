@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip import ops as _ops
+
 
 def same_pad(n, k, s):
     """TF "SAME": total = max((ceil(n/s) - 1) * s + k - n, 0); before = total // 2, after = the rest."""
@@ -36,6 +38,9 @@ class Conv2DSame(nn.Module):
         self.k, self.s = int(kernel_size), int(strides)
         self.conv = nn.Conv2d(in_channels, filters, self.k, self.s, padding=0, bias=use_bias, groups=groups)
         self.act = make_activation(activation, activation_param)
+        # negative-side slope of the activation for the fused epilogue (1 = linear, 0 = ReLU)
+        self.slope = {None: 1.0, "linear": 1.0, "relu": 0.0,
+                      "leaky_relu": 0.1 if activation_param is None else float(activation_param)}.get(activation)
         if kernel_initializer == "truncated_normal":
             std = kernel_initializer_param
             nn.init.trunc_normal_(self.conv.weight, mean=0.0, std=std, a=-2 * std, b=2 * std)
@@ -49,11 +54,16 @@ class Conv2DSame(nn.Module):
     def forward(self, x):
         ph = same_pad(x.shape[2], self.k, self.s)
         pw = same_pad(x.shape[3], self.k, self.s)
+        # on the GPU the bias add + activation (and the bias gradient) run in one gfx950 epilogue kernel
+        fused = x.is_cuda and self.conv.bias is not None and self.slope is not None
+        bias = None if fused else self.conv.bias
         if ph[0] == ph[1] and pw[0] == pw[1]:
-            y = F.conv2d(x, self.conv.weight, self.conv.bias, self.s, (ph[0], pw[0]), 1, self.conv.groups)
+            y = F.conv2d(x, self.conv.weight, bias, self.s, (ph[0], pw[0]), 1, self.conv.groups)
         else:  # stride 2 on an even extent: TF pads (k-2)//2 before and (k-1)//2 after
-            y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), self.conv.weight, self.conv.bias, self.s, 0, 1,
+            y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), self.conv.weight, bias, self.s, 0, 1,
                          self.conv.groups)
+        if fused:
+            return _ops.bias_act(y, self.conv.bias, self.slope)
         return self.act(y)
 
 

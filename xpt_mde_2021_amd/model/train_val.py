@@ -27,10 +27,29 @@ def train_val_factory(mode_sel, model, loss_object, steps_per_epoch, stereo, aug
              "distributed": (ModelTrainerDistrib, ModelValidaterDistrib)}
     if mode_sel not in table:
         raise uc.WrongInputException(f"training mode '{mode_sel}' is NOT available")
+    configure_backend()
     trainer_cls, validater_cls = table[mode_sel]
     trainer = trainer_cls(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
     validater = validater_cls(model, loss_object, steps_per_epoch, stereo)
     return trainer, validater
+
+
+def detach_tree(obj):
+    if torch.is_tensor(obj):
+        return obj.detach()
+    if isinstance(obj, dict):
+        return {k: detach_tree(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(detach_tree(v) for v in obj)
+    return obj
+
+
+def configure_backend():
+    """Library-convolution settings for every trainer.  MIOpen's non-deterministic (atomic split-K) weight-gradient
+    solvers return garbage from the second replay of a captured hipGraph on ROCm 7.0 / torch 2.10 (reproducer:
+    tests/test_graph_replay.py), so the deterministic algorithms are selected; the exhaustive find is off (minutes)."""
+    torch.backends.cudnn.deterministic = True
+    torch.backends.cudnn.benchmark = bool(getattr(opts, "MIOPEN_FIND", False))
 
 
 class TrainValBase:
@@ -86,7 +105,9 @@ class ModelTrainer(TrainValBase):
         preds = self.model(features)
         total_loss, loss_by_type = self.loss_object(preds, features)
         total_loss.backward()
-        return preds, total_loss.detach(), {k: v.detach() for k, v in loss_by_type.items()}
+        # hand back detached values only: a live autograd graph would keep its AccumulateGrad nodes (and their
+        # stream) alive across iterations, which breaks hipGraph capture of the next step
+        return detach_tree(preds), total_loss.detach(), {k: v.detach() for k, v in loss_by_type.items()}
 
     def reduce_gradients(self):
         pass
