@@ -114,42 +114,69 @@ __global__ void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restr
 
 // ---------------------------------------------------------------- weight gradient
 // dw[c,ky,kx] = sum_{b,oy,ox} dy[b,oy,ox,c] * f(x[b,oy*S+ky-pad_t,ox*S+kx-pad_l,c])
-// grid (channel chunks of 64, pixel chunks of PIX); 4 waves: lane = channel, wave w takes pixels w, w+4, ...
-#define DW_WRW_PIX 64
+// Work item = OXT neighbouring outputs of one row ("group"); grid (channel chunks of 64, chunks of DW_WRW_GRP groups).
+// Lanes run along channels; when C <= 32 the spare lanes take further row groups (RG = 64 / C per wave) and are
+// folded with fixed-order shuffles.  Every thread slides the k-wide input window over its OXT outputs in registers.
+#define DW_WRW_GRP 8
 template <typename T, int K, int S>
 __global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
-                                     DwDims d, int relu_in) {
+                                     DwDims d, int relu_in, int RG) {
+  constexpr int OXT = (S == 1) ? 4 : 2;
+  constexpr int IN = (OXT - 1) * S + K;
   __shared__ float red[3][64 * K * K];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const long long npix = (long long)d.B * d.OH * d.OW;
-  const long long p0 = (long long)blockIdx.y * DW_WRW_PIX;
+  const int rg = (RG > 1) ? lane / d.C : 0;
+  const int cl = (RG > 1) ? lane - rg * d.C : lane;
+  const int c = blockIdx.x * 64 + cl;
+  const bool active = (c < d.C) && (rg < RG);
+  const int OXG = (d.OW + OXT - 1) / OXT;
+  const long long ngrp = (long long)d.B * d.OH * OXG;
+  const long long g0 = (long long)blockIdx.y * DW_WRW_GRP;
   float acc[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
-  if (c < d.C) {
-    for (int i = wid; i < DW_WRW_PIX; i += 4) {
-      const long long p = p0 + i;
-      if (p >= npix) break;
-      const int ox = (int)(p % d.OW);
-      const long long r = p / d.OW;
+  if (active) {
+    for (int i = wid * RG + rg; i < DW_WRW_GRP; i += 4 * RG) {
+      const long long g = g0 + i;
+      if (g >= ngrp) break;
+      const int oxg = (int)(g % OXG);
+      const long long r = g / OXG;
       const int oy = (int)(r % d.OH);
       const int b = (int)(r / d.OH);
-      const float g = ldf<T>(dy + p * d.C + c);
+      const int ox0 = oxg * OXT;
+      const int ix0 = ox0 * S - d.pad_l;
+      float gy[OXT];
+      const T* dyp = dy + (((long long)b * d.OH + oy) * d.OW + ox0) * d.C + c;
+#pragma unroll
+      for (int j = 0; j < OXT; ++j) gy[j] = (ox0 + j < d.OW) ? ldf<T>(dyp + (long long)j * d.C) : 0.f;
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         const int iy = oy * S + ky - d.pad_t;
         if (iy < 0 || iy >= d.H) continue;
         const T* row = x + (((long long)b * d.H + iy) * d.W) * d.C + c;
+        float in[IN];
+#pragma unroll
+        for (int t = 0; t < IN; ++t) {
+          const int ix = ix0 + t;
+          float v = (ix >= 0 && ix < d.W) ? ldf<T>(row + (long long)ix * d.C) : 0.f;
+          in[t] = relu_in ? fmaxf(v, 0.f) : v;
+        }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-          const int ix = ox * S + kx - d.pad_l;
-          if (ix < 0 || ix >= d.W) continue;
-          float v = ldf<T>(row + (long long)ix * d.C);
-          if (relu_in) v = fmaxf(v, 0.f);
-          acc[ky * K + kx] += g * v;
+          float a = acc[ky * K + kx];
+#pragma unroll
+          for (int j = 0; j < OXT; ++j) a += gy[j] * in[j * S + kx];
+          acc[ky * K + kx] = a;
         }
       }
+    }
+  }
+  if (RG > 1) {      // fold the row groups of this wave onto lanes [0, C): fixed order -> deterministic
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) {
+      float v = acc[i];
+      for (int r = 1; r < RG; ++r) v += __shfl(acc[i], (cl + r * d.C) & 63, 64);
+      acc[i] = v;
     }
   }
   if (wid > 0) {
@@ -157,19 +184,23 @@ __global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restric
     for (int i = 0; i < K * K; ++i) red[wid - 1][i * 64 + lane] = acc[i];
   }
   __syncthreads();
-  if (wid == 0 && c < d.C) {
+  if (wid == 0 && c < d.C && rg == 0) {
     float* out = part + ((long long)blockIdx.y * d.C + c) * (K * K);
 #pragma unroll
     for (int i = 0; i < K * K; ++i) out[i] = ((acc[i] + red[0][i * 64 + lane]) + red[1][i * 64 + lane]) + red[2][i * 64 + lane];
   }
 }
 
+// dw[i] = sum_k part[k][i]: 16 threads per output, fixed tree -> deterministic.
 __global__ void dw_wrw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int nchunk) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int t = threadIdx.x & 15;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[(long long)k * n + i];
-  dw[i] = s;
+  if (i < n)
+    for (int k = t; k < nchunk; k += 16) s += part[(long long)k * n + i];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 16);
+  if (t == 0 && i < n) dw[i] = s;
 }
 
 inline unsigned grid_for(long long total) {
@@ -200,12 +231,14 @@ int launch_bwd_data(const void* x, const float* w, const void* dy, void* dx, con
 template <typename T, int K, int S>
 int launch_bwd_weight(const void* x, const void* dy, float* dw, float* ws, const DwDims& d, int relu_in,
                       hipStream_t s) {
-  const long long npix = (long long)d.B * d.OH * d.OW;
-  const int nchunk = (int)((npix + DW_WRW_PIX - 1) / DW_WRW_PIX);
+  constexpr int OXT = (S == 1) ? 4 : 2;
+  const long long ngrp = (long long)d.B * d.OH * ((d.OW + OXT - 1) / OXT);
+  const int nchunk = (int)((ngrp + DW_WRW_GRP - 1) / DW_WRW_GRP);
+  const int RG = (d.C <= 32) ? (64 / d.C > DW_WRW_GRP / 4 ? DW_WRW_GRP / 4 : 64 / d.C) : 1;
   hipLaunchKernelGGL((dw_bwd_weight_kernel<T, K, S>), dim3((d.C + 63) / 64, nchunk), dim3(256), 0, s, (const T*)x,
-                     (const T*)dy, ws, d, relu_in);
+                     (const T*)dy, ws, d, relu_in, RG);
   const int n = d.C * K * K;
-  hipLaunchKernelGGL(dw_wrw_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ws, dw, n, nchunk);
+  hipLaunchKernelGGL(dw_wrw_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, s, ws, dw, n, nchunk);
   return xpt_launch_status();
 }
 
@@ -264,8 +297,9 @@ int xpt_dwconv_bwd_data(const void* x, const float* w, const void* dy, void* dx,
 
 size_t xpt_dwconv_bwd_weight_workspace_floats(int B, int OH, int OW, int C, int k) {
   if (B <= 0 || OH <= 0 || OW <= 0 || C <= 0 || k <= 0) return 0;
-  const size_t npix = (size_t)B * OH * OW;
-  return ((npix + DW_WRW_PIX - 1) / DW_WRW_PIX) * (size_t)C * k * k;
+  // groups of OXT (>= 2) neighbouring outputs per row, DW_WRW_GRP groups per workgroup: upper bound with OXT = 2
+  const size_t ngrp = (size_t)B * OH * (((size_t)OW + 1) / 2);
+  return ((ngrp + DW_WRW_GRP - 1) / DW_WRW_GRP) * (size_t)C * k * k;
 }
 
 int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_floats, int B,

@@ -61,20 +61,23 @@ __global__ void affine_act_fwd_kernel(const T* __restrict__ x, Affine a, T* __re
 //   dx = g * scale [* (x > 0) if relu_in]
 //   dbeta[c] = sum g ; dgamma[c] = rstd * (sum g f(x) - mean * sum g)
 // part[blk][2][C] partial sums of (g, g f(x)).
-#define PW_ROWS 128
+// When C <= 32 the spare lanes of a wave take further rows (RG = 64 / C row groups, folded by fixed-order shuffles).
+#define PW_ROWS 32
 template <typename T>
 __global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
                                       Affine a, T* __restrict__ dx, float* __restrict__ part,
-                                      long long rows, int C, float slope, int relu_in, int need_dscale) {
+                                      long long rows, int C, float slope, int relu_in, int need_dscale, int RG) {
   __shared__ float red[2][3][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  const int rg = (RG > 1) ? lane / C : 0;
+  const int cl = (RG > 1) ? lane - rg * C : lane;
+  const int c = blockIdx.x * 64 + cl;
   const long long r0 = (long long)blockIdx.y * PW_ROWS;
   float s_shift = 0.f, s_scale = 0.f;
-  if (c < C) {
+  if (c < C && rg < RG) {
     float sc, sh, rstd, mu;
     affine_coeffs(a, c, sc, sh, rstd, mu);
-    for (int i = wid; i < PW_ROWS; i += 4) {
+    for (int i = wid * RG + rg; i < PW_ROWS; i += 4 * RG) {
       const long long r = r0 + i;
       if (r >= rows) break;
       const long long o = r * C + c;
@@ -92,12 +95,21 @@ __global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restri
       s_scale += g * xv;
     }
   }
+  if (RG > 1) {
+    float v0 = s_shift, v1 = s_scale;
+    for (int r = 1; r < RG; ++r) {
+      v0 += __shfl(s_shift, (cl + r * C) & 63, 64);
+      v1 += __shfl(s_scale, (cl + r * C) & 63, 64);
+    }
+    s_shift = v0;
+    s_scale = v1;
+  }
   if (wid > 0) {
     red[0][wid - 1][lane] = s_shift;
     red[1][wid - 1][lane] = s_scale;
   }
   __syncthreads();
-  if (wid == 0 && c < C) {
+  if (wid == 0 && c < C && rg == 0) {
     float* p = part + (long long)blockIdx.y * 2 * C;
     p[c] = ((s_shift + red[0][0][lane]) + red[0][1][lane]) + red[0][2][lane];
     p[C + c] = ((s_scale + red[1][0][lane]) + red[1][1][lane]) + red[1][2][lane];
@@ -238,13 +250,14 @@ int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float
   }
   const int nblk = (int)((rows + PW_ROWS - 1) / PW_ROWS);
   const dim3 grid((C + 63) / 64, nblk);
+  const int RG = (C <= 32) ? (64 / C > PW_ROWS / 4 ? PW_ROWS / 4 : 64 / C) : 1;
   if (dtype == 0)
     hipLaunchKernelGGL(affine_act_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)y,
-                       (const float*)dy, a, (float*)dx, workspace, rows, C, slope, relu_in, dgamma != nullptr);
+                       (const float*)dy, a, (float*)dx, workspace, rows, C, slope, relu_in, dgamma != nullptr, RG);
   else
     hipLaunchKernelGGL(affine_act_bwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, s, (const __hip_bfloat16*)x,
                        (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, workspace, rows, C,
-                       slope, relu_in, dgamma != nullptr);
+                       slope, relu_in, dgamma != nullptr, RG);
   hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 15) / 16), dim3(256), 0, s, workspace, a, dbeta, dgamma, C, nblk);
   return xpt_launch_status();
 }

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from ...hip import ops as _ops
 from ...utils.util_class import WrongInputException
-from ..model_util.layer_ops import same_pad
+from ..model_util.layer_ops import conv2d_library, same_pad
 
 _DISABLE_HIP_DWCONV = bool(int(__import__("os").environ.get("XPT_DEBUG_MIOPEN_DWCONV", "0")))   # A/B debugging only
 BN_EPS = 1e-3          # keras_applications nasnet: BatchNormalization(momentum=0.9997, epsilon=1e-3)
@@ -298,7 +298,7 @@ class NASNetMobileEncoder(nn.Module):
 
     def forward(self, image):
         taps = _Taps(self.TAP_ACTIVATIONS)
-        x = self.stem_bn(self.stem_conv(self.preprocess(image)))
+        x = self.stem_bn(conv2d_library(self.preprocess(image), self.stem_conv.weight, 2, (0, 0)))
         p = None
         for cell in self.cells:
             x, p = cell(x, x if p is None else p, taps)

@@ -29,6 +29,49 @@ def make_activation(name, param=None):
     raise ValueError(f"unknown activation {name}")
 
 
+class _ConvFp32WeightGrad(torch.autograd.Function):
+    """Library convolution (MIOpen) whose WEIGHT gradient is always evaluated in fp32.
+
+    Forward and data gradient run in the activation dtype (bf16 under autocast).  MIOpen's bf16 weight-gradient
+    solvers accumulate in an fp32 workspace and cast; replayed from a hipGraph on ROCm 7.0 / torch 2.10 that path
+    returns garbage from the second replay on (tests/test_graph_replay.py), and its deterministic replacements are
+    ~25x slower naive kernels.  The fp32 weight-gradient solvers are correct under replay, so x and dy are up-cast
+    for that one call (the gradient is wanted in fp32 for the flat Adam buffers anyway)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, padding, compute_dtype):
+        w = weight.to(compute_dtype)
+        xc = x.to(compute_dtype)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            y = F.conv2d(xc, w, None, stride, padding)
+        ctx.save_for_backward(xc, weight)
+        ctx.cfg = (stride, padding, compute_dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, weight = ctx.saved_tensors
+        stride, padding, compute_dtype = ctx.cfg
+        s2, p2 = [stride, stride], list(padding)
+        dx = dw = None
+        with torch.autocast(device_type=dy.device.type, enabled=False):
+            if ctx.needs_input_grad[0]:
+                dx = torch.ops.aten.convolution_backward(dy.to(compute_dtype), xc, weight.to(compute_dtype), None, s2, p2,
+                                                         [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            if ctx.needs_input_grad[1]:
+                dw = torch.ops.aten.convolution_backward(dy.float(), xc.float(), weight.float(), None, s2, p2, [1, 1],
+                                                         False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw, None, None, None
+
+
+def conv2d_library(x, weight, stride, padding):
+    """Dense (groups = 1) convolution without bias through MIOpen; see _ConvFp32WeightGrad for the backward."""
+    if x.is_cuda and torch.is_autocast_enabled():
+        return _ConvFp32WeightGrad.apply(x, weight, int(stride), (int(padding[0]), int(padding[1])),
+                                         torch.get_autocast_dtype("cuda"))
+    return F.conv2d(x, weight, None, stride, padding)
+
+
 class Conv2DSame(nn.Module):
     """keras.layers.Conv2D(filters, k, strides, padding="same", activation=...) on NCHW tensors."""
 
@@ -57,11 +100,13 @@ class Conv2DSame(nn.Module):
         # on the GPU the bias add + activation (and the bias gradient) run in one gfx950 epilogue kernel
         fused = x.is_cuda and self.conv.bias is not None and self.slope is not None
         bias = None if fused else self.conv.bias
-        if ph[0] == ph[1] and pw[0] == pw[1]:
+        if ph[0] != ph[1] or pw[0] != pw[1]:   # stride 2 on an even extent: TF pads (k-2)//2 before, (k-1)//2 after
+            x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
+            ph, pw = (0, 0), (0, 0)
+        if fused and self.conv.groups == 1:
+            y = conv2d_library(x, self.conv.weight, self.s, (ph[0], pw[0]))
+        else:
             y = F.conv2d(x, self.conv.weight, bias, self.s, (ph[0], pw[0]), 1, self.conv.groups)
-        else:  # stride 2 on an even extent: TF pads (k-2)//2 before and (k-1)//2 after
-            y = F.conv2d(F.pad(x, (pw[0], pw[1], ph[0], ph[1])), self.conv.weight, bias, self.s, 0, 1,
-                         self.conv.groups)
         if fused:
             return _ops.bias_act(y, self.conv.bias, self.slope)
         return self.act(y)

@@ -29,12 +29,27 @@ class FlatParameters:
         self.numel = total
         self.data = torch.zeros(total, dtype=dtype, device=dev)
         self.grad = torch.zeros(total, dtype=dtype, device=dev)
+        self.grad_views = []
         for p, off in zip(params, offsets):
             dview, gview = self._view(self.data, p, off), self._view(self.grad, p, off)
             dview.copy_(p.data)
             p.data = dview
-            p.grad = gview
+            p.grad = None            # autograd then hands over ("steals") each gradient tensor without an add kernel
+            self.grad_views.append(gview)
         self.offsets = offsets
+
+    def gather_grads(self):
+        """Moves the per-parameter gradients autograd produced into the flat buffer with one multi-tensor copy
+        (instead of ~700 accumulate-into-view kernels per step) and releases them.  Parameters that received no
+        gradient keep the zeros the optimizer left behind."""
+        srcs, dsts = [], []
+        for p, gv in zip(self.params, self.grad_views):
+            if p.grad is not None:
+                srcs.append(p.grad)
+                dsts.append(gv)
+                p.grad = None
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
 
     @staticmethod
     def _view(flat, p, off):
@@ -48,12 +63,6 @@ class FlatParameters:
     def zero_grad(self):
         self.grad.zero_()
 
-    def rebind_grads(self):
-        """autograd may replace .grad (e.g. after set_to_none); point every parameter back at its flat view."""
-        for p, off in zip(self.params, self.offsets):
-            g = self._view(self.grad, p, off)
-            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
-                p.grad = g
 
 
 class KerasAdam:

@@ -48,8 +48,13 @@ def configure_backend():
     """Library-convolution settings for every trainer.  MIOpen's non-deterministic (atomic split-K) weight-gradient
     solvers return garbage from the second replay of a captured hipGraph on ROCm 7.0 / torch 2.10 (reproducer:
     tests/test_graph_replay.py), so the deterministic algorithms are selected; the exhaustive find is off (minutes)."""
-    torch.backends.cudnn.deterministic = True
+    import os
+    torch.backends.cudnn.deterministic = bool(int(os.environ.get("XPT_MIOPEN_DETERMINISTIC", "0")))
     torch.backends.cudnn.benchmark = bool(getattr(opts, "MIOPEN_FIND", False))
+    # GEMMs (the 1x1 convolutions) through rocBLAS: hipBLASLt launches cost ~2 ms EACH when replayed from a hipGraph
+    # on this stack (1.18 s / step measured), rocBLAS replays at kernel speed
+    if torch.cuda.is_available():
+        torch.backends.cuda.preferred_blas_library("cublas")
 
 
 class TrainValBase:
@@ -105,6 +110,8 @@ class ModelTrainer(TrainValBase):
         preds = self.model(features)
         total_loss, loss_by_type = self.loss_object(preds, features)
         total_loss.backward()
+        if self.optimizer is not None and getattr(self.optimizer, "flat", None) is not None:
+            self.optimizer.flat.gather_grads()
         # hand back detached values only: a live autograd graph would keep its AccumulateGrad nodes (and their
         # stream) alive across iterations, which breaks hipGraph capture of the next step
         return detach_tree(preds), total_loss.detach(), {k: v.detach() for k, v in loss_by_type.items()}
