@@ -103,6 +103,24 @@ int xpt_photo_bwd(int method, const float* synth, const float* target, const flo
                   float* dsynth, float* workspace, size_t workspace_floats, int B, int N, int h, int w,
                   void* stream);
 
+/* ------------------------------------------------------------------ K2-K5 fused: warp + L1 + SSIM "march"
+ * One pass per scale over (depth, target, sources) that replaces synthesize_batch_view (synthesize_base.py:88-178),
+ * BilinearInterpolation (bilinear_interp.py:7-147), photometric_loss_l1 and photometric_loss_ssim
+ * (loss_util.py:6-25, 52-96) WITHOUT materialising the synthesized views (pass synth = NULL) -- or also writing
+ * them (synth [B,N,h,w,3]) when a caller needs the images.
+ *   src [B,N,h,w,3], depth [B,h,w], T [B,N,4,4], K [B,3,3] unscaled (+ scale), target [B,h,w,3]
+ *   -> loss_l1 [B], loss_ssim [B]  (the reduce=True results: means over N*h*w*3)
+ * bwd: g_l1 [B], g_ssim [B] (gradients of those means) -> ddepth [B,h,w], dT [B,N,4,4] (last row 0); the views are
+ *   re-synthesized on the fly.  workspace: xpt_photo_fused_workspace_floats(B,N,h,w) floats for both directions.
+ * ALGORITHMIC bytes per batch element (P = h*w): fwd P(16 + 12N) [+ 12NP with synth], bwd P(20 + 12N). */
+size_t xpt_photo_fused_workspace_floats(int B, int N, int h, int w);
+int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, const float* K, const float* target,
+                        float* synth, float* loss_l1, float* loss_ssim, float* workspace, size_t workspace_floats,
+                        int B, int N, int h, int w, float scale, void* stream);
+int xpt_photo_fused_bwd(const float* src, const float* depth, const float* T, const float* K, const float* target,
+                        const float* g_l1, const float* g_ssim, float* ddepth, float* dT, float* workspace,
+                        size_t workspace_floats, int B, int N, int h, int w, float scale, void* stream);
+
 /* ------------------------------------------------------------------ K6 (+a4): edge-aware smoothness
  * replaces SmoothenessLossMultiScale.smootheness_loss (losses.py:409-440) for one scale
  * (the caller divides by the scale, losses.py:401-402).

@@ -191,6 +191,53 @@ def test_photometric_fwd_bwd(ops, gpu_device, method, B, N, h, w):
                    what=f"d{method} reduce={reduce}")
 
 
+# ------------------------------------------------------------------------------------------------ K2-K5 fused march
+@pytest.mark.parametrize("B,N,h,w,scale", [(4, 4, 128, 416, 1), (2, 4, 64, 208, 2), (2, 4, 16, 52, 8), (2, 1, 32, 104, 4),
+                                           (1, 3, 9, 70, 1), (1, 4, 3, 5, 1), (1, 2, 37, 130, 1)])
+def test_fused_warp_l1_ssim_fwd_bwd(ops, gpu_device, B, N, h, w, scale):
+    """xpt_photo_fused_{fwd,bwd} == photometric_loss_l1 + photometric_loss_ssim of the synthesized views (oracle),
+    values, synthesized images and gradients w.r.t. depth and pose matrices."""
+    src, depth, K, pose = warp_inputs(B, N, h, w, 300 + h, scale)
+    g = gen(9)
+    tgt = (src[:, 0] * 0.7 + 0.3 * sd.smooth_noise((B, h, w, 3), g)).clamp(-1, 1).contiguous()
+    if h > 4:
+        depth[0, 1:3, 2:5] = 0.0                      # invalid depth -> black pixels inside the image
+    pose[0, -1, 0] = 30.0                             # one view almost completely out of the image
+    gl1, gss = torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5
+    d_ref = depth.clone().double().requires_grad_(True)
+    T_ref = ref_pose.pose_rvec2matr_batch(pose.double()).requires_grad_(True)
+    coords = rs.warp_pixel_coords(d_ref, T_ref, rs.scale_intrinsic(K.double(), scale), h, w)
+    synth_ref = rs.bilinear_interpolation(src.double(), coords, d_ref)
+    l1_ref = ref_loss.photometric_loss_l1(synth_ref, tgt.double())
+    ss_ref = ref_loss.photometric_loss_ssim(synth_ref, tgt.double())
+    ((l1_ref * gl1.double()).sum() + (ss_ref * gss.double()).sum()).backward()
+
+    d = depth.to(gpu_device).requires_grad_(True)
+    T = ref_pose.pose_rvec2matr_batch(pose).to(gpu_device).requires_grad_(True)
+    dev = [t.to(gpu_device) for t in (src, K, tgt)]
+    l1, ss = ops.photo_fused(dev[0], d, T, dev[1], dev[2], scale)
+    ((l1 * gl1.to(gpu_device)).sum() + (ss * gss.to(gpu_device)).sum()).backward()
+    frac_close(l1, l1_ref, 2e-5, rtol=1e-4, what="fused L1")
+    frac_close(ss, ss_ref, 2e-5, rtol=1e-4, what="fused SSIM")
+    l1b, ssb, synth = ops.photo_fused_with_synth(dev[0], d, T, dev[1], dev[2], scale)
+    assert torch.equal(l1b, l1) and torch.equal(ssb, ss)
+    frac_close(synth, synth_ref, 1e-4, max_bad_frac=2e-4, what="fused synth")
+    gs = d_ref.grad.abs().max().item()
+    frac_close(d.grad, d_ref.grad, 2e-4 * gs, rtol=2e-3, max_bad_frac=1e-3, what="fused ddepth")
+    ts = T_ref.grad.abs().max().item()
+    frac_close(T.grad, T_ref.grad, 1e-2 * ts, rtol=1e-2, what="fused dT")
+    # and against the unfused HIP path (same arithmetic, different kernels)
+    d2 = depth.to(gpu_device).requires_grad_(True)
+    T2 = ref_pose.pose_rvec2matr_batch(pose).to(gpu_device).requires_grad_(True)
+    synth2 = ops.warp(dev[0], d2, T2, dev[1], scale)
+    l1u, ssu = ops.photometric("L1", synth2, dev[2]), ops.photometric("SSIM", synth2, dev[2])
+    ((l1u * gl1.to(gpu_device)).sum() + (ssu * gss.to(gpu_device)).sum()).backward()
+    frac_close(l1, l1u, 1e-6, rtol=1e-5, what="fused vs unfused L1")
+    frac_close(ss, ssu, 1e-6, rtol=1e-5, what="fused vs unfused SSIM")
+    frac_close(d.grad, d2.grad, 1e-5 * gs, rtol=1e-3, max_bad_frac=1e-4, what="fused vs unfused ddepth")
+    frac_close(T.grad, T2.grad, 1e-4 * ts, rtol=1e-3, what="fused vs unfused dT")
+
+
 # ------------------------------------------------------------------------------------------------ K6
 @pytest.mark.parametrize("B,h,w", [(4, 128, 416), (2, 16, 52), (1, 2, 2)])
 @pytest.mark.parametrize("is_depth", [False, True])

@@ -1,0 +1,484 @@
+// xpt_fused.hip -- fused view synthesis + L1 + SSIM "march" kernels for gfx950 (the HBM-bound core of the hot path).
+//
+// Replaces, in ONE pass per scale and without materialising the synthesized views:
+//   SynthesizeSingleScale.synthesize_batch_view   model/synthesize/synthesize_base.py:88-178
+//   BilinearInterpolation.__call__                model/synthesize/bilinear_interp.py:7-147
+//   photometric_loss_l1 / photometric_loss_ssim   model/loss_and_metric/loss_util.py:6-25, 52-96
+// (the reference materialises ~430 B per warped pixel for these; algorithmic traffic is
+//  P (16 + 12 N) bytes forward without the synth output, P (20 + 12 N) backward).
+//
+// Mapping (CDNA4, 64-wide waves, no LDS in the forward):
+//   * one WAVE owns a 62-column strip of one source view (lane = column; lanes 0 / 63 are halo columns) and marches
+//     down a chunk of rows keeping the last two rows' horizontal window sums in registers;
+//   * the 3x3 SSIM window = horizontal 3-sums through DPP wave shifts (v_add_f32_dpp wave_shr:1 / wave_shl:1, no
+//     LDS traffic) + a 3-row sliding sum in registers, so every input pixel is loaded once per view;
+//   * lanes are consecutive target pixels -> depth / target rows are contiguous 256 B / 768 B segments and the four
+//     bilinear taps of neighbouring lanes fall into the same or adjacent 128 B lines of the source row;
+//   * the 4 waves of a workgroup take the N = 4 source views of the same strip, so the shared target / depth rows
+//     come from the CU's L1 after the first wave touched them;
+//   * per-wave partial sums go to a workspace and are reduced in a fixed order (deterministic, no float atomics).
+#include "xpt_common.h"
+
+using namespace xpt;
+
+#define SSIM_C1 (0.01f * 0.01f)
+#define SSIM_C2 (0.03f * 0.03f)
+#define STRIP 62          // output columns per wave (64 lanes minus one halo lane on each side)
+
+namespace {
+
+__device__ inline float wave_shr1(float v) {   // lane i <- lane i-1 (0 into lane 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ inline float wave_shl1(float v) {   // lane i <- lane i+1 (0 into lane 63)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ inline float hsum3(float v) { return (wave_shr1(v) + v) + wave_shl1(v); }
+
+__device__ inline float wave_sum_all(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+struct FusedDims {
+  int B, N, h, w, S, CH, R;   // S strips per row, CH row chunks, R rows per chunk
+  float scale;
+};
+
+// One row of the march: everything a lane knows about its pixel of row r.
+struct RowPix {
+  float x[3];     // target
+  float y[3];     // synthesized view
+  bool black;     // mean_c y == 0   (loss_util.py:15-16)
+  bool live;      // inside the image
+};
+
+__device__ inline void synth_pixel(const float* __restrict__ simg, const Cam& cam, const Pose& pose, float d, int u,
+                                   int v, int h, int w, float y[3]) {
+  Warp wp;
+  backproject(cam, (float)u, (float)v, d, wp);
+  project(cam, pose, wp);
+  const Taps t = make_taps(wp.up, wp.vp, h, w, d != 0.f);
+  const float* pff = simg + ((long long)t.vf * w + t.uf) * 3;
+  const float* pfc = simg + ((long long)t.vc * w + t.uf) * 3;
+  const float* pcf = simg + ((long long)t.vf * w + t.uc) * 3;
+  const float* pcc = simg + ((long long)t.vc * w + t.uc) * 3;
+  const float wff = t.wuf * t.wvf, wfc = t.wuf * t.wvc, wcf = t.wuc * t.wvf, wcc = t.wuc * t.wvc;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) y[c] = ((pff[c] * wff + pfc[c] * wfc) + pcf[c] * wcf) + pcc[c] * wcc;
+}
+
+// SSIM loss value of one channel from the 3x3 window sums (loss_util.py:80-93)
+__device__ inline float ssim_loss(float Sx, float Sy, float Sxx, float Syy, float Sxy, float ic) {
+  const float mux = Sx * ic, muy = Sy * ic;
+  const float sx = Sxx * ic - mux * mux, sy = Syy * ic - muy * muy, sxy = Sxy * ic - mux * muy;
+  const float n = (2.f * mux * muy + SSIM_C1) * (2.f * sxy + SSIM_C2);
+  const float dn = (mux * mux + muy * muy + SSIM_C1) * (sx + sy + SSIM_C2);
+  return clampf((1.f - n / dn) * 0.5f, 0.f, 1.f);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// part[wave][2] = (sum of L1 terms, sum of SSIM terms) over the wave's output pixels (3 channels each).
+template <bool EMIT_SYNTH>
+__global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
+                                                        const float* __restrict__ T, const float* __restrict__ K,
+                                                        const float* __restrict__ target, float* __restrict__ synth,
+                                                        float* __restrict__ part, FusedDims d) {
+  const int lane = threadIdx.x & 63;
+  const long long gw = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
+  if (gw >= nwaves) return;                       // no block-level synchronisation in this kernel
+  const int n = (int)(gw % d.N);
+  long long r_ = gw / d.N;
+  const int ck = (int)(r_ % d.CH); r_ /= d.CH;
+  const int s = (int)(r_ % d.S);
+  const int b = (int)(r_ / d.S);
+  const int P = d.h * d.w;
+  const int col = s * STRIP - 1 + lane;
+  const bool col_in = (col >= 0) && (col < d.w);
+  const bool out_lane = (lane >= 1) && (lane <= STRIP) && col_in;
+  const int r0 = ck * d.R, r1 = min(r0 + d.R, d.h);
+  const Cam cam = load_cam(K + 9 * b, d.scale);
+  const Pose pose = load_pose(T + 16 * ((long long)b * d.N + n));
+  const float* simg = src + ((long long)b * d.N + n) * P * 3;
+  const float* dimg = depth + (long long)b * P;
+  const float* timg = target + (long long)b * P * 3;
+  float* oimg = EMIT_SYNTH ? synth + ((long long)b * d.N + n) * P * 3 : nullptr;
+  const float cnt_c = (float)((col > 0 ? 1 : 0) + 1 + (col < d.w - 1 ? 1 : 0));
+
+  float acc_l1 = 0.f, acc_ss = 0.f;
+  // horizontal window sums of the two previous rows: [x(3) y(3) xx(3) yy(3) xy(3)]
+  float hA[15], hB[15], hC[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) { hA[i] = 0.f; hB[i] = 0.f; hC[i] = 0.f; }
+  bool black_prev = true;
+
+  // body(r, cur, m1, m2): loads row r, fills cur, emits the SSIM of row r-1 from (m2, m1, cur)
+  auto body = [&](int r, float (&cur)[15], const float (&m1)[15], const float (&m2)[15]) {
+    float x[3] = {0.f, 0.f, 0.f}, y[3] = {0.f, 0.f, 0.f};
+    const bool row_in = (r >= 0) && (r < d.h);
+    if (row_in && col_in) {
+      const long long p = (long long)r * d.w + col;
+      const float dd = dimg[p];
+      x[0] = timg[3 * p]; x[1] = timg[3 * p + 1]; x[2] = timg[3 * p + 2];
+      synth_pixel(simg, cam, pose, dd, col, r, d.h, d.w, y);
+      if (EMIT_SYNTH && out_lane && r >= r0 && r < r1) {
+        oimg[3 * p] = y[0]; oimg[3 * p + 1] = y[1]; oimg[3 * p + 2] = y[2];
+      }
+    }
+    const bool black = ((y[0] + y[1]) + y[2]) / 3.0f == 0.f;
+    if (out_lane && r >= r0 && r < r1 && !black)
+      acc_l1 += (fabsf(y[0] - x[0]) + fabsf(y[1] - x[1])) + fabsf(y[2] - x[2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      cur[c] = hsum3(x[c]);
+      cur[3 + c] = hsum3(y[c]);
+      cur[6 + c] = hsum3(x[c] * x[c]);
+      cur[9 + c] = hsum3(y[c] * y[c]);
+      cur[12 + c] = hsum3(x[c] * y[c]);
+    }
+    const int rc = r - 1;                          // centre row of the window (m2, m1, cur)
+    if (out_lane && rc >= r0 && rc < r1 && !black_prev) {
+      const float cnt_r = (float)((rc > 0 ? 1 : 0) + 1 + (rc < d.h - 1 ? 1 : 0));
+      const float ic = 1.0f / (cnt_r * cnt_c);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        acc_ss += ssim_loss(m2[c] + m1[c] + cur[c], m2[3 + c] + m1[3 + c] + cur[3 + c], m2[6 + c] + m1[6 + c] + cur[6 + c],
+                            m2[9 + c] + m1[9 + c] + cur[9 + c], m2[12 + c] + m1[12 + c] + cur[12 + c], ic);
+    }
+    black_prev = black;
+  };
+
+  // rows r0-1 .. r1 (one halo row above and below the chunk), three-way rotation keeps the history in registers
+  int r = r0 - 1;
+  const int rend = r1;          // inclusive
+  while (r <= rend) {
+    body(r, hA, hC, hB); ++r;
+    if (r > rend) break;
+    body(r, hB, hA, hC); ++r;
+    if (r > rend) break;
+    body(r, hC, hB, hA); ++r;
+  }
+  acc_l1 = wave_sum_all(acc_l1);
+  acc_ss = wave_sum_all(acc_ss);
+  if (lane == 0) {
+    part[2 * gw] = acc_l1;
+    part[2 * gw + 1] = acc_ss;
+  }
+}
+
+// loss[b] = inv_count * sum over the waves of batch element b (fixed order), 64 threads per b.
+__global__ void fused_reduce_kernel(const float* __restrict__ part, float* __restrict__ loss_l1,
+                                    float* __restrict__ loss_ssim, int waves_per_b, float inv_count) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* q = part + (long long)b * waves_per_b * 2;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = t; k < waves_per_b; k += 64) { s0 += q[2 * k]; s1 += q[2 * k + 1]; }
+  s0 = wave_sum_all(s0);
+  s1 = wave_sum_all(s1);
+  if (t == 0) { loss_l1[b] = s0 * inv_count; loss_ssim[b] = s1 * inv_count; }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// d loss / d y(q,c) = g_l1 sign(y-x) [not black]  +  sum_{p in win(q)} ( A_pc + 2 B_pc y_qc + C_pc x_qc )
+// with, for window centre p:  (A,B,C)_pc = g_ssim * (-1/2) * [not black(p)] * [0 <= (1-ssim)/2 <= 1] / cnt_p *
+//                                          ( dssim/dmu_y, dssim/dE[yy], dssim/dE[xy] )
+// The second 3x3 box sum reuses the same DPP + sliding-row scheme one row later, so the march has three stages per
+// step: A = synthesize row r, B = coefficients of centre row r-1, C = pixel gradients of row r-2.
+#define STRIP_B 60        // output columns per wave in the backward (two halo lanes on each side)
+
+struct RowState {
+  float tap[12];          // the four bilinear taps (ff, fc, cf, cc) x RGB
+  float x[3], y[3];
+  float d;
+  bool black;
+};
+
+__device__ inline void ssim_coeffs(float Sx, float Sy, float Sxx, float Syy, float Sxy, float ic, float g, float& A,
+                                   float& Bq, float& Cq) {
+  const float mux = Sx * ic, muy = Sy * ic;
+  const float sx = Sxx * ic - mux * mux, sy = Syy * ic - muy * muy, sxy = Sxy * ic - mux * muy;
+  const float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sxy + SSIM_C2;
+  const float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sx + sy + SSIM_C2;
+  const float inv12 = 1.0f / (d1 * d2);
+  const float ssim = n1 * n2 * inv12;
+  const float val = (1.f - ssim) * 0.5f;
+  float gg = (val >= 0.f && val <= 1.f) ? g * (-0.5f) * ic : 0.f;      // clip_by_value gradient, pooling divisor
+  A = gg * (2.f * mux * (n2 - n1) * inv12 - 2.f * muy * ssim * (1.0f / d1 - 1.0f / d2));
+  Bq = gg * (-ssim / d2);
+  Cq = gg * (2.f * n1 * inv12);
+}
+
+// MODE 0: N == 4, the 4 waves of a workgroup hold the 4 views of one strip -> d_depth summed through LDS;
+// MODE 1: N == 1 -> direct store;  MODE 2: any other N -> atomicAdd into a zeroed d_depth.
+template <int MODE>
+__global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
+                                                        const float* __restrict__ T, const float* __restrict__ K,
+                                                        const float* __restrict__ target,
+                                                        const float* __restrict__ g_l1, const float* __restrict__ g_ssim,
+                                                        float* __restrict__ ddepth, float* __restrict__ part,
+                                                        FusedDims d, float inv_count) {
+  __shared__ float lds_dd[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long long gw = (long long)blockIdx.x * 4 + wid;
+  const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
+  if (gw >= nwaves) return;                 // MODE 0: nwaves % 4 == 0, whole workgroups leave together
+  const int n = (int)(gw % d.N);
+  long long r_ = gw / d.N;
+  const int ck = (int)(r_ % d.CH); r_ /= d.CH;
+  const int s = (int)(r_ % d.S);
+  const int b = (int)(r_ / d.S);
+  const int P = d.h * d.w;
+  const int col = s * STRIP_B - 2 + lane;
+  const bool col_in = (col >= 0) && (col < d.w);
+  const bool out_lane = (lane >= 2) && (lane < 2 + STRIP_B) && col_in;
+  const int r0 = ck * d.R, r1 = min(r0 + d.R, d.h);
+  const Cam cam = load_cam(K + 9 * b, d.scale);
+  const Pose pose = load_pose(T + 16 * ((long long)b * d.N + n));
+  const float* simg = src + ((long long)b * d.N + n) * P * 3;
+  const float* dimg = depth + (long long)b * P;
+  const float* timg = target + (long long)b * P * 3;
+  float* gimg = ddepth + (long long)b * P;
+  const float cnt_c = (float)((col > 0 ? 1 : 0) + 1 + (col < d.w - 1 ? 1 : 0));
+  const float gl1 = g_l1[b] * inv_count, gss = g_ssim[b] * inv_count;
+
+  float dRt[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) dRt[i] = 0.f;
+  float hA[15], hB[15], hC[15], cA[9], cB[9], cC[9];
+  RowState sA, sB, sC;
+#pragma unroll
+  for (int i = 0; i < 15; ++i) { hA[i] = 0.f; hB[i] = 0.f; hC[i] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { cA[i] = 0.f; cB[i] = 0.f; cC[i] = 0.f; }
+  auto clear_state = [](RowState& st) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) st.tap[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { st.x[i] = 0.f; st.y[i] = 0.f; }
+    st.d = 0.f;
+    st.black = true;
+  };
+  clear_state(sA); clear_state(sB); clear_state(sC);
+
+  auto body = [&](int r, RowState& scur, const RowState& sm1, const RowState& sm2, float (&hcur)[15],
+                  const float (&hm1)[15], const float (&hm2)[15], float (&ccur)[9], const float (&cm1)[9],
+                  const float (&cm2)[9]) {
+    // ---- stage A: synthesize row r
+    clear_state(scur);
+    if (r >= 0 && r < d.h && col_in) {
+      const long long p = (long long)r * d.w + col;
+      scur.d = dimg[p];
+      scur.x[0] = timg[3 * p]; scur.x[1] = timg[3 * p + 1]; scur.x[2] = timg[3 * p + 2];
+      Warp wp;
+      backproject(cam, (float)col, (float)r, scur.d, wp);
+      project(cam, pose, wp);
+      const Taps t = make_taps(wp.up, wp.vp, d.h, d.w, scur.d != 0.f);
+      const float* pff = simg + ((long long)t.vf * d.w + t.uf) * 3;
+      const float* pfc = simg + ((long long)t.vc * d.w + t.uf) * 3;
+      const float* pcf = simg + ((long long)t.vf * d.w + t.uc) * 3;
+      const float* pcc = simg + ((long long)t.vc * d.w + t.uc) * 3;
+      const float wff = t.wuf * t.wvf, wfc = t.wuf * t.wvc, wcf = t.wuc * t.wvf, wcc = t.wuc * t.wvc;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        scur.tap[c] = pff[c]; scur.tap[3 + c] = pfc[c]; scur.tap[6 + c] = pcf[c]; scur.tap[9 + c] = pcc[c];
+        scur.y[c] = ((scur.tap[c] * wff + scur.tap[3 + c] * wfc) + scur.tap[6 + c] * wcf) + scur.tap[9 + c] * wcc;
+      }
+      scur.black = ((scur.y[0] + scur.y[1]) + scur.y[2]) / 3.0f == 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      hcur[c] = hsum3(scur.x[c]);
+      hcur[3 + c] = hsum3(scur.y[c]);
+      hcur[6 + c] = hsum3(scur.x[c] * scur.x[c]);
+      hcur[9 + c] = hsum3(scur.y[c] * scur.y[c]);
+      hcur[12 + c] = hsum3(scur.x[c] * scur.y[c]);
+    }
+    // ---- stage B: SSIM coefficients of centre row p = r-1 (state sm1), then their horizontal sums
+    {
+      const int p = r - 1;
+      float co[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) co[i] = 0.f;
+      if (p >= 0 && p < d.h && col_in && !sm1.black) {
+        const float cnt_r = (float)((p > 0 ? 1 : 0) + 1 + (p < d.h - 1 ? 1 : 0));
+        const float ic = 1.0f / (cnt_r * cnt_c);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          ssim_coeffs(hm2[c] + hm1[c] + hcur[c], hm2[3 + c] + hm1[3 + c] + hcur[3 + c],
+                      hm2[6 + c] + hm1[6 + c] + hcur[6 + c], hm2[9 + c] + hm1[9 + c] + hcur[9 + c],
+                      hm2[12 + c] + hm1[12 + c] + hcur[12 + c], ic, gss, co[c], co[3 + c], co[6 + c]);
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ccur[i] = hsum3(co[i]);
+    }
+    // ---- stage C: gradient of pixel (q = r-2, col) (state sm2); window rows q-1, q, q+1 = cm2, cm1, ccur
+    const int q = r - 2;
+    float dd = 0.f;
+    const bool emit = (q >= r0) && (q < r1);
+    if (emit && out_lane) {
+      float g[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float SA = cm2[c] + cm1[c] + ccur[c];
+        const float SB = cm2[3 + c] + cm1[3 + c] + ccur[3 + c];
+        const float SC = cm2[6 + c] + cm1[6 + c] + ccur[6 + c];
+        const float df = sm2.y[c] - sm2.x[c];
+        const float sg = sm2.black ? 0.f : ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));
+        g[c] = gl1 * sg + SA + 2.f * SB * sm2.y[c] + SC * sm2.x[c];
+      }
+      Warp wp;
+      backproject(cam, (float)col, (float)q, sm2.d, wp);
+      project(cam, pose, wp);
+      const Taps t = make_taps(wp.up, wp.vp, d.h, d.w, sm2.d != 0.f);
+      float du = 0.f, dv = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        du += g[c] * ((sm2.tap[6 + c] - sm2.tap[c]) * t.wvf + (sm2.tap[9 + c] - sm2.tap[3 + c]) * t.wvc);
+        dv += g[c] * ((sm2.tap[3 + c] - sm2.tap[c]) * t.wuf + (sm2.tap[9 + c] - sm2.tap[6 + c]) * t.wuc);
+      }
+      du *= t.mask;
+      dv *= t.mask;
+      const float dq0 = du * wp.zinv, dq1 = dv * wp.zinv;
+      const float dq2 = -(du * wp.up + dv * wp.vp) * wp.zinv;
+      float dXs[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) dXs[j] = cam.k[j] * dq0 + cam.k[3 + j] * dq1 + cam.k[6 + j] * dq2;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        dRt[4 * i + 0] += dXs[i] * wp.X[0];
+        dRt[4 * i + 1] += dXs[i] * wp.X[1];
+        dRt[4 * i + 2] += dXs[i] * wp.X[2];
+        dRt[4 * i + 3] += dXs[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        dd += (pose.r[j] * dXs[0] + pose.r[3 + j] * dXs[1] + pose.r[6 + j] * dXs[2]) * wp.ray[j];
+    }
+    if (emit) {                                   // wave-uniform: every wave of the workgroup shares (r0, r1) in MODE 0
+      if (MODE == 0) {
+        lds_dd[wid][lane] = dd;
+        __syncthreads();
+        if (wid == 0 && out_lane)
+          gimg[(long long)q * d.w + col] = ((lds_dd[0][lane] + lds_dd[1][lane]) + lds_dd[2][lane]) + lds_dd[3][lane];
+        __syncthreads();
+      } else if (MODE == 1) {
+        if (out_lane) gimg[(long long)q * d.w + col] = dd;
+      } else {
+        if (out_lane) atomicAdd(gimg + (long long)q * d.w + col, dd);
+      }
+    }
+  };
+
+  int r = r0 - 2;
+  const int rend = r1 + 1;      // inclusive
+  while (r <= rend) {
+    body(r, sA, sC, sB, hA, hC, hB, cA, cC, cB); ++r;
+    if (r > rend) break;
+    body(r, sB, sA, sC, hB, hA, hC, cB, cA, cC); ++r;
+    if (r > rend) break;
+    body(r, sC, sB, sA, hC, hB, hA, cC, cB, cA); ++r;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const float v = wave_sum_all(dRt[i]);
+    if (lane == 0) part[16 * gw + i] = v;
+  }
+}
+
+// dT[b,n] (4x4, last row 0) = sum over the (strip, chunk) waves of view (b,n), fixed order; 16 threads per entry.
+__global__ void fused_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dT, int BN, int N,
+                                        int waves_per_b) {
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4);      // entry in [0, BN*16)
+  const int t = threadIdx.x & 15;
+  float sum = 0.f;
+  const int bn = e / 16, i = e % 16;
+  if (bn < BN && i < 12) {
+    const int b = bn / N, n = bn % N;
+    const int per_view = waves_per_b / N;
+    for (int k = t; k < per_view; k += 16) sum += part[16 * ((long long)b * waves_per_b + (long long)k * N + n) + i];
+  }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) sum += __shfl_down(sum, off, 16);
+  if (t == 0 && bn < BN) dT[e] = sum;
+}
+
+inline FusedDims make_dims(int B, int N, int h, int w, float scale, int rows_per_chunk, int strip) {
+  FusedDims d;
+  d.B = B; d.N = N; d.h = h; d.w = w; d.scale = scale;
+  d.S = (w + strip - 1) / strip;
+  d.R = rows_per_chunk < h ? rows_per_chunk : h;
+  d.CH = (h + d.R - 1) / d.R;
+  return d;
+}
+
+// Rows per chunk: enough waves to cover 256 CUs x 4 SIMDs a few times over, as few halo rows as possible.
+inline int pick_rows(int B, int N, int h, int w) {
+  const long long strips = (long long)B * N * ((w + STRIP - 1) / STRIP);
+  int R = 32;
+  while (R > 4 && strips * ((h + R - 1) / R) < 4096) R >>= 1;
+  return R;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t xpt_photo_fused_workspace_floats(int B, int N, int h, int w) {
+  if (B <= 0 || N <= 0 || h <= 0 || w <= 0) return 0;
+  const FusedDims d = make_dims(B, N, h, w, 1.f, pick_rows(B, N, h, w), STRIP_B);   // the backward has more strips
+  return (size_t)d.B * d.S * d.CH * d.N * 16;       // per wave: 2 floats forward, 12 (pose gradient) backward
+}
+
+int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, const float* K, const float* target,
+                        float* synth, float* loss_l1, float* loss_ssim, float* workspace, size_t workspace_floats,
+                        int B, int N, int h, int w, float scale, void* stream) {
+  XPT_CHECK_PTR(src); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(T); XPT_CHECK_PTR(K); XPT_CHECK_PTR(target);
+  XPT_CHECK_PTR(loss_l1); XPT_CHECK_PTR(loss_ssim); XPT_CHECK_PTR(workspace);
+  if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f)) return XPT_ERR_SHAPE;
+  if (workspace_floats < xpt_photo_fused_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
+  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w), STRIP);
+  const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
+  const unsigned blocks = (unsigned)((nwaves + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+  if (synth)
+    hipLaunchKernelGGL(fused_fwd_kernel<true>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth, workspace, d);
+  else
+    hipLaunchKernelGGL(fused_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth, workspace, d);
+  hipLaunchKernelGGL(fused_reduce_kernel, dim3(B), dim3(64), 0, s, workspace, loss_l1, loss_ssim, d.S * d.CH * d.N,
+                     1.0f / ((float)N * (float)h * (float)w * 3.0f));
+  return xpt_launch_status();
+}
+
+int xpt_photo_fused_bwd(const float* src, const float* depth, const float* T, const float* K, const float* target,
+                        const float* g_l1, const float* g_ssim, float* ddepth, float* dT, float* workspace,
+                        size_t workspace_floats, int B, int N, int h, int w, float scale, void* stream) {
+  XPT_CHECK_PTR(src); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(T); XPT_CHECK_PTR(K); XPT_CHECK_PTR(target);
+  XPT_CHECK_PTR(g_l1); XPT_CHECK_PTR(g_ssim); XPT_CHECK_PTR(ddepth); XPT_CHECK_PTR(dT); XPT_CHECK_PTR(workspace);
+  if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f)) return XPT_ERR_SHAPE;
+  if (workspace_floats < xpt_photo_fused_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
+  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w), STRIP_B);
+  const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
+  const unsigned blocks = (unsigned)((nwaves + 3) / 4);
+  const float inv_count = 1.0f / ((float)N * (float)h * (float)w * 3.0f);
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+  if (N == 4) {
+    hipLaunchKernelGGL(fused_bwd_kernel<0>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, g_l1, g_ssim, ddepth,
+                       workspace, d, inv_count);
+  } else if (N == 1) {
+    hipLaunchKernelGGL(fused_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, g_l1, g_ssim, ddepth,
+                       workspace, d, inv_count);
+  } else {
+    if (hipMemsetAsync(ddepth, 0, (size_t)B * h * w * sizeof(float), s) != hipSuccess) return XPT_ERR_LAUNCH;
+    hipLaunchKernelGGL(fused_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, g_l1, g_ssim, ddepth,
+                       workspace, d, inv_count);
+  }
+  hipLaunchKernelGGL(fused_bwd_reduce_kernel, dim3((B * N * 16 + 15) / 16), dim3(256), 0, s, workspace, dT, B * N, N,
+                     d.S * d.CH * d.N);
+  return xpt_launch_status();
+}
+
+}  // extern "C"

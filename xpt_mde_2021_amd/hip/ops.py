@@ -187,6 +187,70 @@ def photometric(method, synt_target, orig_target, reduce=True):
     return _Photo.apply(synt_target, orig_target, method, bool(reduce))
 
 
+# ------------------------------------------------------------------------------- K2-K5 fused march
+class _PhotoFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, depth, T, K, target, scale):
+        lib = _lib.load()
+        src, depth, T, K, target = (_dev(src, "src"), _dev(depth, "depth"), _dev(T, "T"), _dev(K, "K"),
+                                    _dev(target, "target"))
+        B, N, h, w, C = src.shape
+        if C != 3 or depth.numel() != B * h * w or T.numel() != B * N * 16 or K.numel() != B * 9 \
+                or tuple(target.shape) != (B, h, w, 3):
+            raise _lib.XptHipError(f"photo_fused: inconsistent shapes src{tuple(src.shape)} depth{tuple(depth.shape)} "
+                                   f"T{tuple(T.shape)} K{tuple(K.shape)} target{tuple(target.shape)}")
+        l1 = torch.empty((B,), dtype=torch.float32, device=src.device)
+        ss = torch.empty((B,), dtype=torch.float32, device=src.device)
+        nws = lib.xpt_photo_fused_workspace_floats(B, N, h, w)
+        ws = torch.empty(nws, dtype=torch.float32, device=src.device)
+        _lib.check(lib.xpt_photo_fused_fwd(_ptr(src), _ptr(depth), _ptr(T), _ptr(K), _ptr(target), None, _ptr(l1),
+                                           _ptr(ss), _ptr(ws), nws, B, N, h, w, float(scale), _stream()),
+                   "xpt_photo_fused_fwd")
+        ctx.save_for_backward(src, depth, T, K, target)
+        ctx.scale = float(scale)
+        return l1, ss
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ss):
+        lib = _lib.load()
+        src, depth, T, K, target = ctx.saved_tensors
+        B, N, h, w, _ = src.shape
+        g_l1 = _dev(g_l1, "g_l1") if g_l1 is not None else torch.zeros(B, device=src.device)
+        g_ss = _dev(g_ss, "g_ssim") if g_ss is not None else torch.zeros(B, device=src.device)
+        ddepth = torch.empty_like(depth)
+        dT = torch.empty_like(T)
+        nws = lib.xpt_photo_fused_workspace_floats(B, N, h, w)
+        ws = torch.empty(nws, dtype=torch.float32, device=src.device)
+        _lib.check(lib.xpt_photo_fused_bwd(_ptr(src), _ptr(depth), _ptr(T), _ptr(K), _ptr(target), _ptr(g_l1), _ptr(g_ss),
+                                           _ptr(ddepth), _ptr(dT), _ptr(ws), nws, B, N, h, w, ctx.scale, _stream()),
+                   "xpt_photo_fused_bwd")
+        return None, ddepth, dT, None, None, None
+
+
+def photo_fused(src, depth, T, K, target, scale):
+    """Fused view synthesis + photometric L1 + SSIM of one scale (no synthesized image is written):
+    src [B,N,h,w,3] at this scale, depth [B,h,w,1], T [B,N,4,4], K [B,3,3] unscaled, target [B,h,w,3]
+    -> (loss_l1 [B], loss_ssim [B]) = (photometric_loss_l1, photometric_loss_ssim)(synth, target) of the reference;
+    differentiable w.r.t. depth and T."""
+    return _PhotoFused.apply(src, depth, T, K, target, scale)
+
+
+def photo_fused_with_synth(src, depth, T, K, target, scale):
+    """Forward only (no autograd): also returns the synthesized views [B,N,h,w,3] (for image logging / tests)."""
+    lib = _lib.load()
+    src, depth, T, K, target = (_dev(src, "src"), _dev(depth.detach(), "depth"), _dev(T.detach(), "T"), _dev(K, "K"),
+                                _dev(target, "target"))
+    B, N, h, w, _ = src.shape
+    l1 = torch.empty((B,), dtype=torch.float32, device=src.device)
+    ss = torch.empty((B,), dtype=torch.float32, device=src.device)
+    synth = torch.empty_like(src)
+    nws = lib.xpt_photo_fused_workspace_floats(B, N, h, w)
+    ws = torch.empty(nws, dtype=torch.float32, device=src.device)
+    _lib.check(lib.xpt_photo_fused_fwd(_ptr(src), _ptr(depth), _ptr(T), _ptr(K), _ptr(target), _ptr(synth), _ptr(l1),
+                                       _ptr(ss), _ptr(ws), nws, B, N, h, w, float(scale), _stream()), "xpt_photo_fused_fwd")
+    return l1, ss, synth
+
+
 # ------------------------------------------------------------------------------- K6 smoothness
 class _Smooth(torch.autograd.Function):
     @staticmethod
