@@ -7,15 +7,18 @@
 // (the reference materialises ~430 B per warped pixel for these; algorithmic traffic is
 //  P (16 + 12 N) bytes forward without the synth output, P (20 + 12 N) backward).
 //
-// Mapping (CDNA4, 64-wide waves, no LDS in the forward):
-//   * one WAVE owns a 62-column strip of one source view (lane = column; lanes 0 / 63 are halo columns) and marches
-//     down a chunk of rows keeping the last two rows' horizontal window sums in registers;
+// Mapping (CDNA4, 64-wide waves):
+//   * one WAVE owns a column strip of one source view (lane = column, 1 or 2 halo lanes per side) and marches down a
+//     chunk of rows keeping the last two rows' horizontal window sums in registers;
 //   * the 3x3 SSIM window = horizontal 3-sums through DPP wave shifts (v_add_f32_dpp wave_shr:1 / wave_shl:1, no
 //     LDS traffic) + a 3-row sliding sum in registers, so every input pixel is loaded once per view;
 //   * lanes are consecutive target pixels -> depth / target rows are contiguous 256 B / 768 B segments and the four
 //     bilinear taps of neighbouring lanes fall into the same or adjacent 128 B lines of the source row;
 //   * the 4 waves of a workgroup take the N = 4 source views of the same strip, so the shared target / depth rows
-//     come from the CU's L1 after the first wave touched them;
+//     come from the CU's L1 after the first wave touched them; in the backward they also combine their d_depth
+//     contributions through LDS so that d_depth is written exactly once;
+//   * everything that is uniform per wave (camera, pose, image bases) is forced into SGPRs (readfirstlane on the
+//     wave index), divisions are v_rcp_f32 (1 ulp; the bar is 1e-4), pixel offsets are 32-bit;
 //   * per-wave partial sums go to a workspace and are reduced in a fixed order (deterministic, no float atomics).
 #include "xpt_common.h"
 
@@ -23,7 +26,8 @@ using namespace xpt;
 
 #define SSIM_C1 (0.01f * 0.01f)
 #define SSIM_C2 (0.03f * 0.03f)
-#define STRIP 62          // output columns per wave (64 lanes minus one halo lane on each side)
+#define STRIP 62          // forward: output columns per wave (one halo lane on each side)
+#define STRIP_B 60        // backward: two halo lanes on each side
 
 namespace {
 
@@ -34,6 +38,7 @@ __device__ inline float wave_shl1(float v) {   // lane i <- lane i+1 (0 into lan
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
 __device__ inline float hsum3(float v) { return (wave_shr1(v) + v) + wave_shl1(v); }
+__device__ inline float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 
 __device__ inline float wave_sum_all(float v) {
 #pragma unroll
@@ -46,27 +51,48 @@ struct FusedDims {
   float scale;
 };
 
-// One row of the march: everything a lane knows about its pixel of row r.
-struct RowPix {
-  float x[3];     // target
-  float y[3];     // synthesized view
-  bool black;     // mean_c y == 0   (loss_util.py:15-16)
-  bool live;      // inside the image
+// Which (batch, view, strip, chunk) a wave works on; all members are wave-uniform (SGPRs).
+struct WaveJob {
+  int b, n, s, ck;
+  bool valid;
 };
 
-__device__ inline void synth_pixel(const float* __restrict__ simg, const Cam& cam, const Pose& pose, float d, int u,
-                                   int v, int h, int w, float y[3]) {
-  Warp wp;
-  backproject(cam, (float)u, (float)v, d, wp);
-  project(cam, pose, wp);
-  const Taps t = make_taps(wp.up, wp.vp, h, w, d != 0.f);
-  const float* pff = simg + ((long long)t.vf * w + t.uf) * 3;
-  const float* pfc = simg + ((long long)t.vc * w + t.uf) * 3;
-  const float* pcf = simg + ((long long)t.vf * w + t.uc) * 3;
-  const float* pcc = simg + ((long long)t.vc * w + t.uc) * 3;
-  const float wff = t.wuf * t.wvf, wfc = t.wuf * t.wvc, wcf = t.wuc * t.wvf, wcc = t.wuc * t.wvc;
+__device__ inline WaveJob wave_job(const FusedDims& d) {
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long long gw = (long long)blockIdx.x * 4 + wid;
+  const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
+  WaveJob j;
+  j.valid = gw < nwaves;
+  j.n = (int)(gw % d.N);
+  long long r = gw / d.N;
+  j.ck = (int)(r % d.CH); r /= d.CH;
+  j.s = (int)(r % d.S);
+  j.b = (int)(r / d.S);
+  return j;
+}
+
+// projection with reciprocal instead of IEEE division
+__device__ inline void project_fast(const Cam& c, const Pose& p, Warp& w) {
+  float Xs[3], q[3];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) y[c] = ((pff[c] * wff + pfc[c] * wfc) + pcf[c] * wcf) + pcc[c] * wcc;
+  for (int i = 0; i < 3; ++i) Xs[i] = p.r[3 * i + 0] * w.X[0] + p.r[3 * i + 1] * w.X[1] + p.r[3 * i + 2] * w.X[2] + p.t[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) q[i] = c.k[3 * i + 0] * Xs[0] + c.k[3 * i + 1] * Xs[1] + c.k[3 * i + 2] * Xs[2];
+  w.zinv = rcpf(q[2] + 1e-10f);
+  w.up = q[0] * w.zinv;
+  w.vp = q[1] * w.zinv;
+}
+
+// loads the four taps (ff, fc, cf, cc) x RGB of a pixel; 32-bit offsets from the (scalar) image base
+__device__ inline void load_taps(const float* __restrict__ simg, int w, const Taps& t, float tap[12]) {
+  const int off = (t.vf * w + t.uf) * 3, oc = (t.vc * w + t.uf) * 3, du = (t.uc - t.uf) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    tap[c] = simg[off + c];
+    tap[3 + c] = simg[oc + c];
+    tap[6 + c] = simg[off + du + c];
+    tap[9 + c] = simg[oc + du + c];
+  }
 }
 
 // SSIM loss value of one channel from the 3x3 window sums (loss_util.py:80-93)
@@ -75,41 +101,43 @@ __device__ inline float ssim_loss(float Sx, float Sy, float Sxx, float Syy, floa
   const float sx = Sxx * ic - mux * mux, sy = Syy * ic - muy * muy, sxy = Sxy * ic - mux * muy;
   const float n = (2.f * mux * muy + SSIM_C1) * (2.f * sxy + SSIM_C2);
   const float dn = (mux * mux + muy * muy + SSIM_C1) * (sx + sy + SSIM_C2);
-  return clampf((1.f - n / dn) * 0.5f, 0.f, 1.f);
+  return clampf((1.f - n * rcpf(dn)) * 0.5f, 0.f, 1.f);
+}
+
+__device__ inline float window_rcp(int r, int h, float cnt_c) {
+  const float cnt_r = (float)((r > 0 ? 1 : 0) + 1 + (r < h - 1 ? 1 : 0));
+  return rcpf(cnt_r * cnt_c);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// part[wave][2] = (sum of L1 terms, sum of SSIM terms) over the wave's output pixels (3 channels each).
+// part[16 * wave + {0,1}] = (sum of L1 terms, sum of SSIM terms) over the wave's output pixels (3 channels each).
 template <bool EMIT_SYNTH>
 __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
                                                         const float* __restrict__ T, const float* __restrict__ K,
                                                         const float* __restrict__ target, float* __restrict__ synth,
                                                         float* __restrict__ part, FusedDims d) {
+  const WaveJob job = wave_job(d);
+  if (!job.valid) return;                          // no block-level synchronisation in this kernel
   const int lane = threadIdx.x & 63;
-  const long long gw = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
-  if (gw >= nwaves) return;                       // no block-level synchronisation in this kernel
-  const int n = (int)(gw % d.N);
-  long long r_ = gw / d.N;
-  const int ck = (int)(r_ % d.CH); r_ /= d.CH;
-  const int s = (int)(r_ % d.S);
-  const int b = (int)(r_ / d.S);
   const int P = d.h * d.w;
-  const int col = s * STRIP - 1 + lane;
+  const int col = job.s * STRIP - 1 + lane;
   const bool col_in = (col >= 0) && (col < d.w);
   const bool out_lane = (lane >= 1) && (lane <= STRIP) && col_in;
-  const int r0 = ck * d.R, r1 = min(r0 + d.R, d.h);
-  const Cam cam = load_cam(K + 9 * b, d.scale);
-  const Pose pose = load_pose(T + 16 * ((long long)b * d.N + n));
-  const float* simg = src + ((long long)b * d.N + n) * P * 3;
-  const float* dimg = depth + (long long)b * P;
-  const float* timg = target + (long long)b * P * 3;
-  float* oimg = EMIT_SYNTH ? synth + ((long long)b * d.N + n) * P * 3 : nullptr;
+  const int r0 = job.ck * d.R, r1 = min(r0 + d.R, d.h);
+  const Cam cam = load_cam(K + 9 * job.b, d.scale);
+  const Pose pose = load_pose(T + 16 * (job.b * d.N + job.n));
+  const float* simg = src + (long long)(job.b * d.N + job.n) * P * 3;
+  const float* dimg = depth + (long long)job.b * P;
+  const float* timg = target + (long long)job.b * P * 3;
+  float* oimg = EMIT_SYNTH ? synth + (long long)(job.b * d.N + job.n) * P * 3 : nullptr;
   const float cnt_c = (float)((col > 0 ? 1 : 0) + 1 + (col < d.w - 1 ? 1 : 0));
+  // ray = Kinv (col, r, 1): the column part is constant along the march
+  float ray_c[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ray_c[i] = cam.ki[3 * i] * (float)col + cam.ki[3 * i + 2];
 
   float acc_l1 = 0.f, acc_ss = 0.f;
-  // horizontal window sums of the two previous rows: [x(3) y(3) xx(3) yy(3) xy(3)]
-  float hA[15], hB[15], hC[15];
+  float hA[15], hB[15], hC[15];                    // horizontal window sums [x(3) y(3) xx(3) yy(3) xy(3)] of 3 rows
 #pragma unroll
   for (int i = 0; i < 15; ++i) { hA[i] = 0.f; hB[i] = 0.f; hC[i] = 0.f; }
   bool black_prev = true;
@@ -117,17 +145,28 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
   // body(r, cur, m1, m2): loads row r, fills cur, emits the SSIM of row r-1 from (m2, m1, cur)
   auto body = [&](int r, float (&cur)[15], const float (&m1)[15], const float (&m2)[15]) {
     float x[3] = {0.f, 0.f, 0.f}, y[3] = {0.f, 0.f, 0.f};
-    const bool row_in = (r >= 0) && (r < d.h);
-    if (row_in && col_in) {
-      const long long p = (long long)r * d.w + col;
+    if (r >= 0 && r < d.h && col_in) {             // r is wave-uniform
+      const int p = r * d.w + col;
       const float dd = dimg[p];
       x[0] = timg[3 * p]; x[1] = timg[3 * p + 1]; x[2] = timg[3 * p + 2];
-      synth_pixel(simg, cam, pose, dd, col, r, d.h, d.w, y);
+      Warp wp;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        wp.ray[i] = ray_c[i] + cam.ki[3 * i + 1] * (float)r;
+        wp.X[i] = wp.ray[i] * dd;
+      }
+      project_fast(cam, pose, wp);
+      const Taps t = make_taps(wp.up, wp.vp, d.h, d.w, dd != 0.f);
+      float tap[12];
+      load_taps(simg, d.w, t, tap);
+      const float wff = t.wuf * t.wvf, wfc = t.wuf * t.wvc, wcf = t.wuc * t.wvf, wcc = t.wuc * t.wvc;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) y[c] = ((tap[c] * wff + tap[3 + c] * wfc) + tap[6 + c] * wcf) + tap[9 + c] * wcc;
       if (EMIT_SYNTH && out_lane && r >= r0 && r < r1) {
         oimg[3 * p] = y[0]; oimg[3 * p + 1] = y[1]; oimg[3 * p + 2] = y[2];
       }
     }
-    const bool black = ((y[0] + y[1]) + y[2]) / 3.0f == 0.f;
+    const bool black = ((y[0] + y[1]) + y[2]) == 0.f;       // mean_c == 0  <=>  sum_c == 0
     if (out_lane && r >= r0 && r < r1 && !black)
       acc_l1 += (fabsf(y[0] - x[0]) + fabsf(y[1] - x[1])) + fabsf(y[2] - x[2]);
 #pragma unroll
@@ -139,13 +178,14 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
       cur[12 + c] = hsum3(x[c] * y[c]);
     }
     const int rc = r - 1;                          // centre row of the window (m2, m1, cur)
-    if (out_lane && rc >= r0 && rc < r1 && !black_prev) {
-      const float cnt_r = (float)((rc > 0 ? 1 : 0) + 1 + (rc < d.h - 1 ? 1 : 0));
-      const float ic = 1.0f / (cnt_r * cnt_c);
+    if (rc >= r0 && rc < r1) {
+      const float ic = window_rcp(rc, d.h, cnt_c);
+      float sum = 0.f;
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        acc_ss += ssim_loss(m2[c] + m1[c] + cur[c], m2[3 + c] + m1[3 + c] + cur[3 + c], m2[6 + c] + m1[6 + c] + cur[6 + c],
-                            m2[9 + c] + m1[9 + c] + cur[9 + c], m2[12 + c] + m1[12 + c] + cur[12 + c], ic);
+        sum += ssim_loss(m2[c] + m1[c] + cur[c], m2[3 + c] + m1[3 + c] + cur[3 + c], m2[6 + c] + m1[6 + c] + cur[6 + c],
+                         m2[9 + c] + m1[9 + c] + cur[9 + c], m2[12 + c] + m1[12 + c] + cur[12 + c], ic);
+      if (out_lane && !black_prev) acc_ss += sum;
     }
     black_prev = black;
   };
@@ -163,8 +203,9 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
   acc_l1 = wave_sum_all(acc_l1);
   acc_ss = wave_sum_all(acc_ss);
   if (lane == 0) {
-    part[2 * gw] = acc_l1;
-    part[2 * gw + 1] = acc_ss;
+    const long long gw = ((long long)(job.b * d.S + job.s) * d.CH + job.ck) * d.N + job.n;
+    part[16 * gw] = acc_l1;
+    part[16 * gw + 1] = acc_ss;
   }
 }
 
@@ -172,9 +213,9 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
 __global__ void fused_reduce_kernel(const float* __restrict__ part, float* __restrict__ loss_l1,
                                     float* __restrict__ loss_ssim, int waves_per_b, float inv_count) {
   const int b = blockIdx.x, t = threadIdx.x;
-  const float* q = part + (long long)b * waves_per_b * 2;
+  const float* q = part + (long long)b * waves_per_b * 16;
   float s0 = 0.f, s1 = 0.f;
-  for (int k = t; k < waves_per_b; k += 64) { s0 += q[2 * k]; s1 += q[2 * k + 1]; }
+  for (int k = t; k < waves_per_b; k += 64) { s0 += q[16 * k]; s1 += q[16 * k + 1]; }
   s0 = wave_sum_all(s0);
   s1 = wave_sum_all(s1);
   if (t == 0) { loss_l1[b] = s0 * inv_count; loss_ssim[b] = s1 * inv_count; }
@@ -186,10 +227,8 @@ __global__ void fused_reduce_kernel(const float* __restrict__ part, float* __res
 //                                          ( dssim/dmu_y, dssim/dE[yy], dssim/dE[xy] )
 // The second 3x3 box sum reuses the same DPP + sliding-row scheme one row later, so the march has three stages per
 // step: A = synthesize row r, B = coefficients of centre row r-1, C = pixel gradients of row r-2.
-#define STRIP_B 60        // output columns per wave in the backward (two halo lanes on each side)
-
 struct RowState {
-  float tap[12];          // the four bilinear taps (ff, fc, cf, cc) x RGB
+  float gu[3], gv[3];     // d y_c / d u', d y_c / d v'   (from the taps and weights of stage A, already masked)
   float x[3], y[3];
   float d;
   bool black;
@@ -201,12 +240,13 @@ __device__ inline void ssim_coeffs(float Sx, float Sy, float Sxx, float Syy, flo
   const float sx = Sxx * ic - mux * mux, sy = Syy * ic - muy * muy, sxy = Sxy * ic - mux * muy;
   const float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sxy + SSIM_C2;
   const float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sx + sy + SSIM_C2;
-  const float inv12 = 1.0f / (d1 * d2);
+  const float i1 = rcpf(d1), i2 = rcpf(d2);
+  const float inv12 = i1 * i2;
   const float ssim = n1 * n2 * inv12;
   const float val = (1.f - ssim) * 0.5f;
-  float gg = (val >= 0.f && val <= 1.f) ? g * (-0.5f) * ic : 0.f;      // clip_by_value gradient, pooling divisor
-  A = gg * (2.f * mux * (n2 - n1) * inv12 - 2.f * muy * ssim * (1.0f / d1 - 1.0f / d2));
-  Bq = gg * (-ssim / d2);
+  const float gg = (val >= 0.f && val <= 1.f) ? g * (-0.5f) * ic : 0.f;      // clip_by_value gradient, pooling divisor
+  A = gg * (2.f * mux * (n2 - n1) * inv12 - 2.f * muy * ssim * (i1 - i2));
+  Bq = gg * (-ssim * i2);
   Cq = gg * (2.f * n1 * inv12);
 }
 
@@ -220,28 +260,26 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
                                                         float* __restrict__ ddepth, float* __restrict__ part,
                                                         FusedDims d, float inv_count) {
   __shared__ float lds_dd[4][64];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const long long gw = (long long)blockIdx.x * 4 + wid;
-  const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
-  if (gw >= nwaves) return;                 // MODE 0: nwaves % 4 == 0, whole workgroups leave together
-  const int n = (int)(gw % d.N);
-  long long r_ = gw / d.N;
-  const int ck = (int)(r_ % d.CH); r_ /= d.CH;
-  const int s = (int)(r_ % d.S);
-  const int b = (int)(r_ / d.S);
+  const WaveJob job = wave_job(d);
+  if (!job.valid) return;                   // MODE 0: nwaves % 4 == 0, whole workgroups leave together
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int P = d.h * d.w;
-  const int col = s * STRIP_B - 2 + lane;
+  const int col = job.s * STRIP_B - 2 + lane;
   const bool col_in = (col >= 0) && (col < d.w);
   const bool out_lane = (lane >= 2) && (lane < 2 + STRIP_B) && col_in;
-  const int r0 = ck * d.R, r1 = min(r0 + d.R, d.h);
-  const Cam cam = load_cam(K + 9 * b, d.scale);
-  const Pose pose = load_pose(T + 16 * ((long long)b * d.N + n));
-  const float* simg = src + ((long long)b * d.N + n) * P * 3;
-  const float* dimg = depth + (long long)b * P;
-  const float* timg = target + (long long)b * P * 3;
-  float* gimg = ddepth + (long long)b * P;
+  const int r0 = job.ck * d.R, r1 = min(r0 + d.R, d.h);
+  const Cam cam = load_cam(K + 9 * job.b, d.scale);
+  const Pose pose = load_pose(T + 16 * (job.b * d.N + job.n));
+  const float* simg = src + (long long)(job.b * d.N + job.n) * P * 3;
+  const float* dimg = depth + (long long)job.b * P;
+  const float* timg = target + (long long)job.b * P * 3;
+  float* gimg = ddepth + (long long)job.b * P;
   const float cnt_c = (float)((col > 0 ? 1 : 0) + 1 + (col < d.w - 1 ? 1 : 0));
-  const float gl1 = g_l1[b] * inv_count, gss = g_ssim[b] * inv_count;
+  const float gl1 = g_l1[job.b] * inv_count, gss = g_ssim[job.b] * inv_count;
+  float ray_c[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ray_c[i] = cam.ki[3 * i] * (float)col + cam.ki[3 * i + 2];
 
   float dRt[12];
 #pragma unroll
@@ -254,9 +292,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
   for (int i = 0; i < 9; ++i) { cA[i] = 0.f; cB[i] = 0.f; cC[i] = 0.f; }
   auto clear_state = [](RowState& st) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) st.tap[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { st.x[i] = 0.f; st.y[i] = 0.f; }
+    for (int i = 0; i < 3; ++i) { st.gu[i] = 0.f; st.gv[i] = 0.f; st.x[i] = 0.f; st.y[i] = 0.f; }
     st.d = 0.f;
     st.black = true;
   };
@@ -265,27 +301,30 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
   auto body = [&](int r, RowState& scur, const RowState& sm1, const RowState& sm2, float (&hcur)[15],
                   const float (&hm1)[15], const float (&hm2)[15], float (&ccur)[9], const float (&cm1)[9],
                   const float (&cm2)[9]) {
-    // ---- stage A: synthesize row r
+    // ---- stage A: synthesize row r; keep y and its derivatives w.r.t. the sampling position
     clear_state(scur);
     if (r >= 0 && r < d.h && col_in) {
-      const long long p = (long long)r * d.w + col;
+      const int p = r * d.w + col;
       scur.d = dimg[p];
       scur.x[0] = timg[3 * p]; scur.x[1] = timg[3 * p + 1]; scur.x[2] = timg[3 * p + 2];
       Warp wp;
-      backproject(cam, (float)col, (float)r, scur.d, wp);
-      project(cam, pose, wp);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        wp.ray[i] = ray_c[i] + cam.ki[3 * i + 1] * (float)r;
+        wp.X[i] = wp.ray[i] * scur.d;
+      }
+      project_fast(cam, pose, wp);
       const Taps t = make_taps(wp.up, wp.vp, d.h, d.w, scur.d != 0.f);
-      const float* pff = simg + ((long long)t.vf * d.w + t.uf) * 3;
-      const float* pfc = simg + ((long long)t.vc * d.w + t.uf) * 3;
-      const float* pcf = simg + ((long long)t.vf * d.w + t.uc) * 3;
-      const float* pcc = simg + ((long long)t.vc * d.w + t.uc) * 3;
+      float tap[12];
+      load_taps(simg, d.w, t, tap);
       const float wff = t.wuf * t.wvf, wfc = t.wuf * t.wvc, wcf = t.wuc * t.wvf, wcc = t.wuc * t.wvc;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        scur.tap[c] = pff[c]; scur.tap[3 + c] = pfc[c]; scur.tap[6 + c] = pcf[c]; scur.tap[9 + c] = pcc[c];
-        scur.y[c] = ((scur.tap[c] * wff + scur.tap[3 + c] * wfc) + scur.tap[6 + c] * wcf) + scur.tap[9 + c] * wcc;
+        scur.y[c] = ((tap[c] * wff + tap[3 + c] * wfc) + tap[6 + c] * wcf) + tap[9 + c] * wcc;
+        scur.gu[c] = ((tap[6 + c] - tap[c]) * t.wvf + (tap[9 + c] - tap[3 + c]) * t.wvc) * t.mask;
+        scur.gv[c] = ((tap[3 + c] - tap[c]) * t.wuf + (tap[9 + c] - tap[6 + c]) * t.wuc) * t.mask;
       }
-      scur.black = ((scur.y[0] + scur.y[1]) + scur.y[2]) / 3.0f == 0.f;
+      scur.black = ((scur.y[0] + scur.y[1]) + scur.y[2]) == 0.f;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -301,72 +340,69 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
       float co[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) co[i] = 0.f;
-      if (p >= 0 && p < d.h && col_in && !sm1.black) {
-        const float cnt_r = (float)((p > 0 ? 1 : 0) + 1 + (p < d.h - 1 ? 1 : 0));
-        const float ic = 1.0f / (cnt_r * cnt_c);
+      if (p >= 0 && p < d.h) {                        // wave-uniform
+        const float ic = window_rcp(p, d.h, cnt_c);
+        const float g = (col_in && !sm1.black) ? gss : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
           ssim_coeffs(hm2[c] + hm1[c] + hcur[c], hm2[3 + c] + hm1[3 + c] + hcur[3 + c],
                       hm2[6 + c] + hm1[6 + c] + hcur[6 + c], hm2[9 + c] + hm1[9 + c] + hcur[9 + c],
-                      hm2[12 + c] + hm1[12 + c] + hcur[12 + c], ic, gss, co[c], co[3 + c], co[6 + c]);
+                      hm2[12 + c] + hm1[12 + c] + hcur[12 + c], ic, g, co[c], co[3 + c], co[6 + c]);
       }
 #pragma unroll
       for (int i = 0; i < 9; ++i) ccur[i] = hsum3(co[i]);
     }
     // ---- stage C: gradient of pixel (q = r-2, col) (state sm2); window rows q-1, q, q+1 = cm2, cm1, ccur
     const int q = r - 2;
-    float dd = 0.f;
-    const bool emit = (q >= r0) && (q < r1);
-    if (emit && out_lane) {
-      float g[3];
+    const bool emit = (q >= r0) && (q < r1);          // wave-uniform
+    if (emit) {
+      float dd = 0.f;
+      if (out_lane) {
+        float du = 0.f, dv = 0.f;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float SA = cm2[c] + cm1[c] + ccur[c];
-        const float SB = cm2[3 + c] + cm1[3 + c] + ccur[3 + c];
-        const float SC = cm2[6 + c] + cm1[6 + c] + ccur[6 + c];
-        const float df = sm2.y[c] - sm2.x[c];
-        const float sg = sm2.black ? 0.f : ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));
-        g[c] = gl1 * sg + SA + 2.f * SB * sm2.y[c] + SC * sm2.x[c];
+        for (int c = 0; c < 3; ++c) {
+          const float SA = cm2[c] + cm1[c] + ccur[c];
+          const float SB = cm2[3 + c] + cm1[3 + c] + ccur[3 + c];
+          const float SC = cm2[6 + c] + cm1[6 + c] + ccur[6 + c];
+          const float df = sm2.y[c] - sm2.x[c];
+          const float sg = sm2.black ? 0.f : ((df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f));
+          const float g = gl1 * sg + SA + 2.f * SB * sm2.y[c] + SC * sm2.x[c];
+          du += g * sm2.gu[c];
+          dv += g * sm2.gv[c];
+        }
+        Warp wp;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          wp.ray[i] = ray_c[i] + cam.ki[3 * i + 1] * (float)q;
+          wp.X[i] = wp.ray[i] * sm2.d;
+        }
+        project_fast(cam, pose, wp);
+        const float dq0 = du * wp.zinv, dq1 = dv * wp.zinv;
+        const float dq2 = -(du * wp.up + dv * wp.vp) * wp.zinv;
+        float dXs[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dXs[j] = cam.k[j] * dq0 + cam.k[3 + j] * dq1 + cam.k[6 + j] * dq2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          dRt[4 * i + 0] += dXs[i] * wp.X[0];
+          dRt[4 * i + 1] += dXs[i] * wp.X[1];
+          dRt[4 * i + 2] += dXs[i] * wp.X[2];
+          dRt[4 * i + 3] += dXs[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          dd += (pose.r[j] * dXs[0] + pose.r[3 + j] * dXs[1] + pose.r[6 + j] * dXs[2]) * wp.ray[j];
       }
-      Warp wp;
-      backproject(cam, (float)col, (float)q, sm2.d, wp);
-      project(cam, pose, wp);
-      const Taps t = make_taps(wp.up, wp.vp, d.h, d.w, sm2.d != 0.f);
-      float du = 0.f, dv = 0.f;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        du += g[c] * ((sm2.tap[6 + c] - sm2.tap[c]) * t.wvf + (sm2.tap[9 + c] - sm2.tap[3 + c]) * t.wvc);
-        dv += g[c] * ((sm2.tap[3 + c] - sm2.tap[c]) * t.wuf + (sm2.tap[9 + c] - sm2.tap[6 + c]) * t.wuc);
-      }
-      du *= t.mask;
-      dv *= t.mask;
-      const float dq0 = du * wp.zinv, dq1 = dv * wp.zinv;
-      const float dq2 = -(du * wp.up + dv * wp.vp) * wp.zinv;
-      float dXs[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) dXs[j] = cam.k[j] * dq0 + cam.k[3 + j] * dq1 + cam.k[6 + j] * dq2;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        dRt[4 * i + 0] += dXs[i] * wp.X[0];
-        dRt[4 * i + 1] += dXs[i] * wp.X[1];
-        dRt[4 * i + 2] += dXs[i] * wp.X[2];
-        dRt[4 * i + 3] += dXs[i];
-      }
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-        dd += (pose.r[j] * dXs[0] + pose.r[3 + j] * dXs[1] + pose.r[6 + j] * dXs[2]) * wp.ray[j];
-    }
-    if (emit) {                                   // wave-uniform: every wave of the workgroup shares (r0, r1) in MODE 0
-      if (MODE == 0) {
+      if (MODE == 0) {                                // every wave of the workgroup shares (r0, r1, strip)
         lds_dd[wid][lane] = dd;
         __syncthreads();
         if (wid == 0 && out_lane)
-          gimg[(long long)q * d.w + col] = ((lds_dd[0][lane] + lds_dd[1][lane]) + lds_dd[2][lane]) + lds_dd[3][lane];
+          gimg[q * d.w + col] = ((lds_dd[0][lane] + lds_dd[1][lane]) + lds_dd[2][lane]) + lds_dd[3][lane];
         __syncthreads();
       } else if (MODE == 1) {
-        if (out_lane) gimg[(long long)q * d.w + col] = dd;
+        if (out_lane) gimg[q * d.w + col] = dd;
       } else {
-        if (out_lane) atomicAdd(gimg + (long long)q * d.w + col, dd);
+        if (out_lane) atomicAdd(gimg + q * d.w + col, dd);
       }
     }
   };
@@ -380,6 +416,7 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
     if (r > rend) break;
     body(r, sC, sB, sA, hC, hB, hA, cC, cB, cA); ++r;
   }
+  const long long gw = ((long long)(job.b * d.S + job.s) * d.CH + job.ck) * d.N + job.n;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     const float v = wave_sum_all(dRt[i]);
@@ -415,9 +452,9 @@ inline FusedDims make_dims(int B, int N, int h, int w, float scale, int rows_per
 
 // Rows per chunk: enough waves to cover 256 CUs x 4 SIMDs a few times over, as few halo rows as possible.
 inline int pick_rows(int B, int N, int h, int w) {
-  const long long strips = (long long)B * N * ((w + STRIP - 1) / STRIP);
+  const long long strips = (long long)B * N * ((w + STRIP_B - 1) / STRIP_B);
   int R = 32;
-  while (R > 4 && strips * ((h + R - 1) / R) < 4096) R >>= 1;
+  while (R > 8 && strips * ((h + R - 1) / R) < 4096) R >>= 1;
   return R;
 }
 
@@ -436,7 +473,7 @@ int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, co
                         int B, int N, int h, int w, float scale, void* stream) {
   XPT_CHECK_PTR(src); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(T); XPT_CHECK_PTR(K); XPT_CHECK_PTR(target);
   XPT_CHECK_PTR(loss_l1); XPT_CHECK_PTR(loss_ssim); XPT_CHECK_PTR(workspace);
-  if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f)) return XPT_ERR_SHAPE;
+  if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f) || (long long)h * w * 3 >= (1LL << 31)) return XPT_ERR_SHAPE;
   if (workspace_floats < xpt_photo_fused_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
   const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w), STRIP);
   const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
@@ -457,7 +494,7 @@ int xpt_photo_fused_bwd(const float* src, const float* depth, const float* T, co
                         size_t workspace_floats, int B, int N, int h, int w, float scale, void* stream) {
   XPT_CHECK_PTR(src); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(T); XPT_CHECK_PTR(K); XPT_CHECK_PTR(target);
   XPT_CHECK_PTR(g_l1); XPT_CHECK_PTR(g_ssim); XPT_CHECK_PTR(ddepth); XPT_CHECK_PTR(dT); XPT_CHECK_PTR(workspace);
-  if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f)) return XPT_ERR_SHAPE;
+  if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f) || (long long)h * w * 3 >= (1LL << 31)) return XPT_ERR_SHAPE;
   if (workspace_floats < xpt_photo_fused_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
   const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w), STRIP_B);
   const long long nwaves = (long long)d.B * d.S * d.CH * d.N;

@@ -29,6 +29,16 @@ class TotalLoss:
         self.loss_weights = loss_weights
         self.stereo = stereo
         self.batch_size = batch_size
+        self.fused = None              # None = decide per call from opts.FUSED_LOSS; True / False forces it
+
+    def use_fused(self, tensor):
+        """The fused warp+L1+SSIM march kernel replaces `synthesize -> photometric_loss_l1/_ssim` when every consumer
+        of the synthesized views is one of those two reduce=True losses (L1 / SSIM / stereoL1 / stereoSSIM); the
+        min-over-sources variants (md2*, moa*) need the images themselves and keep the unfused path."""
+        want = bool(opts.FUSED_LOSS) if self.fused is None else bool(self.fused)
+        plain = all(isinstance(o, (PhotometricLossMultiScale, StereoDepthLoss)) and o.method in ("L1", "SSIM")
+                    for o in (self.loss_objects or {}).values() if isinstance(o, PhotometricLoss))
+        return want and plain and tensor.is_cuda
 
     def __call__(self, predictions, features):
         """
@@ -61,9 +71,14 @@ class TotalLoss:
         if ("depth_ms" + suffix in predictions) and ("pose" + suffix in predictions):
             pred_depth_ms = predictions["depth_ms" + suffix]
             pred_pose = predictions["pose" + suffix]
-            augm_data["target_ms" + suffix] = uf.multi_scale_like_depth(target_image, pred_depth_ms)
-            augm_data["synth_target_ms" + suffix] = SynthesizeMultiScale()(source_image, intrinsic,
-                                                                            pred_depth_ms, pred_pose)
+            target_ms = uf.multi_scale_like_depth(target_image, pred_depth_ms)
+            augm_data["target_ms" + suffix] = target_ms
+            if self.use_fused(image5d):
+                augm_data["fused_photo_ms" + suffix] = SynthesizeMultiScale().photometric_losses(
+                    source_image, intrinsic, pred_depth_ms, pred_pose, target_ms)
+            else:
+                augm_data["synth_target_ms" + suffix] = SynthesizeMultiScale()(source_image, intrinsic,
+                                                                                pred_depth_ms, pred_pose)
         return augm_data
 
     def synethesize_stereo(self, features, predictions, augm_data):
@@ -73,11 +88,18 @@ class TotalLoss:
             return synth_stereo
         # left image from the right image: points move left -> right with inv(T_LR)
         pose_T_RL = cp.pose_matr2rvec_batch(torch.linalg.inv(features["stereo_T_LR"]).unsqueeze(1))
-        synth_stereo["stereo_synth_ms"] = SynthesizeMultiScale()(
-            augm_data["target_R"].unsqueeze(1), features["intrinsic"], predictions["depth_ms"], pose_T_RL)
         pose_T_LR = cp.pose_matr2rvec_batch(features["stereo_T_LR"].unsqueeze(1))
-        synth_stereo["stereo_synth_ms_R"] = SynthesizeMultiScale()(
-            augm_data["target"].unsqueeze(1), features["intrinsic"], predictions["depth_ms_R"], pose_T_LR)
+        left_src, right_src = augm_data["target_R"].unsqueeze(1), augm_data["target"].unsqueeze(1)
+        if self.use_fused(left_src):
+            synth_stereo["fused_stereo_ms"] = SynthesizeMultiScale().photometric_losses(
+                left_src, features["intrinsic"], predictions["depth_ms"], pose_T_RL, augm_data["target_ms"])
+            synth_stereo["fused_stereo_ms_R"] = SynthesizeMultiScale().photometric_losses(
+                right_src, features["intrinsic"], predictions["depth_ms_R"], pose_T_LR, augm_data["target_ms_R"])
+            return synth_stereo
+        synth_stereo["stereo_synth_ms"] = SynthesizeMultiScale()(left_src, features["intrinsic"],
+                                                                 predictions["depth_ms"], pose_T_RL)
+        synth_stereo["stereo_synth_ms_R"] = SynthesizeMultiScale()(right_src, features["intrinsic"],
+                                                                   predictions["depth_ms_R"], pose_T_LR)
         return synth_stereo
 
 
@@ -111,6 +133,9 @@ class PhotometricLoss(LossBase):
 class PhotometricLossMultiScale(PhotometricLoss):
     def __call__(self, features, predictions, augm_data):
         """losses.py:179-195 -> photo_loss [batch, 1]"""
+        fused = augm_data.get("fused_photo_ms" + self.key_suffix)
+        if fused is not None:           # (l1, ssim) per scale from the fused march kernel
+            return self.merge_multi_scale_losses([pair[0 if self.method == "L1" else 1] for pair in fused])
         target_ms = augm_data["target_ms" + self.key_suffix]
         synth_ms = augm_data["synth_target_ms" + self.key_suffix]
         losses = [self.photometric_loss(synt, orig) for synt, orig in zip(synth_ms, target_ms)]
@@ -183,6 +208,11 @@ class StereoDepthLoss(PhotometricLoss):
 
     def __call__(self, features, predictions, augm_data):
         """losses.py:447-478: left-from-right + right-from-left photometric loss per scale."""
+        if "fused_stereo_ms" in augm_data:
+            k = 0 if self.method == "L1" else 1
+            left = [pair[k] for pair in augm_data["fused_stereo_ms"]]
+            right = [pair[k] for pair in augm_data["fused_stereo_ms_R"]]
+            return self.merge_multi_scale_losses([l + r for l, r in zip(left, right)])
         left = self.stereo_photometric_loss(augm_data["stereo_synth_ms"], augm_data["target_ms"])
         right = self.stereo_photometric_loss(augm_data["stereo_synth_ms_R"], augm_data["target_ms_R"], "_R")
         return self.merge_multi_scale_losses([l + r for l, r in zip(left, right)])

@@ -17,6 +17,13 @@ class SynthesizeMultiScale:
         poses_matr = pose_rvec2matr_batch_tf(pred_pose)
         return [SynthesizeSingleScale()(source_image, intrinsic, depth_sc, poses_matr) for depth_sc in pred_depth_ms]
 
+    def photometric_losses(self, source_image, intrinsic, pred_depth_ms, pred_pose, target_ms):
+        """Fused fast path: per scale (photometric L1 [batch], photometric SSIM [batch]) of the synthesized views
+        against target_ms, computed by the warp+L1+SSIM march kernel without materialising the views."""
+        poses_matr = pose_rvec2matr_batch_tf(pred_pose)
+        return [SynthesizeSingleScale().photometric_losses(source_image, intrinsic, depth_sc, poses_matr, target_sc)
+                for depth_sc, target_sc in zip(pred_depth_ms, target_ms)]
+
 
 class SynthesizeSingleScale:
     def __init__(self, shape=(0, 0, 0), numsrc=0, scale=0):
@@ -32,6 +39,14 @@ class SynthesizeSingleScale:
         self.read_shape(source_image, depth_sc)
         source_images_sc = self.resize_source_images(source_image)
         return _ops.warp(source_images_sc, depth_sc, poses_matr, intrinsic, self.scale)
+
+    def photometric_losses(self, source_image, intrinsic, depth_sc, poses_matr, target_sc):
+        """Fused fast path (no reference counterpart as ONE call): photometric_loss_l1 and photometric_loss_ssim
+        (loss_util.py:6-25, 52-96) of the view this object would synthesize, WITHOUT writing the synthesized image:
+        -> (l1 [batch], ssim [batch]).  Same arguments as __call__ plus the scaled target [batch, h, w, 3]."""
+        self.read_shape(source_image, depth_sc)
+        source_images_sc = self.resize_source_images(source_image)
+        return _ops.photo_fused(source_images_sc, depth_sc, poses_matr, intrinsic, target_sc, self.scale)
 
     def read_shape(self, source_image, depth_sc):
         _, self.numsrc, height_orig, _, _ = source_image.shape
