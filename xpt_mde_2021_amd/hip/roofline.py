@@ -76,6 +76,21 @@ def measure_fused(ops, feats, repeats, batch=None):
             {"B": B, "N": N, "h": H, "w": W})
 
 
+def _pmc_traffic(kernel, shape):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE runs with the gfx950 x2 FETCH_SIZE correction); None when no pass exists for this shape."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles",
+                        "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        return table[kernel]["{B}x{N}x{h}x{w}".format(**shape)]["bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
     """bench.py's `roofline` object: the fused forward kernel at the step's own shape (dominant hand-written kernel of
     the loss path), plus the backward, the unfused kernels and a large-batch point that no longer fits the 256 MiB
@@ -94,13 +109,14 @@ def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
     extra["fused_bwd_kernel"] = (b_ms, b_bytes)
     lf_ms, lb_ms, lf_bytes, lb_bytes, lshape = measure_fused(ops, feats, max(repeats // 5, 5), batch=large_batch)
     achieved = f_bytes / (f_ms * 1e-3) / 1e9
+    traffic = _pmc_traffic("fused_fwd_kernel<false>", shape)
 
     def gbs(ms_, nbytes):
         return round(nbytes / (ms_ * 1e-3) / 1e9, 2)
 
     return {"bound": "hbm", "kernel": "fused_fwd_kernel<false> (warp + L1 + SSIM, scale 1)",
             "achieved": round(achieved, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(achieved / hbm_peak_gbs, 4),
-            "traffic": None, "launch_us": round(f_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(f_bytes),
+            "traffic": traffic, "launch_us": round(f_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(f_bytes),
             "bytes_per_warped_pixel": round(f_bytes / (B * N * P), 3), "shape": shape,
             "all": {k: {"launch_us": round(v[0] * 1e3, 3), "GBps": gbs(*v)} for k, v in extra.items()},
             "large_batch": {"shape": lshape,
