@@ -29,7 +29,7 @@ def build(force=False, verbose=True, extra_flags=()):
         raise RuntimeError("hipcc not found: cannot build libxpt_hip.so")
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc, "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function",
+    cmd = [hipcc, "-O3", "-fno-slp-vectorize", f"--offload-arch={ARCH}", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function",
            "-o", OUT] + list(extra_flags) + sources()
     if verbose:
         print("[xpt build]", " ".join(cmd), flush=True)
