@@ -139,9 +139,12 @@ int xpt_smooth_bwd(const float* disp, const float* image, const float* gloss, fl
  * model/train_val.py:86) over FLAT fp32 buffers of n elements (16-byte aligned):
  *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m/(sqrt(v)+eps)
  *   g is first multiplied by grad_scale; `step` is a DEVICE pointer to the float step count t >= 1
- *   (so the launch can be replayed from a hipGraph); zero_grad != 0 clears g in the same pass. */
+ *   (so the launch can be replayed from a hipGraph); zero_grad != 0 clears g in the same pass;
+ *   shadow_bf16 (may be NULL): n bfloat16 values that receive a bf16 copy of the updated parameters (the operands
+ *   of the bf16 convolutions / GEMMs -- no per-layer cast launches in the forward pass). */
 int xpt_adam_step(float* param, float* grad, float* m, float* v, long long n, const float* step, float lr,
-                  float beta1, float beta2, float eps, float grad_scale, int zero_grad, void* stream);
+                  float beta1, float beta2, float eps, float grad_scale, int zero_grad, void* shadow_bf16,
+                  void* stream);
 
 /* ------------------------------------------------------------------ a2: depthwise convolution (NASNet separable convs)
  * replaces the depthwise half of every keras SeparableConv2D(use_bias=False) inside

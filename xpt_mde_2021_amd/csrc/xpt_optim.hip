@@ -4,11 +4,14 @@
 //   lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
 //   p -= lr_t * m / (sqrt(v) + eps)           with eps = 1e-7 applied to the UNcorrected sqrt(v).
 // One pass over 4 streams (p, g, m, v): 28 B / parameter, float4 accesses, HBM-bound.
+#include <hip/hip_bf16.h>
+
 #include "xpt_common.h"
 
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, const float* __restrict__ step_ptr, float lr,
-                            float b1, float b2, float eps, float grad_scale, int zero_grad) {
+                            float b1, float b2, float eps, float grad_scale, int zero_grad,
+                            __hip_bfloat16* __restrict__ shadow) {
   const float t = step_ptr[0];
   const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
   const long long n4 = n >> 2;
@@ -29,6 +32,10 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
     }
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
     if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (shadow) {                      // bf16 copy of the updated weights for the bf16 convolutions / GEMMs
+#pragma unroll
+      for (int k = 0; k < 4; ++k) shadow[4 * i + k] = __float2bfloat16(pa[k]);
+    }
   }
   // tail (n not a multiple of 4)
   for (long long i = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -38,12 +45,13 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
     m[i] = mk; v[i] = vk;
     p[i] -= lr_t * mk / (sqrtf(vk) + eps);
     if (zero_grad) g[i] = 0.f;
+    if (shadow) shadow[i] = __float2bfloat16(p[i]);
   }
 }
 
 extern "C" int xpt_adam_step(float* param, float* grad, float* m, float* v, long long n, const float* step,
                              float lr, float beta1, float beta2, float eps, float grad_scale, int zero_grad,
-                             void* stream) {
+                             void* shadow_bf16, void* stream) {
   XPT_CHECK_PTR(param); XPT_CHECK_PTR(grad); XPT_CHECK_PTR(m); XPT_CHECK_PTR(v); XPT_CHECK_PTR(step);
   if (n <= 0) return XPT_ERR_SHAPE;
   if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return XPT_ERR_ARG;
@@ -52,6 +60,6 @@ extern "C" int xpt_adam_step(float* param, float* grad, float* m, float* v, long
   if (blocks < 1) blocks = 1;
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n,
-                     step, lr, beta1, beta2, eps, grad_scale, zero_grad);
+                     step, lr, beta1, beta2, eps, grad_scale, zero_grad, (__hip_bfloat16*)shadow_bf16);
   return xpt_launch_status();
 }

@@ -43,7 +43,7 @@ SIGNATURES = {
     "xpt_smooth_workspace_floats": (_z, [_i, _i, _i]),
     "xpt_smooth_fwd": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _f, _i, _p]),
     "xpt_smooth_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
-    "xpt_adam_step": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _f, _f, _f, _f, _f, _i, _p]),
+    "xpt_adam_step": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _f, _f, _f, _f, _f, _i, _p, _p]),
     "xpt_dwconv_fwd": (_i, [_p, _p, _p] + [_i] * 12 + [_p]),
     "xpt_dwconv_bwd_data": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p]),
     "xpt_dwconv_bwd_weight_workspace_floats": (_z, [_i] * 5),

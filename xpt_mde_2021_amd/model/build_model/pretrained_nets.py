@@ -44,12 +44,42 @@ class FrozenBatchNorm(nn.Module):
         return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, BN_EPS)
 
 
+class _Conv1x1Bf16(torch.autograd.Function):
+    """1x1 convolution as GEMMs on the bf16 shadow copy of the weight (kept current by the fused Adam kernel):
+    y = x W^T and dx = dy W in bf16, dW = dy^T x accumulated AND written in fp32 (mm out_dtype) -- no cast launches."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        ws = weight.shadow_bf16.reshape(cout, cin)
+        x2 = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, cin)
+        y2 = torch.mm(x2, ws.t())
+        ctx.save_for_backward(x2, ws)
+        ctx.dims = (B, cin, H, W, cout, weight.shape)
+        return y2.view(B, H, W, cout).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, ws = ctx.saved_tensors
+        B, cin, H, W, cout, wshape = ctx.dims
+        dy2 = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, cout)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, ws).view(B, H, W, cin).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = torch.mm(dy2.t(), x2, out_dtype=torch.float32).view(wshape)
+        return dx, dw
+
+
 def conv1x1(x, weight):
     """1x1 convolution (no bias) of an NCHW-indexed tensor.  On the GPU the channels_last tensor IS a row-major
-    [B*H*W, Cin] matrix, so the convolution is one GEMM (rocBLAS / hipBLASLt on MFMA) on a zero-copy view and its
-    weight gradient one more GEMM -- no MIOpen convolution (nor its zero / cast helper launches) involved."""
+    [B*H*W, Cin] matrix, so the convolution is one GEMM (rocBLAS on MFMA) on a zero-copy view and its weight
+    gradient one more GEMM -- no MIOpen convolution (nor its zero / cast helper launches) involved."""
     if not x.is_cuda:
         return F.conv2d(x, weight)
+    if x.dtype == torch.bfloat16 and hasattr(weight, "shadow_bf16") and torch.is_autocast_enabled():
+        return _Conv1x1Bf16.apply(x, weight)
     xv = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)            # [B,H,W,Cin] view
     y = F.linear(xv, weight.reshape(weight.shape[0], weight.shape[1]))                  # [B,H,W,Cout]
     return y.permute(0, 3, 1, 2)                                                        # NCHW-indexed, channels_last

@@ -40,7 +40,7 @@ class _ConvFp32WeightGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride, padding, compute_dtype):
-        w = weight.to(compute_dtype)
+        w = _low_precision_weight(weight, compute_dtype)
         xc = x.to(compute_dtype)
         with torch.autocast(device_type=x.device.type, enabled=False):
             y = F.conv2d(xc, w, None, stride, padding)
@@ -56,12 +56,21 @@ class _ConvFp32WeightGrad(torch.autograd.Function):
         dx = dw = None
         with torch.autocast(device_type=dy.device.type, enabled=False):
             if ctx.needs_input_grad[0]:
-                dx = torch.ops.aten.convolution_backward(dy.to(compute_dtype), xc, weight.to(compute_dtype), None, s2, p2,
+                dx = torch.ops.aten.convolution_backward(dy.to(compute_dtype), xc,
+                                                         _low_precision_weight(weight, compute_dtype), None, s2, p2,
                                                          [1, 1], False, [0, 0], 1, [True, False, False])[0]
             if ctx.needs_input_grad[1]:
                 dw = torch.ops.aten.convolution_backward(dy.float(), xc.float(), weight.float(), None, s2, p2, [1, 1],
                                                          False, [0, 0], 1, [False, True, False])[1]
         return dx, dw, None, None, None
+
+
+def _low_precision_weight(weight, dtype):
+    """bf16 view of the weight: the shadow copy the fused Adam kernel keeps current (no cast launch) when there is one."""
+    shadow = getattr(weight, "shadow_bf16", None)
+    if shadow is not None and dtype == torch.bfloat16:
+        return shadow
+    return weight.to(dtype)
 
 
 def conv2d_library(x, weight, stride, padding):

@@ -30,12 +30,19 @@ class FlatParameters:
         self.data = torch.zeros(total, dtype=dtype, device=dev)
         self.grad = torch.zeros(total, dtype=dtype, device=dev)
         self.grad_views = []
+        # bf16 copy of every weight, refreshed by the fused Adam kernel: the bf16 GEMMs / convolutions read it directly
+        # instead of launching one fp32->bf16 cast per layer and step (and one bf16->fp32 cast per gradient)
+        self.shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
         for p, off in zip(params, offsets):
             dview, gview = self._view(self.data, p, off), self._view(self.grad, p, off)
             dview.copy_(p.data)
             p.data = dview
             p.grad = None            # autograd then hands over ("steals") each gradient tensor without an add kernel
             self.grad_views.append(gview)
+            if self.shadow is not None:
+                p.shadow_bf16 = self._view(self.shadow, p, off)
+        if self.shadow is not None:
+            self.shadow.copy_(self.data)
         self.offsets = offsets
 
     def gather_grads(self):
@@ -88,7 +95,9 @@ class KerasAdam:
             lib = _lib.load()
             _lib.check(lib.xpt_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                          f.numel, self.step_count.data_ptr(), self.lr, self.b1, self.b2, self.eps,
-                                         float(grad_scale), int(zero_grad), torch.cuda.current_stream().cuda_stream),
+                                         float(grad_scale), int(zero_grad),
+                                         None if f.shadow is None else f.shadow.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream),
                        "xpt_adam_step")
             return
         # host tensors (CPU-only unit tests of the data-parallel host logic): same arithmetic with tensor ops

@@ -121,7 +121,10 @@ class ModelTrainer(TrainValBase):
 
     def optimizer_state(self):
         opt = self.optimizer
-        return [opt.flat.data, opt.flat.grad, opt.m, opt.v, opt.step_count]
+        state = [opt.flat.data, opt.flat.grad, opt.m, opt.v, opt.step_count]
+        if getattr(opt.flat, "shadow", None) is not None:
+            state.append(opt.flat.shadow)
+        return state
 
     def train_a_step(self, features):
         """train_val.py:78-92: augment -> model -> loss -> gradients -> optimizer.apply_gradients."""
