@@ -109,7 +109,8 @@ int xpt_photo_bwd(int method, const float* synth, const float* target, const flo
  * (loss_util.py:6-25, 52-96) WITHOUT materialising the synthesized views (pass synth = NULL) -- or also writing
  * them (synth [B,N,h,w,3]) when a caller needs the images.
  *   src [B,N,h,w,3], depth [B,h,w], T [B,N,4,4], K [B,3,3] unscaled (+ scale), target [B,h,w,3]
- *   -> loss_l1 [B], loss_ssim [B]  (the reduce=True results: means over N*h*w*3)
+ *   -> loss_l1 [B], loss_ssim [B]  (the reduce=True results: means over N*h*w*3); both may be NULL, then only the
+ *      per-wave partial sums are left in the workspace (used to time the main kernel alone)
  * bwd: g_l1 [B], g_ssim [B] (gradients of those means) -> ddepth [B,h,w], dT [B,N,4,4] (last row 0); the views are
  *   re-synthesized on the fly.  workspace: xpt_photo_fused_workspace_floats(B,N,h,w) floats for both directions.
  * ALGORITHMIC bytes per batch element (P = h*w): fwd P(16 + 12N) [+ 12NP with synth], bwd P(20 + 12N). */

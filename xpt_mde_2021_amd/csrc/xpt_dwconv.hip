@@ -191,15 +191,15 @@ __global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restric
   }
 }
 
-// dw[i] = sum_k part[k][i]: 16 threads per output, fixed tree -> deterministic.
+// dw[i] = sum_k part[k][i]: 64 threads per output (few dependent round trips), fixed tree -> deterministic.
 __global__ void dw_wrw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int nchunk) {
-  const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int t = threadIdx.x & 15;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int t = threadIdx.x & 63;
   float s = 0.f;
   if (i < n)
-    for (int k = t; k < nchunk; k += 16) s += part[(long long)k * n + i];
+    for (int k = t; k < nchunk; k += 64) s += part[(long long)k * n + i];
 #pragma unroll
-  for (int off = 8; off > 0; off >>= 1) s += __shfl_down(s, off, 16);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if (t == 0 && i < n) dw[i] = s;
 }
 
@@ -238,7 +238,7 @@ int launch_bwd_weight(const void* x, const void* dy, float* dw, float* ws, const
   hipLaunchKernelGGL((dw_bwd_weight_kernel<T, K, S>), dim3((d.C + 63) / 64, nchunk), dim3(256), 0, s, (const T*)x,
                      (const T*)dy, ws, d, relu_in, RG);
   const int n = d.C * K * K;
-  hipLaunchKernelGGL(dw_wrw_reduce_kernel, dim3((n + 15) / 16), dim3(256), 0, s, ws, dw, n, nchunk);
+  hipLaunchKernelGGL(dw_wrw_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ws, dw, n, nchunk);
   return xpt_launch_status();
 }
 

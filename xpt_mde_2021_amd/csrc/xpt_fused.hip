@@ -451,10 +451,10 @@ inline FusedDims make_dims(int B, int N, int h, int w, float scale, int rows_per
 }
 
 // Rows per chunk: enough waves to cover 256 CUs x 4 SIMDs a few times over, as few halo rows as possible.
-inline int pick_rows(int B, int N, int h, int w) {
+inline int pick_rows(int B, int N, int h, int w, long long min_waves) {
   const long long strips = (long long)B * N * ((w + STRIP_B - 1) / STRIP_B);
   int R = 32;
-  while (R > 8 && strips * ((h + R - 1) / R) < 4096) R >>= 1;
+  while (R > 8 && strips * ((h + R - 1) / R) < min_waves) R >>= 1;
   return R;
 }
 
@@ -464,7 +464,7 @@ extern "C" {
 
 size_t xpt_photo_fused_workspace_floats(int B, int N, int h, int w) {
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0) return 0;
-  const FusedDims d = make_dims(B, N, h, w, 1.f, pick_rows(B, N, h, w), STRIP_B);   // the backward has more strips
+  const FusedDims d = make_dims(B, N, h, w, 1.f, pick_rows(B, N, h, w, 4096), STRIP_B);   // upper bound of both directions
   return (size_t)d.B * d.S * d.CH * d.N * 16;       // per wave: 2 floats forward, 12 (pose gradient) backward
 }
 
@@ -472,10 +472,11 @@ int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, co
                         float* synth, float* loss_l1, float* loss_ssim, float* workspace, size_t workspace_floats,
                         int B, int N, int h, int w, float scale, void* stream) {
   XPT_CHECK_PTR(src); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(T); XPT_CHECK_PTR(K); XPT_CHECK_PTR(target);
-  XPT_CHECK_PTR(loss_l1); XPT_CHECK_PTR(loss_ssim); XPT_CHECK_PTR(workspace);
+  XPT_CHECK_PTR(workspace);
+  if ((loss_l1 == nullptr) != (loss_ssim == nullptr)) return XPT_ERR_NULL;     // both, or neither (partials only)
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f) || (long long)h * w * 3 >= (1LL << 31)) return XPT_ERR_SHAPE;
   if (workspace_floats < xpt_photo_fused_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
-  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w), STRIP);
+  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w, 4096), STRIP);
   const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
   const unsigned blocks = (unsigned)((nwaves + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
@@ -484,8 +485,9 @@ int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, co
     hipLaunchKernelGGL(fused_fwd_kernel<true>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth, workspace, d);
   else
     hipLaunchKernelGGL(fused_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth, workspace, d);
-  hipLaunchKernelGGL(fused_reduce_kernel, dim3(B), dim3(64), 0, s, workspace, loss_l1, loss_ssim, d.S * d.CH * d.N,
-                     1.0f / ((float)N * (float)h * (float)w * 3.0f));
+  if (loss_l1)
+    hipLaunchKernelGGL(fused_reduce_kernel, dim3(B), dim3(64), 0, s, workspace, loss_l1, loss_ssim, d.S * d.CH * d.N,
+                       1.0f / ((float)N * (float)h * (float)w * 3.0f));
   return xpt_launch_status();
 }
 
@@ -496,7 +498,7 @@ int xpt_photo_fused_bwd(const float* src, const float* depth, const float* T, co
   XPT_CHECK_PTR(g_l1); XPT_CHECK_PTR(g_ssim); XPT_CHECK_PTR(ddepth); XPT_CHECK_PTR(dT); XPT_CHECK_PTR(workspace);
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f) || (long long)h * w * 3 >= (1LL << 31)) return XPT_ERR_SHAPE;
   if (workspace_floats < xpt_photo_fused_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
-  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w), STRIP_B);
+  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w, 1536), STRIP_B);
   const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
   const unsigned blocks = (unsigned)((nwaves + 3) / 4);
   const float inv_count = 1.0f / ((float)N * (float)h * (float)w * 3.0f);

@@ -159,21 +159,22 @@ __global__ void affine_act_bwd_smallc_kernel(const T* __restrict__ x, const T* _
   }
 }
 
-// per channel c: S0 = sum_k part[k][0][c], S1 = sum_k part[k][1][c]; 16 threads per channel, fixed tree -> deterministic.
+// per channel c: S0 = sum_k part[k][0][c], S1 = sum_k part[k][1][c]; one wave (64 threads) per channel so that the
+// partial rows are fetched with few dependent round trips; fixed tree -> deterministic.
 __global__ void affine_finish_kernel(const float* __restrict__ part, Affine a, float* __restrict__ dbeta,
                                      float* __restrict__ dgamma, int C, int nblk) {
-  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
-  const int t = threadIdx.x & 15;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int t = threadIdx.x & 63;
   float s0 = 0.f, s1 = 0.f;
   if (c < C)
-    for (int k = t; k < nblk; k += 16) {
+    for (int k = t; k < nblk; k += 64) {
       s0 += part[(long long)k * 2 * C + c];
       s1 += part[(long long)k * 2 * C + C + c];
     }
 #pragma unroll
-  for (int off = 8; off > 0; off >>= 1) {
-    s0 += __shfl_down(s0, off, 16);
-    s1 += __shfl_down(s1, off, 16);
+  for (int off = 32; off > 0; off >>= 1) {
+    s0 += __shfl_down(s0, off, 64);
+    s1 += __shfl_down(s1, off, 64);
   }
   if (t == 0 && c < C) {
     dbeta[c] = s0;
@@ -245,7 +246,7 @@ int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float
       hipLaunchKernelGGL(affine_act_bwd_smallc_kernel<__hip_bfloat16>, g1, dim3(256), 0, s, (const __hip_bfloat16*)x,
                          (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, workspace, rows,
                          C, slope, relu_in, dgamma != nullptr);
-    hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 15) / 16), dim3(256), 0, s, workspace, a, dbeta, dgamma, C, nb);
+    hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, a, dbeta, dgamma, C, nb);
     return xpt_launch_status();
   }
   const int nblk = (int)((rows + PW_ROWS - 1) / PW_ROWS);
@@ -258,7 +259,7 @@ int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float
     hipLaunchKernelGGL(affine_act_bwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, s, (const __hip_bfloat16*)x,
                        (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, workspace, rows, C,
                        slope, relu_in, dgamma != nullptr, RG);
-  hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 15) / 16), dim3(256), 0, s, workspace, a, dbeta, dgamma, C, nblk);
+  hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, a, dbeta, dgamma, C, nblk);
   return xpt_launch_status();
 }
 
