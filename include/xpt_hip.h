@@ -183,6 +183,11 @@ int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float
                        float* workspace, size_t workspace_floats, long long rows, int C, float slope, int relu_in,
                        int dtype, void* stream);
 
+/* ------------------------------------------------------------------ input contract helper (host function, no GPU)
+ * CRC-32C of a host buffer: the checksum of the TFRecord framing read by tfrecords/tfrecord_reader.py:61-75
+ * (tf.data.TFRecordDataset); masked value = ((crc >> 15) | (crc << 17)) + 0xa282ead8. */
+uint32_t xpt_crc32c(const void* data, size_t nbytes);
+
 #ifdef __cplusplus
 }
 #endif

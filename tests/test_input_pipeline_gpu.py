@@ -1,0 +1,80 @@
+"""The rows either side of the hot path on the GPU: TFRecord shards -> feature dicts -> augmenter -> captured training
+step (reference: tfrecords/tfrecord_reader.py, model/model_util/augmentation.py, model/train_val.py:78-92)."""
+import numpy as np
+import pytest
+import torch
+
+from xpt_mde_2021_amd.config import opts
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_shards(path, n, h, w, snippet=5):
+    from xpt_mde_2021_amd.tfrecords import tfrecord_reader as tr
+    from xpt_mde_2021_amd.utils import synthetic_data as sd
+    wr = tr.TfrecordWriter(str(path), shard_size=3)
+    feats = sd.make_features(n, h, w, stereo=False, seed=3)
+    for i in range(n):
+        img = ((feats["image5d"][i] + 1) * 127.5).round().clamp(0, 255).to(torch.uint8).numpy()
+        wr.write({"image": img.reshape(snippet * h, w, 3), "intrinsic": feats["intrinsic"][i].numpy(),
+                  "depth_gt": feats["depth_gt"][i].numpy(), "pose_gt": feats["pose_gt"][i].numpy()})
+    wr.close((snippet, h, w, 3))
+
+
+def test_augmenters_on_device_match_cpu(gpu_device):
+    from xpt_mde_2021_amd.model.model_util import augmentation as aug
+    g = torch.Generator().manual_seed(0)
+    feats = {"image5d": torch.rand(2, 5, 32, 48, 3, generator=g) * 2 - 1,
+             "intrinsic": torch.tensor([[[24., 0, 24.], [0, 16., 16.], [0, 0, 1]]]).repeat(2, 1, 1),
+             "depth_gt": torch.rand(2, 32, 48, 1, generator=g),
+             "pose_gt": torch.eye(4).repeat(2, 4, 1, 1) + 0.01 * torch.rand(2, 4, 4, 4, generator=g)}
+    dev = {k: v.to(gpu_device) for k, v in feats.items()}
+    flip_c = aug.TotalAugment([aug.HorizontalFlip(1.1)])(feats)
+    flip_g = aug.TotalAugment([aug.HorizontalFlip(1.1)])(dev)
+    for k in feats:
+        assert torch.equal(flip_g[k].cpu(), flip_c[k]), k
+    box = torch.tensor([0.05, 0.02, 0.93, 0.97])
+    c = aug.crop_and_resize(feats["image5d"].reshape(10, 32, 48, 3), box, (32, 48))
+    gcrop = aug.crop_and_resize(dev["image5d"].reshape(10, 32, 48, 3), box.to(gpu_device), (32, 48))
+    assert torch.allclose(gcrop.cpu(), c, atol=1e-5)
+    j = aug.ColorJitter()
+    assert torch.allclose(j.jitter_color(dev["image5d"], torch.tensor(0.7, device=gpu_device),
+                                         torch.tensor(1.3, device=gpu_device)).cpu(),
+                          j.jitter_color(feats["image5d"], torch.tensor(0.7), torch.tensor(1.3)), atol=1e-5)
+
+
+def test_tfrecords_augment_graph_train(gpu_device, tmp_path):
+    from xpt_mde_2021_amd.model import model_main as mm
+    from xpt_mde_2021_amd.model import train_val as tv
+    from xpt_mde_2021_amd.tfrecords.tfrecord_reader import TfrecordReader
+    h, w = 64, 192
+    _write_shards(tmp_path, 8, h, w)
+    saved = (opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE, dict(opts.IMAGE_SIZES))
+    opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 2
+    opts.IMAGE_SIZES["kitti_raw"] = (h, w)
+    opts.CONV_DTYPE = "fp32"
+    try:
+        torch.manual_seed(0)
+        reader = TfrecordReader(str(tmp_path), shuffle=True, batch_size=2, device=gpu_device, epochs=2)
+        cfg = reader.get_tfr_config()
+        assert reader.get_total_steps() == 4
+        model, augmenter, loss_object, optimizer = mm.create_training_parts(
+            0, cfg, 1e-4, opts.LOSS_RIGID_T1, opts.SCALE_WEIGHT_T1, opts.RIGID_NET, ckpt_name="__test__")
+        assert [type(a).__name__ for a in augmenter.augment_objects] == list(opts.AUGMENT_PROBS)
+        for a in augmenter.augment_objects:
+            a.aug_prob = 0.5                                   # exercise both branches within a few replays
+        trainer, _ = tv.train_val_factory("graph", model, loss_object, 0, False, augmenter, optimizer)
+        losses, params = [], []
+        for feats in reader.get_dataset():
+            assert feats["image5d"].shape == (2, 5, h, w, 3) and feats["image5d"].is_cuda
+            _, loss, by_type = trainer.run_a_batch(feats)
+            losses.append(float(loss))
+            params.append(augmenter.augment_objects[0].param.detach().cpu().clone())
+        assert len(losses) == 8 and np.isfinite(losses).all(), losses
+        # the captured augmenter draws fresh random numbers on every replay
+        assert len({tuple(p.tolist()) for p in params}) > 1, params
+        assert torch.isfinite(optimizer.flat.data).all()
+    finally:
+        opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
+        opts.IMAGE_SIZES.clear()
+        opts.IMAGE_SIZES.update(saved[3])

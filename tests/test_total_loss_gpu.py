@@ -121,7 +121,7 @@ def test_train_step_runs_and_learns(gpu_device):
             model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, opts.LOSS_RIGID_T1,
                                                                           opts.SCALE_WEIGHT_T1, opts.RIGID_NET,
                                                                           ckpt_name="__test__")
-            trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, False, aug, optimizer)
+            trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, False, None, optimizer)   # no random augmentation
             feats = dataset.batches[0]
             hist = []
             for _ in range(8):

@@ -48,6 +48,7 @@ SIGNATURES = {
     "xpt_dwconv_bwd_data": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p]),
     "xpt_dwconv_bwd_weight_workspace_floats": (_z, [_i] * 5),
     "xpt_dwconv_bwd_weight": (_i, [_p, _p, _p, _p, _z] + [_i] * 12 + [_p]),
+    "xpt_crc32c": (ctypes.c_uint32, [_p, _z]),
     "xpt_affine_act_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, ctypes.c_longlong, _i, _f, _i, _i, _p]),
     "xpt_affine_act_bwd_workspace_floats": (_z, [ctypes.c_longlong, _i]),
     "xpt_affine_act_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _z, ctypes.c_longlong, _i, _f, _i, _i, _p]),

@@ -19,6 +19,7 @@ from ..utils import synthetic_data as sd
 from . import train_val as tv
 from .build_model.model_factory import ModelFactory
 from .loss_and_metric.loss_factory import loss_factory
+from .model_util.augmentation import augmentation_factory
 from .model_util.distributer import DistributionStrategy
 from .model_util.optimizers import optimizer_factory
 
@@ -89,7 +90,7 @@ def create_training_parts(initial_epoch, tfr_config, learning_rate, loss_weights
                          pretrained_weight=pretrained_weight).get_model()
     model = try_load_weights(model, ckpt_name, weight_suffix)
     model.to(device())
-    augmenter = None            # augmentation.py (crop / flip / colour) is the "next" row before the path
+    augmenter = augmentation_factory(opts.AUGMENT_PROBS)
     loss_object = loss_factory(tfr_config, loss_weights, scale_weights, opts.STEREO,
                                weights_to_regularize=model.weights_to_regularize(), batch_size=opts.BATCH_SIZE)
     optimizer = optimizer_factory(opts.OPTIMIZER, learning_rate, initial_epoch)
