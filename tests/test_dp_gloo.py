@@ -66,7 +66,7 @@ def _worker(rank, world, port, out_queue):
     for _ in range(3):
         _, loss, _ = trainer.run_a_batch(shard)
         losses.append(float(loss))
-    out_queue.put((rank, optimizer.flat.data.clone(), losses))
+    out_queue.put((rank, optimizer.flat.data.numpy().copy(), losses))   # by value: no shared-memory handle to outlive the worker
     dist.barrier()
     dist.destroy_process_group()
 
@@ -85,6 +85,7 @@ def test_two_ranks_equal_one_process_full_batch():
         p.join(timeout=60)
         assert p.exitcode == 0
     (_, w0, l0), (_, w1, l1) = results
+    w0, w1 = torch.from_numpy(w0), torch.from_numpy(w1)
     assert torch.equal(w0, w1), "replicas diverged"
     # single process, whole batch of 4, starting from rank 0's initial weights (seed 100)
     saved = (opts.CONV_DTYPE, opts.PER_REPLICA_BATCH, opts.BATCH_SIZE)
