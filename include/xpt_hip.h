@@ -183,6 +183,60 @@ int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float
                        float* workspace, size_t workspace_floats, long long rows, int C, float slope, int relu_in,
                        int dtype, void* stream);
 
+/* ------------------------------------------------------------------ a2: weight gradient of the pointwise (1x1) convolutions
+ * replaces the filter gradient of every 1x1 Conv2D / the pointwise half of every SeparableConv2D inside
+ * tf.keras.applications.NASNetMobile (reference call site model/build_model/pretrained_nets.py:36-44; gradients taken
+ * by tape.gradient, model/train_val.py:85-86).
+ *   dy [M, cout], x [M, cin]   bfloat16 rows of NHWC activations (M = B*H*W); pitch_* = row pitch in elements, so a
+ *                              channel slice of a wider tensor is consumed in place;
+ *   dw [cout, cin]             float32 = sum_m dy[m, co] x[m, ci]  (exact products, f32 accumulation on the matrix cores);
+ *   workspace                  xpt_conv1x1_bwd_weight_workspace_floats() floats (split-K partial tiles);
+ *   counters                   >= xpt_conv1x1_bwd_weight_counters() zero-initialised uint32, left zero on return; may be
+ *                              shared by all calls issued to one stream.  Deterministic: partials are added in split order.
+ * xpt_conv1x1_bwd_weight_tune: launch-plan knobs (waves per workgroup 4|16, row pairs per wave, workgroups per launch,
+ * KiB of partial tiles per output tile); process-wide, for benchmarking -- the defaults are the measured optimum. */
+int xpt_conv1x1_bwd_weight_tune(int waves, int pairs_per_wave, int max_blocks, int max_partial_kib);
+size_t xpt_conv1x1_bwd_weight_workspace_floats(long long M, int cout, int cin);
+int xpt_conv1x1_bwd_weight_counters(long long M, int cout, int cin);
+int xpt_conv1x1_bwd_weight(const void* dy, const void* x, float* dw, float* workspace, size_t workspace_floats,
+                           unsigned* counters, int n_counters, long long M, int cout, int cin, long long pitch_dy,
+                           long long pitch_x, void* stream);
+
+/* ------------------------------------------------------------------ deferred parameter gradients (one finishing launch per step)
+ * The *_partials entry points compute the same parameter gradients as xpt_affine_act_bwd / xpt_dwconv_bwd_weight /
+ * xpt_conv1x1_bwd_weight (tape.gradient of the layer variables, model/train_val.py:85-86) but stop at the
+ * per-workgroup partial sums, left in a caller-owned persistent workspace:
+ *   affine:   partials[blocks][2][C]     row 0 -> dbeta (bias gradient), row 1 -> dgamma; blocks = xpt_affine_act_bwd_blocks()
+ *   dwconv:   partials[chunks][C][k][k]  chunks = xpt_dwconv_bwd_weight_chunks()
+ *   conv1x1:  partials[splits][cout][cin] splits = xpt_conv1x1_bwd_weight_splits()
+ * xpt_reduce_partials then finishes all layers at once: block b of the launch serves job blockmap[b].x and the outputs
+ * starting at blockmap[b].y (256 / split_lanes outputs per block);
+ *   dst[i] = sum over segments g < nseg, splits s < nsplit[g] of src[g][s * stride[g] + i],  i < n   (fixed order).
+ * jobs and blockmap are device arrays built once by the host (the layer list of a model is static). */
+typedef struct xpt_reduce_job {
+  float* dst;
+  long long n;
+  int nseg;          /* 1..4 segments (a layer applied several times per step contributes one segment per use) */
+  int split_lanes;   /* 1, 4, 16 or 64 lanes cooperating on one output */
+  const float* src[4];
+  long long stride[4];
+  int nsplit[4];
+} xpt_reduce_job;
+int xpt_reduce_job_bytes(void);
+int xpt_reduce_partials(const void* jobs, const void* blockmap, int nblocks, void* stream);
+int xpt_affine_act_bwd_blocks(long long rows, int C);
+int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
+                                const float* mean, const float* var, float eps, void* dx, float* partials,
+                                size_t partial_floats, long long rows, int C, float slope, int relu_in, int dtype,
+                                void* stream);
+int xpt_dwconv_bwd_weight_chunks(int B, int OH, int OW, int C, int k, int stride);
+int xpt_dwconv_bwd_weight_partials(const void* x, const void* dy, float* partials, size_t partial_floats, int B, int H,
+                                   int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int relu_in,
+                                   int dtype, void* stream);
+int xpt_conv1x1_bwd_weight_splits(long long M, int cout, int cin);
+int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, float* partials, size_t partial_floats, long long M,
+                                    int cout, int cin, long long pitch_dy, long long pitch_x, void* stream);
+
 /* ------------------------------------------------------------------ input contract helper (host function, no GPU)
  * CRC-32C of a host buffer: the checksum of the TFRecord framing read by tfrecords/tfrecord_reader.py:61-75
  * (tf.data.TFRecordDataset); masked value = ((crc >> 15) | (crc << 17)) + 0xa282ead8. */

@@ -56,7 +56,7 @@ def test_graph_replays_match_eager(gpu_device, dtype):
             assert torch.isfinite(g).all(), f"replay {it}: non-finite gradient"
             for (name, p), off in zip(names, flat.offsets):
                 a, b = g[off:off + p.numel()], g_ref[off:off + p.numel()]
-                scale = float(b.abs().max()) + 1e-12
+                scale = max(float(b.abs().max()), 1e-5)       # floor: a bias whose gradient cancels to ~1e-7 is pure rounding noise
                 err = float((a - b).abs().max()) / scale
                 assert err < tol, f"replay {it}: {name} {tuple(p.shape)} rel err {err:.3e} (scale {scale:.3e})"
     finally:

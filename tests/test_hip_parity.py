@@ -343,3 +343,52 @@ def test_depthwise_conv_fwd_bwd(ops, gpu_device, k, stride, dtype, relu_in):
     frac_close(y.float(), y_ref, tol, rtol=tol, what="dwconv y")
     frac_close(xg.grad.float(), x_ref.grad, tol, rtol=tol, what="dwconv dx")
     frac_close(wg.grad, w_ref.grad, 1e-3 if dtype == torch.float32 else 2e-2, rtol=1e-3, what="dwconv dw")
+
+
+# ------------------------------------------------------------------------------- 1x1 conv weight gradient (split-K MFMA)
+@pytest.mark.parametrize("M,cout,cin,pad_dy,pad_x", [
+    (416, 1056, 1056, 0, 0),       # 4x13 maps, widest layer: 17x17 tiles, 3 splits
+    (416, 176, 1056, 0, 0),
+    (1664, 88, 528, 0, 0),
+    (6656, 44, 264, 0, 220),       # x = channel slice of a 6-branch concat (row pitch 264+220)
+    (6656, 264, 44, 88, 0),        # dy = channel slice
+    (26624, 22, 44, 0, 0),
+    (106496, 11, 32, 0, 0),        # stem level: one 32x32 tile, long reduction
+    (106496, 32, 3, 0, 0),
+    (417, 33, 65, 3, 5),           # ragged: odd row count, tiles with one valid row / column
+    (1, 7, 5, 0, 0),
+    (63, 64, 64, 0, 0),            # single split: direct write
+])
+def test_conv1x1_weight_grad(gpu_device, M, cout, cin, pad_dy, pad_x):
+    from xpt_mde_2021_amd.hip import ops
+    g = torch.Generator().manual_seed(M + cout)
+    dy_full = torch.randn(M, cout + pad_dy, generator=g).to(gpu_device, torch.bfloat16)
+    x_full = torch.randn(M, cin + pad_x, generator=g).to(gpu_device, torch.bfloat16)
+    dy2 = dy_full[:, pad_dy // 2:pad_dy // 2 + cout]
+    x2 = x_full[:, pad_x // 2:pad_x // 2 + cin]
+    dw = ops.conv1x1_weight_grad(dy2, x2)
+    ref = dy2.double().t() @ x2.double()
+    assert dw.shape == (cout, cin) and dw.dtype == torch.float32
+    # exact products, fp32 accumulation in a fixed order: error ~ sqrt(M) * 2^-24 * |terms|
+    err = (dw.double() - ref).abs().max().item()
+    assert err < 2e-6 * max(1.0, ref.abs().max().item()) * max(1.0, (M / 64) ** 0.5), err
+    # deterministic, and the arrival counters are left reset: a second call gives the same bits
+    dw2 = ops.conv1x1_weight_grad(dy2, x2)
+    assert torch.equal(dw, dw2)
+    assert int(ops._counters(dy2.device).abs().sum()) == 0
+
+
+def test_as_rows_views(gpu_device):
+    from xpt_mde_2021_amd.hip import ops
+    t = torch.randn(2, 12, 3, 5, device=gpu_device).contiguous(memory_format=torch.channels_last)
+    r = ops.as_rows(t)
+    assert r.data_ptr() == t.data_ptr() and r.shape == (30, 12) and r.stride() == (12, 1)
+    assert torch.equal(r, t.permute(0, 2, 3, 1).reshape(30, 12))
+    s = t[:, 4:9]
+    rs = ops.as_rows(s)
+    assert rs.data_ptr() == s.data_ptr() and rs.stride() == (12, 1)
+    assert torch.equal(rs, s.permute(0, 2, 3, 1).reshape(30, 5))
+    n = torch.randn(2, 12, 3, 5, device=gpu_device)            # NCHW-contiguous: copied
+    assert torch.equal(ops.as_rows(n), n.permute(0, 2, 3, 1).reshape(30, 12))
+    one = torch.randn(4, 6, 1, 1, device=gpu_device)
+    assert torch.equal(ops.as_rows(one), one.reshape(4, 6))

@@ -238,7 +238,7 @@ int launch_bwd_weight(const void* x, const void* dy, float* dw, float* ws, const
   hipLaunchKernelGGL((dw_bwd_weight_kernel<T, K, S>), dim3((d.C + 63) / 64, nchunk), dim3(256), 0, s, (const T*)x,
                      (const T*)dy, ws, d, relu_in, RG);
   const int n = d.C * K * K;
-  hipLaunchKernelGGL(dw_wrw_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ws, dw, n, nchunk);
+  if (dw) hipLaunchKernelGGL(dw_wrw_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ws, dw, n, nchunk);
   return xpt_launch_status();
 }
 
@@ -312,6 +312,26 @@ int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* works
   const DwDims d{B, H, W, C, OH, OW, pad_t, pad_l};
   XPT_BEGIN_LAUNCH();
   DW_DISPATCH(launch_bwd_weight, x, dy, dw, workspace, d, relu_in, (hipStream_t)stream);
+}
+
+int xpt_dwconv_bwd_weight_chunks(int B, int OH, int OW, int C, int k, int stride) {
+  if (B <= 0 || OH <= 0 || OW <= 0 || C <= 0 || k <= 0 || (stride != 1 && stride != 2)) return 0;
+  const int oxt = stride == 1 ? 4 : 2;
+  const long long ngrp = (long long)B * OH * ((OW + oxt - 1) / oxt);
+  return (int)((ngrp + DW_WRW_GRP - 1) / DW_WRW_GRP);
+}
+
+/* Deferred weight gradient: partials[chunk][C][k][k], to be added up later by xpt_reduce_partials. */
+int xpt_dwconv_bwd_weight_partials(const void* x, const void* dy, float* partials, size_t partial_floats, int B, int H,
+                                   int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int relu_in,
+                                   int dtype, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(dy); XPT_CHECK_PTR(partials);
+  const int rc = check_dims(B, H, W, C, k, stride, pad_t, pad_l, OH, OW, dtype);
+  if (rc != XPT_OK) return rc;
+  if (partial_floats < (size_t)xpt_dwconv_bwd_weight_chunks(B, OH, OW, C, k, stride) * C * k * k) return XPT_ERR_WORKSPACE;
+  const DwDims d{B, H, W, C, OH, OW, pad_t, pad_l};
+  XPT_BEGIN_LAUNCH();
+  DW_DISPATCH(launch_bwd_weight, x, dy, (float*)nullptr, partials, d, relu_in, (hipStream_t)stream);
 }
 
 }  // extern "C"

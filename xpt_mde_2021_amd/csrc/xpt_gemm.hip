@@ -1,0 +1,369 @@
+// xpt_gemm.hip -- weight gradient of the pointwise (1x1) convolutions of NASNet-Mobile on the gfx950 matrix cores.
+//
+//   dW[co, ci] = sum_m dy[m, co] * x[m, ci]        m = the B*H*W pixels of an NHWC activation, 416 ... 106496 here
+//
+// The output is tiny (11x32 ... 1056x1056) and the reduction long, the shape the BLAS library serves worst (one or a
+// few workgroups walk the whole K loop: 19-67 us per call, 4.8 ms of a 26 ms step).  This kernel splits the reduction
+// over enough workgroups to fill the chip and finishes in the same launch:
+//   * one wave owns a 32x32 tile of dW and issues v_mfma_f32_32x32x2_f32 (f32 operands, f32 accumulate): its A operand
+//     is dy[k+h][co0 + r], its B operand x[k+h][ci0 + r] (r = lane & 31, h = lane >> 5), i.e. both are read straight
+//     from the row-major activations, coalesced, with no transposition and no LDS; bf16 -> f32 is a 16-bit shift, so
+//     the products are exact and only the accumulation rounds (tighter than a bf16 GEMM);
+//   * a workgroup = 4 waves = up to 4 tile quadrants (64x64, 64x32, 32x64) or, for narrow outputs, several interleaved
+//     slices of the reduction that are combined through LDS;
+//   * the reduction is split over gridDim.z workgroups per tile; each writes its partial tile to the workspace, and the
+//     workgroup that arrives last (one counter per tile, reset for the next call) adds the partials IN SPLIT ORDER and
+//     writes dW: deterministic, no second launch, no float atomics.
+#include "xpt_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradPlan {
+  int tco, tci;        // tile extents (32 or 64)
+  int tiles_co, tiles_ci;
+  int waves;           // waves per workgroup (4 or 16)
+  int nsplit;
+  long long rows_per_block;
+};
+
+// tuning knobs (xpt_conv1x1_bwd_weight_tune; defaults measured on MI355X)
+int g_waves = 16;             // waves per workgroup
+int g_pairs_per_wave = 16;    // row pairs (MFMAs) each wave should at least get
+int g_max_blocks = 1024;      // workgroups per launch
+int g_max_partial_kib = 512;  // partial tiles the finishing workgroup adds, per output tile
+
+inline WgradPlan wgrad_plan(long long M, int cout, int cin, bool defer = false) {
+  WgradPlan p;
+  p.tco = cout <= 32 ? 32 : 64;
+  p.tci = cin <= 32 ? 32 : 64;
+  p.tiles_co = (cout + p.tco - 1) / p.tco;
+  p.tiles_ci = (cin + p.tci - 1) / p.tci;
+  p.waves = g_waves;
+  const long long ntiles = (long long)p.tiles_co * p.tiles_ci;
+  const int quadrants = (p.tco / 32) * (p.tci / 32);
+  const int kslices = p.waves / quadrants;
+  long long rows = 2LL * g_pairs_per_wave * kslices;
+  // splits: bounded by what the finishing workgroup can add (in-kernel finish) or by 8 MiB of partials (deferred)
+  long long smax = defer ? (8LL << 20) / ((long long)cout * cin * 4)
+                         : ((long long)g_max_partial_kib * 1024) / ((long long)p.tco * p.tci * 4);
+  const long long by_blocks = g_max_blocks / ntiles;
+  if (smax > by_blocks) smax = by_blocks;
+  if (smax < 1) smax = 1;
+  long long nsplit = (M + rows - 1) / rows;
+  if (nsplit > smax) {
+    nsplit = smax;
+    rows = (M + nsplit - 1) / nsplit;
+  }
+  rows = (rows + 7) / 8 * 8;
+  p.rows_per_block = rows;
+  p.nsplit = (int)((M + rows - 1) / rows);
+  return p;
+}
+
+__device__ inline float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+
+// staged vector: V consecutive bf16 of one activation row
+template <int V> struct StageVec;
+template <> struct StageVec<8> { typedef uint4 type; };
+template <> struct StageVec<4> { typedef uint2 type; };
+template <> struct StageVec<2> { typedef unsigned type; };
+template <> struct StageVec<1> { typedef unsigned short type; };
+
+// global -> registers: this thread's share of a [RC rows x TW channels] tile (rows >= k_end and channels >= C read as 0)
+template <int V, int TW, int RC, int NT>
+__device__ inline void stage_load(typename StageVec<V>::type (&reg)[(RC * TW / V + NT - 1) / NT],
+                                  const unsigned short* __restrict__ src, long long pitch, long long k0,
+                                  long long k_end, int c0, int C) {
+  typedef typename StageVec<V>::type vec_t;
+  constexpr int VPR = TW / V, NV = RC * VPR, PER = (NV + NT - 1) / NT;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int v = threadIdx.x + i * NT;
+    const int row = v / VPR, c = c0 + (v % VPR) * V;
+    vec_t val = vec_t();
+    if (v < NV && k0 + row < k_end && c < C) val = *(const vec_t*)(src + (k0 + row) * pitch + c);
+    reg[i] = val;
+  }
+}
+
+template <int V, int TW, int RC, int NT>
+__device__ inline void stage_store(unsigned short* dst, const typename StageVec<V>::type (&reg)[(RC * TW / V + NT - 1) / NT]) {
+  typedef typename StageVec<V>::type vec_t;
+  constexpr int VPR = TW / V, NV = RC * VPR, PER = (NV + NT - 1) / NT;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int v = threadIdx.x + i * NT;
+    if (v < NV) *(vec_t*)(dst + (v / VPR) * TW + (v % VPR) * V) = reg[i];
+  }
+}
+
+// TCO x TCI output tile per workgroup of NW waves.  Q = quadrants of 32x32, KS = NW / Q interleaved k slices.
+// VA / VB: elements per global load of dy / x (the host picks the widest the pitch, base and channel count allow).
+template <int TCO, int TCI, int VA, int VB>
+__global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned short* __restrict__ dy,
+                                                              const unsigned short* __restrict__ x,
+                                                              float* __restrict__ dw, float* __restrict__ partial,
+                                                              unsigned* __restrict__ counters, long long M, int cout,
+                                                              int cin, long long pitch_dy, long long pitch_x,
+                                                              long long rows_per_block, int nsplit, int defer) {
+  constexpr int NW = 16, QA = TCO / 32, QB = TCI / 32, Q = QA * QB, KS = NW / Q, NT = NW * 64;
+  constexpr int TILE = TCO * TCI;
+  constexpr int RC = Q == 4 ? 128 : 256;                    // rows staged per chunk: 32 / 48 / 32 KiB of LDS
+  constexpr int STAGE_BYTES = RC * (TCO + TCI) * 2, RED_BYTES = (KS - 1) * Q * 4096;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
+  __shared__ unsigned last_flag;
+  unsigned short* sA = (unsigned short*)smem;               // [RC][TCO] rows of dy
+  unsigned short* sB = sA + RC * TCO;                       // [RC][TCI] rows of x
+  float* red = (float*)smem;                                // reused once the staging buffers are dead
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int quad = wave % Q, ksub = wave / Q;
+  const int qa = quad / QB, qb = quad % QB;
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const int co0 = blockIdx.y * TCO, ci0 = blockIdx.x * TCI;
+  const int split = blockIdx.z;
+
+  const long long k_begin = (long long)split * rows_per_block;
+  long long k_end = k_begin + rows_per_block;
+  if (k_end > M) k_end = M;
+  const int ci = ci0 + qb * 32 + r;
+  const bool ci_ok = ci < cin;
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  // chunk loop: the activations are staged through LDS with the widest loads the layout allows (a per-lane 2-byte
+  // global load costs the texture addresser as much as a 16-byte one), zero-filled outside the tile; each wave then
+  // reads its MFMA operands A = dy[k + h][co], B = x[k + h][ci] as 16-bit LDS reads.  The next chunk's global loads
+  // are in flight (registers) while this chunk's MFMAs run.
+  typename StageVec<VA>::type ga[(RC * TCO / VA + NT - 1) / NT];
+  typename StageVec<VB>::type gb[(RC * TCI / VB + NT - 1) / NT];
+  stage_load<VA, TCO, RC, NT>(ga, dy, pitch_dy, k_begin, k_end, co0, cout);
+  stage_load<VB, TCI, RC, NT>(gb, x, pitch_x, k_begin, k_end, ci0, cin);
+  const unsigned short* myA = sA + h * TCO + qa * 32 + r;
+  const unsigned short* myB = sB + h * TCI + qb * 32 + r;
+  for (long long k0 = k_begin; k0 < k_end; k0 += RC) {
+    __syncthreads();                                        // the previous chunk's operand reads are done
+    stage_store<VA, TCO, RC, NT>(sA, ga);
+    stage_store<VB, TCI, RC, NT>(sB, gb);
+    __syncthreads();
+    if (k0 + RC < k_end) {
+      stage_load<VA, TCO, RC, NT>(ga, dy, pitch_dy, k0 + RC, k_end, co0, cout);
+      stage_load<VB, TCI, RC, NT>(gb, x, pitch_x, k0 + RC, k_end, ci0, cin);
+    }
+    // row pairs ksub, ksub + KS, ... of the chunk (rows past k_end hold zeros); bounds are wave-uniform
+    const long long left = k_end - k0;
+    const int pairs = left >= RC ? RC / 2 : (int)((left + 1) / 2);
+    for (int j = ksub; j < pairs; j += KS) {
+      const float a = bf16_bits_to_f32(myA[2 * j * TCO]);
+      const float b = bf16_bits_to_f32(myB[2 * j * TCI]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  __syncthreads();                                          // staging buffers dead: `red` may overwrite them
+
+  // combine the k slices of one quadrant through LDS (fixed order: slice 0 + slice 1 + ...)
+  if (KS > 1) {
+    if (ksub > 0) {
+      float* dst = red + ((ksub - 1) * Q + quad) * 1024;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dst[i * 64 + lane] = acc[i];
+    }
+    __syncthreads();
+    if (ksub == 0) {
+#pragma unroll
+      for (int s = 1; s < KS; ++s) {
+        const float* src = red + ((s - 1) * Q + quad) * 1024;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += src[i * 64 + lane];
+      }
+    }
+  }
+
+  // accumulator element (reg i, lane) = dW[co0 + qa*32 + (i&3) + 8*(i>>2) + 4*h][ci0 + qb*32 + r]
+  if (defer) {   // partial[split][cout][cin]: added up later, together with every other layer's, by xpt_reduce_partials
+    if (ksub == 0 && ci_ok) {
+      float* mine = partial + (long long)split * cout * cin;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = co0 + qa * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (row < cout) mine[(long long)row * cin + ci] = acc[i];
+      }
+    }
+    return;
+  }
+  if (nsplit == 1) {
+    if (ksub == 0 && ci_ok) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = co0 + qa * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (row < cout) dw[(long long)row * cin + ci] = acc[i];
+      }
+    }
+    return;
+  }
+
+  float* mine = partial + ((long long)tile * nsplit + split) * TILE;
+  if (ksub == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = qa * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      mine[row * TCI + qb * 32 + r] = acc[i];
+    }
+  }
+  // publish the partial tile, then count arrivals.  One thread fences for the workgroup (the barrier orders the other
+  // waves' stores before it): the agent-scope release writes this XCD's L2 back once per workgroup, not once per wave.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned arrived = atomicAdd(&counters[tile], 1u);
+    const unsigned last = (arrived == (unsigned)nsplit - 1u) ? 1u : 0u;
+    if (last) __threadfence();
+    last_flag = last;
+  }
+  __syncthreads();
+  if (last_flag == 0u) return;
+  // the last workgroup adds the partial tiles in split order.  All loads of a batch are issued before the first add
+  // (the partials come from other XCDs' L2 / HBM: one exposed latency per batch, not per split).
+  const float* base = partial + (long long)tile * nsplit * TILE;
+  constexpr int EPT = (TILE + NT - 1) / NT, BATCH = 32 / EPT;
+  float sum[EPT];
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) sum[j] = 0.f;
+  for (int sp0 = 0; sp0 < nsplit; sp0 += BATCH) {
+    float v[EPT][BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int sp = sp0 + u < nsplit ? sp0 + u : nsplit - 1;
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) {
+        const int e = threadIdx.x + j * NT;
+        v[j][u] = __hip_atomic_load(base + (long long)sp * TILE + (e < TILE ? e : 0), __ATOMIC_RELAXED,
+                                    __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const bool live = sp0 + u < nsplit;
+#pragma unroll
+      for (int j = 0; j < EPT; ++j) sum[j] += live ? v[j][u] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EPT; ++j) {
+    const int e = threadIdx.x + j * NT;
+    const int row = co0 + e / TCI, col = ci0 + e % TCI;
+    if (e < TILE && row < cout && col < cin) dw[(long long)row * cin + col] = sum[j];
+  }
+  if (threadIdx.x == 0) counters[tile] = 0u;   // ready for the next call on this stream
+}
+
+}  // namespace
+
+extern "C" int xpt_conv1x1_bwd_weight_tune(int waves, int pairs_per_wave, int max_blocks, int max_partial_kib) {
+  if (waves != 16 || pairs_per_wave < 1 || max_blocks < 1 || max_partial_kib < 16) return XPT_ERR_ARG;
+  g_waves = waves;
+  g_pairs_per_wave = pairs_per_wave;
+  g_max_blocks = max_blocks;
+  g_max_partial_kib = max_partial_kib;
+  return XPT_OK;
+}
+
+extern "C" size_t xpt_conv1x1_bwd_weight_workspace_floats(long long M, int cout, int cin) {
+  if (M <= 0 || cout <= 0 || cin <= 0) return 0;
+  const WgradPlan p = wgrad_plan(M, cout, cin);
+  if (p.nsplit == 1) return 1;
+  return (size_t)p.tiles_co * p.tiles_ci * p.nsplit * p.tco * p.tci;
+}
+
+extern "C" int xpt_conv1x1_bwd_weight_counters(long long M, int cout, int cin) {
+  if (M <= 0 || cout <= 0 || cin <= 0) return 0;
+  const WgradPlan p = wgrad_plan(M, cout, cin);
+  return p.tiles_co * p.tiles_ci;
+}
+
+static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspace, unsigned* counters, long long M,
+                        int cout, int cin, long long pitch_dy, long long pitch_x, const WgradPlan& p, int defer,
+                        void* stream) {
+  const dim3 grid(p.tiles_ci, p.tiles_co, p.nsplit);
+  const dim3 block(1024);
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned short* a = (const unsigned short*)dy;
+  const unsigned short* b = (const unsigned short*)x;
+  // widest staging load (elements) both operands allow: rows must start and end on a vector boundary
+  auto width = [](const void* ptr, long long pitch, int C) {
+    int v = 8;
+    while (v > 1 && (pitch % v != 0 || C % v != 0 || ((uintptr_t)ptr) % (2 * v) != 0)) v >>= 1;
+    return v;
+  };
+  int v = width(dy, pitch_dy, cout);
+  const int vb = width(x, pitch_x, cin);
+  if (vb < v) v = vb;
+  XPT_BEGIN_LAUNCH();
+#define XPT_WGRAD(TCO, TCI, V)                                                                                       \
+  hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V>), grid, block, 0, s, a, b, dw, workspace, counters, M,   \
+                     cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer)
+#define XPT_WGRAD_V(V)                                                                                               \
+  do {                                                                                                               \
+    if (p.tco == 64 && p.tci == 64)                                                                                  \
+      XPT_WGRAD(64, 64, V);                                                                                          \
+    else if (p.tco == 64)                                                                                            \
+      XPT_WGRAD(64, 32, V);                                                                                          \
+    else if (p.tci == 64)                                                                                            \
+      XPT_WGRAD(32, 64, V);                                                                                          \
+    else                                                                                                             \
+      XPT_WGRAD(32, 32, V);                                                                                          \
+  } while (0)
+  if (v == 8)
+    XPT_WGRAD_V(8);
+  else if (v == 4)
+    XPT_WGRAD_V(4);
+  else if (v == 2)
+    XPT_WGRAD_V(2);
+  else
+    XPT_WGRAD_V(1);
+#undef XPT_WGRAD_V
+#undef XPT_WGRAD
+  return xpt_launch_status();
+}
+
+extern "C" int xpt_conv1x1_bwd_weight(const void* dy, const void* x, float* dw, float* workspace,
+                                      size_t workspace_floats, unsigned* counters, int n_counters, long long M,
+                                      int cout, int cin, long long pitch_dy, long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(dy);
+  XPT_CHECK_PTR(x);
+  XPT_CHECK_PTR(dw);
+  XPT_CHECK_PTR(workspace);
+  XPT_CHECK_PTR(counters);
+  if (M <= 0 || cout <= 0 || cin <= 0 || pitch_dy < cout || pitch_x < cin) return XPT_ERR_SHAPE;
+  const WgradPlan p = wgrad_plan(M, cout, cin);
+  if (workspace_floats < xpt_conv1x1_bwd_weight_workspace_floats(M, cout, cin)) return XPT_ERR_WORKSPACE;
+  if (n_counters < p.tiles_co * p.tiles_ci) return XPT_ERR_WORKSPACE;
+  if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
+  return wgrad_launch(dy, x, dw, workspace, counters, M, cout, cin, pitch_dy, pitch_x, p, 0, stream);
+}
+
+extern "C" int xpt_conv1x1_bwd_weight_splits(long long M, int cout, int cin) {
+  if (M <= 0 || cout <= 0 || cin <= 0) return 0;
+  return wgrad_plan(M, cout, cin, true).nsplit;
+}
+
+/* Deferred weight gradient: partials[split][cout][cin] (xpt_conv1x1_bwd_weight_splits() of them), to be added up
+ * later by xpt_reduce_partials; no counters, no in-kernel finishing pass. */
+extern "C" int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, float* partials, size_t partial_floats,
+                                               long long M, int cout, int cin, long long pitch_dy, long long pitch_x,
+                                               void* stream) {
+  XPT_CHECK_PTR(dy);
+  XPT_CHECK_PTR(x);
+  XPT_CHECK_PTR(partials);
+  if (M <= 0 || cout <= 0 || cin <= 0 || pitch_dy < cout || pitch_x < cin) return XPT_ERR_SHAPE;
+  const WgradPlan p = wgrad_plan(M, cout, cin, true);
+  if (partial_floats < (size_t)p.nsplit * cout * cin) return XPT_ERR_WORKSPACE;
+  if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
+  return wgrad_launch(dy, x, nullptr, partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream);
+}

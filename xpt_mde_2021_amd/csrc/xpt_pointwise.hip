@@ -66,7 +66,8 @@ __global__ void affine_act_fwd_kernel(const T* __restrict__ x, Affine a, T* __re
 template <typename T>
 __global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
                                       Affine a, T* __restrict__ dx, float* __restrict__ part,
-                                      long long rows, int C, float slope, int relu_in, int need_dscale, int RG) {
+                                      long long rows, int C, float slope, int relu_in, int need_dscale, int RG,
+                                      int final_partials) {
   __shared__ float red[2][3][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rg = (RG > 1) ? lane / C : 0;
@@ -111,8 +112,15 @@ __global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restri
   __syncthreads();
   if (wid == 0 && c < C && rg == 0) {
     float* p = part + (long long)blockIdx.y * 2 * C;
-    p[c] = ((s_shift + red[0][0][lane]) + red[0][1][lane]) + red[0][2][lane];
-    p[C + c] = ((s_scale + red[1][0][lane]) + red[1][1][lane]) + red[1][2][lane];
+    const float s0 = ((s_shift + red[0][0][lane]) + red[0][1][lane]) + red[0][2][lane];
+    float s1 = ((s_scale + red[1][0][lane]) + red[1][1][lane]) + red[1][2][lane];
+    if (final_partials && need_dscale) {   // this block's share of dgamma itself (the finishing pass only adds)
+      float sc, sh, rstd, mu;
+      affine_coeffs(a, c, sc, sh, rstd, mu);
+      s1 = rstd * (s1 - mu * s0);
+    }
+    p[c] = s0;
+    p[C + c] = s1;
   }
 }
 
@@ -122,7 +130,7 @@ template <typename T>
 __global__ void affine_act_bwd_smallc_kernel(const T* __restrict__ x, const T* __restrict__ y,
                                              const T* __restrict__ dy, Affine a, T* __restrict__ dx,
                                              float* __restrict__ part, long long rows, int C, float slope,
-                                             int relu_in, int need_dscale) {
+                                             int relu_in, int need_dscale, int final_partials) {
   __shared__ float red[4 * 8];
   float acc[8];
 #pragma unroll
@@ -153,8 +161,14 @@ __global__ void affine_act_bwd_smallc_kernel(const T* __restrict__ x, const T* _
   if (threadIdx.x == 0) {
     float* p = part + (long long)blockIdx.y * 2 * C;
     for (int c = 0; c < C; ++c) {
+      float s1 = acc[4 + c];
+      if (final_partials && need_dscale) {
+        float sc, sh, rstd, mu;
+        affine_coeffs(a, c, sc, sh, rstd, mu);
+        s1 = rstd * (s1 - mu * acc[c]);
+      }
       p[c] = acc[c];
-      p[C + c] = acc[4 + c];
+      p[C + c] = s1;
     }
   }
 }
@@ -217,7 +231,50 @@ int xpt_affine_act_fwd(const void* x, const float* gamma, const float* beta, con
 
 size_t xpt_affine_act_bwd_workspace_floats(long long rows, int C) {
   if (rows <= 0 || C <= 0) return 0;
-  return (size_t)((rows + PW_ROWS - 1) / PW_ROWS) * 2 * (size_t)C;
+  return (size_t)((rows + PW_ROWS - 1) / PW_ROWS) * 2 * (size_t)C;   // upper bound of blocks * 2 * C
+}
+
+static int affine_bwd_blocks(long long rows, int C) {
+  return (int)(C <= 4 ? (rows + PW_ROWS * 8 - 1) / (PW_ROWS * 8) : (rows + PW_ROWS - 1) / PW_ROWS);
+}
+
+// dx + per-block partial sums part[blk][2][C]; final_partials: the second row holds the block's share of dgamma
+static void affine_bwd_launch(const void* x, const void* y, const void* dy, const Affine& a, void* dx, float* part,
+                              long long rows, int C, float slope, int relu_in, int need_dscale, int final_partials,
+                              int dtype, hipStream_t s) {
+  const int nblk = affine_bwd_blocks(rows, C);
+  if (C <= 4) {
+    const dim3 g1(1, nblk);
+    if (dtype == 0)
+      hipLaunchKernelGGL(affine_act_bwd_smallc_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (const float*)y,
+                         (const float*)dy, a, (float*)dx, part, rows, C, slope, relu_in, need_dscale, final_partials);
+    else
+      hipLaunchKernelGGL(affine_act_bwd_smallc_kernel<__hip_bfloat16>, g1, dim3(256), 0, s, (const __hip_bfloat16*)x,
+                         (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, part, rows, C,
+                         slope, relu_in, need_dscale, final_partials);
+    return;
+  }
+  const dim3 grid((C + 63) / 64, nblk);
+  const int RG = (C <= 32) ? (64 / C > PW_ROWS / 4 ? PW_ROWS / 4 : 64 / C) : 1;
+  if (dtype == 0)
+    hipLaunchKernelGGL(affine_act_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)y,
+                       (const float*)dy, a, (float*)dx, part, rows, C, slope, relu_in, need_dscale, RG, final_partials);
+  else
+    hipLaunchKernelGGL(affine_act_bwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, s, (const __hip_bfloat16*)x,
+                       (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, part, rows, C,
+                       slope, relu_in, need_dscale, RG, final_partials);
+}
+
+static int affine_bwd_check(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
+                            const float* mean, const float* var, long long rows, int C, float slope, int relu_in,
+                            int dtype) {
+  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(beta);
+  if (slope != 1.f) XPT_CHECK_PTR(y);
+  if (rows <= 0 || C <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  if (gamma && (!mean || !var)) return XPT_ERR_NULL;
+  if ((gamma || relu_in) && !x) return XPT_ERR_NULL;
+  return XPT_OK;
 }
 
 /* dx may be NULL (no data gradient wanted); dgamma must be NULL iff gamma is NULL (bias-only epilogue). */
@@ -225,41 +282,38 @@ int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float
                        const float* mean, const float* var, float eps, void* dx, float* dbeta, float* dgamma,
                        float* workspace, size_t workspace_floats, long long rows, int C, float slope, int relu_in,
                        int dtype, void* stream) {
-  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(dbeta); XPT_CHECK_PTR(workspace);
-  if (slope != 1.f) XPT_CHECK_PTR(y);
-  if (rows <= 0 || C <= 0) return XPT_ERR_SHAPE;
-  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  XPT_CHECK_PTR(dbeta); XPT_CHECK_PTR(workspace);
+  const int rc = affine_bwd_check(x, y, dy, gamma, beta, mean, var, rows, C, slope, relu_in, dtype);
+  if (rc != XPT_OK) return rc;
   if ((gamma == nullptr) != (dgamma == nullptr)) return XPT_ERR_ARG;
-  if (gamma && (!mean || !var)) return XPT_ERR_NULL;
-  if ((dgamma || relu_in) && !x) return XPT_ERR_NULL;
   if (workspace_floats < xpt_affine_act_bwd_workspace_floats(rows, C)) return XPT_ERR_WORKSPACE;
   const Affine a{gamma, beta, mean, var, eps};
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
-  if (C <= 4) {
-    const int nb = (int)((rows + PW_ROWS * 8 - 1) / (PW_ROWS * 8));
-    const dim3 g1(1, nb);
-    if (dtype == 0)
-      hipLaunchKernelGGL(affine_act_bwd_smallc_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (const float*)y,
-                         (const float*)dy, a, (float*)dx, workspace, rows, C, slope, relu_in, dgamma != nullptr);
-    else
-      hipLaunchKernelGGL(affine_act_bwd_smallc_kernel<__hip_bfloat16>, g1, dim3(256), 0, s, (const __hip_bfloat16*)x,
-                         (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, workspace, rows,
-                         C, slope, relu_in, dgamma != nullptr);
-    hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, a, dbeta, dgamma, C, nb);
-    return xpt_launch_status();
-  }
-  const int nblk = (int)((rows + PW_ROWS - 1) / PW_ROWS);
-  const dim3 grid((C + 63) / 64, nblk);
-  const int RG = (C <= 32) ? (64 / C > PW_ROWS / 4 ? PW_ROWS / 4 : 64 / C) : 1;
-  if (dtype == 0)
-    hipLaunchKernelGGL(affine_act_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)y,
-                       (const float*)dy, a, (float*)dx, workspace, rows, C, slope, relu_in, dgamma != nullptr, RG);
-  else
-    hipLaunchKernelGGL(affine_act_bwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, s, (const __hip_bfloat16*)x,
-                       (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, workspace, rows, C,
-                       slope, relu_in, dgamma != nullptr, RG);
-  hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, a, dbeta, dgamma, C, nblk);
+  affine_bwd_launch(x, y, dy, a, dx, workspace, rows, C, slope, relu_in, dgamma != nullptr, 0, dtype, s);
+  hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, a, dbeta, dgamma, C,
+                     affine_bwd_blocks(rows, C));
+  return xpt_launch_status();
+}
+
+int xpt_affine_act_bwd_blocks(long long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return affine_bwd_blocks(rows, C);
+}
+
+/* Deferred parameter gradients: dx as above; partials[blk][0][c] = this block's share of dbeta[c] and, when gamma is
+ * given, partials[blk][1][c] = its share of dgamma[c] -- to be added up later by xpt_reduce_partials. */
+int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
+                                const float* mean, const float* var, float eps, void* dx, float* partials,
+                                size_t partial_floats, long long rows, int C, float slope, int relu_in, int dtype,
+                                void* stream) {
+  XPT_CHECK_PTR(partials);
+  const int rc = affine_bwd_check(x, y, dy, gamma, beta, mean, var, rows, C, slope, relu_in, dtype);
+  if (rc != XPT_OK) return rc;
+  if (partial_floats < (size_t)affine_bwd_blocks(rows, C) * 2 * (size_t)C) return XPT_ERR_WORKSPACE;
+  const Affine a{gamma, beta, mean, var, eps};
+  XPT_BEGIN_LAUNCH();
+  affine_bwd_launch(x, y, dy, a, dx, partials, rows, C, slope, relu_in, gamma != nullptr, 1, dtype, (hipStream_t)stream);
   return xpt_launch_status();
 }
 

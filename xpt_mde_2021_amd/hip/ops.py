@@ -287,6 +287,96 @@ def smoothness(disp, image, grad_factor, input_is_depth=False):
     return _Smooth.apply(disp, image, grad_factor, input_is_depth)
 
 
+# ------------------------------------------------------------------------------- deferred parameter gradients
+class GradSink:
+    """Collects the split-K / per-workgroup partial sums of parameter gradients during one backward pass and finishes
+    them all with ONE launch (xpt_reduce_partials) straight into the flat gradient buffer.
+
+    A parameter takes part when it carries a `flat_grad` attribute: the persistent, contiguous float32 destination
+    (FlatParameters sets it to the parameter's view of the flat gradient buffer).  Layers then call
+    `partials(param, tag, nfloats)` for a persistent workspace, launch their *_partials kernel into it and `add()`
+    the job; autograd gets None for that parameter.  `flush()` runs after loss.backward(): the job table is built on
+    the first step (and rebuilt whenever the set of jobs changes, which it does not for a static model) and lives on
+    the device, so a captured hipGraph replays it unchanged.  A layer applied several times per step contributes one
+    segment per use (at most 4)."""
+
+    def __init__(self):
+        self.enabled = True
+        self.buffers = {}        # (id(dst), tag, use) -> workspace tensor
+        self.uses = {}           # (id(dst), tag) -> uses so far this step
+        self.pending = []        # (dst, src tensor, n, nsplit, stride)
+        self.signature = None
+        self.table = None        # (jobs tensor, blockmap tensor, nblocks)
+
+    def wants(self, param):
+        return self.enabled and param is not None and getattr(param, "flat_grad", None) is not None
+
+    def partials(self, dst, tag, nfloats):
+        use = self.uses.get((id(dst), tag), 0)
+        self.uses[(id(dst), tag)] = use + 1
+        key = (id(dst), tag, use)
+        buf = self.buffers.get(key)
+        if buf is None or buf.numel() < nfloats:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.XptHipError("GradSink: new workspace requested during graph capture (run an eager step first)")
+            buf = self.buffers[key] = torch.empty(nfloats, dtype=torch.float32, device=dst.device)
+        return buf
+
+    def add(self, dst, src, offset, n, nsplit, stride):
+        if not dst.is_contiguous() or dst.dtype != torch.float32 or dst.numel() != n:
+            raise _lib.XptHipError(f"GradSink: destination must be a contiguous float32 tensor of {n} elements")
+        self.pending.append((dst, src, int(offset), int(n), int(nsplit), int(stride)))
+
+    def flush(self):
+        pending, self.pending = self.pending, []
+        self.uses.clear()
+        if not pending:
+            return
+        lib = _lib.load()
+        sig = tuple((d.data_ptr(), s.data_ptr() + 4 * off, n, ns, st) for d, s, off, n, ns, st in pending)
+        if sig != self.signature:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.XptHipError("GradSink: the set of deferred gradients changed during graph capture")
+            self.table = self._build(lib, pending)
+            self.signature = sig
+        jobs, blockmap, nblocks = self.table
+        _lib.check(lib.xpt_reduce_partials(_ptr(jobs), _ptr(blockmap), nblocks, _stream()), "xpt_reduce_partials")
+
+    @staticmethod
+    def _build(lib, pending):
+        import ctypes
+        import numpy as np
+        assert lib.xpt_reduce_job_bytes() == ctypes.sizeof(_lib.ReduceJob)
+        by_dst, order = {}, []
+        for d, s, off, n, ns, st in pending:
+            key = d.data_ptr()
+            if key not in by_dst:
+                by_dst[key] = (d, n, [])
+                order.append(key)
+            by_dst[key][2].append((s.data_ptr() + 4 * off, ns, st))
+        jobs = (_lib.ReduceJob * len(order))()
+        blockmap = []
+        for j, key in enumerate(order):
+            d, n, segs = by_dst[key]
+            if len(segs) > 4:
+                raise _lib.XptHipError("GradSink: a parameter is used more than 4 times per step")
+            most = max(ns for _, ns, _ in segs)
+            lanes = 1 if most <= 8 else 4 if most <= 32 else 16 if most <= 128 else 64
+            job = jobs[j]
+            job.dst, job.n, job.nseg, job.split_lanes = d.data_ptr(), n, len(segs), lanes
+            for g, (ptr, ns, st) in enumerate(segs):
+                job.src[g], job.nsplit[g], job.stride[g] = ptr, ns, st
+            per_block = 256 // lanes
+            blockmap.extend((j, first) for first in range(0, n, per_block))
+        dev = pending[0][0].device
+        jobs_t = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        map_t = torch.from_numpy(np.asarray(blockmap, dtype=np.int32).reshape(-1, 2)).to(dev)
+        return jobs_t, map_t, len(blockmap)
+
+
+grad_sink = GradSink()
+
+
 # ------------------------------------------------------------------------------- depthwise conv (NASNet separable convs)
 def _nhwc(t, name):
     if not t.is_cuda:
@@ -317,6 +407,7 @@ class _DepthwiseConv(torch.autograd.Function):
                                       int(relu_in), dt, _stream()), "xpt_dwconv_fwd")
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad_t, pad_l, OH, OW, int(relu_in), dt, weight.shape)
+        ctx.sink_dst = weight.flat_grad if grad_sink.wants(weight) else None
         return y
 
     @staticmethod
@@ -332,7 +423,15 @@ class _DepthwiseConv(torch.autograd.Function):
             dx = torch.empty_like(x, memory_format=torch.channels_last)
             _lib.check(lib.xpt_dwconv_bwd_data(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), B, H, W, C, k, stride, pad_t,
                                                pad_l, OH, OW, relu_in, dt, _stream()), "xpt_dwconv_bwd_data")
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.sink_dst is not None:
+            nchunk = lib.xpt_dwconv_bwd_weight_chunks(B, OH, OW, C, k, stride)
+            n = C * k * k
+            ws = grad_sink.partials(ctx.sink_dst, "dw", nchunk * n)
+            _lib.check(lib.xpt_dwconv_bwd_weight_partials(_ptr(x), _ptr(dy), _ptr(ws), ws.numel(), B, H, W, C, k, stride,
+                                                          pad_t, pad_l, OH, OW, relu_in, dt, _stream()),
+                       "xpt_dwconv_bwd_weight_partials")
+            grad_sink.add(ctx.sink_dst, ws, 0, n, nchunk, n)
+        elif ctx.needs_input_grad[1]:
             dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
             nws = lib.xpt_dwconv_bwd_weight_workspace_floats(B, OH, OW, C, k)
             ws = torch.empty(nws, dtype=torch.float32, device=x.device)
@@ -368,6 +467,10 @@ class _AffineAct(torch.autograd.Function):
         need_x = (gamma is not None) or relu_in
         ctx.save_for_backward(x if need_x else None, y if slope != 1.0 else None, g_, b_, mean, var)
         ctx.cfg = (float(eps), float(slope), int(relu_in), dt, rows, C)
+        # deferred parameter gradients: both destinations (or the bias alone) must be flat-gradient views
+        ctx.sink_dst = None
+        if grad_sink.wants(beta) and (gamma is None or grad_sink.wants(gamma)):
+            ctx.sink_dst = (None if gamma is None else gamma.flat_grad, beta.flat_grad)
         return y
 
     @staticmethod
@@ -378,6 +481,17 @@ class _AffineAct(torch.autograd.Function):
         ref = x if x is not None else y
         dy = _nhwc(dy if ref is None else dy.to(ref.dtype), "dy")
         dx = torch.empty_like(dy, memory_format=torch.channels_last) if ctx.needs_input_grad[0] else None
+        if ctx.sink_dst is not None:
+            dst_gamma, dst_beta = ctx.sink_dst
+            nblk = lib.xpt_affine_act_bwd_blocks(rows, C)
+            ws = grad_sink.partials(dst_beta, "affine", nblk * 2 * C)
+            _lib.check(lib.xpt_affine_act_bwd_partials(_ptr(x), _ptr(y), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(mean),
+                                                       _ptr(var), eps, _ptr(dx), _ptr(ws), ws.numel(), rows, C, slope,
+                                                       relu_in, dt, _stream()), "xpt_affine_act_bwd_partials")
+            grad_sink.add(dst_beta, ws, 0, C, nblk, 2 * C)
+            if dst_gamma is not None:
+                grad_sink.add(dst_gamma, ws, C, C, nblk, 2 * C)
+            return dx, None, None, None, None, None, None, None
         dbeta = torch.empty(C, dtype=torch.float32, device=dy.device)
         dgamma = torch.empty(C, dtype=torch.float32, device=dy.device) if gamma is not None else None
         nws = lib.xpt_affine_act_bwd_workspace_floats(rows, C)
@@ -398,3 +512,73 @@ def batchnorm_inference(x, gamma, beta, running_mean, running_var, eps, relu_in=
     """keras BatchNormalization in inference mode (moving statistics, trainable gamma / beta), optionally with the
     preceding ReLU fused; differentiable w.r.t. x, gamma, beta."""
     return _AffineAct.apply(x, gamma, beta, running_mean, running_var, eps, 1.0, relu_in)
+
+
+# ------------------------------------------------------------------------------- pointwise (1x1) convolution pieces
+_COUNTERS = {}
+_N_COUNTERS = 1024
+
+
+def _counters(device):
+    """Zero-initialised arrival counters of the split-K kernels (they leave them zero); one array per device, shared
+    by every call because calls on a stream run in order.  Allocated outside any graph capture (warm-up step)."""
+    buf = _COUNTERS.get(device)
+    if buf is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.XptHipError("run one eager step before capturing: the split-K counters are allocated on first use")
+        buf = _COUNTERS[device] = torch.zeros(_N_COUNTERS, dtype=torch.int32, device=device)
+    return buf
+
+
+def as_rows(t):
+    """[B,C,H,W] NCHW-indexed tensor -> ([B*H*W, C] view, copied?) with unit channel stride and a constant row pitch.
+    Dense channels_last tensors AND channel slices of them (what torch.cat's backward hands out) are consumed in
+    place; anything else is first made channels_last-contiguous."""
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if not (sc == 1 and sh == W * sw and sb == H * sh and sw >= C) and not (B * H * W == 1):
+        t = t.contiguous(memory_format=torch.channels_last)
+        sw = C
+    return t.as_strided((B * H * W, C), (sw, 1), t.storage_offset())
+
+
+def conv1x1_weight_grad(dy2, x2):
+    """dW [cout, cin] float32 = dy2^T @ x2 for bf16 row matrices dy2 [M, cout], x2 [M, cin] (unit column stride, any
+    row pitch): the split-K matrix-core kernel of csrc/xpt_gemm.hip."""
+    lib = _lib.load()
+    if not (dy2.is_cuda and x2.is_cuda) or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16:
+        raise _lib.XptHipError("conv1x1_weight_grad: expected bfloat16 CUDA/HIP matrices (no CPU fallback)")
+    if dy2.dim() != 2 or x2.dim() != 2 or dy2.shape[0] != x2.shape[0] or dy2.stride(1) != 1 or x2.stride(1) != 1:
+        raise _lib.XptHipError(f"conv1x1_weight_grad: bad operands {tuple(dy2.shape)} {dy2.stride()} / "
+                               f"{tuple(x2.shape)} {x2.stride()}")
+    M, cout = dy2.shape
+    cin = x2.shape[1]
+    pitch_dy = dy2.stride(0) if M > 1 else cout
+    pitch_x = x2.stride(0) if M > 1 else cin
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=dy2.device)
+    nws = lib.xpt_conv1x1_bwd_weight_workspace_floats(M, cout, cin)
+    ws = torch.empty(nws, dtype=torch.float32, device=dy2.device)
+    cnt = _counters(dy2.device)
+    _lib.check(lib.xpt_conv1x1_bwd_weight(_ptr(dy2), _ptr(x2), _ptr(dw), _ptr(ws), nws, _ptr(cnt), _N_COUNTERS, M, cout,
+                                          cin, pitch_dy, pitch_x, _stream()), "xpt_conv1x1_bwd_weight")
+    return dw
+
+
+def conv1x1_weight_grad_deferred(dy2, x2, dst):
+    """Same product as conv1x1_weight_grad, left as split-K partials for grad_sink.flush() to add into `dst`
+    (the weight's flat-gradient view, [cout, cin(,1,1)] contiguous)."""
+    lib = _lib.load()
+    if not (dy2.is_cuda and x2.is_cuda) or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16:
+        raise _lib.XptHipError("conv1x1_weight_grad: expected bfloat16 CUDA/HIP matrices (no CPU fallback)")
+    if dy2.dim() != 2 or x2.dim() != 2 or dy2.shape[0] != x2.shape[0] or dy2.stride(1) != 1 or x2.stride(1) != 1:
+        raise _lib.XptHipError(f"conv1x1_weight_grad: bad operands {tuple(dy2.shape)} {dy2.stride()} / "
+                               f"{tuple(x2.shape)} {x2.stride()}")
+    M, cout = dy2.shape
+    cin = x2.shape[1]
+    pitch_dy = dy2.stride(0) if M > 1 else cout
+    pitch_x = x2.stride(0) if M > 1 else cin
+    nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
+    ws = grad_sink.partials(dst, "conv1x1", nsplit * cout * cin)
+    _lib.check(lib.xpt_conv1x1_bwd_weight_partials(_ptr(dy2), _ptr(x2), _ptr(ws), ws.numel(), M, cout, cin, pitch_dy,
+                                                   pitch_x, _stream()), "xpt_conv1x1_bwd_weight_partials")
+    grad_sink.add(dst, ws, 0, cout * cin, nsplit, cout * cin)

@@ -24,6 +24,7 @@ from ...hip import ops as _ops
 from ...utils.util_class import WrongInputException
 from ..model_util.layer_ops import conv2d_library, same_pad
 
+_LIBRARY_WGRAD = __import__("os").environ.get("XPT_DEBUG_LIBRARY_WGRAD", "0") == "1"     # A/B switch: rocBLAS weight gradient
 _DISABLE_HIP_DWCONV = bool(int(__import__("os").environ.get("XPT_DEBUG_MIOPEN_DWCONV", "0")))   # A/B debugging only
 BN_EPS = 1e-3          # keras_applications nasnet: BatchNormalization(momentum=0.9997, epsilon=1e-3)
 
@@ -46,29 +47,37 @@ class FrozenBatchNorm(nn.Module):
 
 class _Conv1x1Bf16(torch.autograd.Function):
     """1x1 convolution as GEMMs on the bf16 shadow copy of the weight (kept current by the fused Adam kernel):
-    y = x W^T and dx = dy W in bf16, dW = dy^T x accumulated AND written in fp32 (mm out_dtype) -- no cast launches."""
+    y = x W^T and dx = dy W in bf16 through rocBLAS; dW = dy^T x by the split-K matrix-core kernel of
+    csrc/xpt_gemm.hip (exact products, fp32 accumulation and output).  Operands are [pixels, channels] views with a
+    row pitch, so channel slices (torch.cat's backward) are consumed without a copy."""
 
     @staticmethod
     def forward(ctx, x, weight):
         B, cin, H, W = x.shape
         cout = weight.shape[0]
         ws = weight.shadow_bf16.reshape(cout, cin)
-        x2 = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, cin)
+        x2 = _ops.as_rows(x)
         y2 = torch.mm(x2, ws.t())
         ctx.save_for_backward(x2, ws)
         ctx.dims = (B, cin, H, W, cout, weight.shape)
+        ctx.sink_dst = weight.flat_grad if (_ops.grad_sink.wants(weight) and not _LIBRARY_WGRAD) else None
         return y2.view(B, H, W, cout).permute(0, 3, 1, 2)
 
     @staticmethod
     def backward(ctx, dy):
         x2, ws = ctx.saved_tensors
         B, cin, H, W, cout, wshape = ctx.dims
-        dy2 = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, cout)
+        dy2 = _ops.as_rows(dy.to(torch.bfloat16))
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dy2, ws).view(B, H, W, cin).permute(0, 3, 1, 2)
-        if ctx.needs_input_grad[1]:
-            dw = torch.mm(dy2.t(), x2, out_dtype=torch.float32).view(wshape)
+        if ctx.needs_input_grad[1] and ctx.sink_dst is not None:
+            _ops.conv1x1_weight_grad_deferred(dy2, x2, ctx.sink_dst)      # finished by grad_sink.flush()
+        elif ctx.needs_input_grad[1]:
+            if _LIBRARY_WGRAD:
+                dw = torch.mm(dy2.t(), x2, out_dtype=torch.float32).view(wshape)
+            else:
+                dw = _ops.conv1x1_weight_grad(dy2, x2).view(wshape)
         return dx, dw
 
 

@@ -41,6 +41,10 @@ class FlatParameters:
             self.grad_views.append(gview)
             if self.shadow is not None:
                 p.shadow_bf16 = self._view(self.shadow, p, off)
+                if gview.is_contiguous():
+                    # destination of the deferred gradient finishing (hip/ops.py GradSink): the gfx950 backward kernels
+                    # of this parameter leave partial sums behind and ONE launch per step adds them into this view
+                    p.flat_grad = gview
         if self.shadow is not None:
             self.shadow.copy_(self.data)
         self.offsets = offsets

@@ -16,6 +16,7 @@ import pandas as pd
 import torch
 
 from ..config import opts
+from ..hip import ops as _ops
 from ..utils import util_class as uc
 from ..utils import util_funcs as uf
 from .model_util.distributer import DistributionStrategy
@@ -110,6 +111,8 @@ class ModelTrainer(TrainValBase):
         preds = self.model(features)
         total_loss, loss_by_type = self.loss_object(preds, features)
         total_loss.backward()
+        if total_loss.is_cuda:
+            _ops.grad_sink.flush()       # one launch finishes every deferred parameter gradient into the flat buffer
         if self.optimizer is not None and getattr(self.optimizer, "flat", None) is not None:
             self.optimizer.flat.gather_grads()
         # hand back detached values only: a live autograd graph would keep its AccumulateGrad nodes (and their
