@@ -210,14 +210,14 @@ int xpt_conv1x1_bwd_weight(const void* dy, const void* x, float* dw, float* work
  *   dwconv:   partials[chunks][C][k][k]  chunks = xpt_dwconv_bwd_weight_chunks()
  *   conv1x1:  partials[splits][cout][cin] splits = xpt_conv1x1_bwd_weight_splits()
  * xpt_reduce_partials then finishes all layers at once: block b of the launch serves job blockmap[b].x and the outputs
- * starting at blockmap[b].y (256 / split_lanes outputs per block);
+ * starting at blockmap[b].y (256 outputs per block when split_waves == 1, 64 when it is 4);
  *   dst[i] = sum over segments g < nseg, splits s < nsplit[g] of src[g][s * stride[g] + i],  i < n   (fixed order).
  * jobs and blockmap are device arrays built once by the host (the layer list of a model is static). */
 typedef struct xpt_reduce_job {
   float* dst;
   long long n;
   int nseg;          /* 1..4 segments (a layer applied several times per step contributes one segment per use) */
-  int split_lanes;   /* 1, 4, 16 or 64 lanes cooperating on one output */
+  int split_waves;   /* 1: one output per thread (nsplit <= 8); 4: the 4 waves of a block share 64 outputs */
   const float* src[4];
   long long stride[4];
   int nsplit[4];

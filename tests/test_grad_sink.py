@@ -13,7 +13,7 @@ def test_reduce_partials_jobs(gpu_device):
     from xpt_mde_2021_amd.hip import ops
     sink = ops.GradSink()
     g = torch.Generator().manual_seed(0)
-    cases = [(5, 3), (300, 8), (1100, 9), (77, 32), (1000, 33), (40, 128), (13, 129), (257, 500), (4096, 1)]
+    cases = [(5, 3), (300, 8), (1100, 9), (77, 32), (1000, 33), (40, 128), (13, 257), (257, 500), (70, 3328), (4096, 1)]
     expect, dsts = [], []
     for n, nsplit in cases:
         stride = n + 7

@@ -7,41 +7,48 @@
 //
 //     dst_j[i] = sum_{seg} sum_{s < nsplit_seg} src_seg[s * stride_seg + i]        (fixed order: deterministic)
 //
-// A job with many splits spreads them over `split_lanes` (1, 4, 16 or 64) lanes per output, combined by a fixed
-// shuffle tree; every lane issues its loads in batches of 8 before adding, so a job costs a few memory round trips.
+// Lanes always run along the outputs (coalesced rows of the partial matrices).  A job with few splits (<= 8) gives every
+// thread one output; a job with more gives a 64-output group to the 4 waves of a workgroup, wave w adding the splits
+// w, w + 4, ... and the four sums being combined through LDS in wave order.  Every lane issues its loads in batches of 8
+// before adding, so a job costs a few memory round trips.  The host splits jobs with more than 256 splits into two
+// passes (pass 1 writes <= 64-split group sums to a scratch matrix that pass 2 consumes).
 #include "xpt_common.h"
 
 namespace {
 
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const xpt_reduce_job* __restrict__ jobs,
                                                                const int2* __restrict__ blockmap) {
+  __shared__ float red[3][64];
   const int2 bm = blockmap[blockIdx.x];
   const xpt_reduce_job job = jobs[bm.x];
-  const int SL = job.split_lanes;              // lanes per output
-  const int OUTS = 64 / SL;                    // outputs per wave
+  const int SW = job.split_waves;              // 1 or 4 waves share one 64-output group
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sl = lane / OUTS, o = lane - sl * OUTS;
-  const long long i = (long long)bm.y + wave * OUTS + o;
+  const long long i = (long long)bm.y + (SW == 1 ? threadIdx.x : lane);
+  const int first = SW == 1 ? 0 : wave;
   const bool live = i < job.n;
   float sum = 0.f;
   for (int g = 0; g < job.nseg; ++g) {
     const float* src = job.src[g] + (live ? i : 0);
     const long long stride = job.stride[g];
     const int ns = job.nsplit[g];
-    // this lane's splits: sl, sl + SL, ... ; 8 loads in flight, added in order
-    for (int s0 = sl; s0 < ns; s0 += 8 * SL) {
+    for (int s0 = first; s0 < ns; s0 += 8 * SW) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int s = s0 + u * SL;
+        const int s = s0 + u * SW;
         v[u] = s < ns ? src[(long long)s * stride] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) sum += v[u];
     }
   }
-  for (int off = 32; off >= OUTS; off >>= 1) sum += __shfl_down(sum, off, 64);
-  if (live && sl == 0) job.dst[i] = sum;
+  if (SW == 1) {
+    if (live) job.dst[i] = sum;
+    return;
+  }
+  if (wave > 0) red[wave - 1][lane] = sum;
+  __syncthreads();
+  if (wave == 0 && live) job.dst[i] = ((sum + red[0][lane]) + red[1][lane]) + red[2][lane];
 }
 
 }  // namespace

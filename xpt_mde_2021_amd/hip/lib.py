@@ -73,7 +73,7 @@ SIGNATURES = {
 class ReduceJob(ctypes.Structure):
     """Mirror of xpt_reduce_job (include/xpt_hip.h)."""
     _fields_ = [("dst", ctypes.c_void_p), ("n", ctypes.c_longlong), ("nseg", ctypes.c_int),
-                ("split_lanes", ctypes.c_int), ("src", ctypes.c_void_p * 4), ("stride", ctypes.c_longlong * 4),
+                ("split_waves", ctypes.c_int), ("src", ctypes.c_void_p * 4), ("stride", ctypes.c_longlong * 4),
                 ("nsplit", ctypes.c_int * 4)]
 
 

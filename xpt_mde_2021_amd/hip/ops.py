@@ -306,7 +306,8 @@ class GradSink:
         self.uses = {}           # (id(dst), tag) -> uses so far this step
         self.pending = []        # (dst, src tensor, n, nsplit, stride)
         self.signature = None
-        self.table = None        # (jobs tensor, blockmap tensor, nblocks)
+        self.table = None        # [(jobs tensor, blockmap tensor, nblocks)] per finishing launch
+        self.scratch = None
 
     def wants(self, param):
         return self.enabled and param is not None and getattr(param, "flat_grad", None) is not None
@@ -339,14 +340,17 @@ class GradSink:
                 raise _lib.XptHipError("GradSink: the set of deferred gradients changed during graph capture")
             self.table = self._build(lib, pending)
             self.signature = sig
-        jobs, blockmap, nblocks = self.table
-        _lib.check(lib.xpt_reduce_partials(_ptr(jobs), _ptr(blockmap), nblocks, _stream()), "xpt_reduce_partials")
+        for jobs, blockmap, nblocks in self.table:
+            _lib.check(lib.xpt_reduce_partials(_ptr(jobs), _ptr(blockmap), nblocks, _stream()), "xpt_reduce_partials")
 
-    @staticmethod
-    def _build(lib, pending):
+    MAX_SPLITS = 256       # per job and pass; more are folded by a first pass into groups of GROUP splits
+    GROUP = 64
+
+    def _build(self, lib, pending):
+        """Job tables of the finishing launches: [pass 1 (only when some job has > MAX_SPLITS splits), pass 2]."""
         import ctypes
-        import numpy as np
         assert lib.xpt_reduce_job_bytes() == ctypes.sizeof(_lib.ReduceJob)
+        dev = pending[0][0].device
         by_dst, order = {}, []
         for d, s, off, n, ns, st in pending:
             key = d.data_ptr()
@@ -354,21 +358,42 @@ class GradSink:
                 by_dst[key] = (d, n, [])
                 order.append(key)
             by_dst[key][2].append((s.data_ptr() + 4 * off, ns, st))
-        jobs = (_lib.ReduceJob * len(order))()
-        blockmap = []
-        for j, key in enumerate(order):
+        first, final = [], []          # entries: (dst_ptr, n, [(src_ptr, nsplit, stride), ...])
+        scratch_need = sum(n * -(-ns // self.GROUP) for key in order for _, ns, _ in by_dst[key][2]
+                           if ns > self.MAX_SPLITS for n in [by_dst[key][1]])
+        if scratch_need:
+            self.scratch = torch.empty(scratch_need, dtype=torch.float32, device=dev)
+        used = 0
+        for key in order:
             d, n, segs = by_dst[key]
             if len(segs) > 4:
                 raise _lib.XptHipError("GradSink: a parameter is used more than 4 times per step")
-            most = max(ns for _, ns, _ in segs)
-            lanes = 1 if most <= 8 else 4 if most <= 32 else 16 if most <= 128 else 64
+            folded = []
+            for ptr, ns, st in segs:
+                if ns <= self.MAX_SPLITS:
+                    folded.append((ptr, ns, st))
+                    continue
+                groups = -(-ns // self.GROUP)
+                base = self.scratch.data_ptr() + 4 * used
+                for g in range(groups):
+                    first.append((base + 4 * g * n, n, [(ptr + 4 * g * self.GROUP * st, min(self.GROUP, ns - g * self.GROUP), st)]))
+                folded.append((base, groups, n))
+                used += groups * n
+            final.append((d.data_ptr(), n, folded))
+        return [self._table(entries, dev) for entries in (first, final) if entries]
+
+    @staticmethod
+    def _table(entries, dev):
+        import numpy as np
+        jobs = (_lib.ReduceJob * len(entries))()
+        blockmap = []
+        for j, (dst, n, segs) in enumerate(entries):
+            waves = 1 if max(ns for _, ns, _ in segs) <= 8 else 4
             job = jobs[j]
-            job.dst, job.n, job.nseg, job.split_lanes = d.data_ptr(), n, len(segs), lanes
+            job.dst, job.n, job.nseg, job.split_waves = dst, n, len(segs), waves
             for g, (ptr, ns, st) in enumerate(segs):
                 job.src[g], job.nsplit[g], job.stride[g] = ptr, ns, st
-            per_block = 256 // lanes
-            blockmap.extend((j, first) for first in range(0, n, per_block))
-        dev = pending[0][0].device
+            blockmap.extend((j, first) for first in range(0, n, 256 if waves == 1 else 64))
         jobs_t = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         map_t = torch.from_numpy(np.asarray(blockmap, dtype=np.int32).reshape(-1, 2)).to(dev)
         return jobs_t, map_t, len(blockmap)
