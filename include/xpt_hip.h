@@ -173,15 +173,20 @@ int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* works
  *   gamma != NULL : keras BatchNormalization in inference mode inside NASNetMobile (called without training=True,
  *                   model/train_val.py:82), f = relu when relu_in (the Activation('relu') that precedes it is fused).
  *   x, y [rows, C] (rows = B*H*W pixels of an NHWC tensor), dtype 0 = float32 / 1 = bfloat16; parameters float32.
- * bwd: dy -> dx (may be NULL), dbeta [C], dgamma [C] (NULL iff gamma is NULL); y is only read when slope != 1;
+ *   residual (fwd, may be NULL): y += residual [rows, C] -- the branch sum of a NASNet cell (keras layers.add) fused
+ *                   into the BatchNorm that produces one of its operands; linear epilogues (slope == 1) only; its
+ *                   gradient is dy itself.
+ * bwd: dy [rows, C] with row pitch dy_pitch >= C elements (a channel slice of a wider tensor is read in place)
+ *   -> dx (may be NULL), dbeta [C], dgamma [C] (NULL iff gamma is NULL); y is only read when slope != 1;
  *   workspace xpt_affine_act_bwd_workspace_floats(rows, C) floats; deterministic reduction. */
 int xpt_affine_act_fwd(const void* x, const float* gamma, const float* beta, const float* mean, const float* var,
-                       float eps, void* y, long long rows, int C, float slope, int relu_in, int dtype, void* stream);
-size_t xpt_affine_act_bwd_workspace_floats(long long rows, int C);
-int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
-                       const float* mean, const float* var, float eps, void* dx, float* dbeta, float* dgamma,
-                       float* workspace, size_t workspace_floats, long long rows, int C, float slope, int relu_in,
+                       float eps, const void* residual, void* y, long long rows, int C, float slope, int relu_in,
                        int dtype, void* stream);
+size_t xpt_affine_act_bwd_workspace_floats(long long rows, int C);
+int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, long long dy_pitch, const float* gamma,
+                       const float* beta, const float* mean, const float* var, float eps, void* dx, float* dbeta,
+                       float* dgamma, float* workspace, size_t workspace_floats, long long rows, int C, float slope,
+                       int relu_in, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ a2: weight gradient of the pointwise (1x1) convolutions
  * replaces the filter gradient of every 1x1 Conv2D / the pointwise half of every SeparableConv2D inside
@@ -225,10 +230,10 @@ typedef struct xpt_reduce_job {
 int xpt_reduce_job_bytes(void);
 int xpt_reduce_partials(const void* jobs, const void* blockmap, int nblocks, void* stream);
 int xpt_affine_act_bwd_blocks(long long rows, int C);
-int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
-                                const float* mean, const float* var, float eps, void* dx, float* partials,
-                                size_t partial_floats, long long rows, int C, float slope, int relu_in, int dtype,
-                                void* stream);
+int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, long long dy_pitch, const float* gamma,
+                                const float* beta, const float* mean, const float* var, float eps, void* dx,
+                                float* partials, size_t partial_floats, long long rows, int C, float slope, int relu_in,
+                                int dtype, void* stream);
 int xpt_dwconv_bwd_weight_chunks(int B, int OH, int OW, int C, int k, int stride);
 int xpt_dwconv_bwd_weight_partials(const void* x, const void* dy, float* partials, size_t partial_floats, int B, int H,
                                    int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int relu_in,

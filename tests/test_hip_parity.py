@@ -308,6 +308,49 @@ def test_bias_act_and_batchnorm_epilogues(ops, gpu_device, C, shape, dtype):
         frac_close(bg.grad, br.grad, 2e-3 * (1 + br.grad.abs().max().item()), rtol=2e-3, what=f"bn dbeta relu_in={relu_in}")
 
 
+@pytest.mark.parametrize("C,shape", [(44, (2, 16, 52)), (88, (2, 8, 26)), (11, (1, 32, 104)), (32, (1, 9, 7))])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batchnorm_residual_and_sliced_gradient(ops, gpu_device, C, shape, dtype):
+    """The cell's branch add fused into the BatchNorm epilogue, and a dy that is a channel slice of a wider
+    (concatenated) gradient read in place through its row pitch."""
+    import torch.nn.functional as F
+    g = gen(170 + C)
+    B, H, W = shape
+
+    def rnd(*s):
+        t = torch.randn(s, generator=g)
+        return t.bfloat16().float() if dtype == torch.bfloat16 else t
+
+    x, res = rnd(B, C, H, W), rnd(B, C, H, W)
+    gy_wide = rnd(B, 3 * C + 8, H, W)
+    off = C + 8
+    gamma, bias = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    mean, var = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.3
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+
+    xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yr = F.batch_norm(F.relu(xr), mean, var, gr, br, False, 0.0, 1e-3) + rr
+    yr.backward(gy_wide[:, off:off + C])
+
+    def dev(t):
+        return t.to(gpu_device)
+
+    xg = dev(x).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = dev(res).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gg, bg = dev(gamma).requires_grad_(True), dev(bias).requires_grad_(True)
+    y = ops.batchnorm_inference(xg, gg, bg, dev(mean), dev(var), 1e-3, True, residual=rg)
+    wide = dev(gy_wide).to(dtype).contiguous(memory_format=torch.channels_last)
+    y.backward(wide[:, off:off + C])                      # non-dense: row pitch 3C + 8
+    frac_close(y.float(), yr, tol, rtol=tol, what="bn+res y")
+    frac_close(xg.grad.float(), xr.grad, tol, rtol=tol, what="bn+res dx")
+    frac_close(rg.grad.float(), rr.grad, tol, rtol=tol, what="bn+res dres")
+    frac_close(gg.grad, gr.grad, 2e-3 * (1 + gr.grad.abs().max().item()), rtol=2e-3, what="bn+res dgamma")
+    frac_close(bg.grad, br.grad, 2e-3 * (1 + br.grad.abs().max().item()), rtol=2e-3, what="bn+res dbeta")
+    with pytest.raises(Exception):
+        ops._AffineAct.apply(xg, None, bg, None, None, 0.0, 0.1, False, rg)      # residual needs a linear epilogue
+
+
 # ------------------------------------------------------------------------------------------------ depthwise conv (a2)
 @pytest.mark.parametrize("k,stride", [(3, 1), (5, 1), (7, 1), (3, 2), (5, 2), (7, 2)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

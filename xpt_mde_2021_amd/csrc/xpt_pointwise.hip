@@ -42,8 +42,8 @@ __device__ inline void affine_coeffs(const Affine& a, int c, float& sc, float& s
 }
 
 template <typename T>
-__global__ void affine_act_fwd_kernel(const T* __restrict__ x, Affine a, T* __restrict__ y, long long n, int C,
-                                      float slope, int relu_in) {
+__global__ void affine_act_fwd_kernel(const T* __restrict__ x, Affine a, const T* __restrict__ residual,
+                                      T* __restrict__ y, long long n, int C, float slope, int relu_in) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
     float sc, sh, rstd, mu;
@@ -52,124 +52,126 @@ __global__ void affine_act_fwd_kernel(const T* __restrict__ x, Affine a, T* __re
     if (relu_in) v = fmaxf(v, 0.f);
     v = v * sc + sh;
     v = v > 0.f ? v : v * slope;
+    if (residual) v += ldf<T>(residual + i);     // the cell's branch sum (keras layers.add), linear epilogues only
     stf<T>(y + i, v);
   }
 }
 
-// Backward.  Rows = pixels (n / C), lanes = channels: block (64 channels) x (ROWS pixel rows per block).
-//   g  = dy * act'(y)            (act' from the OUTPUT sign: valid for slope > 0, and for slope == 0 where y == 0 => 0)
-//   dx = g * scale [* (x > 0) if relu_in]
-//   dbeta[c] = sum g ; dgamma[c] = rstd * (sum g f(x) - mean * sum g)
-// part[blk][2][C] partial sums of (g, g f(x)).
-// When C <= 32 the spare lanes of a wave take further rows (RG = 64 / C row groups, folded by fixed-order shuffles).
-#define PW_ROWS 32
-template <typename T>
-__global__ void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y, const T* __restrict__ dy,
-                                      Affine a, T* __restrict__ dx, float* __restrict__ part,
-                                      long long rows, int C, float slope, int relu_in, int need_dscale, int RG,
-                                      int final_partials) {
-  __shared__ float red[2][3][64];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int rg = (RG > 1) ? lane / C : 0;
-  const int cl = (RG > 1) ? lane - rg * C : lane;
-  const int c = blockIdx.x * 64 + cl;
-  const long long r0 = (long long)blockIdx.y * PW_ROWS;
-  float s_shift = 0.f, s_scale = 0.f;
-  if (c < C && rg < RG) {
-    float sc, sh, rstd, mu;
-    affine_coeffs(a, c, sc, sh, rstd, mu);
-    for (int i = wid * RG + rg; i < PW_ROWS; i += 4 * RG) {
-      const long long r = r0 + i;
-      if (r >= rows) break;
-      const long long o = r * C + c;
-      float g = ldf<T>(dy + o);
-      if (slope != 1.f) g = (ldf<T>(y + o) > 0.f) ? g : g * slope;      // y is not read for a linear epilogue
-      float xv = 0.f;
-      if (need_dscale || relu_in) xv = ldf<T>(x + o);
-      float gx = g * sc;
-      if (relu_in) {
-        if (!(xv > 0.f)) gx = 0.f;
-        xv = fmaxf(xv, 0.f);
-      }
-      if (dx) stf<T>(dx + o, gx);
-      s_shift += g;
-      s_scale += g * xv;
-    }
-  }
-  if (RG > 1) {
-    float v0 = s_shift, v1 = s_scale;
-    for (int r = 1; r < RG; ++r) {
-      v0 += __shfl(s_shift, (cl + r * C) & 63, 64);
-      v1 += __shfl(s_scale, (cl + r * C) & 63, 64);
-    }
-    s_shift = v0;
-    s_scale = v1;
-  }
-  if (wid > 0) {
-    red[0][wid - 1][lane] = s_shift;
-    red[1][wid - 1][lane] = s_scale;
-  }
-  __syncthreads();
-  if (wid == 0 && c < C && rg == 0) {
-    float* p = part + (long long)blockIdx.y * 2 * C;
-    const float s0 = ((s_shift + red[0][0][lane]) + red[0][1][lane]) + red[0][2][lane];
-    float s1 = ((s_scale + red[1][0][lane]) + red[1][1][lane]) + red[1][2][lane];
-    if (final_partials && need_dscale) {   // this block's share of dgamma itself (the finishing pass only adds)
-      float sc, sh, rstd, mu;
-      affine_coeffs(a, c, sc, sh, rstd, mu);
-      s1 = rstd * (s1 - mu * s0);
-    }
-    p[c] = s0;
-    p[C + c] = s1;
-  }
+// V consecutive channels of one pixel row as one load / store
+template <typename T, int V> struct RowVec;
+template <> struct RowVec<float, 4> { typedef float4 type; };
+template <> struct RowVec<float, 2> { typedef float2 type; };
+template <> struct RowVec<float, 1> { typedef float type; };
+template <> struct RowVec<__hip_bfloat16, 8> { typedef uint4 type; };
+template <> struct RowVec<__hip_bfloat16, 4> { typedef uint2 type; };
+template <> struct RowVec<__hip_bfloat16, 2> { typedef unsigned type; };
+template <> struct RowVec<__hip_bfloat16, 1> { typedef unsigned short type; };
+
+template <typename T, int V>
+__device__ inline void load_row(const T* p, float (&out)[V]) {
+  typename RowVec<T, V>::type raw = *(const typename RowVec<T, V>::type*)p;
+  const T* e = (const T*)&raw;
+#pragma unroll
+  for (int i = 0; i < V; ++i) out[i] = ldf<T>(e + i);
 }
 
-// Few channels (C <= 4, e.g. the 1-channel depth heads): one thread per pixel row keeps the C running sums in
-// registers; the block then reduces them.  Same outputs / partial layout as the kernel above (gridDim.x == 1).
-template <typename T>
-__global__ void affine_act_bwd_smallc_kernel(const T* __restrict__ x, const T* __restrict__ y,
-                                             const T* __restrict__ dy, Affine a, T* __restrict__ dx,
-                                             float* __restrict__ part, long long rows, int C, float slope,
-                                             int relu_in, int need_dscale, int final_partials) {
-  __shared__ float red[4 * 8];
-  float acc[8];
+template <typename T, int V>
+__device__ inline void store_row(T* p, const float (&v)[V]) {
+  typename RowVec<T, V>::type raw;
+  T* e = (T*)&raw;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  const long long r0 = (long long)blockIdx.y * (PW_ROWS * 8);
-  for (int i = threadIdx.x; i < PW_ROWS * 8; i += blockDim.x) {
-    const long long r = r0 + i;
-    if (r >= rows) break;
-    for (int c = 0; c < C; ++c) {
-      float sc, sh, rstd, mu;
-      affine_coeffs(a, c, sc, sh, rstd, mu);
-      const long long o = r * C + c;
-      float g = ldf<T>(dy + o);
-      if (slope != 1.f) g = (ldf<T>(y + o) > 0.f) ? g : g * slope;
-      float xv = 0.f;
-      if (need_dscale || relu_in) xv = ldf<T>(x + o);
-      float gx = g * sc;
-      if (relu_in) {
-        if (!(xv > 0.f)) gx = 0.f;
-        xv = fmaxf(xv, 0.f);
+  for (int i = 0; i < V; ++i) stf<T>(e + i, v[i]);
+  *(typename RowVec<T, V>::type*)p = raw;
+}
+
+// Backward.  A thread owns V consecutive channels (one 16-byte load per tensor and pixel when the layout allows) and
+// walks the pixel rows of its workgroup's slice, keeping its 2 V running sums in registers; the row slots of a
+// workgroup are then folded through LDS in slot order (deterministic).
+//   g  = dy * act'(y)            (act' from the OUTPUT sign: valid for slope > 0, and for slope == 0 where y == 0 => 0)
+//   dx = g * scale [* (x > 0) if relu_in]
+//   part[blk][0][c] = sum g  (dbeta);  part[blk][1][c] = sum g f(x)  or, with final_partials, the block's share of
+//   dgamma = rstd * (sum g f(x) - mean * sum g).
+// grid (channel tiles of 64 V-groups, row slices); dy may have a row pitch (a channel slice of a wider tensor).
+#define PW_MAX_GROUPS 64
+template <typename T, int V>
+__global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                              const T* __restrict__ dy, long long dy_pitch, Affine a,
+                                                              T* __restrict__ dx, float* __restrict__ part,
+                                                              long long rows, int C, long long rows_per_block,
+                                                              float slope, int relu_in, int need_dscale,
+                                                              int final_partials) {
+  __shared__ float red[2][256 * V];
+  const int groups = C / V;                                   // V divides C
+  const int g0 = blockIdx.x * PW_MAX_GROUPS;
+  const int gt = min(groups - g0, PW_MAX_GROUPS);             // V-groups of this channel tile
+  const int slots = 256 / gt;                                 // pixel rows in flight per iteration
+  const int grp = threadIdx.x % gt, slot = threadIdx.x / gt;
+  const int c0 = (g0 + grp) * V;
+  const long long r_begin = (long long)blockIdx.y * rows_per_block;
+  const long long r_end = min(rows, r_begin + rows_per_block);
+  float s_shift[V], s_scale[V], sc[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s_shift[i] = s_scale[i] = 0.f;
+  if (slot < slots) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float sh, rstd, mu;
+      affine_coeffs(a, c0 + i, sc[i], sh, rstd, mu);
+    }
+    for (long long r = r_begin + slot; r < r_end; r += slots) {
+      const long long o = r * C + c0;
+      float g[V], xv[V], gx[V];
+      load_row<T, V>(dy + r * dy_pitch + c0, g);
+      if (slope != 1.f) {                                     // y is not read for a linear epilogue
+        float yv[V];
+        load_row<T, V>(y + o, yv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) g[i] = yv[i] > 0.f ? g[i] : g[i] * slope;
       }
-      if (dx) stf<T>(dx + o, gx);
-      acc[c] += g;
-      acc[4 + c] += g * xv;
+      if (need_dscale || relu_in) {
+        load_row<T, V>(x + o, xv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) xv[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        gx[i] = g[i] * sc[i];
+        if (relu_in) {
+          if (!(xv[i] > 0.f)) gx[i] = 0.f;
+          xv[i] = fmaxf(xv[i], 0.f);
+        }
+        s_shift[i] += g[i];
+        s_scale[i] += g[i] * xv[i];
+      }
+      if (dx) store_row<T, V>(dx + o, gx);
     }
   }
-  xpt::block_sum_n<8>(acc, red);
-  if (threadIdx.x == 0) {
-    float* p = part + (long long)blockIdx.y * 2 * C;
-    for (int c = 0; c < C; ++c) {
-      float s1 = acc[4 + c];
-      if (final_partials && need_dscale) {
-        float sc, sh, rstd, mu;
-        affine_coeffs(a, c, sc, sh, rstd, mu);
-        s1 = rstd * (s1 - mu * acc[c]);
-      }
-      p[c] = acc[c];
-      p[C + c] = s1;
+  // fold the row slots: red[q][slot][grp * V + i]
+  const int width = gt * V;
+  if (slot < slots) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      red[0][slot * width + grp * V + i] = s_shift[i];
+      red[1][slot * width + grp * V + i] = s_scale[i];
     }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < width; e += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < slots; ++k) {
+      s0 += red[0][k * width + e];
+      s1 += red[1][k * width + e];
+    }
+    const int c = g0 * V + e;
+    if (final_partials && need_dscale) {   // this block's share of dgamma itself (the finishing pass only adds)
+      float scc, sh, rstd, mu;
+      affine_coeffs(a, c, scc, sh, rstd, mu);
+      s1 = rstd * (s1 - mu * s0);
+    }
+    float* p = part + (long long)blockIdx.y * 2 * C;
+    p[c] = s0;
+    p[C + c] = s1;
   }
 }
 
@@ -207,62 +209,53 @@ inline unsigned grid_for(long long total) {
   return (unsigned)blocks;
 }
 
-}  // namespace
-
-extern "C" {
-
-int xpt_affine_act_fwd(const void* x, const float* gamma, const float* beta, const float* mean, const float* var,
-                       float eps, void* y, long long rows, int C, float slope, int relu_in, int dtype, void* stream) {
-  XPT_CHECK_PTR(x); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(y);
-  if (gamma && (!mean || !var)) return XPT_ERR_NULL;
-  if (rows <= 0 || C <= 0) return XPT_ERR_SHAPE;
-  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
-  const long long n = rows * C;
-  const Affine a{gamma, beta, mean, var, eps};
-  XPT_BEGIN_LAUNCH();
-  if (dtype == 0)
-    hipLaunchKernelGGL(affine_act_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)x, a, (float*)y, n, C, slope, relu_in);
-  else
-    hipLaunchKernelGGL(affine_act_fwd_kernel<__hip_bfloat16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16*)x, a, (__hip_bfloat16*)y, n, C, slope, relu_in);
-  return xpt_launch_status();
-}
-
-size_t xpt_affine_act_bwd_workspace_floats(long long rows, int C) {
-  if (rows <= 0 || C <= 0) return 0;
-  return (size_t)((rows + PW_ROWS - 1) / PW_ROWS) * 2 * (size_t)C;   // upper bound of blocks * 2 * C
+// pixel rows per workgroup: at most ~512 row slices per launch, at least 64 rows each
+static long long affine_bwd_rows_per_block(long long rows) {
+  long long rpb = (rows + 511) / 512;
+  if (rpb < 64) rpb = 64;
+  return (rpb + 7) / 8 * 8;
 }
 
 static int affine_bwd_blocks(long long rows, int C) {
-  return (int)(C <= 4 ? (rows + PW_ROWS * 8 - 1) / (PW_ROWS * 8) : (rows + PW_ROWS - 1) / PW_ROWS);
+  const long long rpb = affine_bwd_rows_per_block(rows);
+  return (int)((rows + rpb - 1) / rpb);
+}
+
+template <typename T, int V>
+static void affine_bwd_launch_v(const void* x, const void* y, const void* dy, long long dy_pitch, const Affine& a,
+                                void* dx, float* part, long long rows, int C, float slope, int relu_in,
+                                int need_dscale, int final_partials, hipStream_t s) {
+  const int groups = C / V;
+  const dim3 grid((groups + PW_MAX_GROUPS - 1) / PW_MAX_GROUPS, affine_bwd_blocks(rows, C));
+  hipLaunchKernelGGL((affine_act_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy,
+                     dy_pitch, a, (T*)dx, part, rows, C, affine_bwd_rows_per_block(rows), slope, relu_in, need_dscale,
+                     final_partials);
 }
 
 // dx + per-block partial sums part[blk][2][C]; final_partials: the second row holds the block's share of dgamma
-static void affine_bwd_launch(const void* x, const void* y, const void* dy, const Affine& a, void* dx, float* part,
-                              long long rows, int C, float slope, int relu_in, int need_dscale, int final_partials,
-                              int dtype, hipStream_t s) {
-  const int nblk = affine_bwd_blocks(rows, C);
-  if (C <= 4) {
-    const dim3 g1(1, nblk);
-    if (dtype == 0)
-      hipLaunchKernelGGL(affine_act_bwd_smallc_kernel<float>, g1, dim3(256), 0, s, (const float*)x, (const float*)y,
-                         (const float*)dy, a, (float*)dx, part, rows, C, slope, relu_in, need_dscale, final_partials);
-    else
-      hipLaunchKernelGGL(affine_act_bwd_smallc_kernel<__hip_bfloat16>, g1, dim3(256), 0, s, (const __hip_bfloat16*)x,
-                         (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, part, rows, C,
-                         slope, relu_in, need_dscale, final_partials);
-    return;
+static void affine_bwd_launch(const void* x, const void* y, const void* dy, long long dy_pitch, const Affine& a,
+                              void* dx, float* part, long long rows, int C, float slope, int relu_in, int need_dscale,
+                              int final_partials, int dtype, hipStream_t s) {
+  // widest vector (elements) every tensor involved allows
+  const int esz = dtype == 0 ? 4 : 2;
+  int v = dtype == 0 ? 4 : 8;
+  auto ok = [&](const void* p, long long pitch) {
+    return p == nullptr || (((uintptr_t)p) % (size_t)(v * esz) == 0 && pitch % v == 0);
+  };
+  while (v > 1 && !(C % v == 0 && ok(x, C) && ok(y, C) && ok(dy, dy_pitch) && ok(dx, C))) v >>= 1;
+#define XPT_AFF(T, V) \
+  affine_bwd_launch_v<T, V>(x, y, dy, dy_pitch, a, dx, part, rows, C, slope, relu_in, need_dscale, final_partials, s)
+  if (dtype == 0) {
+    if (v == 4) XPT_AFF(float, 4);
+    else if (v == 2) XPT_AFF(float, 2);
+    else XPT_AFF(float, 1);
+  } else {
+    if (v == 8) XPT_AFF(__hip_bfloat16, 8);
+    else if (v == 4) XPT_AFF(__hip_bfloat16, 4);
+    else if (v == 2) XPT_AFF(__hip_bfloat16, 2);
+    else XPT_AFF(__hip_bfloat16, 1);
   }
-  const dim3 grid((C + 63) / 64, nblk);
-  const int RG = (C <= 32) ? (64 / C > PW_ROWS / 4 ? PW_ROWS / 4 : 64 / C) : 1;
-  if (dtype == 0)
-    hipLaunchKernelGGL(affine_act_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)y,
-                       (const float*)dy, a, (float*)dx, part, rows, C, slope, relu_in, need_dscale, RG, final_partials);
-  else
-    hipLaunchKernelGGL(affine_act_bwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, s, (const __hip_bfloat16*)x,
-                       (const __hip_bfloat16*)y, (const __hip_bfloat16*)dy, a, (__hip_bfloat16*)dx, part, rows, C,
-                       slope, relu_in, need_dscale, RG, final_partials);
+#undef XPT_AFF
 }
 
 static int affine_bwd_check(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
@@ -277,9 +270,40 @@ static int affine_bwd_check(const void* x, const void* y, const void* dy, const 
   return XPT_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int xpt_affine_act_fwd(const void* x, const float* gamma, const float* beta, const float* mean, const float* var,
+                       float eps, const void* residual, void* y, long long rows, int C, float slope, int relu_in,
+                       int dtype, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(y);
+  if (residual && slope != 1.f) return XPT_ERR_ARG;   // the backward reads act' off the output sign
+  if (gamma && (!mean || !var)) return XPT_ERR_NULL;
+  if (rows <= 0 || C <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  const long long n = rows * C;
+  const Affine a{gamma, beta, mean, var, eps};
+  XPT_BEGIN_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(affine_act_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, a, (const float*)residual, (float*)y, n, C, slope, relu_in);
+  else
+    hipLaunchKernelGGL(affine_act_fwd_kernel<__hip_bfloat16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)x, a, (const __hip_bfloat16*)residual, (__hip_bfloat16*)y, n, C, slope,
+                       relu_in);
+  return xpt_launch_status();
+}
+
+size_t xpt_affine_act_bwd_workspace_floats(long long rows, int C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)affine_bwd_blocks(rows, C) * 2 * (size_t)C;
+}
+
 /* dx may be NULL (no data gradient wanted); dgamma must be NULL iff gamma is NULL (bias-only epilogue). */
-int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
-                       const float* mean, const float* var, float eps, void* dx, float* dbeta, float* dgamma,
+int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, long long dy_pitch, const float* gamma,
+                       const float* beta, const float* mean, const float* var, float eps, void* dx, float* dbeta,
+                       float* dgamma,
                        float* workspace, size_t workspace_floats, long long rows, int C, float slope, int relu_in,
                        int dtype, void* stream) {
   XPT_CHECK_PTR(dbeta); XPT_CHECK_PTR(workspace);
@@ -290,7 +314,8 @@ int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, const float
   const Affine a{gamma, beta, mean, var, eps};
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
-  affine_bwd_launch(x, y, dy, a, dx, workspace, rows, C, slope, relu_in, dgamma != nullptr, 0, dtype, s);
+  if (dy_pitch < C) return XPT_ERR_SHAPE;
+  affine_bwd_launch(x, y, dy, dy_pitch, a, dx, workspace, rows, C, slope, relu_in, dgamma != nullptr, 0, dtype, s);
   hipLaunchKernelGGL(affine_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, workspace, a, dbeta, dgamma, C,
                      affine_bwd_blocks(rows, C));
   return xpt_launch_status();
@@ -303,8 +328,9 @@ int xpt_affine_act_bwd_blocks(long long rows, int C) {
 
 /* Deferred parameter gradients: dx as above; partials[blk][0][c] = this block's share of dbeta[c] and, when gamma is
  * given, partials[blk][1][c] = its share of dgamma[c] -- to be added up later by xpt_reduce_partials. */
-int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, const float* gamma, const float* beta,
-                                const float* mean, const float* var, float eps, void* dx, float* partials,
+int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, long long dy_pitch, const float* gamma,
+                                const float* beta, const float* mean, const float* var, float eps, void* dx,
+                                float* partials,
                                 size_t partial_floats, long long rows, int C, float slope, int relu_in, int dtype,
                                 void* stream) {
   XPT_CHECK_PTR(partials);
@@ -313,7 +339,9 @@ int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, co
   if (partial_floats < (size_t)affine_bwd_blocks(rows, C) * 2 * (size_t)C) return XPT_ERR_WORKSPACE;
   const Affine a{gamma, beta, mean, var, eps};
   XPT_BEGIN_LAUNCH();
-  affine_bwd_launch(x, y, dy, a, dx, partials, rows, C, slope, relu_in, gamma != nullptr, 1, dtype, (hipStream_t)stream);
+  if (dy_pitch < C) return XPT_ERR_SHAPE;
+  affine_bwd_launch(x, y, dy, dy_pitch, a, dx, partials, rows, C, slope, relu_in, gamma != nullptr, 1, dtype,
+                    (hipStream_t)stream);
   return xpt_launch_status();
 }
 

@@ -56,16 +56,18 @@ SIGNATURES = {
     "xpt_reduce_job_bytes": (_i, []),
     "xpt_reduce_partials": (_i, [_p, _p, _i, _p]),
     "xpt_affine_act_bwd_blocks": (_i, [ctypes.c_longlong, _i]),
-    "xpt_affine_act_bwd_partials": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _z, ctypes.c_longlong, _i, _f, _i, _i, _p]),
+    "xpt_affine_act_bwd_partials": (_i, [_p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f, _p, _p, _z, ctypes.c_longlong,
+                                         _i, _f, _i, _i, _p]),
     "xpt_dwconv_bwd_weight_chunks": (_i, [_i] * 6),
     "xpt_dwconv_bwd_weight_partials": (_i, [_p, _p, _p, _z] + [_i] * 12 + [_p]),
     "xpt_conv1x1_bwd_weight_splits": (_i, [ctypes.c_longlong, _i, _i]),
     "xpt_conv1x1_bwd_weight_partials": (_i, [_p, _p, _p, _z, ctypes.c_longlong, _i, _i, ctypes.c_longlong,
                                              ctypes.c_longlong, _p]),
     "xpt_crc32c": (ctypes.c_uint32, [_p, _z]),
-    "xpt_affine_act_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, ctypes.c_longlong, _i, _f, _i, _i, _p]),
+    "xpt_affine_act_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, ctypes.c_longlong, _i, _f, _i, _i, _p]),
     "xpt_affine_act_bwd_workspace_floats": (_z, [ctypes.c_longlong, _i]),
-    "xpt_affine_act_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _z, ctypes.c_longlong, _i, _f, _i, _i, _p]),
+    "xpt_affine_act_bwd": (_i, [_p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f, _p, _p, _p, _p, _z, ctypes.c_longlong,
+                                _i, _f, _i, _i, _p]),
 }
 
 

@@ -474,9 +474,19 @@ def depthwise_conv2d(x, weight, stride=1, padding=(0, 0, 0, 0), relu_in=False):
 
 
 # ------------------------------------------------------------------------------- per-channel conv epilogues
+def _rows_with_pitch(t):
+    """NCHW-indexed tensor -> (tensor, row pitch in elements) readable as [B*H*W rows, C] with unit channel stride:
+    dense channels_last tensors and channel slices of them as they are, anything else after a channels_last copy."""
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if (sc == 1 and sh == W * sw and sb == H * sh and sw >= C) and B * H * W > 1:
+        return t, sw
+    return t.contiguous(memory_format=torch.channels_last), C
+
+
 class _AffineAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, mean, var, eps, slope, relu_in):
+    def forward(ctx, x, gamma, beta, mean, var, eps, slope, relu_in, residual):
         lib = _lib.load()
         x = _nhwc(x, "x")
         B, C, H, W = x.shape
@@ -484,14 +494,18 @@ class _AffineAct(torch.autograd.Function):
         for name, t in (("gamma", gamma), ("beta", beta), ("mean", mean), ("var", var)):
             if t is not None and (t.dtype != torch.float32 or not t.is_cuda or t.numel() != C):
                 raise _lib.XptHipError(f"affine_act: {name} must be a float32 CUDA vector of {C} elements")
+        if residual is not None:
+            if residual.shape != x.shape or slope != 1.0:
+                raise _lib.XptHipError("affine_act: residual needs the shape of x and a linear epilogue")
+            residual = _nhwc(residual.to(x.dtype), "residual")
         y = torch.empty_like(x, memory_format=torch.channels_last)
         dt = 0 if x.dtype == torch.float32 else 1
         g_, b_ = (None if gamma is None else gamma.detach().contiguous()), beta.detach().contiguous()
-        _lib.check(lib.xpt_affine_act_fwd(_ptr(x), _ptr(g_), _ptr(b_), _ptr(mean), _ptr(var), float(eps), _ptr(y), rows,
-                                          C, float(slope), int(relu_in), dt, _stream()), "xpt_affine_act_fwd")
+        _lib.check(lib.xpt_affine_act_fwd(_ptr(x), _ptr(g_), _ptr(b_), _ptr(mean), _ptr(var), float(eps), _ptr(residual),
+                                          _ptr(y), rows, C, float(slope), int(relu_in), dt, _stream()), "xpt_affine_act_fwd")
         need_x = (gamma is not None) or relu_in
         ctx.save_for_backward(x if need_x else None, y if slope != 1.0 else None, g_, b_, mean, var)
-        ctx.cfg = (float(eps), float(slope), int(relu_in), dt, rows, C)
+        ctx.cfg = (float(eps), float(slope), int(relu_in), dt, rows, C, x.dtype)
         # deferred parameter gradients: both destinations (or the bias alone) must be flat-gradient views
         ctx.sink_dst = None
         if grad_sink.wants(beta) and (gamma is None or grad_sink.wants(gamma)):
@@ -499,44 +513,46 @@ class _AffineAct(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy_in):
         lib = _lib.load()
         x, y, gamma, beta, mean, var = ctx.saved_tensors
-        eps, slope, relu_in, dt, rows, C = ctx.cfg
-        ref = x if x is not None else y
-        dy = _nhwc(dy if ref is None else dy.to(ref.dtype), "dy")
-        dx = torch.empty_like(dy, memory_format=torch.channels_last) if ctx.needs_input_grad[0] else None
+        eps, slope, relu_in, dt, rows, C, dtype = ctx.cfg
+        dy, pitch = _rows_with_pitch(dy_in.to(dtype))
+        dres = dy_in if ctx.needs_input_grad[8] else None          # d(residual) = dy: no kernel
+        dx = torch.empty(dy.shape, dtype=dtype, device=dy.device,
+                         memory_format=torch.channels_last) if ctx.needs_input_grad[0] else None
         if ctx.sink_dst is not None:
             dst_gamma, dst_beta = ctx.sink_dst
             nblk = lib.xpt_affine_act_bwd_blocks(rows, C)
             ws = grad_sink.partials(dst_beta, "affine", nblk * 2 * C)
-            _lib.check(lib.xpt_affine_act_bwd_partials(_ptr(x), _ptr(y), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(mean),
-                                                       _ptr(var), eps, _ptr(dx), _ptr(ws), ws.numel(), rows, C, slope,
-                                                       relu_in, dt, _stream()), "xpt_affine_act_bwd_partials")
+            _lib.check(lib.xpt_affine_act_bwd_partials(_ptr(x), _ptr(y), _ptr(dy), pitch, _ptr(gamma), _ptr(beta),
+                                                       _ptr(mean), _ptr(var), eps, _ptr(dx), _ptr(ws), ws.numel(), rows,
+                                                       C, slope, relu_in, dt, _stream()), "xpt_affine_act_bwd_partials")
             grad_sink.add(dst_beta, ws, 0, C, nblk, 2 * C)
             if dst_gamma is not None:
                 grad_sink.add(dst_gamma, ws, C, C, nblk, 2 * C)
-            return dx, None, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, dres
         dbeta = torch.empty(C, dtype=torch.float32, device=dy.device)
         dgamma = torch.empty(C, dtype=torch.float32, device=dy.device) if gamma is not None else None
         nws = lib.xpt_affine_act_bwd_workspace_floats(rows, C)
         ws = torch.empty(nws, dtype=torch.float32, device=dy.device)
-        _lib.check(lib.xpt_affine_act_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(var), eps,
-                                          _ptr(dx), _ptr(dbeta), _ptr(dgamma), _ptr(ws), nws, rows, C, slope, relu_in, dt,
-                                          _stream()), "xpt_affine_act_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None
+        _lib.check(lib.xpt_affine_act_bwd(_ptr(x), _ptr(y), _ptr(dy), pitch, _ptr(gamma), _ptr(beta), _ptr(mean),
+                                          _ptr(var), eps, _ptr(dx), _ptr(dbeta), _ptr(dgamma), _ptr(ws), nws, rows, C,
+                                          slope, relu_in, dt, _stream()), "xpt_affine_act_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None, dres
 
 
 def bias_act(x, bias, slope=1.0):
     """y = LeakyReLU_slope(x + bias[c]) on an NCHW-indexed channels_last tensor (slope 1 = linear): the epilogue of
     CustomConv2D (layer_ops.py:31-35).  x float32 or bfloat16; bias float32; differentiable w.r.t. both."""
-    return _AffineAct.apply(x, None, bias, None, None, 0.0, slope, False)
+    return _AffineAct.apply(x, None, bias, None, None, 0.0, slope, False, None)
 
 
-def batchnorm_inference(x, gamma, beta, running_mean, running_var, eps, relu_in=False):
+def batchnorm_inference(x, gamma, beta, running_mean, running_var, eps, relu_in=False, residual=None):
     """keras BatchNormalization in inference mode (moving statistics, trainable gamma / beta), optionally with the
-    preceding ReLU fused; differentiable w.r.t. x, gamma, beta."""
-    return _AffineAct.apply(x, gamma, beta, running_mean, running_var, eps, 1.0, relu_in)
+    preceding ReLU fused and with `residual` added to the result (the cell's layers.add); differentiable w.r.t. x,
+    gamma, beta and residual."""
+    return _AffineAct.apply(x, gamma, beta, running_mean, running_var, eps, 1.0, relu_in, residual)
 
 
 # ------------------------------------------------------------------------------- pointwise (1x1) convolution pieces

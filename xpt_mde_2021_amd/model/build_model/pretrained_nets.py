@@ -39,10 +39,25 @@ class FrozenBatchNorm(nn.Module):
         self.register_buffer("running_mean", torch.zeros(channels))
         self.register_buffer("running_var", torch.ones(channels))
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual: added to the normalised output -- the `layers.add` that joins two branches of a NASNet cell,
+        fused into the epilogue kernel of the branch that ends in this BatchNorm."""
         if x.is_cuda:      # one gfx950 streaming pass (and one for dx / dgamma / dbeta in the backward)
-            return _ops.batchnorm_inference(x, self.weight, self.bias, self.running_mean, self.running_var, BN_EPS)
-        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, BN_EPS)
+            return _ops.batchnorm_inference(x, self.weight, self.bias, self.running_mean, self.running_var, BN_EPS,
+                                            residual=residual)
+        y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, BN_EPS)
+        return y if residual is None else y + residual
+
+
+def shared_relu(x):
+    """relu(x), computed once per tensor: a cell output is the `ip` of the next cell and the `p` of the one after,
+    and both start with Activation('relu') on it."""
+    cached = getattr(x, "_xpt_relu", None)
+    if cached is None:
+        cached = F.relu(x)
+        if x.is_cuda:
+            x._xpt_relu = cached
+    return cached
 
 
 class _Conv1x1Bf16(torch.autograd.Function):
@@ -146,16 +161,17 @@ class SepConvBlock(nn.Module):
         self.conv2 = SeparableConv(filters, filters, k, 1)
         self.bn2 = FrozenBatchNorm(filters)
 
-    def forward(self, x, taps):
+    def forward(self, x, taps, residual=None):
+        """residual: the other operand of the cell's `add` (fused into the last BatchNorm's epilogue)."""
         if taps.wants(self.act_id1) or taps.wants(self.act_id2):      # a tapped activation must be materialised
             x = F.relu(x)
             taps.offer(self.act_id1, x)
             x = self.bn1(self.conv1(x))
             x = F.relu(x)
             taps.offer(self.act_id2, x)
-            return self.bn2(self.conv2(x))
+            return self.bn2(self.conv2(x), residual)
         x = self.bn1(self.conv1(x, relu_in=True))
-        return self.bn2(self.conv2(x, relu_in=True))
+        return self.bn2(self.conv2(x, relu_in=True), residual)
 
 
 class AdjustBlock(nn.Module):
@@ -183,13 +199,13 @@ class AdjustBlock(nn.Module):
 
     def forward(self, p, taps):
         if self.mode == "spatial":
-            p = F.relu(p)
+            p = shared_relu(p)
             p1 = conv1x1(p[:, :, ::2, ::2], self.conv1.weight)                       # AveragePooling2D((1,1), strides 2)
             p2 = F.pad(p, (0, 1, 0, 1))[:, :, 1:, 1:]                # ZeroPadding2D(((0,1),(0,1))) + Cropping2D(((1,0),(1,0)))
             p2 = conv1x1(p2[:, :, ::2, ::2], self.conv2.weight)
             return self.bn(torch.cat([p1, p2], dim=1))
         if self.mode == "project":
-            p = F.relu(p)
+            p = shared_relu(p)
             taps.offer(self.act_id, p)
             return self.bn(conv1x1(p, self.conv.weight))
         return p
@@ -220,14 +236,15 @@ class NormalCell(nn.Module):
 
     def forward(self, ip, p, taps):
         p = self.adjust(p, taps)
-        h = F.relu(ip)
+        h = shared_relu(ip)
         taps.offer(self.act_id, h)
         h = self.bn(conv1x1(h, self.conv.weight))
-        x1 = self.left1(h, taps) + self.right1(p, taps)
-        x2 = self.left2(p, taps) + self.right2(p, taps)
+        # every `add` whose operand ends in a BatchNorm rides in that BatchNorm's epilogue kernel
+        x1 = self.left1(h, taps, residual=self.right1(p, taps))
+        x2 = self.left2(p, taps, residual=self.right2(p, taps))
         x3 = avg_pool_same(h) + p
-        x4 = avg_pool_same(p) + avg_pool_same(p)
-        x5 = self.left5(h, taps) + h
+        x4 = avg_pool_same(p) * 2.0                      # add([avg(p), avg(p)]): x + x == 2 x exactly
+        x5 = self.left5(h, taps, residual=h)
         return torch.cat([p, x1, x2, x3, x4, x5], dim=1), ip
 
 
@@ -251,15 +268,16 @@ class ReductionCell(nn.Module):
 
     def forward(self, ip, p, taps):
         p = self.adjust(p, taps)
-        h = F.relu(ip)
+        h = shared_relu(ip)
         taps.offer(self.act_id, h)
         h = self.bn(conv1x1(h, self.conv.weight))
         h3 = zero_pad(h, correct_pad(h.shape[2], h.shape[3], 3))
-        x1 = self.left1(h, taps) + self.right1(p, taps)
-        x2 = F.max_pool2d(h3, 3, 2) + self.right2(p, taps)
-        x3 = F.avg_pool2d(h3, 3, 2) + self.right3(p, taps)
+        mp = F.max_pool2d(h3, 3, 2)                      # MaxPooling2D of h feeds x2 and x5: pooled once
+        x1 = self.left1(h, taps, residual=self.right1(p, taps))
+        x2 = self.right2(p, taps, residual=mp)
+        x3 = self.right3(p, taps, residual=F.avg_pool2d(h3, 3, 2))
         x4 = x2 + avg_pool_same(x1)
-        x5 = self.left4(x1, taps) + F.max_pool2d(h3, 3, 2)
+        x5 = self.left4(x1, taps, residual=mp)
         return torch.cat([x2, x3, x4, x5], dim=1), ip
 
 
