@@ -114,6 +114,8 @@ int xpt_photo_bwd(int method, const float* synth, const float* target, const flo
  * bwd: g_l1 [B], g_ssim [B] (gradients of those means) -> ddepth [B,h,w], dT [B,N,4,4] (last row 0); the views are
  *   re-synthesized on the fly.  workspace: xpt_photo_fused_workspace_floats(B,N,h,w) floats for both directions.
  * ALGORITHMIC bytes per batch element (P = h*w): fwd P(16 + 12N) [+ 12NP with synth], bwd P(20 + 12N). */
+/* launch-plan knob (process-wide, for benchmarking): minimum number of waves before the row chunks stop shrinking */
+int xpt_photo_fused_tune(int fwd_min_waves, int bwd_min_waves);
 size_t xpt_photo_fused_workspace_floats(int B, int N, int h, int w);
 int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, const float* K, const float* target,
                         float* synth, float* loss_l1, float* loss_ssim, float* workspace, size_t workspace_floats,
@@ -206,6 +208,13 @@ int xpt_conv1x1_bwd_weight_counters(long long M, int cout, int cin);
 int xpt_conv1x1_bwd_weight(const void* dy, const void* x, float* dw, float* workspace, size_t workspace_floats,
                            unsigned* counters, int n_counters, long long M, int cout, int cin, long long pitch_dy,
                            long long pitch_x, void* stream);
+
+/* ------------------------------------------------------------------ a2: gradient fan-in of a multiply used activation
+ * out [rows, C] = sum_i inputs[i] [rows, C] (row pitch pitches[i] >= C elements; n = 2..8; dtype 0 float32 / 1 bfloat16,
+ * fp32 accumulation in input order).  Replaces the chain of pairwise adds autograd (tape.gradient, train_val.py:85)
+ * performs for a NASNet cell input that feeds up to six branches. */
+int xpt_sum_rows(const void* const* inputs, const long long* pitches, int n, void* out, long long rows, int C, int dtype,
+                 void* stream);
 
 /* ------------------------------------------------------------------ deferred parameter gradients (one finishing launch per step)
  * The *_partials entry points compute the same parameter gradients as xpt_affine_act_bwd / xpt_dwconv_bwd_weight /

@@ -435,3 +435,29 @@ def test_as_rows_views(gpu_device):
     assert torch.equal(ops.as_rows(n), n.permute(0, 2, 3, 1).reshape(30, 12))
     one = torch.randn(4, 6, 1, 1, device=gpu_device)
     assert torch.equal(ops.as_rows(one), one.reshape(4, 6))
+
+
+# ------------------------------------------------------------------------------- gradient fan-in
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sum_rows_and_fan_out(ops, gpu_device, dtype):
+    g = gen(300)
+    B, C, H, W = 2, 44, 5, 7
+    wide = torch.randn((B, 3 * C + 4, H, W), generator=g).to(gpu_device, dtype).contiguous(memory_format=torch.channels_last)
+    parts = [torch.randn((B, C, H, W), generator=g).to(gpu_device, dtype).contiguous(memory_format=torch.channels_last)
+             for _ in range(3)]
+    parts.append(wide[:, 4:4 + C])                                   # channel slice: row pitch 3C + 4
+    parts.append(torch.randn((B, C, H, W), generator=g).to(gpu_device, dtype))     # NCHW-contiguous operand
+    out = ops.sum_rows(parts)
+    ref = sum(p.float() for p in parts)
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    assert out.dtype == dtype and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.allclose(out.float(), ref, atol=tol * (1 + ref.abs().max().item()))
+    # fan_out: same gradient as plain reuse of the tensor
+    x = parts[0].detach().float().requires_grad_(True)
+    w = [torch.randn((B, C, H, W), generator=g).to(gpu_device) for _ in range(4)]
+    a, b, c, d = ops.fan_out(x, 4)
+    (a * w[0] + torch.relu(b) * w[1] + c[:, :C] * w[2]).sum().backward()          # d unused: its gradient is None
+    x2 = parts[0].detach().float().requires_grad_(True)
+    (x2 * w[0] + torch.relu(x2) * w[1] + x2 * w[2]).sum().backward()
+    assert torch.allclose(x.grad, x2.grad, atol=1e-5)
+    assert ops.fan_out(parts[0], 3)[0] is parts[0]                   # no grad needed: plain aliases

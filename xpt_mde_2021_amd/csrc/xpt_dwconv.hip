@@ -14,6 +14,8 @@
 //   * the weight gradient is reduced deterministically: per-workgroup partials + a fixed-order sum.
 #include <hip/hip_bf16.h>
 
+#include <initializer_list>
+
 #include "xpt_common.h"
 
 namespace {
@@ -73,6 +75,114 @@ __global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__
 #pragma unroll
     for (int i = 0; i < OXT; ++i)
       if (ox0 + i < d.OW) stf<T>(out + (long long)i * d.C, acc[i]);
+  }
+}
+
+// ---------------------------------------------------------------- vectorised stencil (forward, stride-1 data gradient)
+// The texture addresser spends the same ~16 cycles on a wave's 2-byte load as on a 16-byte one, so the scalar kernels
+// above are address-bound.  Here a thread owns V consecutive channels of OXT neighbouring outputs: activations move as
+// 8 / 16-byte vectors, and the filter taps (w[c][ky][kx], 100-196 bytes apart between neighbouring channels) are
+// staged once per workgroup in LDS as sW[tap][c], read back as one vector per tap.
+//   FLIP = 0: y = conv(f(x), w)                                 (f = relu when relu_in)
+//   FLIP = 1: the stride-1 data gradient  dx = conv(dy, w rotated by 180 deg) with pad' = K - 1 - pad, masked by
+//             (x > 0) when the forward applied the ReLU on the way in (`mask` = x).
+template <typename T, int V> struct ChanVec;
+template <> struct ChanVec<float, 4> { typedef float4 type; };
+template <> struct ChanVec<float, 2> { typedef float2 type; };
+template <> struct ChanVec<__hip_bfloat16, 8> { typedef uint4 type; };
+template <> struct ChanVec<__hip_bfloat16, 4> { typedef uint2 type; };
+template <> struct ChanVec<__hip_bfloat16, 2> { typedef unsigned type; };
+
+template <typename T, int V>
+__device__ inline void load_chan(const T* p, float (&out)[V]) {
+  typename ChanVec<T, V>::type raw = *(const typename ChanVec<T, V>::type*)p;
+  const T* e = (const T*)&raw;
+#pragma unroll
+  for (int i = 0; i < V; ++i) out[i] = ldf<T>(e + i);
+}
+
+template <typename T, int V>
+__device__ inline void store_chan(T* p, const float (&v)[V]) {
+  typename ChanVec<T, V>::type raw;
+  T* e = (T*)&raw;
+#pragma unroll
+  for (int i = 0; i < V; ++i) stf<T>(e + i, v[i]);
+  *(typename ChanVec<T, V>::type*)p = raw;
+}
+
+template <typename T, int K, int S, int V, int OXT, int FLIP>
+__global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const T* __restrict__ mask, T* __restrict__ y, DwDims d,
+                                                          int relu_in) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];       // [K*K][C]
+  for (int i = threadIdx.x; i < d.C * K * K; i += 256) {
+    const int c = i / (K * K), tap = i - c * (K * K);
+    sW[(FLIP ? K * K - 1 - tap : tap) * d.C + c] = w[i];
+  }
+  __syncthreads();
+  const int CG = d.C / V;
+  const int OXG = (d.OW + OXT - 1) / OXT;
+  const long long total = (long long)d.B * d.OH * OXG * CG;
+  constexpr int IN = (OXT - 1) * S + K;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % CG) * V;
+    long long r = idx / CG;
+    const int oxg = (int)(r % OXG); r /= OXG;
+    const int oy = (int)(r % d.OH);
+    const int b = (int)(r / d.OH);
+    const int ox0 = oxg * OXT;
+    const int ix0 = ox0 * S - d.pad_l;
+    float acc[OXT][V];
+#pragma unroll
+    for (int i = 0; i < OXT; ++i)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[i][v] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * S + ky - d.pad_t;
+      if (iy < 0 || iy >= d.H) continue;
+      const T* row = x + (((long long)b * d.H + iy) * d.W) * d.C + c0;
+      float in[IN][V];
+#pragma unroll
+      for (int i = 0; i < IN; ++i) {
+        const int ix = ix0 + i;
+        if (ix >= 0 && ix < d.W) {
+          load_chan<T, V>(row + (long long)ix * d.C, in[i]);
+          if (relu_in && !FLIP) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) in[i][v] = fmaxf(in[i][v], 0.f);
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v) in[i][v] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        float wv[V];
+        const float* wp = sW + (ky * K + kx) * d.C + c0;
+#pragma unroll
+        for (int v = 0; v < V; ++v) wv[v] = wp[v];
+#pragma unroll
+        for (int i = 0; i < OXT; ++i)
+#pragma unroll
+          for (int v = 0; v < V; ++v) acc[i][v] += in[i * S + kx][v] * wv[v];
+      }
+    }
+    const long long o = (((long long)b * d.OH + oy) * d.OW + ox0) * d.C + c0;
+#pragma unroll
+    for (int i = 0; i < OXT; ++i) {
+      if (ox0 + i >= d.OW) break;
+      if (FLIP && relu_in) {
+        float m[V];
+        load_chan<T, V>(mask + o + (long long)i * d.C, m);
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (!(m[v] > 0.f)) acc[i][v] = 0.f;
+      }
+      store_chan<T, V>(y + o + (long long)i * d.C, acc[i]);
+    }
   }
 }
 
@@ -210,9 +320,50 @@ inline unsigned grid_for(long long total) {
   return (unsigned)blocks;
 }
 
+// widest channel vector (elements) the tensors allow; 1 = use the scalar kernels
+template <typename T>
+inline int chan_vec(const DwDims& d, int K, std::initializer_list<const void*> ptrs) {
+  if ((size_t)d.C * K * K * sizeof(float) > 48 * 1024) return 1;          // taps must fit the LDS staging buffer
+  // Small maps (everything below the stem at batch 8) are launch/latency-bound: there the scalar kernels' 4-8x more
+  // threads win over fewer, fatter ones (measured: 8x176x4x13 k5 7.9 vs 12.9 us; 8x32x64x208 k7 s2 29.4 vs 17.7 us).
+  if ((long long)d.B * d.H * d.W * d.C < (1LL << 21)) return 1;
+  int v = sizeof(T) == 2 ? 8 : 4;
+  while (v > 1) {
+    bool ok = d.C % v == 0;
+    for (const void* p : ptrs) ok = ok && (p == nullptr || ((uintptr_t)p) % (v * sizeof(T)) == 0);
+    if (ok) break;
+    v >>= 1;
+  }
+  return v;
+}
+
+template <typename T, int K, int S, int OXT, int FLIP>
+void launch_stencil(int v, const void* x, const float* w, const void* mask, void* y, const DwDims& d, int relu_in,
+                    hipStream_t s) {
+  const long long total = (long long)d.B * d.OH * ((d.OW + OXT - 1) / OXT) * (d.C / v);
+  const size_t lds = (size_t)d.C * K * K * sizeof(float);
+  const dim3 grid(grid_for(total));
+#define XPT_STENCIL(V)                                                                                                \
+  hipLaunchKernelGGL((dw_stencil_kernel<T, K, S, V, OXT, FLIP>), grid, dim3(256), lds, s, (const T*)x, w, (const T*)mask, \
+                     (T*)y, d, relu_in)
+  if (sizeof(T) == 2 && v == 8) {
+    if constexpr (sizeof(T) == 2) XPT_STENCIL(8);
+  } else if (v == 4) {
+    XPT_STENCIL(4);
+  } else {
+    XPT_STENCIL(2);
+  }
+#undef XPT_STENCIL
+}
+
 template <typename T, int K, int S>
 int launch_fwd(const void* x, const float* w, void* y, const DwDims& d, int relu_in, hipStream_t s) {
   constexpr int OXT = (S == 1) ? 4 : 2;
+  const int v = chan_vec<T>(d, K, {x, y});
+  if (v > 1) {
+    launch_stencil<T, K, S, OXT, 0>(v, x, w, nullptr, y, d, relu_in, s);
+    return xpt_launch_status();
+  }
   const long long total = (long long)d.B * d.OH * ((d.OW + OXT - 1) / OXT) * d.C;
   hipLaunchKernelGGL((dw_fwd_kernel<T, K, S, OXT>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, w, (T*)y, d,
                      relu_in);
@@ -222,6 +373,15 @@ int launch_fwd(const void* x, const float* w, void* y, const DwDims& d, int relu
 template <typename T, int K, int S>
 int launch_bwd_data(const void* x, const float* w, const void* dy, void* dx, const DwDims& d, int relu_in,
                     hipStream_t s) {
+  if (S == 1) {
+    // dx = conv(dy, rot180(w)) with pad' = K - 1 - pad: the forward stencil on (dy -> dx) with swapped extents
+    const DwDims t{d.B, d.OH, d.OW, d.C, d.H, d.W, K - 1 - d.pad_t, K - 1 - d.pad_l};
+    const int v = chan_vec<T>(t, K, {dy, dx, relu_in ? x : nullptr});
+    if (v > 1 && t.pad_t >= 0 && t.pad_l >= 0) {
+      launch_stencil<T, K, 1, 4, 1>(v, dy, w, x, dx, t, relu_in, s);
+      return xpt_launch_status();
+    }
+  }
   const long long total = (long long)d.B * d.H * d.W * d.C;
   hipLaunchKernelGGL((dw_bwd_data_kernel<T, K, S>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, w,
                      (const T*)dy, (T*)dx, d, relu_in);

@@ -32,10 +32,10 @@ using namespace xpt;
 namespace {
 
 __device__ inline float wave_shr1(float v) {   // lane i <- lane i-1 (0 into lane 0)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 }
 __device__ inline float wave_shl1(float v) {   // lane i <- lane i+1 (0 into lane 63)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 __device__ inline float hsum3(float v) { return (wave_shr1(v) + v) + wave_shl1(v); }
 __device__ inline float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -104,6 +104,19 @@ __device__ inline float ssim_loss(float Sx, float Sy, float Sxx, float Syy, floa
   return clampf((1.f - n * rcpf(dn)) * 0.5f, 0.f, 1.f);
 }
 
+// two channels at once on packed-fp32 VALU ops (v_pk_add/mul/fma_f32: two results per issue slot)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ inline f32x2 ssim_loss2(f32x2 Sx, f32x2 Sy, f32x2 Sxx, f32x2 Syy, f32x2 Sxy, float ic) {
+  const f32x2 mux = Sx * ic, muy = Sy * ic;
+  const f32x2 sx = Sxx * ic - mux * mux, sy = Syy * ic - muy * muy, sxy = Sxy * ic - mux * muy;
+  const f32x2 n = (2.f * mux * muy + SSIM_C1) * (2.f * sxy + SSIM_C2);
+  const f32x2 dn = (mux * mux + muy * muy + SSIM_C1) * (sx + sy + SSIM_C2);
+  f32x2 l;
+  l.x = clampf((1.f - n.x * rcpf(dn.x)) * 0.5f, 0.f, 1.f);
+  l.y = clampf((1.f - n.y * rcpf(dn.y)) * 0.5f, 0.f, 1.f);
+  return l;
+}
+
 __device__ inline float window_rcp(int r, int h, float cnt_c) {
   const float cnt_r = (float)((r > 0 ? 1 : 0) + 1 + (r < h - 1 ? 1 : 0));
   return rcpf(cnt_r * cnt_c);
@@ -131,10 +144,28 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
   const float* timg = target + (long long)job.b * P * 3;
   float* oimg = EMIT_SYNTH ? synth + (long long)(job.b * d.N + job.n) * P * 3 : nullptr;
   const float cnt_c = (float)((col > 0 ? 1 : 0) + 1 + (col < d.w - 1 ? 1 : 0));
-  // ray = Kinv (col, r, 1): the column part is constant along the march
-  float ray_c[3];
+  // K (R (d Kinv (col, r, 1)) + t) = d (M (col, r, 1)) + K t with M = K R Kinv: the two wave-uniform 3x3 products are
+  // folded once per wave, leaving 3 FMAs per row for M (col, r, 1) and 3 for the depth (the reference's chain of
+  // pixel2cam / transform / cam2pixel, synthesize_base.py:106-178, re-associated: coordinates move by ~1e-7 relative)
+  float M[9], kt[3], m_c[3];
+  {
+    float KR[9];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) ray_c[i] = cam.ki[3 * i] * (float)col + cam.ki[3 * i + 2];
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        KR[3 * i + j] = cam.k[3 * i] * pose.r[j] + cam.k[3 * i + 1] * pose.r[3 + j] + cam.k[3 * i + 2] * pose.r[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        M[3 * i + j] = KR[3 * i] * cam.ki[j] + KR[3 * i + 1] * cam.ki[3 + j] + KR[3 * i + 2] * cam.ki[6 + j];
+      kt[i] = cam.k[3 * i] * pose.t[0] + cam.k[3 * i + 1] * pose.t[1] + cam.k[3 * i + 2] * pose.t[2];
+      m_c[i] = M[3 * i] * (float)col + M[3 * i + 2];
+    }
+  }
+  const float fu_max = (float)(d.w - 2), fv_max = (float)(d.h - 2);
+  const int row3 = 3 * d.w;
 
   float acc_l1 = 0.f, acc_ss = 0.f;
   float hA[15], hB[15], hC[15];                    // horizontal window sums [x(3) y(3) xx(3) yy(3) xy(3)] of 3 rows
@@ -149,19 +180,28 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
       const int p = r * d.w + col;
       const float dd = dimg[p];
       x[0] = timg[3 * p]; x[1] = timg[3 * p + 1]; x[2] = timg[3 * p + 2];
-      Warp wp;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        wp.ray[i] = ray_c[i] + cam.ki[3 * i + 1] * (float)r;
-        wp.X[i] = wp.ray[i] * dd;
-      }
-      project_fast(cam, pose, wp);
-      const Taps t = make_taps(wp.up, wp.vp, d.h, d.w, dd != 0.f);
-      float tap[12];
-      load_taps(simg, d.w, t, tap);
-      const float wff = t.wuf * t.wvf, wfc = t.wuf * t.wvc, wcf = t.wuc * t.wvf, wcc = t.wuc * t.wvc;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) y[c] = ((tap[c] * wff + tap[3 + c] * wfc) + tap[6 + c] * wcf) + tap[9 + c] * wcc;
+      const float fr = (float)r;
+      const float q0 = (M[1] * fr + m_c[0]) * dd + kt[0];
+      const float q1 = (M[4] * fr + m_c[1]) * dd + kt[1];
+      const float q2 = (M[7] * fr + m_c[2]) * dd + kt[2];
+      const float zinv = rcpf(q2 + 1e-10f);
+      const float up = q0 * zinv, vp = q1 * zinv;
+      // BilinearInterpolation (bilinear_interp.py:34-102): with floor(u') = fu the clipped neighbours satisfy
+      // uf + 1 == uc exactly when 0 <= fu <= w - 2 (same for v), so validity is four compares and the four taps sit
+      // at fixed offsets (0, 3, 3 w, 3 w + 3) from one address; invalid pixels read tap 0 and are zeroed below
+      const float fu = floorf(up), fv = floorf(vp);
+      const bool ok = (fu >= 0.f) && (fu <= fu_max) && (fv >= 0.f) && (fv <= fv_max) && (dd != 0.f);
+      const int off = ok ? ((int)fv * d.w + (int)fu) * 3 : 0;
+      const float wuf = (fu + 1.f) - up, wuc = up - fu, wvf = (fv + 1.f) - vp, wvc = vp - fv;
+      const float wff = wuf * wvf, wfc = wuf * wvc, wcf = wuc * wvf, wcc = wuc * wvc;
+      const float* t0 = simg + off;
+      const float* t1 = t0 + row3;
+      const f32x2 v01 = ((f32x2{t0[0], t0[1]} * wff + f32x2{t1[0], t1[1]} * wfc) + f32x2{t0[3], t0[4]} * wcf) +
+                        f32x2{t1[3], t1[4]} * wcc;
+      const float v2 = ((t0[2] * wff + t1[2] * wfc) + t0[5] * wcf) + t1[5] * wcc;
+      y[0] = ok ? v01.x : 0.f;
+      y[1] = ok ? v01.y : 0.f;
+      y[2] = ok ? v2 : 0.f;
       if (EMIT_SYNTH && out_lane && r >= r0 && r < r1) {
         oimg[3 * p] = y[0]; oimg[3 * p + 1] = y[1]; oimg[3 * p + 2] = y[2];
       }
@@ -169,22 +209,27 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
     const bool black = ((y[0] + y[1]) + y[2]) == 0.f;       // mean_c == 0  <=>  sum_c == 0
     if (out_lane && r >= r0 && r < r1 && !black)
       acc_l1 += (fabsf(y[0] - x[0]) + fabsf(y[1] - x[1])) + fabsf(y[2] - x[2]);
+    {
+      const f32x2 x01{x[0], x[1]}, y01{y[0], y[1]}, xy2{x[2], y[2]};
+      const f32x2 xx01 = x01 * x01, yy01 = y01 * y01, xy01 = x01 * y01, sq2 = xy2 * xy2;
+      const float p[15] = {x[0], x[1], x[2], y[0], y[1], y[2], xx01.x, xx01.y, sq2.x, yy01.x, yy01.y, sq2.y,
+                           xy01.x, xy01.y, x[2] * y[2]};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      cur[c] = hsum3(x[c]);
-      cur[3 + c] = hsum3(y[c]);
-      cur[6 + c] = hsum3(x[c] * x[c]);
-      cur[9 + c] = hsum3(y[c] * y[c]);
-      cur[12 + c] = hsum3(x[c] * y[c]);
+      for (int i = 0; i < 15; ++i) cur[i] = hsum3(p[i]);
     }
     const int rc = r - 1;                          // centre row of the window (m2, m1, cur)
     if (rc >= r0 && rc < r1) {
       const float ic = window_rcp(rc, d.h, cnt_c);
-      float sum = 0.f;
+      // channels 0 and 1 ride together in packed registers, channel 2 stays scalar (same operation order per channel)
+      f32x2 W[5];
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        sum += ssim_loss(m2[c] + m1[c] + cur[c], m2[3 + c] + m1[3 + c] + cur[3 + c], m2[6 + c] + m1[6 + c] + cur[6 + c],
-                         m2[9 + c] + m1[9 + c] + cur[9 + c], m2[12 + c] + m1[12 + c] + cur[12 + c], ic);
+      for (int q = 0; q < 5; ++q)
+        W[q] = (f32x2{m2[3 * q], m2[3 * q + 1]} + f32x2{m1[3 * q], m1[3 * q + 1]}) + f32x2{cur[3 * q], cur[3 * q + 1]};
+      const f32x2 l01 = ssim_loss2(W[0], W[1], W[2], W[3], W[4], ic);
+      const f32x2 Wa = (f32x2{m2[2], m2[5]} + f32x2{m1[2], m1[5]}) + f32x2{cur[2], cur[5]};        // (x, y) of channel 2
+      const f32x2 Wb = (f32x2{m2[8], m2[11]} + f32x2{m1[8], m1[11]}) + f32x2{cur[8], cur[11]};     // (xx, yy)
+      const float l2 = ssim_loss(Wa.x, Wa.y, Wb.x, Wb.y, m2[14] + m1[14] + cur[14], ic);
+      const float sum = (l01.x + l01.y) + l2;
       if (out_lane && !black_prev) acc_ss += sum;
     }
     black_prev = black;
@@ -450,6 +495,8 @@ inline FusedDims make_dims(int B, int N, int h, int w, float scale, int rows_per
   return d;
 }
 
+int g_fwd_min_waves = 4096, g_bwd_min_waves = 1536;
+
 // Rows per chunk: enough waves to cover 256 CUs x 4 SIMDs a few times over, as few halo rows as possible.
 inline int pick_rows(int B, int N, int h, int w, long long min_waves) {
   const long long strips = (long long)B * N * ((w + STRIP_B - 1) / STRIP_B);
@@ -462,9 +509,16 @@ inline int pick_rows(int B, int N, int h, int w, long long min_waves) {
 
 extern "C" {
 
+int xpt_photo_fused_tune(int fwd_min_waves, int bwd_min_waves) {
+  if (fwd_min_waves < 1 || bwd_min_waves < 1 || fwd_min_waves > 8192 || bwd_min_waves > 8192) return XPT_ERR_ARG;
+  g_fwd_min_waves = fwd_min_waves;
+  g_bwd_min_waves = bwd_min_waves;
+  return XPT_OK;
+}
+
 size_t xpt_photo_fused_workspace_floats(int B, int N, int h, int w) {
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0) return 0;
-  const FusedDims d = make_dims(B, N, h, w, 1.f, pick_rows(B, N, h, w, 4096), STRIP_B);   // upper bound of both directions
+  const FusedDims d = make_dims(B, N, h, w, 1.f, pick_rows(B, N, h, w, 8192), STRIP_B);   // upper bound of both directions
   return (size_t)d.B * d.S * d.CH * d.N * 16;       // per wave: 2 floats forward, 12 (pose gradient) backward
 }
 
@@ -476,7 +530,7 @@ int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, co
   if ((loss_l1 == nullptr) != (loss_ssim == nullptr)) return XPT_ERR_NULL;     // both, or neither (partials only)
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f) || (long long)h * w * 3 >= (1LL << 31)) return XPT_ERR_SHAPE;
   if (workspace_floats < xpt_photo_fused_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
-  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w, 4096), STRIP);
+  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w, g_fwd_min_waves), STRIP);
   const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
   const unsigned blocks = (unsigned)((nwaves + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
@@ -498,7 +552,7 @@ int xpt_photo_fused_bwd(const float* src, const float* depth, const float* T, co
   XPT_CHECK_PTR(g_l1); XPT_CHECK_PTR(g_ssim); XPT_CHECK_PTR(ddepth); XPT_CHECK_PTR(dT); XPT_CHECK_PTR(workspace);
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f) || (long long)h * w * 3 >= (1LL << 31)) return XPT_ERR_SHAPE;
   if (workspace_floats < xpt_photo_fused_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
-  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w, 1536), STRIP_B);
+  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w, g_bwd_min_waves), STRIP_B);
   const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
   const unsigned blocks = (unsigned)((nwaves + 3) / 4);
   const float inv_count = 1.0f / ((float)N * (float)h * (float)w * 3.0f);

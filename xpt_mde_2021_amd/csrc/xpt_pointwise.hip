@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict
       float sh, rstd, mu;
       affine_coeffs(a, c0 + i, sc[i], sh, rstd, mu);
     }
+#pragma unroll 2
     for (long long r = r_begin + slot; r < r_end; r += slots) {
       const long long o = r * C + c0;
       float g[V], xv[V], gx[V];
@@ -175,6 +176,34 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict
   }
 }
 
+// out[r, c] = sum_i in_i[r * pitch_i + c]: the gradients that reach a tensor feeding several branches of a NASNet cell
+// (autograd would add them pairwise, one launch per extra consumer); inputs may be channel slices (row pitch).
+struct SumInputs {
+  const void* ptr[8];
+  long long pitch[8];
+  int n;
+};
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void sum_rows_kernel(SumInputs in, T* __restrict__ out, long long rows, int C) {
+  const int groups = C / V;
+  const long long total = rows * groups;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const long long r = idx / groups;
+    const int c0 = (int)(idx - r * groups) * V;
+    float acc[V];
+    load_row<T, V>((const T*)in.ptr[0] + r * in.pitch[0] + c0, acc);
+    for (int i = 1; i < in.n; ++i) {
+      float v[V];
+      load_row<T, V>((const T*)in.ptr[i] + r * in.pitch[i] + c0, v);
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += v[j];
+    }
+    store_row<T, V>(out + r * C + c0, acc);
+  }
+}
+
 // per channel c: S0 = sum_k part[k][0][c], S1 = sum_k part[k][1][c]; one wave (64 threads) per channel so that the
 // partial rows are fetched with few dependent round trips; fixed tree -> deterministic.
 __global__ void affine_finish_kernel(const float* __restrict__ part, Affine a, float* __restrict__ dbeta,
@@ -209,10 +238,11 @@ inline unsigned grid_for(long long total) {
   return (unsigned)blocks;
 }
 
-// pixel rows per workgroup: at most ~512 row slices per launch, at least 64 rows each
+// pixel rows per workgroup: ~512 row slices per launch (small maps: at least 8 rows each, so that even a 4x13 map
+// spreads over ~50 workgroups instead of walking its rows in a few long dependent loops)
 static long long affine_bwd_rows_per_block(long long rows) {
   long long rpb = (rows + 511) / 512;
-  if (rpb < 64) rpb = 64;
+  if (rpb < 8) rpb = 8;
   return (rpb + 7) / 8 * 8;
 }
 
@@ -342,6 +372,49 @@ int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, lo
   if (dy_pitch < C) return XPT_ERR_SHAPE;
   affine_bwd_launch(x, y, dy, dy_pitch, a, dx, partials, rows, C, slope, relu_in, gamma != nullptr, 1, dtype,
                     (hipStream_t)stream);
+  return xpt_launch_status();
+}
+
+/* out [rows, C] (dense) = sum of n (2..8) inputs [rows, C] with row pitches >= C; fp32 accumulation in input order. */
+int xpt_sum_rows(const void* const* inputs, const long long* pitches, int n, void* out, long long rows, int C, int dtype,
+                 void* stream) {
+  XPT_CHECK_PTR(inputs); XPT_CHECK_PTR(pitches); XPT_CHECK_PTR(out);
+  if (n < 2 || n > 8) return XPT_ERR_ARG;
+  if (rows <= 0 || C <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  SumInputs in;
+  in.n = n;
+  const int esz = dtype == 0 ? 4 : 2;
+  int v = dtype == 0 ? 4 : 8;
+  for (int i = 0; i < n; ++i) {
+    if (inputs[i] == nullptr) return XPT_ERR_NULL;
+    if (pitches[i] < C) return XPT_ERR_SHAPE;
+    in.ptr[i] = inputs[i];
+    in.pitch[i] = pitches[i];
+  }
+  auto ok = [&](const void* p, long long pitch) { return ((uintptr_t)p) % (size_t)(v * esz) == 0 && pitch % v == 0; };
+  for (;;) {
+    bool all = C % v == 0 && ok(out, C);
+    for (int i = 0; i < n && all; ++i) all = ok(inputs[i], pitches[i]);
+    if (all || v == 1) break;
+    v >>= 1;
+  }
+  const long long total = rows * (C / v);
+  const dim3 grid(grid_for(total));
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+#define XPT_SUM(T, V) hipLaunchKernelGGL((sum_rows_kernel<T, V>), grid, dim3(256), 0, s, in, (T*)out, rows, C)
+  if (dtype == 0) {
+    if (v == 4) XPT_SUM(float, 4);
+    else if (v == 2) XPT_SUM(float, 2);
+    else XPT_SUM(float, 1);
+  } else {
+    if (v == 8) XPT_SUM(__hip_bfloat16, 8);
+    else if (v == 4) XPT_SUM(__hip_bfloat16, 4);
+    else if (v == 2) XPT_SUM(__hip_bfloat16, 2);
+    else XPT_SUM(__hip_bfloat16, 1);
+  }
+#undef XPT_SUM
   return xpt_launch_status();
 }
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "xpt_photo_workspace_floats": (_z, [_i, _i, _i, _i]),
     "xpt_photo_fwd": (_i, [_i, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     "xpt_photo_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
+    "xpt_photo_fused_tune": (_i, [_i, _i]),
     "xpt_photo_fused_workspace_floats": (_z, [_i, _i, _i, _i]),
     "xpt_photo_fused_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _f, _p]),
     "xpt_photo_fused_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _f, _p]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "xpt_conv1x1_bwd_weight_splits": (_i, [ctypes.c_longlong, _i, _i]),
     "xpt_conv1x1_bwd_weight_partials": (_i, [_p, _p, _p, _z, ctypes.c_longlong, _i, _i, ctypes.c_longlong,
                                              ctypes.c_longlong, _p]),
+    "xpt_sum_rows": (_i, [_p, _p, _i, _p, ctypes.c_longlong, _i, _i, _p]),
     "xpt_crc32c": (ctypes.c_uint32, [_p, _z]),
     "xpt_affine_act_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, ctypes.c_longlong, _i, _f, _i, _i, _p]),
     "xpt_affine_act_bwd_workspace_floats": (_z, [ctypes.c_longlong, _i]),

@@ -555,6 +555,55 @@ def batchnorm_inference(x, gamma, beta, running_mean, running_var, eps, relu_in=
     return _AffineAct.apply(x, gamma, beta, running_mean, running_var, eps, 1.0, relu_in, residual)
 
 
+# ------------------------------------------------------------------------------- gradient fan-in
+def sum_rows(tensors):
+    """Sum of 2..8 NCHW-indexed tensors of one shape / dtype in ONE launch (dense channels_last result); operands may
+    be channel slices of wider tensors (read in place through their row pitch)."""
+    import ctypes
+    lib = _lib.load()
+    first = tensors[0]
+    B, C, H, W = first.shape
+    prepared = [_rows_with_pitch(t if t.dtype == first.dtype else t.to(first.dtype)) for t in tensors]
+    out = torch.empty((B, C, H, W), dtype=first.dtype, device=first.device, memory_format=torch.channels_last)
+    n = len(prepared)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in prepared])
+    pitches = (ctypes.c_longlong * n)(*[p for _, p in prepared])
+    _lib.check(lib.xpt_sum_rows(ptrs, pitches, n, _ptr(out), B * H * W, C, 0 if first.dtype == torch.float32 else 1,
+                                _stream()), "xpt_sum_rows")
+    return out
+
+
+class _FanOut(torch.autograd.Function):
+    """n aliases of x for n consumers; the backward adds the n incoming gradients with one kernel instead of the
+    n - 1 pairwise adds of autograd's accumulation."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [g for g in grads if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        if len(live) > 8 or live[0].dim() != 4 or not live[0].is_cuda or live[0].dtype not in (torch.float32, torch.bfloat16):
+            total = live[0]
+            for g in live[1:]:
+                total = total + g
+            return total, None
+        return sum_rows(live), None
+
+
+def fan_out(x, n):
+    """x -> n aliases, one per consumer (see _FanOut); a no-op for tensors that do not require grad."""
+    if n == 1 or not (x.requires_grad and torch.is_grad_enabled()) or not x.is_cuda:
+        return (x,) * n
+    return _FanOut.apply(x, n)
+
+
 # ------------------------------------------------------------------------------- pointwise (1x1) convolution pieces
 _COUNTERS = {}
 _N_COUNTERS = 1024

@@ -239,12 +239,16 @@ class NormalCell(nn.Module):
         h = shared_relu(ip)
         taps.offer(self.act_id, h)
         h = self.bn(conv1x1(h, self.conv.weight))
-        # every `add` whose operand ends in a BatchNorm rides in that BatchNorm's epilogue kernel
-        x1 = self.left1(h, taps, residual=self.right1(p, taps))
-        x2 = self.left2(p, taps, residual=self.right2(p, taps))
-        x3 = avg_pool_same(h) + p
-        x4 = avg_pool_same(p) * 2.0                      # add([avg(p), avg(p)]): x + x == 2 x exactly
-        x5 = self.left5(h, taps, residual=h)
+        # every `add` whose operand ends in a BatchNorm rides in that BatchNorm's epilogue kernel; h and p feed several
+        # branches each: their gradients are summed by one fan-in kernel instead of a chain of pairwise adds
+        h1, h2, h3, h4 = _ops.fan_out(h, 4)
+        p1, p2, p3, p4, p5, p6 = _ops.fan_out(p, 6)
+        x1 = self.left1(h1, taps, residual=self.right1(p1, taps))
+        x2 = self.left2(p2, taps, residual=self.right2(p3, taps))
+        x3 = avg_pool_same(h2) + p4
+        x4 = avg_pool_same(p5) * 2.0                     # add([avg(p), avg(p)]): x + x == 2 x exactly
+        x5 = self.left5(h3, taps, residual=h4)
+        p = p6
         return torch.cat([p, x1, x2, x3, x4, x5], dim=1), ip
 
 
@@ -273,11 +277,16 @@ class ReductionCell(nn.Module):
         h = self.bn(conv1x1(h, self.conv.weight))
         h3 = zero_pad(h, correct_pad(h.shape[2], h.shape[3], 3))
         mp = F.max_pool2d(h3, 3, 2)                      # MaxPooling2D of h feeds x2 and x5: pooled once
-        x1 = self.left1(h, taps, residual=self.right1(p, taps))
-        x2 = self.right2(p, taps, residual=mp)
-        x3 = self.right3(p, taps, residual=F.avg_pool2d(h3, 3, 2))
-        x4 = x2 + avg_pool_same(x1)
-        x5 = self.left4(x1, taps, residual=mp)
+        mp1, mp2 = _ops.fan_out(mp, 2)
+        p1, p2, p3 = _ops.fan_out(p, 3)
+        x1 = self.left1(h, taps, residual=self.right1(p1, taps))
+        x1a, x1b = _ops.fan_out(x1, 2)
+        x2 = self.right2(p2, taps, residual=mp1)
+        x2a, x2b = _ops.fan_out(x2, 2)
+        x3 = self.right3(p3, taps, residual=F.avg_pool2d(h3, 3, 2))
+        x4 = x2a + avg_pool_same(x1a)
+        x5 = self.left4(x1b, taps, residual=mp2)
+        x2 = x2b
         return torch.cat([x2, x3, x4, x5], dim=1), ip
 
 
