@@ -191,3 +191,14 @@ def test_oracle_gradcheck_fp64():
         return ref_loss.photometric_loss_l2(synth, tgt) + ref_loss.photometric_loss_ssim(synth, tgt)
 
     assert torch.autograd.gradcheck(fn, (depth, pose), eps=1e-7, atol=1e-5, rtol=1e-3, nondet_tol=0.0)
+
+
+def test_rigid_inverse_matches_general_inverse():
+    """utils/convert_pose.rigid_inverse (closed form, capturable) == tf.linalg.inv on poses (losses.py:90, 229)."""
+    import torch
+    from oracle import ref_pose
+    from xpt_mde_2021_amd.utils import convert_pose as cp
+    T = ref_pose.pose_rvec2matr_batch(torch.rand(3, 2, 6, dtype=torch.float64) * 2 - 1)
+    inv = cp.rigid_inverse(T)
+    assert torch.allclose(inv, torch.linalg.inv(T), atol=1e-12)
+    assert torch.allclose(inv @ T, torch.eye(4, dtype=torch.float64).expand_as(T), atol=1e-12)

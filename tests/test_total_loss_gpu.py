@@ -138,3 +138,37 @@ def test_train_step_runs_and_learns(gpu_device):
         opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
         opts.IMAGE_SIZES.clear()
         opts.IMAGE_SIZES.update(saved[3])
+
+
+def test_stereo_train_step_in_graph(gpu_device):
+    """configs[4]-style step (stereo feature dict, LOSS_RIGID_T2: mono + stereo L1/SSIM + stereoPose) captured as a
+    hipGraph: nothing in it may synchronise with the host (the pose inverses are closed-form), every layer is applied
+    to the left and to the right snippet, so each deferred parameter gradient has two segments."""
+    from xpt_mde_2021_amd.model import model_main as mm
+    from xpt_mde_2021_amd.model import train_val as tv
+    saved = (opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE, dict(opts.IMAGE_SIZES), opts.STEREO)
+    opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 2
+    opts.IMAGE_SIZES["kitti_raw"] = (64, 192)
+    opts.STEREO = True
+    try:
+        losses = {}
+        for mode in ("eager", "graph"):
+            opts.CONV_DTYPE = "fp32"
+            torch.manual_seed(0)
+            dataset, cfg, _ = mm.get_dataset("synthetic_stereo", "train", True)
+            model, _, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, opts.LOSS_RIGID_T2,
+                                                                       opts.SCALE_WEIGHT_T1, opts.RIGID_NET,
+                                                                       ckpt_name="__test__")
+            trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, True, None, optimizer)
+            hist = [float(trainer.run_a_batch(dataset.batches[0])[1]) for _ in range(5)]
+            assert all(h == h for h in hist) and hist[-1] < hist[0], (mode, hist)
+            losses[mode] = hist
+        a, b = losses["eager"], losses["graph"]
+        # the synthetic pair is rectified: border rows sit exactly on the validity boundary (DESIGN.md section 8), so the
+        # two runs may disagree on a few rows through last-bit differences of the library convolutions
+        assert abs(a[0] - b[0]) < 2e-3 * abs(a[0]) and abs(a[-1] - b[-1]) < 5e-2 * abs(a[-1]), (a, b)
+    finally:
+        opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
+        opts.IMAGE_SIZES.clear()
+        opts.IMAGE_SIZES.update(saved[3])
+        opts.STEREO = saved[4]

@@ -87,7 +87,7 @@ class TotalLoss:
         if ("stereo_T_LR" not in features) or ("depth_ms" not in predictions):
             return synth_stereo
         # left image from the right image: points move left -> right with inv(T_LR)
-        pose_T_RL = cp.pose_matr2rvec_batch(torch.linalg.inv(features["stereo_T_LR"]).unsqueeze(1))
+        pose_T_RL = cp.pose_matr2rvec_batch(cp.rigid_inverse(features["stereo_T_LR"]).unsqueeze(1))
         pose_T_LR = cp.pose_matr2rvec_batch(features["stereo_T_LR"].unsqueeze(1))
         left_src, right_src = augm_data["target_R"].unsqueeze(1), augm_data["target"].unsqueeze(1)
         if self.use_fused(left_src):
@@ -226,7 +226,7 @@ class StereoPoseLoss(LossBase):
         """losses.py:481-494: MSE between the known stereo extrinsic (as twist) and the PoseNet's
         left<->right predictions, mean over numsrc -> [batch]"""
         pose_lr_true_mat = features["stereo_T_LR"].unsqueeze(1)
-        pose_rl_true_mat = torch.linalg.inv(pose_lr_true_mat)
+        pose_rl_true_mat = cp.rigid_inverse(pose_lr_true_mat)
         pose_lr_true = cp.pose_matr2rvec_batch(pose_lr_true_mat)
         pose_rl_true = cp.pose_matr2rvec_batch(pose_rl_true_mat)
         loss = torch.mean(torch.square(pose_lr_true - predictions["pose_LR"]), dim=-1) \

@@ -25,3 +25,15 @@ def pose_matr2rvec_batch(poses):
     axis = torch.stack([R[..., 1, 2] - R[..., 2, 1], R[..., 2, 0] - R[..., 0, 2], R[..., 0, 1] - R[..., 1, 0]], dim=-1)
     rvec = torch.where(torch.abs(theta) < 0.00001, axis / 2., axis / (2 * torch.sin(theta)) * theta)
     return torch.cat([poses[..., :3, 3], rvec], dim=-1)
+
+
+def rigid_inverse(T):
+    """Inverse of rigid transforms [..., 4, 4] in closed form: [R t; 0 1]^-1 = [R^T, -R^T t; 0 1].  Stands in for the
+    reference's tf.linalg.inv on poses (losses.py:90, 229): no LU factorisation, no host synchronisation, so it can be
+    captured into the hipGraph step; identical to the general inverse up to rounding for valid poses."""
+    R = T[..., :3, :3]
+    t = T[..., :3, 3:]
+    Rt = R.transpose(-1, -2)
+    top = torch.cat([Rt, -(Rt @ t)], dim=-1)
+    bottom = T[..., 3:, :]
+    return torch.cat([top, bottom], dim=-2)
