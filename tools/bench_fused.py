@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from xpt_mde_2021_amd.hip import ops, roofline as rf, lib as _lib
 from xpt_mde_2021_amd.utils import synthetic_data as sd
 lib = _lib.load()

@@ -1,6 +1,6 @@
 """Per-shape timing of the 1x1-conv weight gradient: split-K MFMA kernel (several launch plans) vs rocBLAS."""
 import sys, collections, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from xpt_mde_2021_amd.config import opts
 from xpt_mde_2021_amd.hip import ops, lib as _lib
 from xpt_mde_2021_amd.model import model_main as mm, train_val as tv

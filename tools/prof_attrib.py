@@ -1,6 +1,6 @@
 """Attribute the small elementwise launches of one eager training step to source lines."""
 import sys, collections, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from xpt_mde_2021_amd.config import opts
 from xpt_mde_2021_amd.model import model_main as mm, train_val as tv
 from torch.profiler import profile, ProfilerActivity

@@ -1,6 +1,10 @@
+"""Stand-alone reproducer (no code of this repo in the network) of the ROCm 7.0 / torch 2.10 defect described in
+DESIGN.md section 6: gradients of convolution biases / MIOpen bf16 weight gradients are garbage from the SECOND replay
+of a captured hipGraph.  Usage: python tools/repro_conv_grad_graph_replay.py <variant>  (variant: plain | sepbias | det |
+nomiopen, combinable with '-')."""
 import sys, torch
 import torch.nn as nn, torch.nn.functional as F
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from xpt_mde_2021_amd.utils import synthetic_data as sd
 variant = sys.argv[1]
 if "det" in variant: torch.backends.cudnn.deterministic = True
