@@ -114,8 +114,9 @@ int xpt_photo_bwd(int method, const float* synth, const float* target, const flo
  * bwd: g_l1 [B], g_ssim [B] (gradients of those means) -> ddepth [B,h,w], dT [B,N,4,4] (last row 0); the views are
  *   re-synthesized on the fly.  workspace: xpt_photo_fused_workspace_floats(B,N,h,w) floats for both directions.
  * ALGORITHMIC bytes per batch element (P = h*w): fwd P(16 + 12N) [+ 12NP with synth], bwd P(20 + 12N). */
-/* launch-plan knob (process-wide, for benchmarking): minimum number of waves before the row chunks stop shrinking */
-int xpt_photo_fused_tune(int fwd_min_waves, int bwd_min_waves);
+/* launch-plan knobs (process-wide, for benchmarking): the row chunks (32, 16, 8 ... min_rows) shrink until the launch has
+ * at least this many waves */
+int xpt_photo_fused_tune(int fwd_min_waves, int bwd_min_waves, int min_rows);
 size_t xpt_photo_fused_workspace_floats(int B, int N, int h, int w);
 int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, const float* K, const float* target,
                         float* synth, float* loss_l1, float* loss_ssim, float* workspace, size_t workspace_floats,

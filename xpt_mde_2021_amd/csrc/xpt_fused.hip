@@ -495,13 +495,13 @@ inline FusedDims make_dims(int B, int N, int h, int w, float scale, int rows_per
   return d;
 }
 
-int g_fwd_min_waves = 4096, g_bwd_min_waves = 1536;
+int g_fwd_min_waves = 4096, g_bwd_min_waves = 1536, g_min_rows = 8;
 
 // Rows per chunk: enough waves to cover 256 CUs x 4 SIMDs a few times over, as few halo rows as possible.
 inline int pick_rows(int B, int N, int h, int w, long long min_waves) {
   const long long strips = (long long)B * N * ((w + STRIP_B - 1) / STRIP_B);
   int R = 32;
-  while (R > 8 && strips * ((h + R - 1) / R) < min_waves) R >>= 1;
+  while (R > g_min_rows && strips * ((h + R - 1) / R) < min_waves) R >>= 1;
   return R;
 }
 
@@ -509,16 +509,18 @@ inline int pick_rows(int B, int N, int h, int w, long long min_waves) {
 
 extern "C" {
 
-int xpt_photo_fused_tune(int fwd_min_waves, int bwd_min_waves) {
-  if (fwd_min_waves < 1 || bwd_min_waves < 1 || fwd_min_waves > 8192 || bwd_min_waves > 8192) return XPT_ERR_ARG;
+int xpt_photo_fused_tune(int fwd_min_waves, int bwd_min_waves, int min_rows) {
+  if (fwd_min_waves < 1 || bwd_min_waves < 1 || fwd_min_waves > 16384 || bwd_min_waves > 16384) return XPT_ERR_ARG;
+  if (min_rows != 2 && min_rows != 4 && min_rows != 8 && min_rows != 16 && min_rows != 32) return XPT_ERR_ARG;
   g_fwd_min_waves = fwd_min_waves;
   g_bwd_min_waves = bwd_min_waves;
+  g_min_rows = min_rows;
   return XPT_OK;
 }
 
 size_t xpt_photo_fused_workspace_floats(int B, int N, int h, int w) {
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0) return 0;
-  const FusedDims d = make_dims(B, N, h, w, 1.f, pick_rows(B, N, h, w, 8192), STRIP_B);   // upper bound of both directions
+  const FusedDims d = make_dims(B, N, h, w, 1.f, 2, STRIP_B);   // upper bound of both directions (smallest row chunk)
   return (size_t)d.B * d.S * d.CH * d.N * 16;       // per wave: 2 floats forward, 12 (pose gradient) backward
 }
 

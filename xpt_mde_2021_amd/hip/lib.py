@@ -37,7 +37,7 @@ SIGNATURES = {
     "xpt_photo_workspace_floats": (_z, [_i, _i, _i, _i]),
     "xpt_photo_fwd": (_i, [_i, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     "xpt_photo_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
-    "xpt_photo_fused_tune": (_i, [_i, _i]),
+    "xpt_photo_fused_tune": (_i, [_i, _i, _i]),
     "xpt_photo_fused_workspace_floats": (_z, [_i, _i, _i, _i]),
     "xpt_photo_fused_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _f, _p]),
     "xpt_photo_fused_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _f, _p]),
