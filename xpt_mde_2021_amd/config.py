@@ -133,6 +133,9 @@ class VodeOptions(LossOptions):
     FRAME_PER_DRIVE = 0
     TOTAL_FRAME_LIMIT = 0
     VALIDATION_FRAMES = 500
+    # PoseNet on a side HIP stream next to DepthNet (forked / joined inside the hipGraph).  Off: on ROCm 7.0 a graph with
+    # a parallel branch replays SLOWER (20.97 vs 19.60 ms per step at batch 8; 2.9 vs 1.75 us per node in a synthetic test)
+    NET_STREAMS = False
     AUGMENT_PROBS = {"CropAndResize": 0.2, "HorizontalFlip": 0.2, "ColorJitter": 0.2}
 
     # ---- training options (:216-253)

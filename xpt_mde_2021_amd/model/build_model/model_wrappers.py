@@ -35,8 +35,31 @@ class ModelWrapper:
     # ------------------------------------------------------------------ model_wrappers.py:41-51
     def predict_batch(self, features, suffix=""):
         predictions = dict()
-        for netname, model in self.models.items():
-            predictions.update(self._run(model, features["image5d" + suffix]))
+        image5d = features["image5d" + suffix]
+        nets = list(self.models.values())
+        if image5d.is_cuda and len(nets) > 1 and getattr(opts, "NET_STREAMS", False):
+            # DepthNet and PoseNet are independent until the loss: the small PoseNet runs on a side HIP stream next
+            # to the (launch-latency-bound) encoder, forward and -- because autograd replays every node on the stream
+            # of its forward -- backward.  Inside a hipGraph capture this forks / joins the captured graph.
+            main = torch.cuda.current_stream()
+            if not hasattr(self, "_side_streams"):
+                self._side_streams = [torch.cuda.Stream() for _ in nets[1:]]
+            side_out = []
+            for model, side in zip(nets[1:], self._side_streams):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    side_out.append(self._run(model, image5d))
+            predictions.update(self._run(nets[0], image5d))
+            for out, side in zip(side_out, self._side_streams):
+                main.wait_stream(side)
+                for value in out.values():
+                    for t in (value if isinstance(value, (list, tuple)) else [value]):
+                        if torch.is_tensor(t):
+                            t.record_stream(main)
+                predictions.update(out)
+        else:
+            for model in nets:
+                predictions.update(self._run(model, image5d))
         if "depth_ms" in predictions:
             predictions["disp_ms"] = uf.safe_reciprocal_number_ms(predictions["depth_ms"])
         return {key + suffix: value for key, value in predictions.items()}
