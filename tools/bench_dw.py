@@ -55,10 +55,18 @@ for (shape, k, stride, pad, relu), n in sorted(dw_shapes.items()):
     ws = torch.empty(nchunk * C * k * k, device="cuda")
     f = timeit(lambda: lib.xpt_dwconv_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, C, k, stride, pt, pl, OH, OW, int(relu), 1, torch.cuda.current_stream().cuda_stream))
     bd = timeit(lambda: lib.xpt_dwconv_bwd_data(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, H, W, C, k, stride, pt, pl, OH, OW, int(relu), 1, torch.cuda.current_stream().cuda_stream))
-    bw = timeit(lambda: lib.xpt_dwconv_bwd_weight_partials(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, C, k, stride, pt, pl, OH, OW, int(relu), 1, torch.cuda.current_stream().cuda_stream))
+    bws = []
+    for grp in (0, 4, 8, 16):
+        lib.xpt_dwconv_tune(grp)
+        nchunk = lib.xpt_dwconv_bwd_weight_chunks(B, OH, OW, C, k, stride)
+        ws = torch.empty(nchunk * C * k * k, device="cuda")
+        bws.append(timeit(lambda: lib.xpt_dwconv_bwd_weight_partials(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, C, k, stride, pt, pl, OH, OW, int(relu), 1, torch.cuda.current_stream().cuda_stream)))
+        tot[f"dw_bw_g{grp}"] += bws[-1] * n
+    lib.xpt_dwconv_tune(0)
+    bw = bws[0]
     mb = (x.numel() + y.numel()) * 2 / 1e6
     tot["dw_fwd"] += f * n; tot["dw_bd"] += bd * n; tot["dw_bw"] += bw * n
-    print(f"{str(shape):22s} k{k} s{stride} r{int(relu)} x{n:3d} | {f:6.1f} {bd:6.1f} {bw:6.1f} | {mb:6.2f} MB  chunks {nchunk}", flush=True)
+    print(f"{str(shape):22s} k{k} s{stride} r{int(relu)} x{n:3d} | {f:6.1f} {bd:6.1f} | bw grp auto/4/8/16: " + " ".join(f"{t:6.1f}" for t in bws) + f" | {mb:6.2f} MB", flush=True)
 print("== affine: shape gamma slope relu_in residual dtype n | fwd bwd(partials) us")
 for (shape, has_g, slope, relu, res, dt), n in sorted(bn_shapes.items()):
     B, C, H, W = shape

@@ -52,17 +52,19 @@ __global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__
 #pragma unroll
     for (int i = 0; i < OXT; ++i) acc[i] = 0.f;
     const float* wc = w + (long long)c * K * K;
+    // Loads are unconditional on clamped coordinates and zeroed by a select: a guarded load compiles to a branch with
+    // its own s_waitcnt, which serialises the ~K*IN loads of a thread into as many memory round trips.
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
       const int iy = oy * S + ky - d.pad_t;
-      if (iy < 0 || iy >= d.H) continue;
-      const T* row = x + (((long long)b * d.H + iy) * d.W) * d.C + c;
+      const bool row_ok = iy >= 0 && iy < d.H;
+      const T* row = x + (((long long)b * d.H + min(max(iy, 0), d.H - 1)) * d.W) * d.C + c;
       float in[IN];
 #pragma unroll
       for (int i = 0; i < IN; ++i) {
         const int ix = ix0 + i;
-        float v = (ix >= 0 && ix < d.W) ? ldf<T>(row + (long long)ix * d.C) : 0.f;
-        in[i] = relu_in ? fmaxf(v, 0.f) : v;
+        const float v = ldf<T>(row + (long long)min(max(ix, 0), d.W - 1) * d.C);
+        in[i] = (row_ok && ix >= 0 && ix < d.W) ? (relu_in ? fmaxf(v, 0.f) : v) : 0.f;
       }
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
       const int iy = oy * S + ky - d.pad_t;
-      if (iy < 0 || iy >= d.H) continue;
+      if (iy < 0 || iy >= d.H) continue;           // (guarded loads here: with wide vectors all K rows in flight would spill)
       const T* row = x + (((long long)b * d.H + iy) * d.W) * d.C + c0;
       float in[IN][V];
 #pragma unroll
@@ -201,20 +203,25 @@ __global__ void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restr
     const int b = (int)(r / d.H);
     const float* wc = w + (long long)c * K * K;
     float acc = 0.f;
+    // stride 2: only the taps of matching parity reach an output, ky = py, py + 2, ... (a quarter of the K*K taps)
+    const int py = (S == 1) ? 0 : ((iy + d.pad_t) & 1), px = (S == 1) ? 0 : ((ix + d.pad_l) & 1);
+    constexpr int KT = (K + S - 1) / S;
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      const int ty = iy + d.pad_t - ky;
-      if (ty < 0 || (S > 1 && (ty % S) != 0)) continue;
+    for (int jy = 0; jy < KT; ++jy) {
+      const int ky = py + jy * S;
+      const int ty = iy + d.pad_t - ky;                // a multiple of S by construction
       const int oy = ty / S;
-      if (oy >= d.OH) continue;
-      const T* row = dy + (((long long)b * d.OH + oy) * d.OW) * d.C + c;
+      const bool row_ok = ky < K && ty >= 0 && oy < d.OH;
+      const T* row = dy + (((long long)b * d.OH + min(max(oy, 0), d.OH - 1)) * d.OW) * d.C + c;
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
+      for (int jx = 0; jx < KT; ++jx) {
+        const int kx = px + jx * S;
         const int tx = ix + d.pad_l - kx;
-        if (tx < 0 || (S > 1 && (tx % S) != 0)) continue;
         const int ox = tx / S;
-        if (ox >= d.OW) continue;
-        acc += ldf<T>(row + (long long)ox * d.C) * wc[ky * K + kx];
+        const bool ok = row_ok && kx < K && tx >= 0 && ox < d.OW;
+        const float v = ldf<T>(row + (long long)min(max(ox, 0), d.OW - 1) * d.C);     // unconditional, see dw_fwd_kernel
+        const float wv = wc[min(ky, K - 1) * K + min(kx, K - 1)];
+        acc += ok ? v * wv : 0.f;
       }
     }
     if (relu_in && !(ldf<T>(x + idx) > 0.f)) acc = 0.f;
@@ -224,13 +231,28 @@ __global__ void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restr
 
 // ---------------------------------------------------------------- weight gradient
 // dw[c,ky,kx] = sum_{b,oy,ox} dy[b,oy,ox,c] * f(x[b,oy*S+ky-pad_t,ox*S+kx-pad_l,c])
-// Work item = OXT neighbouring outputs of one row ("group"); grid (channel chunks of 64, chunks of DW_WRW_GRP groups).
+// Work item = OXT neighbouring outputs of one row ("group"); grid (channel chunks of 64, chunks of GRP groups).
 // Lanes run along channels; when C <= 32 the spare lanes take further row groups (RG = 64 / C per wave) and are
 // folded with fixed-order shuffles.  Every thread slides the k-wide input window over its OXT outputs in registers.
-#define DW_WRW_GRP 8
+int g_dw_wrw_grp = 0;   // groups of OXT outputs per workgroup; 0 = chosen per shape (xpt_dwconv_tune overrides)
+
+// One group per wave keeps the per-wave dependent work shortest (measured: time grows linearly with the groups a wave
+// walks); narrow tensors need 4 x (row groups packed into a wave) groups to fill their lanes, very large maps larger
+// chunks to bound the number of partial rows.
+inline int wrw_groups(long long ngrp, int C) {
+  if (g_dw_wrw_grp) return g_dw_wrw_grp;
+  int grp = 4;
+  if (C <= 32) {
+    const int rg = 64 / C;                       // row groups a wave can hold side by side
+    grp = rg >= 4 ? 16 : (rg >= 2 ? 8 : 4);
+  }
+  const long long cchunks = (C + 63) / 64;
+  while (grp < 32 && ((ngrp + grp - 1) / grp) * cchunks > 2048) grp <<= 1;
+  return grp;
+}
 template <typename T, int K, int S>
 __global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
-                                     DwDims d, int relu_in, int RG) {
+                                     DwDims d, int relu_in, int RG, int GRP) {
   constexpr int OXT = (S == 1) ? 4 : 2;
   constexpr int IN = (OXT - 1) * S + K;
   __shared__ float red[3][64 * K * K];
@@ -241,12 +263,12 @@ __global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restric
   const bool active = (c < d.C) && (rg < RG);
   const int OXG = (d.OW + OXT - 1) / OXT;
   const long long ngrp = (long long)d.B * d.OH * OXG;
-  const long long g0 = (long long)blockIdx.y * DW_WRW_GRP;
+  const long long g0 = (long long)blockIdx.y * GRP;
   float acc[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
   if (active) {
-    for (int i = wid * RG + rg; i < DW_WRW_GRP; i += 4 * RG) {
+    for (int i = wid * RG + rg; i < GRP; i += 4 * RG) {
       const long long g = g0 + i;
       if (g >= ngrp) break;
       const int oxg = (int)(g % OXG);
@@ -258,18 +280,21 @@ __global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restric
       float gy[OXT];
       const T* dyp = dy + (((long long)b * d.OH + oy) * d.OW + ox0) * d.C + c;
 #pragma unroll
-      for (int j = 0; j < OXT; ++j) gy[j] = (ox0 + j < d.OW) ? ldf<T>(dyp + (long long)j * d.C) : 0.f;
+      for (int j = 0; j < OXT; ++j) {
+        const float v = ldf<T>(dyp + (long long)min(j, d.OW - 1 - ox0) * d.C);            // unconditional, see dw_fwd_kernel
+        gy[j] = (ox0 + j < d.OW) ? v : 0.f;
+      }
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
         const int iy = oy * S + ky - d.pad_t;
-        if (iy < 0 || iy >= d.H) continue;
-        const T* row = x + (((long long)b * d.H + iy) * d.W) * d.C + c;
+        const bool row_ok = iy >= 0 && iy < d.H;
+        const T* row = x + (((long long)b * d.H + min(max(iy, 0), d.H - 1)) * d.W) * d.C + c;
         float in[IN];
 #pragma unroll
         for (int t = 0; t < IN; ++t) {
           const int ix = ix0 + t;
-          float v = (ix >= 0 && ix < d.W) ? ldf<T>(row + (long long)ix * d.C) : 0.f;
-          in[t] = relu_in ? fmaxf(v, 0.f) : v;
+          const float v = ldf<T>(row + (long long)min(max(ix, 0), d.W - 1) * d.C);
+          in[t] = (row_ok && ix >= 0 && ix < d.W) ? (relu_in ? fmaxf(v, 0.f) : v) : 0.f;
         }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
@@ -393,10 +418,11 @@ int launch_bwd_weight(const void* x, const void* dy, float* dw, float* ws, const
                       hipStream_t s) {
   constexpr int OXT = (S == 1) ? 4 : 2;
   const long long ngrp = (long long)d.B * d.OH * ((d.OW + OXT - 1) / OXT);
-  const int nchunk = (int)((ngrp + DW_WRW_GRP - 1) / DW_WRW_GRP);
-  const int RG = (d.C <= 32) ? (64 / d.C > DW_WRW_GRP / 4 ? DW_WRW_GRP / 4 : 64 / d.C) : 1;
+  const int GRP = wrw_groups(ngrp, d.C);
+  const int nchunk = (int)((ngrp + GRP - 1) / GRP);
+  const int RG = (d.C <= 32) ? (64 / d.C > GRP / 4 ? (GRP / 4 > 0 ? GRP / 4 : 1) : 64 / d.C) : 1;
   hipLaunchKernelGGL((dw_bwd_weight_kernel<T, K, S>), dim3((d.C + 63) / 64, nchunk), dim3(256), 0, s, (const T*)x,
-                     (const T*)dy, ws, d, relu_in, RG);
+                     (const T*)dy, ws, d, relu_in, RG, GRP);
   const int n = d.C * K * K;
   if (dw) hipLaunchKernelGGL(dw_wrw_reduce_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ws, dw, n, nchunk);
   return xpt_launch_status();
@@ -457,9 +483,9 @@ int xpt_dwconv_bwd_data(const void* x, const float* w, const void* dy, void* dx,
 
 size_t xpt_dwconv_bwd_weight_workspace_floats(int B, int OH, int OW, int C, int k) {
   if (B <= 0 || OH <= 0 || OW <= 0 || C <= 0 || k <= 0) return 0;
-  // groups of OXT (>= 2) neighbouring outputs per row, DW_WRW_GRP groups per workgroup: upper bound with OXT = 2
+  // groups of OXT (>= 2) neighbouring outputs per row, g_dw_wrw_grp groups per workgroup: upper bound with OXT = 2
   const size_t ngrp = (size_t)B * OH * (((size_t)OW + 1) / 2);
-  return ((ngrp + DW_WRW_GRP - 1) / DW_WRW_GRP) * (size_t)C * k * k;
+  return ((ngrp + 3) / 4) * (size_t)C * k * k;
 }
 
 int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_floats, int B,
@@ -474,11 +500,20 @@ int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* works
   DW_DISPATCH(launch_bwd_weight, x, dy, dw, workspace, d, relu_in, (hipStream_t)stream);
 }
 
+/* launch-plan knob (process-wide, for benchmarking): groups of 4 (stride 1) / 2 (stride 2) outputs per workgroup of the
+ * weight-gradient kernel; 4, 8, 16 or 32, 0 = automatic */
+int xpt_dwconv_tune(int wrw_groups) {
+  if (wrw_groups != 0 && wrw_groups != 4 && wrw_groups != 8 && wrw_groups != 16 && wrw_groups != 32) return XPT_ERR_ARG;
+  g_dw_wrw_grp = wrw_groups;
+  return XPT_OK;
+}
+
 int xpt_dwconv_bwd_weight_chunks(int B, int OH, int OW, int C, int k, int stride) {
   if (B <= 0 || OH <= 0 || OW <= 0 || C <= 0 || k <= 0 || (stride != 1 && stride != 2)) return 0;
   const int oxt = stride == 1 ? 4 : 2;
   const long long ngrp = (long long)B * OH * ((OW + oxt - 1) / oxt);
-  return (int)((ngrp + DW_WRW_GRP - 1) / DW_WRW_GRP);
+  const int grp = wrw_groups(ngrp, C);
+  return (int)((ngrp + grp - 1) / grp);
 }
 
 /* Deferred weight gradient: partials[chunk][C][k][k], to be added up later by xpt_reduce_partials. */

@@ -47,6 +47,7 @@ SIGNATURES = {
     "xpt_adam_step": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _f, _f, _f, _f, _f, _i, _p, _p]),
     "xpt_dwconv_fwd": (_i, [_p, _p, _p] + [_i] * 12 + [_p]),
     "xpt_dwconv_bwd_data": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p]),
+    "xpt_dwconv_tune": (_i, [_i]),
     "xpt_dwconv_bwd_weight_workspace_floats": (_z, [_i] * 5),
     "xpt_dwconv_bwd_weight": (_i, [_p, _p, _p, _p, _z] + [_i] * 12 + [_p]),
     "xpt_conv1x1_bwd_weight_workspace_floats": (_z, [ctypes.c_longlong, _i, _i]),
