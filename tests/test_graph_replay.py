@@ -45,7 +45,7 @@ def test_graph_replays_match_eager(gpu_device, dtype):
         torch.cuda.synchronize()
         flat.grad.zero_()
         graph = tv._StepGraph(trainer.forward_backward, state=trainer.optimizer_state)
-        tol = 5e-1 if dtype == "bf16" else 2e-3              # bf16: rounding noise of small gradients; replay garbage is >= 1e3
+        tol = 5e-1 if dtype == "bf16" else 5e-3              # bf16: rounding noise of small gradients; replay garbage is >= 1e3
         for it in range(5):
             flat.grad.zero_()
             _, loss, _ = graph(batches[it % 2])

@@ -82,9 +82,12 @@ __device__ inline void stage_load(typename StageVec<V>::type (&reg)[(RC * TW / V
   for (int i = 0; i < PER; ++i) {
     const int v = threadIdx.x + i * NT;
     const int row = v / VPR, c = c0 + (v % VPR) * V;
-    vec_t val = vec_t();
-    if (v < NV && k0 + row < k_end && c < C) val = *(const vec_t*)(src + (k0 + row) * pitch + c);
-    reg[i] = val;
+    // unconditional load from a clamped (row, channel) and a select: guarded loads would each get a branch and their
+    // own s_waitcnt, serialising the up to 8 loads of a thread
+    const bool ok = v < NV && k0 + row < k_end && c < C;
+    const long long rr = k0 + row < k_end ? k0 + row : k_end - 1;
+    const vec_t val = *(const vec_t*)(src + rr * pitch + (c < C ? c : C - V));
+    reg[i] = ok ? val : vec_t();
   }
 }
 

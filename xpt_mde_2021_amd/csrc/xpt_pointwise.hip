@@ -192,14 +192,18 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(SumInputs in, T* __restri
        idx += (long long)gridDim.x * blockDim.x) {
     const long long r = idx / groups;
     const int c0 = (int)(idx - r * groups) * V;
-    float acc[V];
+    // all (up to 8) operand rows are requested before the first add: unused slots re-read operand 0 and add zero
+    float acc[V], v[7][V];
     load_row<T, V>((const T*)in.ptr[0] + r * in.pitch[0] + c0, acc);
-    for (int i = 1; i < in.n; ++i) {
-      float v[V];
-      load_row<T, V>((const T*)in.ptr[i] + r * in.pitch[i] + c0, v);
 #pragma unroll
-      for (int j = 0; j < V; ++j) acc[j] += v[j];
+    for (int i = 1; i < 8; ++i) {
+      const int k = i < in.n ? i : 0;
+      load_row<T, V>((const T*)in.ptr[k] + r * in.pitch[k] + c0, v[i - 1]);
     }
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += i < in.n ? v[i - 1][j] : 0.f;
     store_row<T, V>(out + r * C + c0, acc);
   }
 }

@@ -34,9 +34,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const xpt_reduce_j
     for (int s0 = first; s0 < ns; s0 += 8 * SW) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int s = s0 + u * SW;
-        v[u] = s < ns ? src[(long long)s * stride] : 0.f;
+      for (int u = 0; u < 8; ++u) {   // unconditional loads from a clamped split, zeroed by a select: a guarded load
+        const int s = s0 + u * SW;    // would get its own branch and s_waitcnt, i.e. one memory round trip per split
+        const float x = src[(long long)min(s, ns - 1) * stride];
+        v[u] = s < ns ? x : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) sum += v[u];
