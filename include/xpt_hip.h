@@ -251,6 +251,15 @@ int xpt_dwconv_bwd_weight_partials(const void* x, const void* dy, float* partial
                                    int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int relu_in,
                                    int dtype, void* stream);
 int xpt_conv1x1_bwd_weight_splits(long long M, int cout, int cin);
+/* conv1x1 -> BatchNormalization backward in ONE launch (the BN layer that follows every pointwise convolution of a
+ * NASNet cell, keras nasnet._separable_conv_block / _adjust_block / cell heads): dy = gradient of the BN output,
+ * ypre = the convolution output the BN saw.  Writes g_out [M, cout] bf16 = dy * gamma * rsqrt(var + eps) (operand of the
+ * data-gradient GEMM), the filter-gradient partials w_partials [splits][cout][cin] of g^T x, and bn_partials
+ * [splits][2][cout] (row 0 -> dbeta, row 1 -> dgamma); splits = xpt_conv1x1_bwd_weight_splits(). */
+int xpt_conv1x1_bn_bwd_partials(const void* dy, const void* ypre, const void* x, const float* gamma, const float* var,
+                                const float* mean, float eps, void* g_out, float* w_partials, size_t w_partial_floats,
+                                float* bn_partials, size_t bn_partial_floats, long long M, int cout, int cin,
+                                long long pitch_dy, long long pitch_x, void* stream);
 int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, float* partials, size_t partial_floats, long long M,
                                     int cout, int cin, long long pitch_dy, long long pitch_x, void* stream);
 

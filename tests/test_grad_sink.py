@@ -99,3 +99,58 @@ def test_deferred_equals_immediate(gpu_device, dtype):
         opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
         opts.IMAGE_SIZES.clear()
         opts.IMAGE_SIZES.update(saved[3])
+
+
+@pytest.mark.parametrize("shape", [(2, 44, 88, 5, 7), (1, 264, 44, 16, 52), (3, 22, 11, 9, 13), (2, 176, 176, 4, 13)])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_fused_conv1x1_bn_backward(gpu_device, shape, with_residual):
+    """BatchNorm(conv1x1(x)) (+ residual) with the BN backward folded into the weight-gradient launch, against fp32
+    autograd of the same bf16-rounded operands."""
+    import torch.nn.functional as F
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
+    B, cin, cout, H, W = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16()
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).bfloat16()
+    res = torch.randn(B, cout, H, W, generator=g).bfloat16()
+    gy = torch.randn(B, cout, H, W, generator=g).bfloat16()
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    mean, var = torch.randn(cout, generator=g) * 0.2, torch.rand(cout, generator=g) + 0.3
+    # reference: fp32 autograd; the kernel path rounds the convolution output to bf16 before the BatchNorm
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    gr, br, rr = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True), res.float().requires_grad_(True)
+    ypre = F.conv2d(xr, wr)
+    yr = F.batch_norm(ypre, mean, var, gr, br, False, 0.0, pn.BN_EPS) + (rr if with_residual else 0)
+    yr.backward(gy.float())
+
+    dev = gpu_device
+    weight = torch.nn.Parameter(w.float().to(dev))
+    weight.shadow_bf16 = w.to(dev)
+    weight.flat_grad = torch.zeros(cout, cin, 1, 1, device=dev)
+    bn = pn.FrozenBatchNorm(cout).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta); bn.running_mean.copy_(mean); bn.running_var.copy_(var)
+    bn.weight.flat_grad = torch.zeros(cout, device=dev)
+    bn.bias.flat_grad = torch.zeros(cout, device=dev)
+    xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = res.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        y = pn.conv1x1_bn(xg, weight, bn, rg if with_residual else None)
+    assert y.grad_fn is not None and "Conv1x1Bn" in type(y.grad_fn).__name__
+    y.backward(gy.to(dev))
+    ops.grad_sink.flush()
+    torch.cuda.synchronize()
+
+    def close(a, b, tol, what):
+        scale = max(1.0, float(b.abs().max()))
+        err = float((a.float().cpu() - b).abs().max()) / scale
+        assert err < tol, (what, err)
+
+    close(y, yr.detach(), 3e-2, "y")
+    close(xg.grad, xr.grad, 3e-2, "dx")
+    close(weight.flat_grad, wr.grad, 2e-2, "dW")
+    close(bn.weight.flat_grad, gr.grad, 2e-2, "dgamma")
+    close(bn.bias.flat_grad, br.grad, 1e-2, "dbeta")
+    if with_residual:
+        close(rg.grad, rr.grad, 1e-6, "dres")

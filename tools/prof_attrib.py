@@ -30,12 +30,12 @@ print("total launches", sum(v[0] for v in agg.values()))
 print("---- copy_/add_/add/mul/fill_ by shapes")
 agg2 = collections.defaultdict(int)
 for ev in prof.events():
-    if ev.kernels and ev.name in ("aten::copy_", "aten::add_", "aten::add", "aten::mul", "aten::fill_", "aten::clamp_min", "aten::threshold_backward"):
+    if ev.kernels and ev.name.startswith("aten::") and ev.name not in ("aten::mm", "aten::miopen_convolution", "aten::convolution_backward"):
         par = ev.cpu_parent
         chain = []
         while par is not None and len(chain) < 4:
             chain.append(par.name)
             par = par.cpu_parent
         agg2[(ev.name, ev.kernels[0].name[:50], str(ev.input_shapes)[:60], " < ".join(chain)[:110])] += 1
-for k, n in sorted(agg2.items(), key=lambda kv: -kv[1])[:90]:
+for k, n in sorted(agg2.items(), key=lambda kv: -kv[1])[:140]:
     print(n, k)

@@ -102,23 +102,71 @@ __device__ inline void stage_store(unsigned short* dst, const typename StageVec<
   }
 }
 
+// Optional fusion of the BatchNorm backward that precedes the convolution's backward (conv -> BN in the forward):
+//   the incoming gradient dy is the gradient of the BN OUTPUT; g = dy * s (s = gamma * rsqrt(var + eps)) is the gradient
+//   of the convolution output.  The kernel scales its A operand by s (so D = g^T x is the filter gradient itself), the
+//   workgroups of the first input-channel tile also write g (bf16, for the data-gradient GEMM) and the per-split
+//   partials of dbeta = sum dy and dgamma = rstd (sum dy * ypre - mean * sum dy), ypre = the convolution output.
+struct BnFuse {
+  const float* gamma;
+  const float* var;
+  const float* mean;
+  float eps;
+  const unsigned short* ypre;   // [M, cout] bf16, dense
+  unsigned short* g_out;        // [M, cout] bf16, dense
+  float* partial;               // [nsplit][2][cout]
+};
+
+__device__ inline unsigned short f32_to_bf16_bits(float f) {   // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// g = dy * s for this thread's staged vectors of dy, written to g_out (rows / channels outside the tensor skipped)
+template <int V, int TW, int RC, int NT>
+__device__ inline void store_scaled(unsigned short* __restrict__ g_out, const float* sS,
+                                    const typename StageVec<V>::type (&reg)[(RC * TW / V + NT - 1) / NT],
+                                    long long pitch, long long k0, long long k_end, int c0, int C) {
+  typedef typename StageVec<V>::type vec_t;
+  constexpr int VPR = TW / V, NV = RC * VPR, PER = (NV + NT - 1) / NT;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int v = threadIdx.x + i * NT;
+    const int row = v / VPR, cl = (v % VPR) * V;
+    if (v < NV && k0 + row < k_end && c0 + cl < C) {
+      vec_t in = reg[i], out;
+      const unsigned short* e = (const unsigned short*)&in;
+      unsigned short* o = (unsigned short*)&out;
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = f32_to_bf16_bits(bf16_bits_to_f32(e[j]) * sS[cl + j]);
+      *(vec_t*)(g_out + (k0 + row) * pitch + c0 + cl) = out;
+    }
+  }
+}
+
 // TCO x TCI output tile per workgroup of NW waves.  Q = quadrants of 32x32, KS = NW / Q interleaved k slices.
 // VA / VB: elements per global load of dy / x (the host picks the widest the pitch, base and channel count allow).
-template <int TCO, int TCI, int VA, int VB>
+template <int TCO, int TCI, int VA, int VB, bool BN>
 __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned short* __restrict__ dy,
                                                               const unsigned short* __restrict__ x,
                                                               float* __restrict__ dw, float* __restrict__ partial,
                                                               unsigned* __restrict__ counters, long long M, int cout,
                                                               int cin, long long pitch_dy, long long pitch_x,
-                                                              long long rows_per_block, int nsplit, int defer) {
+                                                              long long rows_per_block, int nsplit, int defer,
+                                                              BnFuse bn) {
   constexpr int NW = 16, QA = TCO / 32, QB = TCI / 32, Q = QA * QB, KS = NW / Q, NT = NW * 64;
   constexpr int TILE = TCO * TCI;
-  constexpr int RC = Q == 4 ? 128 : 256;                    // rows staged per chunk: 32 / 48 / 32 KiB of LDS
-  constexpr int STAGE_BYTES = RC * (TCO + TCI) * 2, RED_BYTES = (KS - 1) * Q * 4096;
+  // rows staged per chunk: 32 / 48 / 32 KiB of LDS (BN fusion: a third buffer for ypre, 48 / 40 / 48 KiB)
+  constexpr int RC = BN ? (Q == 1 ? 256 : 128) : (Q == 4 ? 128 : 256);
+  constexpr int STAGE_BYTES = RC * (TCO + TCI + (BN ? TCO : 0)) * 2, RED_BYTES = (KS - 1) * Q * 4096;
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
   __shared__ unsigned last_flag;
+  __shared__ float sS[BN ? TCO : 1];                        // BN scale of the tile's output channels
+  __shared__ float bnred[BN ? KS * QA * 64 : 1];            // column sums of the k slices
   unsigned short* sA = (unsigned short*)smem;               // [RC][TCO] rows of dy
   unsigned short* sB = sA + RC * TCO;                       // [RC][TCI] rows of x
+  unsigned short* sY = sB + RC * TCI;                       // [RC][TCO] rows of ypre (BN fusion, first ci tile only)
   float* red = (float*)smem;                                // reused once the staging buffers are dead
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -134,6 +182,17 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
   if (k_end > M) k_end = M;
   const int ci = ci0 + qb * 32 + r;
   const bool ci_ok = ci < cin;
+  const bool bn_tile = BN && blockIdx.x == 0;               // this workgroup also emits g and the BN partial sums
+  const bool bn_sums = bn_tile && qb == 0;                  // ... summed by the waves of the first column quadrant
+  if (BN) {
+    if (threadIdx.x < TCO) {
+      const int c = co0 + threadIdx.x;
+      sS[threadIdx.x] = c < cout ? bn.gamma[c] * rsqrtf(bn.var[c] + bn.eps) : 0.f;
+    }
+    __syncthreads();
+  }
+  const float a_scale = BN ? sS[qa * 32 + r] : 1.f;
+  float sum_dy = 0.f, sum_dyy = 0.f;
 
   f32x16 acc;
 #pragma unroll
@@ -145,29 +204,69 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
   // are in flight (registers) while this chunk's MFMAs run.
   typename StageVec<VA>::type ga[(RC * TCO / VA + NT - 1) / NT];
   typename StageVec<VB>::type gb[(RC * TCI / VB + NT - 1) / NT];
+  typename StageVec<VA>::type gy[BN ? (RC * TCO / VA + NT - 1) / NT : 1];
   stage_load<VA, TCO, RC, NT>(ga, dy, pitch_dy, k_begin, k_end, co0, cout);
   stage_load<VB, TCI, RC, NT>(gb, x, pitch_x, k_begin, k_end, ci0, cin);
+  if constexpr (BN) {
+    if (bn_tile) stage_load<VA, TCO, RC, NT>(gy, bn.ypre, cout, k_begin, k_end, co0, cout);
+  }
   const unsigned short* myA = sA + h * TCO + qa * 32 + r;
   const unsigned short* myB = sB + h * TCI + qb * 32 + r;
+  const unsigned short* myY = sY + h * TCO + qa * 32 + r;
   for (long long k0 = k_begin; k0 < k_end; k0 += RC) {
     __syncthreads();                                        // the previous chunk's operand reads are done
     stage_store<VA, TCO, RC, NT>(sA, ga);
     stage_store<VB, TCI, RC, NT>(sB, gb);
+    if constexpr (BN) {
+      if (bn_tile) {
+        stage_store<VA, TCO, RC, NT>(sY, gy);
+        store_scaled<VA, TCO, RC, NT>(bn.g_out, sS, ga, cout, k0, k_end, co0, cout);
+      }
+    }
     __syncthreads();
     if (k0 + RC < k_end) {
       stage_load<VA, TCO, RC, NT>(ga, dy, pitch_dy, k0 + RC, k_end, co0, cout);
       stage_load<VB, TCI, RC, NT>(gb, x, pitch_x, k0 + RC, k_end, ci0, cin);
+      if constexpr (BN) {
+        if (bn_tile) stage_load<VA, TCO, RC, NT>(gy, bn.ypre, cout, k0 + RC, k_end, co0, cout);
+      }
     }
     // row pairs ksub, ksub + KS, ... of the chunk (rows past k_end hold zeros); bounds are wave-uniform
     const long long left = k_end - k0;
     const int pairs = left >= RC ? RC / 2 : (int)((left + 1) / 2);
     for (int j = ksub; j < pairs; j += KS) {
-      const float a = bf16_bits_to_f32(myA[2 * j * TCO]);
+      const float a_raw = bf16_bits_to_f32(myA[2 * j * TCO]);
       const float b = bf16_bits_to_f32(myB[2 * j * TCI]);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      if (BN && bn_sums) {
+        sum_dy += a_raw;
+        sum_dyy += a_raw * bf16_bits_to_f32(myY[2 * j * TCO]);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(BN ? a_raw * a_scale : a_raw, b, acc, 0, 0, 0);
+    }
+  }
+  if (BN && bn_sums) {       // fold the two row halves of the wave, park the k slice's column sums
+    sum_dy += __shfl_xor(sum_dy, 32, 64);
+    sum_dyy += __shfl_xor(sum_dyy, 32, 64);
+    if (lane < 32) {
+      bnred[(ksub * QA + qa) * 64 + r] = sum_dy;
+      bnred[(ksub * QA + qa) * 64 + 32 + r] = sum_dyy;
     }
   }
   __syncthreads();                                          // staging buffers dead: `red` may overwrite them
+  if (BN && bn_sums && ksub == 0 && lane < 32) {            // k slices in order -> this split's share of dbeta / dgamma
+    float t1 = 0.f, t2 = 0.f;
+    for (int ks = 0; ks < KS; ++ks) {
+      t1 += bnred[(ks * QA + qa) * 64 + r];
+      t2 += bnred[(ks * QA + qa) * 64 + 32 + r];
+    }
+    const int c = co0 + qa * 32 + r;
+    if (c < cout) {
+      const float rstd = rsqrtf(bn.var[c] + bn.eps);
+      float* P = bn.partial + (long long)split * 2 * cout;
+      P[c] = t1;
+      P[cout + c] = rstd * (t2 - bn.mean[c] * t1);
+    }
+  }
 
   // combine the k slices of one quadrant through LDS (fixed order: slice 0 + slice 1 + ...)
   if (KS > 1) {
@@ -292,13 +391,13 @@ extern "C" int xpt_conv1x1_bwd_weight_counters(long long M, int cout, int cin) {
 
 static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspace, unsigned* counters, long long M,
                         int cout, int cin, long long pitch_dy, long long pitch_x, const WgradPlan& p, int defer,
-                        void* stream) {
+                        void* stream, const BnFuse* bn = nullptr) {
   const dim3 grid(p.tiles_ci, p.tiles_co, p.nsplit);
   const dim3 block(1024);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* a = (const unsigned short*)dy;
   const unsigned short* b = (const unsigned short*)x;
-  // widest staging load (elements) both operands allow: rows must start and end on a vector boundary
+  // widest staging load (elements) all operands allow: rows must start and end on a vector boundary
   auto width = [](const void* ptr, long long pitch, int C) {
     int v = 8;
     while (v > 1 && (pitch % v != 0 || C % v != 0 || ((uintptr_t)ptr) % (2 * v) != 0)) v >>= 1;
@@ -307,10 +406,22 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
   int v = width(dy, pitch_dy, cout);
   const int vb = width(x, pitch_x, cin);
   if (vb < v) v = vb;
+  if (bn) {
+    const int vy = width(bn->ypre, cout, cout), vg = width(bn->g_out, cout, cout);
+    if (vy < v) v = vy;
+    if (vg < v) v = vg;
+  }
+  const BnFuse none{};
   XPT_BEGIN_LAUNCH();
-#define XPT_WGRAD(TCO, TCI, V)                                                                                       \
-  hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V>), grid, block, 0, s, a, b, dw, workspace, counters, M,   \
-                     cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer)
+#define XPT_WGRAD(TCO, TCI, V)                                                                                        \
+  do {                                                                                                                \
+    if (bn)                                                                                                           \
+      hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, true>), grid, block, 0, s, a, b, dw, workspace,        \
+                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, *bn);          \
+    else                                                                                                              \
+      hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, false>), grid, block, 0, s, a, b, dw, workspace,       \
+                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, none);         \
+  } while (0)
 #define XPT_WGRAD_V(V)                                                                                               \
   do {                                                                                                               \
     if (p.tco == 64 && p.tci == 64)                                                                                  \
@@ -369,4 +480,25 @@ extern "C" int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, fl
   if (partial_floats < (size_t)p.nsplit * cout * cin) return XPT_ERR_WORKSPACE;
   if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
   return wgrad_launch(dy, x, nullptr, partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream);
+}
+
+/* conv -> BatchNorm backward in one launch (see BnFuse): dy is the gradient of the BN output.
+ *   g_out [M, cout] bf16 = dy * gamma * rsqrt(var + eps)      (input of the data-gradient GEMM)
+ *   w_partials [splits][cout][cin]                            filter-gradient partials, D = g^T x
+ *   bn_partials [splits][2][cout]                             row 0: dbeta partials, row 1: dgamma partials
+ * splits = xpt_conv1x1_bwd_weight_splits(M, cout, cin); all partials are finished by xpt_reduce_partials. */
+extern "C" int xpt_conv1x1_bn_bwd_partials(const void* dy, const void* ypre, const void* x, const float* gamma,
+                                           const float* var, const float* mean, float eps, void* g_out,
+                                           float* w_partials, size_t w_partial_floats, float* bn_partials,
+                                           size_t bn_partial_floats, long long M, int cout, int cin,
+                                           long long pitch_dy, long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(x); XPT_CHECK_PTR(gamma); XPT_CHECK_PTR(var);
+  XPT_CHECK_PTR(mean); XPT_CHECK_PTR(g_out); XPT_CHECK_PTR(w_partials); XPT_CHECK_PTR(bn_partials);
+  if (M <= 0 || cout <= 0 || cin <= 0 || pitch_dy < cout || pitch_x < cin) return XPT_ERR_SHAPE;
+  const WgradPlan p = wgrad_plan(M, cout, cin, true);
+  if (w_partial_floats < (size_t)p.nsplit * cout * cin) return XPT_ERR_WORKSPACE;
+  if (bn_partial_floats < (size_t)p.nsplit * 2 * cout) return XPT_ERR_WORKSPACE;
+  if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
+  const BnFuse bn{gamma, var, mean, eps, (const unsigned short*)ypre, (unsigned short*)g_out, bn_partials};
+  return wgrad_launch(dy, x, nullptr, w_partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream, &bn);
 }

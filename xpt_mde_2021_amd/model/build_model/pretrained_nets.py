@@ -109,6 +109,75 @@ def conv1x1(x, weight):
     return y.permute(0, 3, 1, 2)                                                        # NCHW-indexed, channels_last
 
 
+class _Conv1x1BnBf16(torch.autograd.Function):
+    """BatchNorm(conv1x1(x)) [+ residual] with the BatchNorm backward folded into the convolution's weight-gradient
+    launch (csrc/xpt_gemm.hip, BnFuse): backward = ONE gfx950 launch (g = dy * s for the data-gradient GEMM, split-K
+    partials of dW, dgamma, dbeta -> GradSink) + ONE rocBLAS GEMM, instead of BN-backward kernel + weight-gradient
+    kernel + GEMM.  Only used when all three parameters are deferred-gradient views (training on flat buffers)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, mean, var, eps, residual):
+        lib = _ops._lib.load()
+        B, cin, H, W = x.shape
+        cout = weight.shape[0]
+        ws = weight.shadow_bf16.reshape(cout, cin)
+        x2 = _ops.as_rows(x)
+        ypre = torch.mm(x2, ws.t())                                     # [M, cout] bf16, dense
+        M = ypre.shape[0]
+        y = torch.empty((B, cout, H, W), dtype=ypre.dtype, device=x.device, memory_format=torch.channels_last)
+        if residual is not None:
+            residual = residual.to(ypre.dtype).contiguous(memory_format=torch.channels_last)
+        g_, b_ = gamma.detach(), beta.detach()
+        _ops._lib.check(lib.xpt_affine_act_fwd(ypre.data_ptr(), g_.data_ptr(), b_.data_ptr(), mean.data_ptr(),
+                                               var.data_ptr(), float(eps), _ops._ptr(residual), y.data_ptr(), M, cout,
+                                               1.0, 0, 1, _ops._stream()), "xpt_affine_act_fwd")
+        ctx.save_for_backward(x2, ws, ypre, g_, mean, var)
+        ctx.dims = (B, cin, H, W, cout, float(eps))
+        ctx.dst = (weight.flat_grad, gamma.flat_grad, beta.flat_grad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _ops._lib.load()
+        x2, ws, ypre, gamma, mean, var = ctx.saved_tensors
+        B, cin, H, W, cout, eps = ctx.dims
+        w_dst, g_dst, b_dst = ctx.dst
+        dy2 = _ops.as_rows(dy.to(torch.bfloat16))
+        M = dy2.shape[0]
+        g = torch.empty((M, cout), dtype=torch.bfloat16, device=dy.device)
+        nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
+        sink = _ops.grad_sink
+        wpart = sink.partials(w_dst, "conv1x1", nsplit * cout * cin)
+        bpart = sink.partials(b_dst, "bnfuse", nsplit * 2 * cout)
+        pitch_dy = dy2.stride(0) if M > 1 else cout
+        pitch_x = x2.stride(0) if M > 1 else cin
+        _ops._lib.check(lib.xpt_conv1x1_bn_bwd_partials(dy2.data_ptr(), ypre.data_ptr(), x2.data_ptr(), gamma.data_ptr(),
+                                                        var.data_ptr(), mean.data_ptr(), eps, g.data_ptr(),
+                                                        wpart.data_ptr(), wpart.numel(), bpart.data_ptr(), bpart.numel(),
+                                                        M, cout, cin, pitch_dy, pitch_x, _ops._stream()),
+                        "xpt_conv1x1_bn_bwd_partials")
+        sink.add(w_dst, wpart, 0, cout * cin, nsplit, cout * cin)
+        sink.add(b_dst, bpart, 0, cout, nsplit, 2 * cout)
+        sink.add(g_dst, bpart, cout, cout, nsplit, 2 * cout)
+        dx = torch.mm(g, ws).view(B, H, W, cin).permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None
+        dres = dy if ctx.needs_input_grad[7] else None
+        return dx, None, None, None, None, None, None, dres
+
+
+_FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
+
+
+def conv1x1_bn(x, weight, bn, residual=None):
+    """bn(conv1x1(x, weight)) [+ residual]: the fused-backward path when training on flat (deferred-gradient)
+    parameters in bf16, the two separate ops otherwise."""
+    sink = _ops.grad_sink
+    if (_FUSE_CONV_BN and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_autocast_enabled()
+            and torch.is_grad_enabled() and hasattr(weight, "shadow_bf16") and not _LIBRARY_WGRAD
+            and sink.wants(weight) and sink.wants(bn.weight) and sink.wants(bn.bias)):
+        return _Conv1x1BnBf16.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS, residual)
+    return bn(conv1x1(x, weight), residual)
+
+
 def correct_pad(h, w, k):
     """keras imagenet_utils.correct_pad for a stride-2 VALID conv: ((k//2 - adj_h, k//2), (k//2 - adj_w, k//2))
     with adj = 1 for an even extent -- identical to TF SAME padding at stride 2."""
@@ -131,21 +200,25 @@ class SeparableConv(nn.Module):
         nn.init.kaiming_normal_(self.depthwise.weight, mode="fan_in", nonlinearity="relu")
         nn.init.kaiming_normal_(self.pointwise.weight, mode="fan_in", nonlinearity="relu")
 
-    def forward(self, x, relu_in=False):
+    def forward(self, x, relu_in=False, bn=None, residual=None):
         """relu_in: apply the ReLU that precedes the convolution in _separable_conv_block (fused into the gfx950
-        depthwise kernel on the GPU)."""
+        depthwise kernel on the GPU).  bn / residual: the BatchNorm (and branch add) that follow the pointwise half,
+        applied here so that their backward can ride in the pointwise weight-gradient launch."""
         if x.is_cuda and not _DISABLE_HIP_DWCONV:
             if self.stride == 2:
                 (pt, pb), (pl, pr) = correct_pad(x.shape[2], x.shape[3], self.k)
             else:
                 pt = pb = pl = pr = self.k // 2
             y = _ops.depthwise_conv2d(x, self.depthwise.weight, self.stride, (pt, pb, pl, pr), relu_in)
+            if bn is not None:
+                return conv1x1_bn(y, self.pointwise.weight, bn, residual)
             return conv1x1(y, self.pointwise.weight)
         if relu_in:                       # host tensors (CPU baseline / unit tests): library convolution
             x = F.relu(x)
         if self.stride == 2:
             x = zero_pad(x, correct_pad(x.shape[2], x.shape[3], self.k))
-        return self.pointwise(self.depthwise(x))
+        y = self.pointwise(self.depthwise(x))
+        return y if bn is None else bn(y, residual)
 
 
 class SepConvBlock(nn.Module):
@@ -166,12 +239,12 @@ class SepConvBlock(nn.Module):
         if taps.wants(self.act_id1) or taps.wants(self.act_id2):      # a tapped activation must be materialised
             x = F.relu(x)
             taps.offer(self.act_id1, x)
-            x = self.bn1(self.conv1(x))
+            x = self.conv1(x, bn=self.bn1)
             x = F.relu(x)
             taps.offer(self.act_id2, x)
-            return self.bn2(self.conv2(x), residual)
-        x = self.bn1(self.conv1(x, relu_in=True))
-        return self.bn2(self.conv2(x, relu_in=True), residual)
+            return self.conv2(x, bn=self.bn2, residual=residual)
+        x = self.conv1(x, relu_in=True, bn=self.bn1)
+        return self.conv2(x, relu_in=True, bn=self.bn2, residual=residual)
 
 
 class AdjustBlock(nn.Module):
@@ -207,7 +280,7 @@ class AdjustBlock(nn.Module):
         if self.mode == "project":
             p = shared_relu(p)
             taps.offer(self.act_id, p)
-            return self.bn(conv1x1(p, self.conv.weight))
+            return conv1x1_bn(p, self.conv.weight, self.bn)
         return p
 
 
@@ -238,7 +311,7 @@ class NormalCell(nn.Module):
         p = self.adjust(p, taps)
         h = shared_relu(ip)
         taps.offer(self.act_id, h)
-        h = self.bn(conv1x1(h, self.conv.weight))
+        h = conv1x1_bn(h, self.conv.weight, self.bn)
         # every `add` whose operand ends in a BatchNorm rides in that BatchNorm's epilogue kernel; h and p feed several
         # branches each: their gradients are summed by one fan-in kernel instead of a chain of pairwise adds
         h1, h2, h3, h4 = _ops.fan_out(h, 4)
@@ -274,7 +347,7 @@ class ReductionCell(nn.Module):
         p = self.adjust(p, taps)
         h = shared_relu(ip)
         taps.offer(self.act_id, h)
-        h = self.bn(conv1x1(h, self.conv.weight))
+        h = conv1x1_bn(h, self.conv.weight, self.bn)
         h3 = zero_pad(h, correct_pad(h.shape[2], h.shape[3], 3))
         mp = F.max_pool2d(h3, 3, 2)                      # MaxPooling2D of h feeds x2 and x5: pooled once
         mp1, mp2 = _ops.fan_out(mp, 2)
