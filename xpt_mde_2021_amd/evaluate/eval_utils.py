@@ -43,3 +43,71 @@ def evaluate_depth(depth_pred_batch, depth_true_batch):
         if p.size:
             rows.append(compute_depth_metrics(p, t))
     return np.mean(np.asarray(rows), axis=0) if rows else np.full(7, np.nan)
+
+
+# ------------------------------------------------------------------------------------------------ pose metrics
+def pose_rvec2matr_batch_np(poses):
+    """Twist (tx, ty, tz, rx, ry, rz) [batch, N, 6] -> [batch, N, 4, 4] with the reference's negated-skew Rodrigues
+    convention (utils/convert_pose.py:74-117): R = I + sin(t) W + (1 - cos(t)) W^2, W = -[w]_x."""
+    poses = np.asarray(poses, dtype=np.float64)
+    trans, uvec = poses[..., :3], poses[..., 3:]
+    theta = np.linalg.norm(uvec, axis=-1, keepdims=True)
+    safe = np.where(np.isclose(theta, 0), 1.0, theta)
+    w = uvec / safe
+    z = np.zeros_like(theta)
+    w1, w2, w3 = w[..., 0:1], w[..., 1:2], w[..., 2:3]
+    w_hat = np.concatenate([z, w3, -w2, -w3, z, w1, w2, -w1, z], axis=-1).reshape(poses.shape[:-1] + (3, 3))
+    th = theta[..., None]
+    rot = np.eye(3) + np.sin(th) * w_hat + (1.0 - np.cos(th)) * (w_hat @ w_hat)
+    mat = np.zeros(poses.shape[:-1] + (4, 4))
+    mat[..., :3, :3] = rot
+    mat[..., :3, 3] = trans
+    mat[..., 3, 3] = 1.0
+    return mat
+
+
+class PoseMetricNumpy:
+    """Snippet pose errors (evaluate/eval_utils.py:9-87): absolute / scale-aligned trajectory error in metres and
+    rotational error in radians, all poses re-based on the first frame of the snippet."""
+
+    def __init__(self):
+        self.trj_abs_err = np.array([])
+        self.trj_rel_err = np.array([])
+        self.rot_err = np.array([])
+
+    def compute_pose_errors(self, pose_pred, pose_true_mat):
+        """pose_pred [batch, numsrc, 6] twists, pose_true_mat [batch, numsrc, 4, 4] -> errors [batch, numsrc]."""
+        if hasattr(pose_pred, "detach"):
+            pose_pred = pose_pred.detach().cpu().numpy()
+        if hasattr(pose_true_mat, "detach"):
+            pose_true_mat = pose_true_mat.detach().cpu().numpy()
+        pred = self.snippet_pose_from_first(pose_rvec2matr_batch_np(pose_pred))
+        true = self.snippet_pose_from_first(np.asarray(pose_true_mat, dtype=np.float64))
+        self.trj_abs_err = self.calc_trajectory_error(pred, true, True)
+        self.trj_rel_err = self.calc_trajectory_error(pred, true, False)
+        self.rot_err = self.calc_rotational_error(pred, true)
+
+    def snippet_pose_from_first(self, poses):
+        """[batch, numsrc, 4, 4] -> [batch, numsrc + 1, 4, 4]: the (identity) target pose inserted in the middle of the
+        snippet, everything expressed relative to the first frame (eval_utils.py:27-40)."""
+        target = np.tile(np.identity(4).reshape(1, 1, 4, 4), (poses.shape[0], 1, 1, 1))
+        mats = np.concatenate([poses[:, :2], target, poses[:, 2:]], axis=1)
+        return np.matmul(np.linalg.inv(mats[:, 0:1]), mats)
+
+    def calc_trajectory_error(self, pose_pred_mat, pose_true_mat, abs_scale=False):
+        xyz_pred, xyz_true = pose_pred_mat[:, :, :3, 3], pose_true_mat[:, :, :3, 3]
+        if abs_scale:
+            err = xyz_true - xyz_pred
+        else:      # least-squares scale per frame: the monocular estimate has no absolute scale (0/0 at the origin frame)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                scale = np.sum(xyz_true * xyz_pred, axis=2) / np.sum(xyz_pred ** 2, axis=2)
+            err = xyz_true - xyz_pred * scale[..., np.newaxis]
+        return np.sqrt(np.sum(err ** 2, axis=2))[:, 1:]
+
+    def calc_rotational_error(self, pose_pred_mat, pose_true_mat):
+        rel = np.matmul(np.linalg.inv(pose_pred_mat[:, :, :3, :3]), pose_true_mat[:, :, :3, :3])
+        cosine = np.clip((np.trace(rel, axis1=2, axis2=3) - 1.0) / 2.0, -1.0, 1.0)
+        return np.arccos(cosine)[:, 1:]
+
+    def get_mean_pose_error(self):
+        return np.mean(self.trj_abs_err), np.mean(self.trj_rel_err), np.mean(self.rot_err)
