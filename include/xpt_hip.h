@@ -212,6 +212,17 @@ int xpt_conv1x1_bwd_weight(const void* dy, const void* x, float* dw, float* work
                            unsigned* counters, int n_counters, long long M, int cout, int cin, long long pitch_dy,
                            long long pitch_x, void* stream);
 
+/* ------------------------------------------------------------------ a2: pointwise convolution + BatchNorm forward
+ * replaces a 1x1 Conv2D / the pointwise half of a SeparableConv2D together with the BatchNormalization (inference
+ * mode) and the `layers.add` that follow it inside tf.keras.applications.NASNetMobile (pretrained_nets.py:36-44):
+ *   x [M, cin] bf16 rows (pitch_x elements apart), w [cout, cin] bf16 ->
+ *   ypre [M, cout] bf16 = x w^T (fp32 accumulation on the matrix cores), y [M, cout] bf16 = BN(ypre) (+ residual [M, cout]).
+ * cin and pitch_x must be multiples of 4 and the bases 8-byte aligned (XPT_ERR_ARG otherwise: use a GEMM library and
+ * xpt_affine_act_fwd). */
+int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const float* beta, const float* mean,
+                      const float* var, float eps, const void* residual, void* ypre, void* y, long long M, int cin,
+                      int cout, long long pitch_x, void* stream);
+
 /* ------------------------------------------------------------------ a2: gradient fan-in of a multiply used activation
  * out [rows, C] = sum_i inputs[i] [rows, C] (row pitch pitches[i] >= C elements; n = 2..8; dtype 0 float32 / 1 bfloat16,
  * fp32 accumulation in input order).  Replaces the chain of pairwise adds autograd (tape.gradient, train_val.py:85)

@@ -1,0 +1,151 @@
+// xpt_pwconv.hip -- forward of a pointwise (1x1) convolution with its BatchNorm (+ branch add) as ONE launch.
+//
+//   ypre[m, co] = sum_ci x[m, ci] * W[co, ci]                (bf16 operands, fp32 accumulation, stored as bf16)
+//   y[m, co]    = ypre * s[co] + shift[co] (+ residual[m, co]),   s = gamma * rsqrt(var + eps), shift = beta - mean * s
+//
+// Every pointwise convolution of NASNet-A-Mobile (the second half of each SeparableConv2D and the cell heads) is followed
+// by an inference-mode BatchNormalization (keras nasnet._separable_conv_block / _adjust_block / _normal_a_cell); with a
+// library GEMM that is a second launch re-reading the GEMM output.  Both operands are k-contiguous (activation rows
+// and filter rows), which is exactly the operand layout of v_mfma_f32_32x32x16_bf16: lane (r = lane & 31, h = lane >> 5)
+// holds A[row r][k = 8h .. 8h+7] and B[k = 8h .. 8h+7][col r], i.e. one 16-byte global load per operand and k step with
+// no LDS staging and no transposition.  A wave owns a 32x32 output tile; the 4 waves of a workgroup stack along the
+// pixel axis and share the filter rows through the L1.  The k loop issues the loads of up to 8 k steps (16 per lane)
+// before the MFMAs that consume them.  ypre is kept because the fused conv+BN backward (xpt_gemm.hip, BnFuse) needs it
+// for dgamma.  Layouts whose rows are not 8-byte aligned (cin not a multiple of 4) are rejected (the host then uses
+// the GEMM library and the stand-alone epilogue kernel).
+#include "xpt_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ inline unsigned short f32_to_bf16_bits(float f) {   // round to nearest even
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// 8 consecutive bf16 of one row starting at element k (k < K guaranteed for the first V elements; the rest zero)
+template <int V>
+__device__ inline uint4 load_frag(const unsigned short* __restrict__ row, int k, int K) {
+  uint4 f;
+  if (V == 8) {
+    f = *(const uint4*)(row + k);
+  } else {   // V == 4: rows are only 8-byte aligned; the second half may lie past the end of the row
+    const uint2 lo = *(const uint2*)(row + k);
+    const int k2 = k + 4 < K ? k + 4 : k;
+    const uint2 hi = *(const uint2*)(row + k2);
+    f.x = lo.x; f.y = lo.y;
+    f.z = k + 4 < K ? hi.x : 0u;
+    f.w = k + 4 < K ? hi.y : 0u;
+  }
+  return f;
+}
+
+struct PwBn {
+  const float* gamma;
+  const float* beta;
+  const float* mean;
+  const float* var;
+  float eps;
+};
+
+constexpr int PW_G = 8;   // k steps (of 16) whose loads are issued together
+
+template <int V>
+__global__ __launch_bounds__(256) void pwconv_bn_fwd_kernel(const unsigned short* __restrict__ x,
+                                                             const unsigned short* __restrict__ w, PwBn bn,
+                                                             const unsigned short* __restrict__ residual,
+                                                             unsigned short* __restrict__ ypre,
+                                                             unsigned short* __restrict__ y, long long M, int cin,
+                                                             int cout, long long pitch_x) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const long long m0 = ((long long)blockIdx.y * 4 + wave) * 32;
+  const int n0 = blockIdx.x * 32;
+  if (m0 >= M) return;                                   // wave-uniform; no block-level synchronisation below
+  const long long am = m0 + r < M ? m0 + r : M - 1;      // rows past the end re-read the last row (never stored)
+  const int bn_ = n0 + r;
+  const bool col_ok = bn_ < cout;
+  const unsigned short* arow = x + am * pitch_x;
+  const unsigned short* brow = w + (long long)(col_ok ? bn_ : cout - 1) * cin;
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  const int ksteps = (cin + 15) / 16;
+  for (int s0 = 0; s0 < ksteps; s0 += PW_G) {
+    uint4 fa[PW_G], fb[PW_G];
+#pragma unroll
+    for (int g = 0; g < PW_G; ++g) {                     // unconditional loads from clamped k, zeroed by select
+      const int k = (s0 + g) * 16 + 8 * h;
+      const bool ok = k < cin;
+      const int kc = ok ? k : 0;
+      const uint4 a = load_frag<V>(arow, kc, cin), b = load_frag<V>(brow, kc, cin);
+      const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+      fa[g] = ok ? a : zero;
+      fb[g] = (ok && col_ok) ? b : zero;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < PW_G; ++g)
+      if (s0 + g < ksteps)                               // wave-uniform
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[g]),
+                                                      __builtin_bit_cast(bf16x8, fb[g]), acc, 0, 0, 0);
+  }
+
+  // accumulator (reg i, lane): output row m0 + (i & 3) + 8 (i >> 2) + 4 h, column n0 + r
+  if (!col_ok) return;
+  const float sc = bn.gamma[bn_] * rsqrtf(bn.var[bn_] + bn.eps);
+  const float sh = bn.beta[bn_] - bn.mean[bn_] * sc;
+  float res[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const long long m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    const long long mc = m < M ? m : M - 1;
+    res[i] = residual ? bf16_bits_to_f32(residual[mc * cout + bn_]) : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const long long m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    if (m < M) {
+      const unsigned short pre = f32_to_bf16_bits(acc[i]);
+      ypre[m * cout + bn_] = pre;
+      // the BatchNorm sees the ROUNDED convolution output, as it does after a library GEMM with bf16 output
+      y[m * cout + bn_] = f32_to_bf16_bits(bf16_bits_to_f32(pre) * sc + sh + res[i]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const float* beta, const float* mean,
+                                 const float* var, float eps, const void* residual, void* ypre, void* y, long long M,
+                                 int cin, int cout, long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(gamma); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(mean);
+  XPT_CHECK_PTR(var); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(y);
+  if (M <= 0 || cin <= 0 || cout <= 0 || pitch_x < cin) return XPT_ERR_SHAPE;
+  // operand rows must start on an 8-byte boundary (16 for the wide path)
+  int v = 8;
+  while (v >= 4 && (cin % v != 0 || pitch_x % v != 0 || ((uintptr_t)x) % (2 * v) != 0 || ((uintptr_t)w) % (2 * v) != 0))
+    v >>= 1;
+  if (v < 4) return XPT_ERR_ARG;
+  const long long mblocks = (M + 127) / 128;
+  if (mblocks > 65535) return XPT_ERR_SHAPE;
+  const dim3 grid((cout + 31) / 32, (unsigned)mblocks);
+  const PwBn bn{gamma, beta, mean, var, eps};
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+  if (v == 8)
+    hipLaunchKernelGGL(pwconv_bn_fwd_kernel<8>, grid, dim3(256), 0, s, (const unsigned short*)x,
+                       (const unsigned short*)w, bn, (const unsigned short*)residual, (unsigned short*)ypre,
+                       (unsigned short*)y, M, cin, cout, pitch_x);
+  else
+    hipLaunchKernelGGL(pwconv_bn_fwd_kernel<4>, grid, dim3(256), 0, s, (const unsigned short*)x,
+                       (const unsigned short*)w, bn, (const unsigned short*)residual, (unsigned short*)ypre,
+                       (unsigned short*)y, M, cin, cout, pitch_x);
+  return xpt_launch_status();
+}

@@ -122,15 +122,27 @@ class _Conv1x1BnBf16(torch.autograd.Function):
         cout = weight.shape[0]
         ws = weight.shadow_bf16.reshape(cout, cin)
         x2 = _ops.as_rows(x)
-        ypre = torch.mm(x2, ws.t())                                     # [M, cout] bf16, dense
-        M = ypre.shape[0]
-        y = torch.empty((B, cout, H, W), dtype=ypre.dtype, device=x.device, memory_format=torch.channels_last)
+        M = x2.shape[0]
+        pitch_x = x2.stride(0) if M > 1 else cin
+        y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
         if residual is not None:
-            residual = residual.to(ypre.dtype).contiguous(memory_format=torch.channels_last)
+            residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         g_, b_ = gamma.detach(), beta.detach()
-        _ops._lib.check(lib.xpt_affine_act_fwd(ypre.data_ptr(), g_.data_ptr(), b_.data_ptr(), mean.data_ptr(),
-                                               var.data_ptr(), float(eps), _ops._ptr(residual), y.data_ptr(), M, cout,
-                                               1.0, 0, 1, _ops._stream()), "xpt_affine_act_fwd")
+        # one wave walks the whole reduction: beyond ~20 k steps (cin > 320; 14 of the 190 layers, all on 4x13 / 8x26
+        # maps with too few tiles to fill the chip) the library's split kernels win (measured, tools/bench_pwconv.py)
+        if (not _LIBRARY_PWCONV and cin <= _PWCONV_MAX_CIN and cin % 4 == 0 and pitch_x % 4 == 0
+                and x2.data_ptr() % 8 == 0 and ws.data_ptr() % 8 == 0):
+            # GEMM + BatchNorm (+ branch add) in one gfx950 launch (csrc/xpt_pwconv.hip)
+            ypre = torch.empty((M, cout), dtype=torch.bfloat16, device=x.device)
+            _ops._lib.check(lib.xpt_pwconv_bn_fwd(x2.data_ptr(), ws.data_ptr(), g_.data_ptr(), b_.data_ptr(),
+                                                  mean.data_ptr(), var.data_ptr(), float(eps), _ops._ptr(residual),
+                                                  ypre.data_ptr(), y.data_ptr(), M, cin, cout, pitch_x, _ops._stream()),
+                            "xpt_pwconv_bn_fwd")
+        else:
+            ypre = torch.mm(x2, ws.t())                                 # [M, cout] bf16, dense
+            _ops._lib.check(lib.xpt_affine_act_fwd(ypre.data_ptr(), g_.data_ptr(), b_.data_ptr(), mean.data_ptr(),
+                                                   var.data_ptr(), float(eps), _ops._ptr(residual), y.data_ptr(), M,
+                                                   cout, 1.0, 0, 1, _ops._stream()), "xpt_affine_act_fwd")
         ctx.save_for_backward(x2, ws, ypre, g_, mean, var)
         ctx.dims = (B, cin, H, W, cout, float(eps))
         ctx.dst = (weight.flat_grad, gamma.flat_grad, beta.flat_grad)
@@ -165,6 +177,8 @@ class _Conv1x1BnBf16(torch.autograd.Function):
 
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
+_PWCONV_MAX_CIN = 320
+_LIBRARY_PWCONV = __import__("os").environ.get("XPT_DEBUG_LIBRARY_PWCONV", "0") == "1"    # A/B: rocBLAS GEMM + epilogue launch
 
 
 def conv1x1_bn(x, weight, bn, residual=None):

@@ -16,7 +16,7 @@ class FlatParameters:
     """Re-homes `params` (list of nn.Parameter) into flat data / grad buffers, preserving each parameter's memory
     format (channels_last conv kernels stay channels_last views)."""
 
-    def __init__(self, params, align=4):
+    def __init__(self, params, align=8):       # 8 elements: 16-byte aligned bf16 shadow rows for the matrix-core kernels
         params = [p for p in params if p.requires_grad]
         if not params:
             raise WrongInputException("no trainable parameters")
