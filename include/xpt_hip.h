@@ -223,6 +223,13 @@ int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const fl
                       const float* var, float eps, const void* residual, void* ypre, void* y, long long M, int cin,
                       int cout, long long pitch_x, void* stream);
 
+/* ------------------------------------------------------------------ a2: the cells' 3x3 average pooling
+ * keras AveragePooling2D((3,3), strides (1,1), padding='same') inside NASNetMobile (divisor = number of in-image taps),
+ * times `scale` (add([avg(p), avg(p)]) of the normal cell = scale 2).  in [B,H,W,C] NHWC with row pitch in_pitch >= C
+ * elements, out dense; dtype 0 float32 / 1 bfloat16; adjoint = 1 applies the transposed operator (the backward). */
+int xpt_avgpool3_same(const void* in, long long in_pitch, void* out, int B, int H, int W, int C, float scale, int adjoint,
+                      int dtype, void* stream);
+
 /* ------------------------------------------------------------------ a2: gradient fan-in of a multiply used activation
  * out [rows, C] = sum_i inputs[i] [rows, C] (row pitch pitches[i] >= C elements; n = 2..8; dtype 0 float32 / 1 bfloat16,
  * fp32 accumulation in input order).  Replaces the chain of pairwise adds autograd (tape.gradient, train_val.py:85)

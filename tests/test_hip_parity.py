@@ -469,3 +469,28 @@ def test_sum_rows_and_fan_out(ops, gpu_device, dtype):
     (x2 * w[0] + torch.relu(x2) * w[1] + x2 * w[2]).sum().backward()
     assert torch.allclose(x.grad, x2.grad, atol=1e-5)
     assert ops.fan_out(parts[0], 3)[0] is parts[0]                   # no grad needed: plain aliases
+
+
+# ------------------------------------------------------------------------------- 3x3 SAME average pooling
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 44, 6, 9), (1, 11, 1, 5), (2, 8, 3, 1)])
+def test_avg_pool3_same(ops, gpu_device, dtype, shape):
+    import torch.nn.functional as F
+    g = gen(400 + shape[1])
+    B, C, H, W = shape
+    x = torch.randn(shape, generator=g)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    gy_wide = torch.randn((B, 2 * C + 4, H, W), generator=g)
+    if dtype == torch.bfloat16:
+        gy_wide = gy_wide.bfloat16().float()
+    xr = x.clone().requires_grad_(True)
+    yr = F.avg_pool2d(xr, 3, 1, 1, count_include_pad=False) * 2.0
+    yr.backward(gy_wide[:, 4:4 + C])
+    xg = x.to(gpu_device, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.avg_pool3_same(xg, 2.0)
+    wide = gy_wide.to(gpu_device, dtype).contiguous(memory_format=torch.channels_last)
+    y.backward(wide[:, 4:4 + C])                      # channel slice: read through its row pitch
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    frac_close(y.float(), yr, tol, rtol=tol, what="avgpool y")
+    frac_close(xg.grad.float(), xr.grad, tol, rtol=tol, what="avgpool dx")

@@ -208,6 +208,51 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(SumInputs in, T* __restri
   }
 }
 
+// 3x3 stride-1 SAME average pooling whose divisor excludes the padding (keras AveragePooling2D((3,3), strides 1,
+// padding='same') of the NASNet cells), times `scale`.  adjoint == 0: out = scale / cnt(out px) * sum of the valid
+// neighbours; adjoint == 1 (the backward): out = sum over the valid neighbours n of in[n] * scale / cnt(n).
+// The input may be a channel slice of a wider tensor (row pitch); loads are unconditional on clamped coordinates.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void avgpool3_kernel(const T* __restrict__ in, long long in_pitch, T* __restrict__ out,
+                                                       int B, int H, int W, int C, float scale, int adjoint) {
+  const int groups = C / V;
+  const long long total = (long long)B * H * W * groups;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % groups) * V;
+    long long p = idx / groups;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int ny = y + dy, nx = x + dx;
+        const bool ok = ny >= 0 && ny < H && nx >= 0 && nx < W;
+        const int cy = min(max(ny, 0), H - 1), cx = min(max(nx, 0), W - 1);
+        float v[V];
+        load_row<T, V>(in + (((long long)b * H + cy) * W + cx) * in_pitch + c0, v);
+        float wgt = ok ? 1.f : 0.f;
+        if (adjoint) {      // weight of neighbour n: 1 / (valid taps of n's own window)
+          const int cnt = ((cy > 0) + 1 + (cy < H - 1)) * ((cx > 0) + 1 + (cx < W - 1));
+          wgt = ok ? 1.f / (float)cnt : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += v[j] * wgt;
+      }
+    }
+    float norm = scale;
+    if (!adjoint) norm = scale / (float)(((y > 0) + 1 + (y < H - 1)) * ((x > 0) + 1 + (x < W - 1)));
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] *= norm;
+    store_row<T, V>(out + (((long long)b * H + y) * W + x) * C + c0, acc);
+  }
+}
+
 // per channel c: S0 = sum_k part[k][0][c], S1 = sum_k part[k][1][c]; one wave (64 threads) per channel so that the
 // partial rows are fetched with few dependent round trips; fixed tree -> deterministic.
 __global__ void affine_finish_kernel(const float* __restrict__ part, Affine a, float* __restrict__ dbeta,
@@ -376,6 +421,38 @@ int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, lo
   if (dy_pitch < C) return XPT_ERR_SHAPE;
   affine_bwd_launch(x, y, dy, dy_pitch, a, dx, partials, rows, C, slope, relu_in, gamma != nullptr, 1, dtype,
                     (hipStream_t)stream);
+  return xpt_launch_status();
+}
+
+/* 3x3 / stride 1 / SAME average pooling (divisor excludes the padding) of an NHWC tensor, times `scale`; adjoint = 1
+ * applies the transposed operator (the backward).  in: row pitch in_pitch >= C elements; out dense. */
+int xpt_avgpool3_same(const void* in, long long in_pitch, void* out, int B, int H, int W, int C, float scale, int adjoint,
+                      int dtype, void* stream) {
+  XPT_CHECK_PTR(in); XPT_CHECK_PTR(out);
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || in_pitch < C) return XPT_ERR_SHAPE;
+  if ((dtype != 0 && dtype != 1) || (adjoint != 0 && adjoint != 1)) return XPT_ERR_ARG;
+  const int esz = dtype == 0 ? 4 : 2;
+  int v = dtype == 0 ? 4 : 8;
+  while (v > 1 && !(C % v == 0 && in_pitch % v == 0 && ((uintptr_t)in) % (size_t)(v * esz) == 0 &&
+                    ((uintptr_t)out) % (size_t)(v * esz) == 0))
+    v >>= 1;
+  const long long total = (long long)B * H * W * (C / v);
+  const dim3 grid(grid_for(total));
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+#define XPT_POOL(T, V) \
+  hipLaunchKernelGGL((avgpool3_kernel<T, V>), grid, dim3(256), 0, s, (const T*)in, in_pitch, (T*)out, B, H, W, C, scale, adjoint)
+  if (dtype == 0) {
+    if (v == 4) XPT_POOL(float, 4);
+    else if (v == 2) XPT_POOL(float, 2);
+    else XPT_POOL(float, 1);
+  } else {
+    if (v == 8) XPT_POOL(__hip_bfloat16, 8);
+    else if (v == 4) XPT_POOL(__hip_bfloat16, 4);
+    else if (v == 2) XPT_POOL(__hip_bfloat16, 2);
+    else XPT_POOL(__hip_bfloat16, 1);
+  }
+#undef XPT_POOL
   return xpt_launch_status();
 }
 

@@ -555,6 +555,44 @@ def batchnorm_inference(x, gamma, beta, running_mean, running_var, eps, relu_in=
     return _AffineAct.apply(x, gamma, beta, running_mean, running_var, eps, 1.0, relu_in, residual)
 
 
+# ------------------------------------------------------------------------------- 3x3 SAME average pooling
+class _AvgPool3Same(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        lib = _lib.load()
+        xr, pitch = _rows_with_pitch(_nhwc_any(x))
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        dt = 0 if x.dtype == torch.float32 else 1
+        _lib.check(lib.xpt_avgpool3_same(_ptr(xr), pitch, _ptr(y), B, H, W, C, float(scale), 0, dt, _stream()),
+                   "xpt_avgpool3_same")
+        ctx.cfg = (float(scale), dt, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        scale, dt, dtype = ctx.cfg
+        dyr, pitch = _rows_with_pitch(dy.to(dtype))
+        B, C, H, W = dy.shape
+        dx = torch.empty((B, C, H, W), dtype=dtype, device=dy.device, memory_format=torch.channels_last)
+        _lib.check(lib.xpt_avgpool3_same(_ptr(dyr), pitch, _ptr(dx), B, H, W, C, scale, 1, dt, _stream()),
+                   "xpt_avgpool3_same")
+        return dx, None
+
+
+def _nhwc_any(t):
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.XptHipError("avg_pool3_same: expected a float32 / bfloat16 CUDA/HIP tensor (no CPU fallback)")
+    return t
+
+
+def avg_pool3_same(x, scale=1.0):
+    """scale * AveragePooling2D((3,3), strides 1, padding='same')(x) with the divisor excluding the padding; one launch
+    forward, one backward (its transposed stencil), channel slices read in place."""
+    return _AvgPool3Same.apply(x, scale)
+
+
 # ------------------------------------------------------------------------------- gradient fan-in
 def sum_rows(tensors):
     """Sum of 2..8 NCHW-indexed tensors of one shape / dtype in ONE launch (dense channels_last result); operands may

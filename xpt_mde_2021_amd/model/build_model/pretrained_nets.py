@@ -298,9 +298,12 @@ class AdjustBlock(nn.Module):
         return p
 
 
-def avg_pool_same(x):
-    """AveragePooling2D((3,3), strides 1, padding='same'): the divisor excludes the padding."""
-    return F.avg_pool2d(x, 3, 1, 1, count_include_pad=False)
+def avg_pool_same(x, scale=1.0):
+    """scale * AveragePooling2D((3,3), strides 1, padding='same')(x): the divisor excludes the padding."""
+    if x.is_cuda:
+        return _ops.avg_pool3_same(x, scale)
+    y = F.avg_pool2d(x, 3, 1, 1, count_include_pad=False)
+    return y if scale == 1.0 else y * scale
 
 
 class NormalCell(nn.Module):
@@ -333,7 +336,7 @@ class NormalCell(nn.Module):
         x1 = self.left1(h1, taps, residual=self.right1(p1, taps))
         x2 = self.left2(p2, taps, residual=self.right2(p3, taps))
         x3 = avg_pool_same(h2) + p4
-        x4 = avg_pool_same(p5) * 2.0                     # add([avg(p), avg(p)]): x + x == 2 x exactly
+        x4 = avg_pool_same(p5, 2.0)                      # add([avg(p), avg(p)]): x + x == 2 x exactly
         x5 = self.left5(h3, taps, residual=h4)
         p = p6
         return torch.cat([p, x1, x2, x3, x4, x5], dim=1), ip
