@@ -51,15 +51,47 @@ class TotalLoss:
             augm_data.update(self.append_data(features, predictions, "_R"))
             augm_data.update(self.synethesize_stereo(features, predictions, augm_data))
 
-        total_loss = None
-        loss_by_type = dict()
-        for loss_name, loss_object in self.loss_objects.items():
-            loss_batch = loss_object(features, predictions, augm_data)
-            loss_mean = torch.sum(loss_batch) / self.batch_size        # tf.nn.compute_average_loss
-            weighted = loss_mean * self.loss_weights[loss_name]
-            total_loss = weighted if total_loss is None else total_loss + weighted
-            loss_by_type[loss_name] = loss_mean
+        # Every loss object hands back its raw per-scale [batch] terms with their host-side weights instead of
+        # combining them with a dozen tiny tensor ops each; all terms of all loss types are then reduced together:
+        #   rs = rowsum(stack(terms));  total = <c, rs>;  loss_by_type = A rs      (c, A: constant device tensors)
+        # = 4 launches forward and 2 backward for the whole merge (losses.py:46-55 and :147-154 in one step).
+        LossBase._collector = collected = []
+        try:
+            outputs = {name: obj(features, predictions, augm_data) for name, obj in self.loss_objects.items()}
+        finally:
+            LossBase._collector = None
+        terms, coef, rows = [], [], []
+        for loss_name, out in outputs.items():
+            pairs = collected[out.index] if isinstance(out, _DeferredTerms) else [(out, 1.0)]
+            w_type = float(self.loss_weights[loss_name])
+            row = {}
+            for tensor, w in pairs:
+                row[len(terms)] = w / self.batch_size
+                coef.append(w * w_type / self.batch_size)           # tf.nn.compute_average_loss, then the type weight
+                terms.append(tensor.reshape(-1))
+            rows.append(row)
+        stacked = torch.stack(terms)                                  # [terms, batch]
+        c_vec, a_mat = self._merge_constants(coef, rows, stacked.device)
+        row_sums = stacked.sum(dim=1)
+        total_loss = torch.dot(c_vec, row_sums)
+        by_type = torch.mv(a_mat, row_sums.detach())
+        loss_by_type = {name: by_type[i] for i, name in enumerate(outputs)}
         return total_loss, loss_by_type
+
+    def _merge_constants(self, coef, rows, device):
+        """Constant operands of the merge, built on the first (eager, warm-up) call and cached: a host->device copy is
+        not capturable into the hipGraph step."""
+        key = (tuple(coef), tuple(tuple(sorted(r.items())) for r in rows), str(device))
+        cached = getattr(self, "_merge_cache", None)
+        if cached is None or cached[0] != key:
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise WrongInputException("loss configuration changed during graph capture")
+            a = torch.zeros((len(rows), len(coef)), dtype=torch.float32)
+            for i, r in enumerate(rows):
+                for j, w in r.items():
+                    a[i, j] = w
+            self._merge_cache = (key, torch.tensor(coef, dtype=torch.float32).to(device), a.to(device))
+        return self._merge_cache[1], self._merge_cache[2]
 
     def append_data(self, features, predictions, suffix=""):
         """losses.py:57-104: source/target split (TARGET FRAME LAST), multi-scale target, synthesized views."""
@@ -103,18 +135,36 @@ class TotalLoss:
         return synth_stereo
 
 
+class _DeferredTerms:
+    """Placeholder a loss object returns while TotalLoss collects raw per-scale terms."""
+
+    def __init__(self, index):
+        self.index = index
+
+
 class LossBase:
     scale_weights = None
+    _collector = None            # list filled by merge_multi_scale_losses while TotalLoss.__call__ runs
 
     def __call__(self, features, predictions, augm_data):
         raise NotImplementedError()
 
-    def merge_multi_scale_losses(self, losses, name=""):
-        """losses.py:147-154: [scales, batch]^T x scale_weights[scales, 1] -> [batch, 1]."""
+    def merge_multi_scale_losses(self, losses, name="", factors=None):
+        """losses.py:147-154: [scales, batch]^T x scale_weights[scales, 1] -> [batch, 1].
+        `losses` may hold several groups of per-scale terms (stereo: left + right); `factors` multiplies the scale
+        weights (smoothness: 1 / scale)."""
         # the weights are host constants: fold them in as scalars (no H2D copy -> hipGraph-capturable)
         weights = [float(w) for w in np.asarray(self.scale_weights, dtype=np.float64).reshape(-1)]
+        groups = losses if isinstance(losses[0], (list, tuple)) else [losses]
+        pairs = []
+        for group in groups:
+            for i, (w, loss) in enumerate(zip(weights, group)):
+                pairs.append((loss, w * (1.0 if factors is None else float(factors[i]))))
+        if LossBase._collector is not None:
+            LossBase._collector.append(pairs)
+            return _DeferredTerms(len(LossBase._collector) - 1)
         merged = None
-        for w, loss in zip(weights, losses):
+        for loss, w in pairs:
             merged = loss * w if merged is None else merged + loss * w
         return merged.unsqueeze(1)
 
@@ -191,11 +241,11 @@ class SmoothenessLossMultiScale(LossBase):
         disp_ms = predictions["disp_ms" + self.key_suffix]
         target_ms = augm_data["target_ms" + self.key_suffix]
         orig_width = target_ms[0].shape[2]
-        losses = []
+        losses, factors = [], []
         for disp, image in zip(disp_ms, target_ms):
-            scale = orig_width / image.shape[2]
-            losses.append(self.smootheness_loss(disp, image) / scale)
-        return self.merge_multi_scale_losses(losses)
+            losses.append(self.smootheness_loss(disp, image))
+            factors.append(image.shape[2] / orig_width)              # each scale's loss divided by its scale factor
+        return self.merge_multi_scale_losses(losses, factors=factors)
 
     def smootheness_loss(self, disp, image):
         """losses.py:409-440 -> [batch]"""
@@ -212,10 +262,10 @@ class StereoDepthLoss(PhotometricLoss):
             k = 0 if self.method == "L1" else 1
             left = [pair[k] for pair in augm_data["fused_stereo_ms"]]
             right = [pair[k] for pair in augm_data["fused_stereo_ms_R"]]
-            return self.merge_multi_scale_losses([l + r for l, r in zip(left, right)])
+            return self.merge_multi_scale_losses([left, right])
         left = self.stereo_photometric_loss(augm_data["stereo_synth_ms"], augm_data["target_ms"])
         right = self.stereo_photometric_loss(augm_data["stereo_synth_ms_R"], augm_data["target_ms_R"], "_R")
-        return self.merge_multi_scale_losses([l + r for l, r in zip(left, right)])
+        return self.merge_multi_scale_losses([left, right])
 
     def stereo_photometric_loss(self, synth_target_ms, target_ms, suffix=""):
         return [self.photometric_loss(s, t) for s, t in zip(synth_target_ms, target_ms)]
