@@ -268,6 +268,11 @@ int xpt_dwconv_bwd_weight_chunks(int B, int OH, int OW, int C, int k, int stride
 int xpt_dwconv_bwd_weight_partials(const void* x, const void* dy, float* partials, size_t partial_floats, int B, int H,
                                    int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int relu_in,
                                    int dtype, void* stream);
+/* data gradient + weight-gradient partials of one depthwise layer in ONE launch (same results as xpt_dwconv_bwd_data and
+ * xpt_dwconv_bwd_weight_partials; the two computations only share their inputs) */
+int xpt_dwconv_bwd_both(const void* x, const float* w, const void* dy, void* dx, float* partials, size_t partial_floats,
+                        int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int relu_in,
+                        int dtype, void* stream);
 int xpt_conv1x1_bwd_weight_splits(long long M, int cout, int cin);
 /* conv1x1 -> BatchNormalization backward in ONE launch (the BN layer that follows every pointwise convolution of a
  * NASNet cell, keras nasnet._separable_conv_block / _adjust_block / cell heads): dy = gradient of the BN output,

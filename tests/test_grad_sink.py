@@ -162,3 +162,35 @@ def test_fused_conv1x1_bn_backward(gpu_device, shape, with_residual, library_for
     close(bn.bias.flat_grad, br.grad, 1e-2, "dbeta")
     if with_residual:
         close(rg.grad, rr.grad, 1e-6, "dres")
+
+
+@pytest.mark.parametrize("k,stride,C", [(3, 1, 44), (5, 1, 88), (7, 2, 22), (5, 2, 11), (3, 1, 176)])
+@pytest.mark.parametrize("relu_in", [False, True])
+def test_depthwise_backward_in_one_launch(gpu_device, k, stride, C, relu_in):
+    """xpt_dwconv_bwd_both (data gradient + deferred weight-gradient partials in one launch) against fp32 autograd."""
+    import torch.nn.functional as F
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.model_util.layer_ops import same_pad
+    g = torch.Generator().manual_seed(k * 100 + C)
+    B, H, W = 2, 12, 18
+    if stride == 2:
+        (pt, pb), (pl, pr) = same_pad(H, k, 2), same_pad(W, k, 2)
+    else:
+        pt = pb = pl = pr = k // 2
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    w = torch.randn(C, 1, k, k, generator=g) * 0.2
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv2d(F.pad(F.relu(xr) if relu_in else xr, (pl, pr, pt, pb)), wr, None, stride, 0, 1, C)
+    gy = torch.randn(yr.shape, generator=g).bfloat16().float()
+    yr.backward(gy)
+    weight = torch.nn.Parameter(w.to(gpu_device))
+    weight.flat_grad = torch.full((C, 1, k, k), float("nan"), device=gpu_device)
+    xg = x.to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.depthwise_conv2d(xg, weight, stride, (pt, pb, pl, pr), relu_in)
+    y.backward(gy.to(gpu_device, torch.bfloat16))
+    assert weight.grad is None                                       # deferred: nothing handed to autograd
+    ops.grad_sink.flush()
+    torch.cuda.synchronize()
+    sx, sw = max(1.0, float(xr.grad.abs().max())), max(1.0, float(wr.grad.abs().max()))
+    assert float((xg.grad.float().cpu() - xr.grad).abs().max()) / sx < 3e-2
+    assert float((weight.flat_grad.cpu() - wr.grad).abs().max()) / sw < 2e-2

@@ -191,11 +191,11 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x
 // ---------------------------------------------------------------- data gradient
 // dx[b,iy,ix,c] = [x>0 if relu] * sum_{ky,kx : (iy+pad_t-ky) % S == 0, ...} dy[b,(iy+pad_t-ky)/S,(ix+pad_l-kx)/S,c] * w[c,ky,kx]
 template <typename T, int K, int S>
-__global__ void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy,
-                                   T* __restrict__ dx, DwDims d, int relu_in) {
+__device__ inline void dw_bwd_data_body(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy,
+                                        T* __restrict__ dx, const DwDims& d, int relu_in, long long block,
+                                        long long nblocks) {
   const long long total = (long long)d.B * d.H * d.W * d.C;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
     const int c = (int)(idx % d.C);
     long long r = idx / d.C;
     const int ix = (int)(r % d.W); r /= d.W;
@@ -229,6 +229,12 @@ __global__ void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restr
   }
 }
 
+template <typename T, int K, int S>
+__global__ void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy,
+                                   T* __restrict__ dx, DwDims d, int relu_in) {
+  dw_bwd_data_body<T, K, S>(x, w, dy, dx, d, relu_in, blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------- weight gradient
 // dw[c,ky,kx] = sum_{b,oy,ox} dy[b,oy,ox,c] * f(x[b,oy*S+ky-pad_t,ox*S+kx-pad_l,c])
 // Work item = OXT neighbouring outputs of one row ("group"); grid (channel chunks of 64, chunks of GRP groups).
@@ -251,19 +257,20 @@ inline int wrw_groups(long long ngrp, int C) {
   return grp;
 }
 template <typename T, int K, int S>
-__global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
-                                     DwDims d, int relu_in, int RG, int GRP) {
+__device__ inline void dw_bwd_weight_body(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                                          const DwDims& d, int relu_in, int RG, int GRP, int block_c,
+                                          long long block_g) {
   constexpr int OXT = (S == 1) ? 4 : 2;
   constexpr int IN = (OXT - 1) * S + K;
   __shared__ float red[3][64 * K * K];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rg = (RG > 1) ? lane / d.C : 0;
   const int cl = (RG > 1) ? lane - rg * d.C : lane;
-  const int c = blockIdx.x * 64 + cl;
+  const int c = block_c * 64 + cl;
   const bool active = (c < d.C) && (rg < RG);
   const int OXG = (d.OW + OXT - 1) / OXT;
   const long long ngrp = (long long)d.B * d.OH * OXG;
-  const long long g0 = (long long)blockIdx.y * GRP;
+  const long long g0 = block_g * GRP;
   float acc[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
@@ -320,9 +327,31 @@ __global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restric
   }
   __syncthreads();
   if (wid == 0 && c < d.C && rg == 0) {
-    float* out = part + ((long long)blockIdx.y * d.C + c) * (K * K);
+    float* out = part + (block_g * d.C + c) * (K * K);
 #pragma unroll
     for (int i = 0; i < K * K; ++i) out[i] = ((acc[i] + red[0][i * 64 + lane]) + red[1][i * 64 + lane]) + red[2][i * 64 + lane];
+  }
+}
+
+template <typename T, int K, int S>
+__global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+                                     DwDims d, int relu_in, int RG, int GRP) {
+  dw_bwd_weight_body<T, K, S>(x, dy, part, d, relu_in, RG, GRP, blockIdx.x, blockIdx.y);
+}
+
+// Data gradient and weight-gradient partials of one layer in ONE launch: the two only share their inputs (dy, x, w), so
+// the first `data_blocks` workgroups run the data-gradient body and the rest the weight-gradient body -- at batch 8
+// both are launch-latency-bound and a second dependent launch costs as much as the work itself.
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dw_bwd_both_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const T* __restrict__ dy, T* __restrict__ dx,
+                                                          float* __restrict__ part, DwDims d, int relu_in, int RG,
+                                                          int GRP, int data_blocks, int cchunks) {
+  if ((int)blockIdx.x < data_blocks) {
+    dw_bwd_data_body<T, K, S>(x, w, dy, dx, d, relu_in, blockIdx.x, data_blocks);
+  } else {
+    const int t = (int)blockIdx.x - data_blocks;
+    dw_bwd_weight_body<T, K, S>(x, dy, part, d, relu_in, RG, GRP, t % cchunks, t / cchunks);
   }
 }
 
@@ -428,6 +457,21 @@ int launch_bwd_weight(const void* x, const void* dy, float* dw, float* ws, const
   return xpt_launch_status();
 }
 
+template <typename T, int K, int S>
+int launch_bwd_both(const void* x, const float* w, const void* dy, void* dx, float* ws, const DwDims& d, int relu_in,
+                    hipStream_t s) {
+  constexpr int OXT = (S == 1) ? 4 : 2;
+  const long long ngrp = (long long)d.B * d.OH * ((d.OW + OXT - 1) / OXT);
+  const int GRP = wrw_groups(ngrp, d.C);
+  const int nchunk = (int)((ngrp + GRP - 1) / GRP);
+  const int RG = (d.C <= 32) ? (64 / d.C > GRP / 4 ? (GRP / 4 > 0 ? GRP / 4 : 1) : 64 / d.C) : 1;
+  const int cchunks = (d.C + 63) / 64;
+  const int data_blocks = (int)grid_for((long long)d.B * d.H * d.W * d.C);
+  hipLaunchKernelGGL((dw_bwd_both_kernel<T, K, S>), dim3(data_blocks + cchunks * nchunk), dim3(256), 0, s, (const T*)x, w,
+                     (const T*)dy, (T*)dx, ws, d, relu_in, RG, GRP, data_blocks, cchunks);
+  return xpt_launch_status();
+}
+
 #define DW_DISPATCH(FN, ...)                                                   \
   do {                                                                         \
     if (dtype == 0) {                                                          \
@@ -527,6 +571,19 @@ int xpt_dwconv_bwd_weight_partials(const void* x, const void* dy, float* partial
   const DwDims d{B, H, W, C, OH, OW, pad_t, pad_l};
   XPT_BEGIN_LAUNCH();
   DW_DISPATCH(launch_bwd_weight, x, dy, (float*)nullptr, partials, d, relu_in, (hipStream_t)stream);
+}
+
+/* dx (as xpt_dwconv_bwd_data) and the weight-gradient partials (as xpt_dwconv_bwd_weight_partials) in one launch. */
+int xpt_dwconv_bwd_both(const void* x, const float* w, const void* dy, void* dx, float* partials, size_t partial_floats,
+                        int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int relu_in,
+                        int dtype, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(dy); XPT_CHECK_PTR(dx); XPT_CHECK_PTR(partials);
+  const int rc = check_dims(B, H, W, C, k, stride, pad_t, pad_l, OH, OW, dtype);
+  if (rc != XPT_OK) return rc;
+  if (partial_floats < (size_t)xpt_dwconv_bwd_weight_chunks(B, OH, OW, C, k, stride) * C * k * k) return XPT_ERR_WORKSPACE;
+  const DwDims d{B, H, W, C, OH, OW, pad_t, pad_l};
+  XPT_BEGIN_LAUNCH();
+  DW_DISPATCH(launch_bwd_both, x, w, dy, dx, partials, d, relu_in, (hipStream_t)stream);
 }
 
 }  // extern "C"

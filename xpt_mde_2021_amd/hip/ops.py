@@ -444,6 +444,16 @@ class _DepthwiseConv(torch.autograd.Function):
         B, C, H, W = x.shape
         k = w.shape[-1]
         dx = dw = None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.sink_dst is not None and x.numel() < (1 << 21):
+            # small maps (everything but the stem at batch 8): both gradients in one launch
+            dx = torch.empty_like(x, memory_format=torch.channels_last)
+            nchunk = lib.xpt_dwconv_bwd_weight_chunks(B, OH, OW, C, k, stride)
+            n = C * k * k
+            ws = grad_sink.partials(ctx.sink_dst, "dw", nchunk * n)
+            _lib.check(lib.xpt_dwconv_bwd_both(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(ws), ws.numel(), B, H, W, C, k,
+                                               stride, pad_t, pad_l, OH, OW, relu_in, dt, _stream()), "xpt_dwconv_bwd_both")
+            grad_sink.add(ctx.sink_dst, ws, 0, n, nchunk, n)
+            return dx, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x, memory_format=torch.channels_last)
             _lib.check(lib.xpt_dwconv_bwd_data(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), B, H, W, C, k, stride, pad_t,
