@@ -194,3 +194,45 @@ def test_depthwise_backward_in_one_launch(gpu_device, k, stride, C, relu_in):
     sx, sw = max(1.0, float(xr.grad.abs().max())), max(1.0, float(wr.grad.abs().max()))
     assert float((xg.grad.float().cpu() - xr.grad).abs().max()) / sx < 3e-2
     assert float((weight.flat_grad.cpu() - wr.grad).abs().max()) / sw < 2e-2
+
+
+@pytest.mark.parametrize("C,deferred", [(44, True), (88, False), (22, True), (11, False)])
+def test_multi_depthwise_matches_single_layers(gpu_device, C, deferred):
+    """xpt_dwconv_multi_{fwd,bwd}: five branch convolutions on two inputs in one launch each way == five separate layers
+    (outputs, summed input gradients, weight gradients with and without the gradient sink)."""
+    from xpt_mde_2021_amd.hip import ops
+    g = torch.Generator().manual_seed(C)
+    B, H, W = 2, 10, 14
+    ks = [5, 3, 3, 5, 3]
+    h = torch.randn(B, C, H, W, generator=g).to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    p = torch.randn(B, C, H, W, generator=g).to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(C, 1, k, k, generator=g) * 0.2).to(gpu_device) for k in ks]
+    gys = [torch.randn(B, C, H, W, generator=g).to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+           for _ in ks]
+
+    def run(multi):
+        hh, pp = h.clone().requires_grad_(True), p.clone().requires_grad_(True)
+        params = [torch.nn.Parameter(w.clone()) for w in ws]
+        if deferred:
+            for q in params:
+                q.flat_grad = torch.zeros_like(q)
+        ins = [hh, hh, pp, pp, pp]
+        if multi:
+            ys = ops.multi_depthwise(ins, params, relu_in=True)
+        else:
+            ys = [ops.depthwise_conv2d(x, q, 1, (k // 2,) * 4, True) for x, q, k in zip(ins, params, ks)]
+        torch.autograd.backward(ys, gys)
+        ops.grad_sink.flush()
+        torch.cuda.synchronize()
+        gw = [q.flat_grad if deferred else q.grad for q in params]
+        return [y.detach().float() for y in ys], hh.grad.float(), pp.grad.float(), gw
+
+    ya, gha, gpa, gwa = run(True)
+    yb, ghb, gpb, gwb = run(False)
+    for a, b in zip(ya, yb):
+        assert torch.equal(a, b)
+    # input gradients: one fp32 sum rounded once (multi) vs per-layer bf16 results added by autograd
+    assert torch.allclose(gha, ghb, atol=3e-2 * float(ghb.abs().max()))
+    assert torch.allclose(gpa, gpb, atol=3e-2 * float(gpb.abs().max()))
+    for a, b in zip(gwa, gwb):
+        assert torch.allclose(a, b, atol=1e-4 * max(1.0, float(b.abs().max())))

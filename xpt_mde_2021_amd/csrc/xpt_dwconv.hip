@@ -34,13 +34,12 @@ struct DwDims {
 // ---------------------------------------------------------------- forward
 // y[b,oy,ox,c] = sum_{ky,kx} f(x[b, oy*S+ky-pad_t, ox*S+kx-pad_l, c]) * w[c,ky,kx],  f = relu or identity.
 template <typename T, int K, int S, int OXT>
-__global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, DwDims d,
-                              int relu_in) {
+__device__ inline void dw_fwd_body(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                   const DwDims& d, int relu_in, long long block, long long nblocks) {
   const int OXG = (d.OW + OXT - 1) / OXT;
   const long long total = (long long)d.B * d.OH * OXG * d.C;
   constexpr int IN = (OXT - 1) * S + K;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
     const int c = (int)(idx % d.C);
     long long r = idx / d.C;
     const int oxg = (int)(r % OXG); r /= OXG;
@@ -78,6 +77,39 @@ __global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__
     for (int i = 0; i < OXT; ++i)
       if (ox0 + i < d.OW) stf<T>(out + (long long)i * d.C, acc[i]);
   }
+}
+
+template <typename T, int K, int S, int OXT>
+__global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, DwDims d,
+                              int relu_in) {
+  dw_fwd_body<T, K, S, OXT>(x, w, y, d, relu_in, blockIdx.x, gridDim.x);
+}
+
+// Several stride-1 depthwise layers of one shape in ONE launch (the five branch convolutions of a NASNet normal cell
+// read only two tensors and are mutually independent): job = blockIdx.x / blocks_per_job, kernel size per job.
+#define DW_MAX_JOBS 6
+struct DwMultiFwd {
+  const void* x[DW_MAX_JOBS];
+  const float* w[DW_MAX_JOBS];
+  void* y[DW_MAX_JOBS];
+  int k[DW_MAX_JOBS];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void dw_multi_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, int blocks_per_job) {
+  const int job = blockIdx.x / blocks_per_job, blk = blockIdx.x - job * blocks_per_job;
+  const int k = m.k[job];
+  DwDims dj = d;
+  dj.pad_t = dj.pad_l = k / 2;
+  const T* x = (const T*)m.x[job];
+  const float* w = m.w[job];
+  T* y = (T*)m.y[job];
+  if (k == 3)
+    dw_fwd_body<T, 3, 1, 4>(x, w, y, dj, relu_in, blk, blocks_per_job);
+  else if (k == 5)
+    dw_fwd_body<T, 5, 1, 4>(x, w, y, dj, relu_in, blk, blocks_per_job);
+  else
+    dw_fwd_body<T, 7, 1, 4>(x, w, y, dj, relu_in, blk, blocks_per_job);
 }
 
 // ---------------------------------------------------------------- vectorised stencil (forward, stride-1 data gradient)
@@ -190,6 +222,36 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x
 
 // ---------------------------------------------------------------- data gradient
 // dx[b,iy,ix,c] = [x>0 if relu] * sum_{ky,kx : (iy+pad_t-ky) % S == 0, ...} dy[b,(iy+pad_t-ky)/S,(ix+pad_l-kx)/S,c] * w[c,ky,kx]
+// sum over the taps of one input element: dy[b, (iy+pad_t-ky)/S, (ix+pad_l-kx)/S, c] * w[c, ky, kx]
+template <typename T, int K, int S>
+__device__ inline float dw_bwd_data_value(const float* __restrict__ w, const T* __restrict__ dy, const DwDims& d, int c,
+                                          int iy, int ix, int b) {
+  const float* wc = w + (long long)c * K * K;
+  float acc = 0.f;
+  // stride 2: only the taps of matching parity reach an output, ky = py, py + 2, ... (a quarter of the K*K taps)
+  const int py = (S == 1) ? 0 : ((iy + d.pad_t) & 1), px = (S == 1) ? 0 : ((ix + d.pad_l) & 1);
+  constexpr int KT = (K + S - 1) / S;
+#pragma unroll
+  for (int jy = 0; jy < KT; ++jy) {
+    const int ky = py + jy * S;
+    const int ty = iy + d.pad_t - ky;                // a multiple of S by construction
+    const int oy = ty / S;
+    const bool row_ok = ky < K && ty >= 0 && oy < d.OH;
+    const T* row = dy + (((long long)b * d.OH + min(max(oy, 0), d.OH - 1)) * d.OW) * d.C + c;
+#pragma unroll
+    for (int jx = 0; jx < KT; ++jx) {
+      const int kx = px + jx * S;
+      const int tx = ix + d.pad_l - kx;
+      const int ox = tx / S;
+      const bool ok = row_ok && kx < K && tx >= 0 && ox < d.OW;
+      const float v = ldf<T>(row + (long long)min(max(ox, 0), d.OW - 1) * d.C);     // unconditional, see dw_fwd_body
+      const float wv = wc[min(ky, K - 1) * K + min(kx, K - 1)];
+      acc += ok ? v * wv : 0.f;
+    }
+  }
+  return acc;
+}
+
 template <typename T, int K, int S>
 __device__ inline void dw_bwd_data_body(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy,
                                         T* __restrict__ dx, const DwDims& d, int relu_in, long long block,
@@ -201,29 +263,7 @@ __device__ inline void dw_bwd_data_body(const T* __restrict__ x, const float* __
     const int ix = (int)(r % d.W); r /= d.W;
     const int iy = (int)(r % d.H);
     const int b = (int)(r / d.H);
-    const float* wc = w + (long long)c * K * K;
-    float acc = 0.f;
-    // stride 2: only the taps of matching parity reach an output, ky = py, py + 2, ... (a quarter of the K*K taps)
-    const int py = (S == 1) ? 0 : ((iy + d.pad_t) & 1), px = (S == 1) ? 0 : ((ix + d.pad_l) & 1);
-    constexpr int KT = (K + S - 1) / S;
-#pragma unroll
-    for (int jy = 0; jy < KT; ++jy) {
-      const int ky = py + jy * S;
-      const int ty = iy + d.pad_t - ky;                // a multiple of S by construction
-      const int oy = ty / S;
-      const bool row_ok = ky < K && ty >= 0 && oy < d.OH;
-      const T* row = dy + (((long long)b * d.OH + min(max(oy, 0), d.OH - 1)) * d.OW) * d.C + c;
-#pragma unroll
-      for (int jx = 0; jx < KT; ++jx) {
-        const int kx = px + jx * S;
-        const int tx = ix + d.pad_l - kx;
-        const int ox = tx / S;
-        const bool ok = row_ok && kx < K && tx >= 0 && ox < d.OW;
-        const float v = ldf<T>(row + (long long)min(max(ox, 0), d.OW - 1) * d.C);     // unconditional, see dw_fwd_kernel
-        const float wv = wc[min(ky, K - 1) * K + min(kx, K - 1)];
-        acc += ok ? v * wv : 0.f;
-      }
-    }
+    float acc = dw_bwd_data_value<T, K, S>(w, dy, d, c, iy, ix, b);
     if (relu_in && !(ldf<T>(x + idx) > 0.f)) acc = 0.f;
     stf<T>(dx + idx, acc);
   }
@@ -353,6 +393,67 @@ __global__ __launch_bounds__(256) void dw_bwd_both_kernel(const T* __restrict__ 
     const int t = (int)blockIdx.x - data_blocks;
     dw_bwd_weight_body<T, K, S>(x, dy, part, d, relu_in, RG, GRP, t % cchunks, t / cchunks);
   }
+}
+
+// Backward of dw_multi_fwd_kernel in one launch: the first n_inputs * data_blocks workgroups write the data gradient of
+// each DISTINCT input (summed over the jobs that read it: no gradient fan-in pass), the rest the weight-gradient
+// partials of every job.
+struct DwMultiBwd {
+  const void* xin[DW_MAX_JOBS];     // distinct inputs
+  void* dxin[DW_MAX_JOBS];
+  const void* dy[DW_MAX_JOBS];      // per job
+  const float* w[DW_MAX_JOBS];
+  float* part[DW_MAX_JOBS];
+  int k[DW_MAX_JOBS];
+  int input_of[DW_MAX_JOBS];
+  int n, n_inputs;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims d, int relu_in, int RG, int GRP,
+                                                           int data_blocks, int cchunks, int wblocks_per_job) {
+  const int ndata = m.n_inputs * data_blocks;
+  if ((int)blockIdx.x < ndata) {
+    const int u = blockIdx.x / data_blocks, blk = blockIdx.x - u * data_blocks;
+    const T* x = (const T*)m.xin[u];
+    T* dx = (T*)m.dxin[u];
+    const long long total = (long long)d.B * d.H * d.W * d.C;
+    for (long long idx = blk * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)data_blocks * blockDim.x) {
+      const int c = (int)(idx % d.C);
+      long long r = idx / d.C;
+      const int ix = (int)(r % d.W); r /= d.W;
+      const int iy = (int)(r % d.H);
+      const int b = (int)(r / d.H);
+      float acc = 0.f;
+      for (int j = 0; j < m.n; ++j) {
+        if (m.input_of[j] != u) continue;
+        DwDims dj = d;
+        dj.pad_t = dj.pad_l = m.k[j] / 2;
+        const T* dy = (const T*)m.dy[j];
+        if (m.k[j] == 3)
+          acc += dw_bwd_data_value<T, 3, 1>(m.w[j], dy, dj, c, iy, ix, b);
+        else if (m.k[j] == 5)
+          acc += dw_bwd_data_value<T, 5, 1>(m.w[j], dy, dj, c, iy, ix, b);
+        else
+          acc += dw_bwd_data_value<T, 7, 1>(m.w[j], dy, dj, c, iy, ix, b);
+      }
+      if (relu_in && !(ldf<T>(x + idx) > 0.f)) acc = 0.f;
+      stf<T>(dx + idx, acc);
+    }
+    return;
+  }
+  const int t = (int)blockIdx.x - ndata;
+  const int job = t / wblocks_per_job, tt = t - job * wblocks_per_job;
+  DwDims dj = d;
+  dj.pad_t = dj.pad_l = m.k[job] / 2;
+  const T* x = (const T*)m.xin[m.input_of[job]];
+  const T* dy = (const T*)m.dy[job];
+  if (m.k[job] == 3)
+    dw_bwd_weight_body<T, 3, 1>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
+  else if (m.k[job] == 5)
+    dw_bwd_weight_body<T, 5, 1>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
+  else
+    dw_bwd_weight_body<T, 7, 1>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
 }
 
 // dw[i] = sum_k part[k][i]: 64 threads per output (few dependent round trips), fixed tree -> deterministic.
@@ -584,6 +685,72 @@ int xpt_dwconv_bwd_both(const void* x, const float* w, const void* dy, void* dx,
   const DwDims d{B, H, W, C, OH, OW, pad_t, pad_l};
   XPT_BEGIN_LAUNCH();
   DW_DISPATCH(launch_bwd_both, x, w, dy, dx, partials, d, relu_in, (hipStream_t)stream);
+}
+
+/* n (<= 6) stride-1 SAME depthwise layers of one activation shape in one launch: y[j] = dwconv(f(x[j]), w[j]), kernel
+ * size k[j] in {3, 5, 7}; inputs may repeat. */
+int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* const* y, const int* k, int n, int B, int H,
+                         int W, int C, int relu_in, int dtype, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(y); XPT_CHECK_PTR(k);
+  if (n < 1 || n > DW_MAX_JOBS) return XPT_ERR_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  DwMultiFwd m{};
+  for (int j = 0; j < n; ++j) {
+    if (!x[j] || !w[j] || !y[j]) return XPT_ERR_NULL;
+    if (k[j] != 3 && k[j] != 5 && k[j] != 7) return XPT_ERR_ARG;
+    m.x[j] = x[j]; m.w[j] = w[j]; m.y[j] = y[j]; m.k[j] = k[j];
+  }
+  const DwDims d{B, H, W, C, H, W, 0, 0};
+  const int bpj = (int)grid_for((long long)B * H * ((W + 3) / 4) * C);
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(dw_multi_fwd_kernel<float>, dim3(bpj * n), dim3(256), 0, s, m, d, relu_in, bpj);
+  else
+    hipLaunchKernelGGL(dw_multi_fwd_kernel<__hip_bfloat16>, dim3(bpj * n), dim3(256), 0, s, m, d, relu_in, bpj);
+  return xpt_launch_status();
+}
+
+/* Backward of xpt_dwconv_multi_fwd in one launch.  xin / dxin: the n_inputs distinct inputs and their gradients (each
+ * the sum over the jobs reading it); per job j: dy[j], w[j], k[j], input_of[j] (index into xin) and partials[j]
+ * (xpt_dwconv_bwd_weight_chunks(B, H, W, C, k[j], 1) * C * k[j]^2 floats, finished by xpt_reduce_partials). */
+int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs, const void* const* dy,
+                         const float* const* w, float* const* partials, const int* k, const int* input_of, int n, int B,
+                         int H, int W, int C, int relu_in, int dtype, void* stream) {
+  XPT_CHECK_PTR(xin); XPT_CHECK_PTR(dxin); XPT_CHECK_PTR(dy); XPT_CHECK_PTR(w); XPT_CHECK_PTR(partials);
+  XPT_CHECK_PTR(k); XPT_CHECK_PTR(input_of);
+  if (n < 1 || n > DW_MAX_JOBS || n_inputs < 1 || n_inputs > n) return XPT_ERR_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  DwMultiBwd m{};
+  m.n = n; m.n_inputs = n_inputs;
+  for (int u = 0; u < n_inputs; ++u) {
+    if (!xin[u] || !dxin[u]) return XPT_ERR_NULL;
+    m.xin[u] = xin[u]; m.dxin[u] = dxin[u];
+  }
+  for (int j = 0; j < n; ++j) {
+    if (!dy[j] || !w[j] || !partials[j]) return XPT_ERR_NULL;
+    if ((k[j] != 3 && k[j] != 5 && k[j] != 7) || input_of[j] < 0 || input_of[j] >= n_inputs) return XPT_ERR_ARG;
+    m.dy[j] = dy[j]; m.w[j] = w[j]; m.part[j] = partials[j]; m.k[j] = k[j]; m.input_of[j] = input_of[j];
+  }
+  const DwDims d{B, H, W, C, H, W, 0, 0};
+  const long long ngrp = (long long)B * H * ((W + 3) / 4);
+  const int GRP = wrw_groups(ngrp, C);
+  const int nchunk = (int)((ngrp + GRP - 1) / GRP);
+  const int RG = (C <= 32) ? (64 / C > GRP / 4 ? (GRP / 4 > 0 ? GRP / 4 : 1) : 64 / C) : 1;
+  const int cchunks = (C + 63) / 64;
+  const int data_blocks = (int)grid_for((long long)B * H * W * C);
+  const int wbpj = cchunks * nchunk;
+  const dim3 grid(n_inputs * data_blocks + n * wbpj);
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(dw_multi_bwd_kernel<float>, grid, dim3(256), 0, s, m, d, relu_in, RG, GRP, data_blocks, cchunks, wbpj);
+  else
+    hipLaunchKernelGGL(dw_multi_bwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, s, m, d, relu_in, RG, GRP, data_blocks,
+                       cchunks, wbpj);
+  return xpt_launch_status();
 }
 
 }  // extern "C"

@@ -177,6 +177,7 @@ class _Conv1x1BnBf16(torch.autograd.Function):
 
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
+_WIDE_CELL = __import__("os").environ.get("XPT_DEBUG_NARROW_CELL", "0") != "1"          # A/B: per-branch depthwise launches
 _PWCONV_MAX_CIN = 320
 _LIBRARY_PWCONV = __import__("os").environ.get("XPT_DEBUG_LIBRARY_PWCONV", "0") == "1"    # A/B: rocBLAS GEMM + epilogue launch
 
@@ -329,6 +330,25 @@ class NormalCell(nn.Module):
         h = shared_relu(ip)
         taps.offer(self.act_id, h)
         h = conv1x1_bn(h, self.conv.weight, self.bn)
+        blocks = (self.left1, self.left5, self.right1, self.left2, self.right2)
+        if h.is_cuda and not _DISABLE_HIP_DWCONV and _WIDE_CELL and not any(
+                taps.wants(b.act_id1) or taps.wants(b.act_id2) for b in blocks):
+            # The five separable-conv branches are mutually independent and of one shape: their depthwise halves run as
+            # ONE launch per stage (and one backward launch each, which also sums the gradients of h and p over the
+            # branches); the pointwise + BatchNorm halves follow per branch, the branch adds in their epilogues.
+            hs = _ops.fan_out(h, 3)
+            ps = _ops.fan_out(p, 4)
+            y1 = _ops.multi_depthwise([hs[0], hs[0], ps[0], ps[0], ps[0]], [b.conv1.depthwise.weight for b in blocks])
+            z1 = [conv1x1_bn(y, b.conv1.pointwise.weight, b.bn1) for y, b in zip(y1, blocks)]
+            y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
+            r1 = conv1x1_bn(y2[2], self.right1.conv2.pointwise.weight, self.right1.bn2)
+            r2 = conv1x1_bn(y2[4], self.right2.conv2.pointwise.weight, self.right2.bn2)
+            x1 = conv1x1_bn(y2[0], self.left1.conv2.pointwise.weight, self.left1.bn2, residual=r1)
+            x2 = conv1x1_bn(y2[3], self.left2.conv2.pointwise.weight, self.left2.bn2, residual=r2)
+            x5 = conv1x1_bn(y2[1], self.left5.conv2.pointwise.weight, self.left5.bn2, residual=hs[2])
+            x3 = avg_pool_same(hs[1]) + ps[1]
+            x4 = avg_pool_same(ps[2], 2.0)                   # add([avg(p), avg(p)]): x + x == 2 x exactly
+            return torch.cat([ps[3], x1, x2, x3, x4, x5], dim=1), ip
         # every `add` whose operand ends in a BatchNorm rides in that BatchNorm's epilogue kernel; h and p feed several
         # branches each: their gradients are summed by one fan-in kernel instead of a chain of pairwise adds
         h1, h2, h3, h4 = _ops.fan_out(h, 4)
