@@ -230,6 +230,12 @@ int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const fl
 int xpt_avgpool3_same(const void* in, long long in_pitch, void* out, int B, int H, int W, int C, float scale, int adjoint,
                       int dtype, void* stream);
 
+/* the same for n (<= 6) independent layers of one shape in one launch (arrays of n pointers; residual[j] may be NULL) */
+int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* const* w, const float* const* gamma,
+                            const float* const* beta, const float* const* mean, const float* const* var, float eps,
+                            const void* const* residual, void* const* ypre, void* const* y, long long M, int cin, int cout,
+                            long long pitch_x, void* stream);
+
 /* ------------------------------------------------------------------ a2: gradient fan-in of a multiply used activation
  * out [rows, C] = sum_i inputs[i] [rows, C] (row pitch pitches[i] >= C elements; n = 2..8; dtype 0 float32 / 1 bfloat16,
  * fp32 accumulation in input order).  Replaces the chain of pairwise adds autograd (tape.gradient, train_val.py:85)

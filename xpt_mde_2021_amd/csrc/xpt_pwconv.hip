@@ -55,12 +55,10 @@ struct PwBn {
 constexpr int PW_G = 8;   // k steps (of 16) whose loads are issued together
 
 template <int V>
-__global__ __launch_bounds__(256) void pwconv_bn_fwd_kernel(const unsigned short* __restrict__ x,
-                                                             const unsigned short* __restrict__ w, PwBn bn,
-                                                             const unsigned short* __restrict__ residual,
-                                                             unsigned short* __restrict__ ypre,
-                                                             unsigned short* __restrict__ y, long long M, int cin,
-                                                             int cout, long long pitch_x) {
+__device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
+                                          const PwBn& bn, const unsigned short* __restrict__ residual,
+                                          unsigned short* __restrict__ ypre, unsigned short* __restrict__ y,
+                                          long long M, int cin, int cout, long long pitch_x) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const long long m0 = ((long long)blockIdx.y * 4 + wave) * 32;
@@ -120,7 +118,70 @@ __global__ __launch_bounds__(256) void pwconv_bn_fwd_kernel(const unsigned short
   }
 }
 
+template <int V>
+__global__ __launch_bounds__(256) void pwconv_bn_fwd_kernel(const unsigned short* __restrict__ x,
+                                                             const unsigned short* __restrict__ w, PwBn bn,
+                                                             const unsigned short* __restrict__ residual,
+                                                             unsigned short* __restrict__ ypre,
+                                                             unsigned short* __restrict__ y, long long M, int cin,
+                                                             int cout, long long pitch_x) {
+  pwconv_bn_fwd_body<V>(x, w, bn, residual, ypre, y, M, cin, cout, pitch_x);
+}
+
+// up to 6 independent layers of one shape (the branch convolutions of a cell stage): job = blockIdx.z
+#define PW_MAX_JOBS 6
+struct PwMulti {
+  const unsigned short* x[PW_MAX_JOBS];
+  const unsigned short* w[PW_MAX_JOBS];
+  const unsigned short* residual[PW_MAX_JOBS];
+  unsigned short* ypre[PW_MAX_JOBS];
+  unsigned short* y[PW_MAX_JOBS];
+  PwBn bn[PW_MAX_JOBS];
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void pwconv_bn_multi_fwd_kernel(PwMulti m, long long M, int cin, int cout,
+                                                                   long long pitch_x) {
+  const int j = blockIdx.z;
+  pwconv_bn_fwd_body<V>(m.x[j], m.w[j], m.bn[j], m.residual[j], m.ypre[j], m.y[j], M, cin, cout, pitch_x);
+}
+
 }  // namespace
+
+extern "C" int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* const* w, const float* const* gamma,
+                                       const float* const* beta, const float* const* mean, const float* const* var,
+                                       float eps, const void* const* residual, void* const* ypre, void* const* y,
+                                       long long M, int cin, int cout, long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(gamma); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(mean);
+  XPT_CHECK_PTR(var); XPT_CHECK_PTR(residual); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(y);
+  if (n < 1 || n > PW_MAX_JOBS) return XPT_ERR_ARG;
+  if (M <= 0 || cin <= 0 || cout <= 0 || pitch_x < cin) return XPT_ERR_SHAPE;
+  int v = 8;
+  PwMulti m{};
+  for (int j = 0; j < n; ++j) {
+    if (!x[j] || !w[j] || !gamma[j] || !beta[j] || !mean[j] || !var[j] || !ypre[j] || !y[j]) return XPT_ERR_NULL;
+    while (v >= 4 && (cin % v != 0 || pitch_x % v != 0 || ((uintptr_t)x[j]) % (2 * v) != 0 ||
+                      ((uintptr_t)w[j]) % (2 * v) != 0))
+      v >>= 1;
+    m.x[j] = (const unsigned short*)x[j];
+    m.w[j] = (const unsigned short*)w[j];
+    m.residual[j] = (const unsigned short*)residual[j];
+    m.ypre[j] = (unsigned short*)ypre[j];
+    m.y[j] = (unsigned short*)y[j];
+    m.bn[j] = PwBn{gamma[j], beta[j], mean[j], var[j], eps};
+  }
+  if (v < 4) return XPT_ERR_ARG;
+  const long long mblocks = (M + 127) / 128;
+  if (mblocks > 65535) return XPT_ERR_SHAPE;
+  const dim3 grid((cout + 31) / 32, (unsigned)mblocks, n);
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+  if (v == 8)
+    hipLaunchKernelGGL(pwconv_bn_multi_fwd_kernel<8>, grid, dim3(256), 0, s, m, M, cin, cout, pitch_x);
+  else
+    hipLaunchKernelGGL(pwconv_bn_multi_fwd_kernel<4>, grid, dim3(256), 0, s, m, M, cin, cout, pitch_x);
+  return xpt_launch_status();
+}
 
 extern "C" int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const float* beta, const float* mean,
                                  const float* var, float eps, const void* residual, void* ypre, void* y, long long M,

@@ -150,30 +150,109 @@ class _Conv1x1BnBf16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = _ops._lib.load()
         x2, ws, ypre, gamma, mean, var = ctx.saved_tensors
-        B, cin, H, W, cout, eps = ctx.dims
-        w_dst, g_dst, b_dst = ctx.dst
-        dy2 = _ops.as_rows(dy.to(torch.bfloat16))
-        M = dy2.shape[0]
-        g = torch.empty((M, cout), dtype=torch.bfloat16, device=dy.device)
-        nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
-        sink = _ops.grad_sink
-        wpart = sink.partials(w_dst, "conv1x1", nsplit * cout * cin)
-        bpart = sink.partials(b_dst, "bnfuse", nsplit * 2 * cout)
-        pitch_dy = dy2.stride(0) if M > 1 else cout
-        pitch_x = x2.stride(0) if M > 1 else cin
-        _ops._lib.check(lib.xpt_conv1x1_bn_bwd_partials(dy2.data_ptr(), ypre.data_ptr(), x2.data_ptr(), gamma.data_ptr(),
-                                                        var.data_ptr(), mean.data_ptr(), eps, g.data_ptr(),
-                                                        wpart.data_ptr(), wpart.numel(), bpart.data_ptr(), bpart.numel(),
-                                                        M, cout, cin, pitch_dy, pitch_x, _ops._stream()),
-                        "xpt_conv1x1_bn_bwd_partials")
-        sink.add(w_dst, wpart, 0, cout * cin, nsplit, cout * cin)
-        sink.add(b_dst, bpart, 0, cout, nsplit, 2 * cout)
-        sink.add(g_dst, bpart, cout, cout, nsplit, 2 * cout)
-        dx = torch.mm(g, ws).view(B, H, W, cin).permute(0, 3, 1, 2) if ctx.needs_input_grad[0] else None
+        dx = _conv_bn_backward(x2, ws, ypre, gamma, mean, var, ctx.dims, ctx.dst, dy, ctx.needs_input_grad[0])
         dres = dy if ctx.needs_input_grad[7] else None
         return dx, None, None, None, None, None, None, dres
+
+
+def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx):
+    """One gfx950 launch (g = dy * s, split-K partials of dW / dgamma / dbeta -> GradSink) + one rocBLAS GEMM (dx)."""
+    lib = _ops._lib.load()
+    B, cin, H, W, cout, eps = dims
+    w_dst, g_dst, b_dst = dst
+    dy2 = _ops.as_rows(dy.to(torch.bfloat16))
+    M = dy2.shape[0]
+    g = torch.empty((M, cout), dtype=torch.bfloat16, device=dy.device)
+    nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
+    sink = _ops.grad_sink
+    wpart = sink.partials(w_dst, "conv1x1", nsplit * cout * cin)
+    bpart = sink.partials(b_dst, "bnfuse", nsplit * 2 * cout)
+    pitch_dy = dy2.stride(0) if M > 1 else cout
+    pitch_x = x2.stride(0) if M > 1 else cin
+    _ops._lib.check(lib.xpt_conv1x1_bn_bwd_partials(dy2.data_ptr(), ypre.data_ptr(), x2.data_ptr(), gamma.data_ptr(),
+                                                    var.data_ptr(), mean.data_ptr(), eps, g.data_ptr(),
+                                                    wpart.data_ptr(), wpart.numel(), bpart.data_ptr(), bpart.numel(),
+                                                    M, cout, cin, pitch_dy, pitch_x, _ops._stream()),
+                    "xpt_conv1x1_bn_bwd_partials")
+    sink.add(w_dst, wpart, 0, cout * cin, nsplit, cout * cin)
+    sink.add(b_dst, bpart, 0, cout, nsplit, 2 * cout)
+    sink.add(g_dst, bpart, cout, cout, nsplit, 2 * cout)
+    return torch.mm(g, ws).view(B, H, W, cin).permute(0, 3, 1, 2) if need_dx else None
+
+
+class _MultiConv1x1Bn(torch.autograd.Function):
+    """n independent conv1x1 + BatchNorm (+ residual) layers of one shape: ONE forward launch (xpt_pwconv_bn_multi_fwd);
+    the backward runs the fused per-layer kernels of _Conv1x1BnBf16.  args = (n, eps, xs..., weights..., gammas...,
+    betas..., means..., vars..., residuals-or-None...)."""
+
+    @staticmethod
+    def forward(ctx, n, eps, *a):
+        import ctypes
+        lib = _ops._lib.load()
+        xs, ws_, gs, bs, ms, vs, rs = (a[i * n:(i + 1) * n] for i in range(7))
+        B, cin, H, W = xs[0].shape
+        cout = ws_[0].shape[0]
+        x2s = [_ops.as_rows(x) for x in xs]
+        M = x2s[0].shape[0]
+        pitch = x2s[0].stride(0) if M > 1 else cin
+        shadows = [w.shadow_bf16.reshape(cout, cin) for w in ws_]
+        res = [None if r is None else r.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for r in rs]
+        ypres = [torch.empty((M, cout), dtype=torch.bfloat16, device=xs[0].device) for _ in range(n)]
+        ys = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=xs[0].device, memory_format=torch.channels_last)
+              for _ in range(n)]
+        P = ctypes.c_void_p * n
+        ptr = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])
+        _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd(n, ptr(x2s), ptr(shadows), ptr([g.detach() for g in gs]),
+                                                    ptr([b.detach() for b in bs]), ptr(ms), ptr(vs), float(eps), ptr(res),
+                                                    ptr(ypres), ptr(ys), M, cin, cout, pitch, _ops._stream()),
+                        "xpt_pwconv_bn_multi_fwd")
+        ctx.save_for_backward(*x2s, *shadows, *ypres, *[g.detach() for g in gs], *ms, *vs)
+        ctx.n = n
+        ctx.dims = (B, cin, H, W, cout, float(eps))
+        ctx.dsts = [(w.flat_grad, g.flat_grad, b.flat_grad) for w, g, b in zip(ws_, gs, bs)]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        t = ctx.saved_tensors
+        x2s, shadows, ypres, gs, ms, vs = (t[i * n:(i + 1) * n] for i in range(6))
+        dxs, dres = [], []
+        for j in range(n):
+            if dys[j] is None:
+                dxs.append(None)
+                dres.append(None)
+                continue
+            dxs.append(_conv_bn_backward(x2s[j], shadows[j], ypres[j], gs[j], ms[j], vs[j], ctx.dims, ctx.dsts[j], dys[j],
+                                         ctx.needs_input_grad[2 + j]))
+            dres.append(dys[j] if ctx.needs_input_grad[2 + 6 * n + j] else None)
+        none = [None] * n
+        return (None, None, *dxs, *none, *none, *none, *none, *none, *dres)
+
+
+def multi_conv1x1_bn(xs, weights, bns, residuals=None):
+    """[bn_j(conv1x1(x_j, w_j)) (+ residual_j)] for layers of one shape: one forward launch when the fused path applies
+    (same conditions as conv1x1_bn), the per-layer calls otherwise."""
+    n = len(xs)
+    residuals = [None] * n if residuals is None else residuals
+    sink = _ops.grad_sink
+    x0, w0 = xs[0], weights[0]
+    cin = w0.shape[1]
+    ok = (_FUSE_CONV_BN and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD and 1 < n <= 6 and x0.is_cuda
+          and x0.dtype == torch.bfloat16 and torch.is_autocast_enabled() and torch.is_grad_enabled()
+          and cin <= _PWCONV_MAX_CIN and cin % 4 == 0
+          and all(x.shape == x0.shape and x.dtype == x0.dtype for x in xs)
+          and all(w.shape == w0.shape and hasattr(w, "shadow_bf16") and sink.wants(w) and w.shadow_bf16.data_ptr() % 8 == 0
+                  for w in weights)
+          and all(sink.wants(b.weight) and sink.wants(b.bias) for b in bns))
+    if ok:
+        rows = [_ops.as_rows(x) for x in xs]
+        ok = all(r.stride(0) == rows[0].stride(0) and r.stride(0) % 4 == 0 and r.data_ptr() % 8 == 0 for r in rows)
+    if not ok:
+        return [conv1x1_bn(x, w, b, r) for x, w, b, r in zip(xs, weights, bns, residuals)]
+    return list(_MultiConv1x1Bn.apply(n, BN_EPS, *xs, *weights, *[b.weight for b in bns], *[b.bias for b in bns],
+                                      *[b.running_mean for b in bns], *[b.running_var for b in bns], *residuals))
 
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
@@ -339,13 +418,15 @@ class NormalCell(nn.Module):
             hs = _ops.fan_out(h, 3)
             ps = _ops.fan_out(p, 4)
             y1 = _ops.multi_depthwise([hs[0], hs[0], ps[0], ps[0], ps[0]], [b.conv1.depthwise.weight for b in blocks])
-            z1 = [conv1x1_bn(y, b.conv1.pointwise.weight, b.bn1) for y, b in zip(y1, blocks)]
+            z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
             y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
-            r1 = conv1x1_bn(y2[2], self.right1.conv2.pointwise.weight, self.right1.bn2)
-            r2 = conv1x1_bn(y2[4], self.right2.conv2.pointwise.weight, self.right2.bn2)
-            x1 = conv1x1_bn(y2[0], self.left1.conv2.pointwise.weight, self.left1.bn2, residual=r1)
-            x2 = conv1x1_bn(y2[3], self.left2.conv2.pointwise.weight, self.left2.bn2, residual=r2)
-            x5 = conv1x1_bn(y2[1], self.left5.conv2.pointwise.weight, self.left5.bn2, residual=hs[2])
+            # second pointwise stage in two launches: the right branches first, then the left ones with their adds
+            r1, r2 = multi_conv1x1_bn([y2[2], y2[4]], [self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight],
+                                      [self.right1.bn2, self.right2.bn2])
+            x1, x2, x5 = multi_conv1x1_bn([y2[0], y2[3], y2[1]],
+                                          [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight,
+                                           self.left5.conv2.pointwise.weight],
+                                          [self.left1.bn2, self.left2.bn2, self.left5.bn2], [r1, r2, hs[2]])
             x3 = avg_pool_same(hs[1]) + ps[1]
             x4 = avg_pool_same(ps[2], 2.0)                   # add([avg(p), avg(p)]): x + x == 2 x exactly
             return torch.cat([ps[3], x1, x2, x3, x4, x5], dim=1), ip
