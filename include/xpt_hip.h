@@ -279,6 +279,13 @@ int xpt_dwconv_bwd_weight_partials(const void* x, const void* dy, float* partial
 int xpt_dwconv_bwd_both(const void* x, const float* w, const void* dy, void* dx, float* partials, size_t partial_floats,
                         int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int relu_in,
                         int dtype, void* stream);
+/* xpt_conv1x1_bn_bwd_partials for n (<= 6) layers of one shape (M, cout, cin, pitch_x) in one launch: arrays of n
+ * pointers, pitch_dy per layer; every partial buffer sized as for the single call. */
+int xpt_conv1x1_bn_multi_bwd_partials(int n, const void* const* dy, const long long* pitch_dy, const void* const* ypre,
+                                      const void* const* x, const float* const* gamma, const float* const* var,
+                                      const float* const* mean, float eps, void* const* g_out, float* const* w_partials,
+                                      float* const* bn_partials, size_t w_partial_floats, size_t bn_partial_floats,
+                                      long long M, int cout, int cin, long long pitch_x, void* stream);
 /* Several stride-1 SAME depthwise layers of one activation shape in one launch (the five mutually independent branch
  * convolutions of a NASNet normal cell): forward y[j] = dwconv(f(x[j]), w[j]) with kernel size k[j] in {3,5,7}; backward:
  * dxin[u] = gradient of the u-th DISTINCT input summed over the jobs reading it (input_of[j]), partials[j] = the

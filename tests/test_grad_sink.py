@@ -236,3 +236,61 @@ def test_multi_depthwise_matches_single_layers(gpu_device, C, deferred):
     assert torch.allclose(gpa, gpb, atol=3e-2 * float(gpb.abs().max()))
     for a, b in zip(gwa, gwb):
         assert torch.allclose(a, b, atol=1e-4 * max(1.0, float(b.abs().max())))
+
+
+def test_multi_conv1x1_bn_matches_single_layers(gpu_device):
+    """multi_conv1x1_bn (one forward launch, one fused backward launch + n GEMMs) == n x conv1x1_bn, bit for bit in the
+    forward and to rounding in the gradients; the incoming gradients are channel slices with different pitches."""
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
+    dev = gpu_device
+    g = torch.Generator().manual_seed(7)
+    B, C, H, W, n = 2, 44, 8, 13, 3
+
+    def make():
+        layers = []
+        gg = torch.Generator().manual_seed(11)
+        for _ in range(n):
+            w = torch.nn.Parameter((torch.randn(C, C, 1, 1, generator=gg) * 0.2).to(dev))
+            w.shadow_bf16 = w.detach().bfloat16()
+            w.flat_grad = torch.zeros_like(w)
+            bn = pn.FrozenBatchNorm(C).to(dev)
+            with torch.no_grad():
+                bn.weight.copy_(torch.rand(C, generator=gg) + 0.5); bn.bias.copy_(torch.randn(C, generator=gg) * 0.3)
+                bn.running_mean.copy_(torch.randn(C, generator=gg) * 0.2); bn.running_var.copy_(torch.rand(C, generator=gg) + 0.3)
+            bn.weight.flat_grad = torch.zeros(C, device=dev)
+            bn.bias.flat_grad = torch.zeros(C, device=dev)
+            layers.append((w, bn))
+        return layers
+
+    xs0 = [torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(n)]
+    res0 = torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    wide = torch.randn(B, 3 * C + 8, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gys = [wide[:, :C], wide[:, C + 8:2 * C + 8], torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)]
+
+    def run(multi):
+        layers = make()
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        res = res0.clone().requires_grad_(True)
+        residuals = [None, res, None]
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            if multi:
+                ys = pn.multi_conv1x1_bn(xs, [w for w, _ in layers], [b for _, b in layers], residuals)
+                assert "MultiConv1x1Bn" in type(ys[0].grad_fn).__name__
+            else:
+                ys = [pn.conv1x1_bn(x, w, b, r) for x, (w, b), r in zip(xs, layers, residuals)]
+        torch.autograd.backward(ys, gys)
+        ops.grad_sink.flush()
+        torch.cuda.synchronize()
+        grads = [x.grad.float() for x in xs] + [res.grad.float()]
+        params = [t.flat_grad.clone() for w, b in layers for t in (w, b.weight, b.bias)]
+        return [y.detach().float() for y in ys], grads, params
+
+    ya, ga, pa = run(True)
+    yb, gb, pb = run(False)
+    for a, b in zip(ya, yb):
+        assert torch.equal(a, b)
+    for a, b in zip(ga, gb):
+        assert torch.equal(a, b)
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, atol=1e-5 * max(1.0, float(b.abs().max())))

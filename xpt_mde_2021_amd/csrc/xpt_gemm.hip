@@ -147,14 +147,40 @@ __device__ inline void store_scaled(unsigned short* __restrict__ g_out, const fl
 
 // TCO x TCI output tile per workgroup of NW waves.  Q = quadrants of 32x32, KS = NW / Q interleaved k slices.
 // VA / VB: elements per global load of dy / x (the host picks the widest the pitch, base and channel count allow).
+// Several layers of one shape in one launch (the branch convolutions of a cell stage): job = blockIdx.z / nsplit.
+#define WG_MAX_JOBS 6
+struct WgradMulti {
+  const unsigned short* dy[WG_MAX_JOBS];
+  const unsigned short* x[WG_MAX_JOBS];
+  float* partial[WG_MAX_JOBS];
+  long long pitch_dy[WG_MAX_JOBS];
+  BnFuse bn[WG_MAX_JOBS];
+  int n;                                                    // 0: single layer, the scalar arguments are used
+};
+
 template <int TCO, int TCI, int VA, int VB, bool BN>
-__global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned short* __restrict__ dy,
-                                                              const unsigned short* __restrict__ x,
-                                                              float* __restrict__ dw, float* __restrict__ partial,
+__global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned short* __restrict__ dy_,
+                                                              const unsigned short* __restrict__ x_,
+                                                              float* __restrict__ dw, float* __restrict__ partial_,
                                                               unsigned* __restrict__ counters, long long M, int cout,
-                                                              int cin, long long pitch_dy, long long pitch_x,
+                                                              int cin, long long pitch_dy_, long long pitch_x,
                                                               long long rows_per_block, int nsplit, int defer,
-                                                              BnFuse bn) {
+                                                              BnFuse bn_, WgradMulti mj) {
+  const unsigned short* __restrict__ dy = dy_;
+  const unsigned short* __restrict__ x = x_;
+  float* __restrict__ partial = partial_;
+  long long pitch_dy = pitch_dy_;
+  BnFuse bn = bn_;
+  int split = blockIdx.z;
+  if (BN && mj.n > 0) {
+    const int job = blockIdx.z / nsplit;
+    split = blockIdx.z - job * nsplit;
+    dy = mj.dy[job];
+    x = mj.x[job];
+    partial = mj.partial[job];
+    pitch_dy = mj.pitch_dy[job];
+    bn = mj.bn[job];
+  }
   constexpr int NW = 16, QA = TCO / 32, QB = TCI / 32, Q = QA * QB, KS = NW / Q, NT = NW * 64;
   constexpr int TILE = TCO * TCI;
   // rows staged per chunk: 32 / 48 / 32 KiB of LDS (BN fusion: a third buffer for ypre, 48 / 40 / 48 KiB)
@@ -175,7 +201,6 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
   const int qa = quad / QB, qb = quad % QB;
   const int tile = blockIdx.y * gridDim.x + blockIdx.x;
   const int co0 = blockIdx.y * TCO, ci0 = blockIdx.x * TCI;
-  const int split = blockIdx.z;
 
   const long long k_begin = (long long)split * rows_per_block;
   long long k_end = k_begin + rows_per_block;
@@ -391,8 +416,8 @@ extern "C" int xpt_conv1x1_bwd_weight_counters(long long M, int cout, int cin) {
 
 static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspace, unsigned* counters, long long M,
                         int cout, int cin, long long pitch_dy, long long pitch_x, const WgradPlan& p, int defer,
-                        void* stream, const BnFuse* bn = nullptr) {
-  const dim3 grid(p.tiles_ci, p.tiles_co, p.nsplit);
+                        void* stream, const BnFuse* bn = nullptr, const WgradMulti* multi = nullptr) {
+  const dim3 grid(p.tiles_ci, p.tiles_co, p.nsplit * (multi ? multi->n : 1));
   const dim3 block(1024);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* a = (const unsigned short*)dy;
@@ -411,16 +436,26 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
     if (vy < v) v = vy;
     if (vg < v) v = vg;
   }
+  WgradMulti mj{};
+  if (multi) {
+    mj = *multi;
+    for (int j = 0; j < mj.n; ++j) {
+      const int c[4] = {width(mj.dy[j], mj.pitch_dy[j], cout), width(mj.x[j], pitch_x, cin),
+                        width(mj.bn[j].ypre, cout, cout), width(mj.bn[j].g_out, cout, cout)};
+      for (int q = 0; q < 4; ++q)
+        if (c[q] < v) v = c[q];
+    }
+  }
   const BnFuse none{};
   XPT_BEGIN_LAUNCH();
 #define XPT_WGRAD(TCO, TCI, V)                                                                                        \
   do {                                                                                                                \
     if (bn)                                                                                                           \
       hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, true>), grid, block, 0, s, a, b, dw, workspace,        \
-                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, *bn);          \
+                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, *bn, mj);      \
     else                                                                                                              \
       hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, false>), grid, block, 0, s, a, b, dw, workspace,       \
-                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, none);         \
+                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, none, mj);     \
   } while (0)
 #define XPT_WGRAD_V(V)                                                                                               \
   do {                                                                                                               \
@@ -501,4 +536,38 @@ extern "C" int xpt_conv1x1_bn_bwd_partials(const void* dy, const void* ypre, con
   if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
   const BnFuse bn{gamma, var, mean, eps, (const unsigned short*)ypre, (unsigned short*)g_out, bn_partials};
   return wgrad_launch(dy, x, nullptr, w_partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream, &bn);
+}
+
+/* The same for n (<= 6) layers of one shape (M, cout, cin, pitch_x) in one launch; arrays of n pointers, pitch_dy per
+ * layer (the incoming gradients may be channel slices of different concatenations). */
+extern "C" int xpt_conv1x1_bn_multi_bwd_partials(int n, const void* const* dy, const long long* pitch_dy,
+                                                 const void* const* ypre, const void* const* x,
+                                                 const float* const* gamma, const float* const* var,
+                                                 const float* const* mean, float eps, void* const* g_out,
+                                                 float* const* w_partials, float* const* bn_partials,
+                                                 size_t w_partial_floats, size_t bn_partial_floats, long long M,
+                                                 int cout, int cin, long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(pitch_dy); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(x); XPT_CHECK_PTR(gamma);
+  XPT_CHECK_PTR(var); XPT_CHECK_PTR(mean); XPT_CHECK_PTR(g_out); XPT_CHECK_PTR(w_partials); XPT_CHECK_PTR(bn_partials);
+  if (n < 1 || n > WG_MAX_JOBS) return XPT_ERR_ARG;
+  if (M <= 0 || cout <= 0 || cin <= 0 || pitch_x < cin) return XPT_ERR_SHAPE;
+  const WgradPlan p = wgrad_plan(M, cout, cin, true);
+  if (w_partial_floats < (size_t)p.nsplit * cout * cin || bn_partial_floats < (size_t)p.nsplit * 2 * cout)
+    return XPT_ERR_WORKSPACE;
+  if (p.tiles_co > 65535 || (long long)p.nsplit * n > 65535) return XPT_ERR_SHAPE;
+  WgradMulti m{};
+  m.n = n;
+  for (int j = 0; j < n; ++j) {
+    if (!dy[j] || !ypre[j] || !x[j] || !gamma[j] || !var[j] || !mean[j] || !g_out[j] || !w_partials[j] || !bn_partials[j])
+      return XPT_ERR_NULL;
+    if (pitch_dy[j] < cout) return XPT_ERR_SHAPE;
+    m.dy[j] = (const unsigned short*)dy[j];
+    m.x[j] = (const unsigned short*)x[j];
+    m.partial[j] = w_partials[j];
+    m.pitch_dy[j] = pitch_dy[j];
+    m.bn[j] = BnFuse{gamma[j], var[j], mean[j], eps, (const unsigned short*)ypre[j], (unsigned short*)g_out[j],
+                     bn_partials[j]};
+  }
+  return wgrad_launch(dy[0], x[0], nullptr, w_partials[0], nullptr, M, cout, cin, pitch_dy[0], pitch_x, p, 1, stream,
+                      &m.bn[0], &m);
 }

@@ -215,19 +215,43 @@ class _MultiConv1x1Bn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dys):
+        import ctypes
         n = ctx.n
         t = ctx.saved_tensors
         x2s, shadows, ypres, gs, ms, vs = (t[i * n:(i + 1) * n] for i in range(6))
-        dxs, dres = [], []
-        for j in range(n):
-            if dys[j] is None:
-                dxs.append(None)
-                dres.append(None)
-                continue
-            dxs.append(_conv_bn_backward(x2s[j], shadows[j], ypres[j], gs[j], ms[j], vs[j], ctx.dims, ctx.dsts[j], dys[j],
-                                         ctx.needs_input_grad[2 + j]))
-            dres.append(dys[j] if ctx.needs_input_grad[2 + 6 * n + j] else None)
+        B, cin, H, W, cout, eps = ctx.dims
         none = [None] * n
+        dres = [dys[j] if (dys[j] is not None and ctx.needs_input_grad[2 + 6 * n + j]) else None for j in range(n)]
+        if any(d is None for d in dys):                      # a branch without gradient: per-layer path
+            dxs = [None if dys[j] is None else
+                   _conv_bn_backward(x2s[j], shadows[j], ypres[j], gs[j], ms[j], vs[j], ctx.dims, ctx.dsts[j], dys[j],
+                                     ctx.needs_input_grad[2 + j]) for j in range(n)]
+            return (None, None, *dxs, *none, *none, *none, *none, *none, *dres)
+        # ONE launch for the n layers: g_j = dy_j * s_j, split-K partials of dW_j / dgamma_j / dbeta_j
+        lib = _ops._lib.load()
+        sink = _ops.grad_sink
+        dy2s = [_ops.as_rows(d.to(torch.bfloat16)) for d in dys]
+        M = dy2s[0].shape[0]
+        nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
+        g_all = torch.empty((n, M, cout), dtype=torch.bfloat16, device=dys[0].device)
+        wparts, bparts = [], []
+        for w_dst, g_dst, b_dst in ctx.dsts:
+            wparts.append(sink.partials(w_dst, "conv1x1", nsplit * cout * cin))
+            bparts.append(sink.partials(b_dst, "bnfuse", nsplit * 2 * cout))
+        P, LL = ctypes.c_void_p * n, ctypes.c_longlong * n
+        ptr = lambda ts: P(*[x.data_ptr() for x in ts])
+        pitch_x = x2s[0].stride(0) if M > 1 else cin
+        _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_partials(
+            n, ptr(dy2s), LL(*[(d.stride(0) if M > 1 else cout) for d in dy2s]), ptr(ypres), ptr(x2s), ptr(gs), ptr(vs),
+            ptr(ms), eps, P(*[g_all[j].data_ptr() for j in range(n)]), ptr(wparts), ptr(bparts), wparts[0].numel(),
+            bparts[0].numel(), M, cout, cin, pitch_x, _ops._stream()), "xpt_conv1x1_bn_multi_bwd_partials")
+        dxs = []
+        for j, (w_dst, g_dst, b_dst) in enumerate(ctx.dsts):
+            sink.add(w_dst, wparts[j], 0, cout * cin, nsplit, cout * cin)
+            sink.add(b_dst, bparts[j], 0, cout, nsplit, 2 * cout)
+            sink.add(g_dst, bparts[j], cout, cout, nsplit, 2 * cout)
+            dxs.append(torch.mm(g_all[j], shadows[j]).view(B, H, W, cin).permute(0, 3, 1, 2)
+                       if ctx.needs_input_grad[2 + j] else None)
         return (None, None, *dxs, *none, *none, *none, *none, *none, *dres)
 
 
