@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--mode", default=None, help="eager | graph | distributed (default: graph at N=1, distributed at N>1)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--stereo", action="store_true", help="stereo feature dict + LOSS_RIGID_T2 (configs[4]-style)")
-    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (slow first steps)")
+    ap.add_argument("--no-miopen-find", action="store_true", help="MIOpen immediate-mode heuristics instead of the fast find")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
@@ -62,7 +62,7 @@ def build_step(args, world):
         from xpt_mde_2021_amd.model.model_util.distributer import DistributionStrategy
         DistributionStrategy.get_strategy()                     # per-rank data seeds, global batch = replicas x per-GPU
         opts.BATCH_SIZE = args.batch * world
-    opts.MIOPEN_FIND = bool(args.miopen_find)                   # exhaustive MIOpen find takes many minutes on NASNet
+    opts.MIOPEN_FIND = not args.no_miopen_find                  # fast find over the ~30 dense convolutions (seconds)
     name = "synthetic_stereo" if args.stereo else "synthetic"
     dataset, tfr_config, _ = mm.get_dataset(name, "train", True)
     loss_weights = opts.LOSS_RIGID_T2 if args.stereo else opts.LOSS_RIGID_T1

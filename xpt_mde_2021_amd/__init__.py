@@ -7,3 +7,9 @@ arithmetic runs in hand-written gfx950 HIP kernels (``csrc/``) behind the C ABI 
 ``include/xpt_hip.h``; there is no CPU fallback for those ops.
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+# MIOpen's FAST find mode for the few dense convolutions that still go through the library (train_val.configure_backend);
+# set at import so that it precedes MIOpen's initialisation.
+_os.environ.setdefault("MIOPEN_FIND_MODE", "2")

@@ -71,7 +71,7 @@ def set_configs():
     if opts.TRAIN_MODE == "distributed":
         DistributionStrategy.get_strategy()
     if torch.cuda.is_available():
-        torch.backends.cudnn.benchmark = bool(getattr(opts, "MIOPEN_FIND", False))   # exhaustive find: minutes on NASNet
+        torch.backends.cudnn.benchmark = bool(getattr(opts, "MIOPEN_FIND", True))    # fast find (train_val.configure_backend)
         print("Visible GPUs:", torch.cuda.device_count(), torch.cuda.get_device_name(torch.cuda.current_device()))
 
 

@@ -46,12 +46,19 @@ def detach_tree(obj):
 
 
 def configure_backend():
-    """Library-convolution settings for every trainer.  MIOpen's non-deterministic (atomic split-K) weight-gradient
-    solvers return garbage from the second replay of a captured hipGraph on ROCm 7.0 / torch 2.10 (reproducer:
-    tests/test_graph_replay.py), so the deterministic algorithms are selected; the exhaustive find is off (minutes)."""
+    """Library-convolution settings for every trainer.
+
+    * MIOpen "find" is on in its FAST mode (MIOPEN_FIND_MODE=2 unless the environment says otherwise): only the ~30 dense
+      3x3 / 5x5 / 7x7 convolutions of the decoder and PoseNet still go through MIOpen (depthwise and pointwise layers are
+      gfx950 kernels of this repo), so the search takes seconds, not the minutes of the exhaustive find over all ~230
+      NASNet layer shapes, and the kernels it picks are 1.15 ms per step faster than the immediate-mode heuristics.
+    * MIOpen's bf16 weight-gradient solvers return garbage from the second replay of a captured hipGraph on ROCm 7.0 /
+      torch 2.10 (tests/test_graph_replay.py); weight gradients therefore run in fp32 (layer_ops._ConvFp32WeightGrad).
+      XPT_MIOPEN_DETERMINISTIC=1 selects the (25x slower) deterministic solvers instead."""
     import os
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     torch.backends.cudnn.deterministic = bool(int(os.environ.get("XPT_MIOPEN_DETERMINISTIC", "0")))
-    torch.backends.cudnn.benchmark = bool(getattr(opts, "MIOPEN_FIND", False))
+    torch.backends.cudnn.benchmark = bool(getattr(opts, "MIOPEN_FIND", True))
     # GEMMs (the 1x1 convolutions) through rocBLAS: hipBLASLt launches cost ~2 ms EACH when replayed from a hipGraph
     # on this stack (1.18 s / step measured), rocBLAS replays at kernel speed
     if torch.cuda.is_available():
