@@ -223,6 +223,13 @@ int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const fl
                       const float* var, float eps, const void* residual, void* ypre, void* y, long long M, int cin,
                       int cout, long long pitch_x, void* stream);
 
+/* ------------------------------------------------------------------ a2/a4: depth head activation
+ * InverseSigmoid (model/build_model/model_factory.py:134-138) and safe_reciprocal_number (utils/util_funcs.py:157-160):
+ *   depth = safe_rcp(sigmoid(x) + 0.01), disp = safe_rcp(depth), safe_rcp(v) = (1 / v) [v > 1e-5]; float32, n elements.
+ * bwd: gx = d depth/dx (g_depth + d disp/d depth g_disp); g_depth or g_disp may be NULL (not both). */
+int xpt_depth_head_fwd(const float* x, float* depth, float* disp, long long n, void* stream);
+int xpt_depth_head_bwd(const float* x, const float* g_depth, const float* g_disp, float* gx, long long n, void* stream);
+
 /* ------------------------------------------------------------------ a2: the cells' 3x3 average pooling
  * keras AveragePooling2D((3,3), strides (1,1), padding='same') inside NASNetMobile (divisor = number of in-image taps),
  * times `scale` (add([avg(p), avg(p)]) of the normal cell = scale 2).  in [B,H,W,C] NHWC with row pitch in_pitch >= C

@@ -494,3 +494,30 @@ def test_avg_pool3_same(ops, gpu_device, dtype, shape):
     tol = 1e-5 if dtype == torch.float32 else 3e-2
     frac_close(y.float(), yr, tol, rtol=tol, what="avgpool y")
     frac_close(xg.grad.float(), xr.grad, tol, rtol=tol, what="avgpool dx")
+
+
+# ------------------------------------------------------------------------------- depth head activation
+def test_inverse_sigmoid_depth(ops, gpu_device):
+    """depth = safe_rcp(sigmoid(x) + 0.01), disp = safe_rcp(depth) and their joint backward vs the tensor-op chain
+    (model_factory.py:134-138, util_funcs.py:157-160)."""
+    from xpt_mde_2021_amd.utils import util_funcs as uf
+    g = gen(500)
+    x = torch.randn((2, 1, 9, 13), generator=g) * 4
+    gd, gs = torch.randn(x.shape, generator=g), torch.randn(x.shape, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    depth_r = uf.safe_reciprocal_number(torch.sigmoid(xr) + 0.01)
+    disp_r = uf.safe_reciprocal_number(depth_r)
+    (depth_r * gd.double() + disp_r * gs.double()).sum().backward()
+    xg = x.to(gpu_device).requires_grad_(True)
+    depth, disp = ops.inverse_sigmoid_depth(xg)
+    (depth * gd.to(gpu_device) + disp * gs.to(gpu_device)).sum().backward()
+    assert torch.allclose(depth.cpu().double(), depth_r.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(disp.cpu().double(), disp_r.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(xg.grad.cpu().double(), xr.grad, rtol=1e-4, atol=1e-5)
+    assert depth.min() > 0.99 and depth.max() < 100.0
+    # only one of the two outputs used
+    x2 = x.to(gpu_device).requires_grad_(True)
+    ops.inverse_sigmoid_depth(x2)[1].sum().backward()
+    x2r = x.clone().double().requires_grad_(True)
+    uf.safe_reciprocal_number(uf.safe_reciprocal_number(torch.sigmoid(x2r) + 0.01)).sum().backward()
+    assert torch.allclose(x2.grad.cpu().double(), x2r.grad, rtol=1e-4, atol=1e-6)

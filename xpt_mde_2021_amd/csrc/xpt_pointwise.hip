@@ -253,6 +253,34 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(const T* __restrict__ in,
   }
 }
 
+// Depth head activation (model_factory.py:134-138 InverseSigmoid + util_funcs.py:157-160 safe_reciprocal_number):
+//   depth = safe_rcp(sigmoid(x) + 0.01),  disp = safe_rcp(depth),  safe_rcp(v) = (1 / v) * [v > 1e-5]
+// and its backward gx = d depth/dx * (g_depth + d disp/d depth * g_disp): one launch each instead of ~10 / ~7
+// elementwise launches per scale.
+__global__ void depth_head_fwd_kernel(const float* __restrict__ x, float* __restrict__ depth, float* __restrict__ disp,
+                                      long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float sg = 1.f / (1.f + expf(-x[i]));
+    const float u = sg + 0.01f;
+    const float d = u > 1e-5f ? 1.f / u : 0.f;
+    depth[i] = d;
+    disp[i] = d > 1e-5f ? 1.f / d : 0.f;
+  }
+}
+
+__global__ void depth_head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g_depth,
+                                      const float* __restrict__ g_disp, float* __restrict__ gx, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float sg = 1.f / (1.f + expf(-x[i]));
+    const float u = sg + 0.01f;
+    const float d = u > 1e-5f ? 1.f / u : 0.f;
+    float gd = g_depth ? g_depth[i] : 0.f;
+    if (g_disp && d > 1e-5f) gd -= g_disp[i] / (d * d);
+    const float gu = u > 1e-5f ? -gd / (u * u) : 0.f;
+    gx[i] = gu * sg * (1.f - sg);
+  }
+}
+
 // per channel c: S0 = sum_k part[k][0][c], S1 = sum_k part[k][1][c]; one wave (64 threads) per channel so that the
 // partial rows are fetched with few dependent round trips; fixed tree -> deterministic.
 __global__ void affine_finish_kernel(const float* __restrict__ part, Affine a, float* __restrict__ dbeta,
@@ -421,6 +449,24 @@ int xpt_affine_act_bwd_partials(const void* x, const void* y, const void* dy, lo
   if (dy_pitch < C) return XPT_ERR_SHAPE;
   affine_bwd_launch(x, y, dy, dy_pitch, a, dx, partials, rows, C, slope, relu_in, gamma != nullptr, 1, dtype,
                     (hipStream_t)stream);
+  return xpt_launch_status();
+}
+
+/* depth = safe_rcp(sigmoid(x) + 0.01), disp = safe_rcp(depth) (float32, n elements); backward: g_depth / g_disp may be NULL. */
+int xpt_depth_head_fwd(const float* x, float* depth, float* disp, long long n, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(disp);
+  if (n <= 0) return XPT_ERR_SHAPE;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(depth_head_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, depth, disp, n);
+  return xpt_launch_status();
+}
+
+int xpt_depth_head_bwd(const float* x, const float* g_depth, const float* g_disp, float* gx, long long n, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(gx);
+  if (!g_depth && !g_disp) return XPT_ERR_NULL;
+  if (n <= 0) return XPT_ERR_SHAPE;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(depth_head_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, g_depth, g_disp, gx, n);
   return xpt_launch_status();
 }
 

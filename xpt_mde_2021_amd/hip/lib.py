@@ -75,6 +75,8 @@ SIGNATURES = {
     "xpt_pwconv_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, ctypes.c_longlong, _i, _i, ctypes.c_longlong, _p]),
     "xpt_avgpool3_same": (_i, [_p, ctypes.c_longlong, _p, _i, _i, _i, _i, _f, _i, _i, _p]),
     "xpt_pwconv_bn_multi_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, ctypes.c_longlong, _i, _i, ctypes.c_longlong, _p]),
+    "xpt_depth_head_fwd": (_i, [_p, _p, _p, ctypes.c_longlong, _p]),
+    "xpt_depth_head_bwd": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p]),
     "xpt_sum_rows": (_i, [_p, _p, _i, _p, ctypes.c_longlong, _i, _i, _p]),
     "xpt_crc32c": (ctypes.c_uint32, [_p, _z]),
     "xpt_affine_act_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, ctypes.c_longlong, _i, _f, _i, _i, _p]),

@@ -645,6 +645,37 @@ def batchnorm_inference(x, gamma, beta, running_mean, running_var, eps, relu_in=
     return _AffineAct.apply(x, gamma, beta, running_mean, running_var, eps, 1.0, relu_in, residual)
 
 
+# ------------------------------------------------------------------------------- depth head activation
+class _DepthHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        x = _dev(x, "x")
+        depth, disp = torch.empty_like(x), torch.empty_like(x)
+        _lib.check(lib.xpt_depth_head_fwd(_ptr(x), _ptr(depth), _ptr(disp), x.numel(), _stream()), "xpt_depth_head_fwd")
+        ctx.save_for_backward(x)
+        return depth, disp
+
+    @staticmethod
+    def backward(ctx, g_depth, g_disp):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        if g_depth is None and g_disp is None:
+            return None
+        gd = None if g_depth is None else g_depth.contiguous().float()
+        gs = None if g_disp is None else g_disp.contiguous().float()
+        gx = torch.empty_like(x)
+        _lib.check(lib.xpt_depth_head_bwd(_ptr(x), _ptr(gd), _ptr(gs), _ptr(gx), x.numel(), _stream()), "xpt_depth_head_bwd")
+        return gx
+
+
+def inverse_sigmoid_depth(x):
+    """(depth, disp) = (safe_rcp(sigmoid(x) + 0.01), safe_rcp(depth)) in one launch (one more for the backward)."""
+    ctx_mat = _DepthHead.apply(x)
+    return ctx_mat[0], ctx_mat[1]
+
+
 # ------------------------------------------------------------------------------- 3x3 SAME average pooling
 class _AvgPool3Same(torch.autograd.Function):
     @staticmethod

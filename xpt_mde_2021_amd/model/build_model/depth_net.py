@@ -41,7 +41,10 @@ class ScaledDepthHead(nn.Module):
     def forward(self, src, dst_height, dst_width):
         with torch.autocast(device_type=src.device.type, enabled=False):
             conv = self.conv(src.float())
-            depth = self.predict_depth(conv)
+            if hasattr(self.predict_depth, "with_disparity"):
+                depth, self.last_disp = self.predict_depth.with_disparity(conv)
+            else:
+                depth, self.last_disp = self.predict_depth(conv), None
             conv_up = lo.resize_image(conv, dst_height, dst_width)
         return depth, conv_up, conv
 
@@ -88,5 +91,9 @@ class DepthNetPretrained(nn.Module):
         def nhwc1(x):      # [B,1,h,w] -> [B,h,w,1]: same memory, the reference's axis order
             return x.contiguous().reshape(x.shape[0], x.shape[2], x.shape[3], 1)
 
-        return {"depth_ms": [nhwc1(depth0), nhwc1(depth1), nhwc1(depth2), nhwc1(depth3)],
-                "debug_out": [dpconv0, upconv0, dpconv3, upconv3]}
+        out = {"depth_ms": [nhwc1(depth0), nhwc1(depth1), nhwc1(depth2), nhwc1(depth3)],
+               "debug_out": [dpconv0, upconv0, dpconv3, upconv3]}
+        disps = [h.last_disp for h in (self.depth0, self.depth1, self.depth2, self.depth3)]
+        if all(d is not None for d in disps):      # model_wrappers.py:48-49 would compute it with four more elementwise ops per scale
+            out["disp_ms"] = [nhwc1(d) for d in disps]
+        return out

@@ -60,7 +60,7 @@ class ModelWrapper:
         else:
             for model in nets:
                 predictions.update(self._run(model, image5d))
-        if "depth_ms" in predictions:
+        if "depth_ms" in predictions and "disp_ms" not in predictions:
             predictions["disp_ms"] = uf.safe_reciprocal_number_ms(predictions["depth_ms"])
         return {key + suffix: value for key, value in predictions.items()}
 
