@@ -97,8 +97,9 @@ class TotalLoss:
         """losses.py:57-104: source/target split (TARGET FRAME LAST), multi-scale target, synthesized views."""
         image5d = features["image5d" + suffix]
         intrinsic = features["intrinsic" + suffix]
-        source_image = image5d[:, :-1]
-        target_image = image5d[:, -1]
+        # one dense copy each, made here once: every scale would otherwise re-copy the strided slices (4 x 25 MB)
+        source_image = image5d[:, :-1].contiguous()
+        target_image = image5d[:, -1].contiguous()
         augm_data = {"source" + suffix: source_image, "target" + suffix: target_image}
         if ("depth_ms" + suffix in predictions) and ("pose" + suffix in predictions):
             pred_depth_ms = predictions["depth_ms" + suffix]
