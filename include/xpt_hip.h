@@ -293,15 +293,18 @@ int xpt_conv1x1_bn_multi_bwd_partials(int n, const void* const* dy, const long l
                                       const float* const* mean, float eps, void* const* g_out, float* const* w_partials,
                                       float* const* bn_partials, size_t w_partial_floats, size_t bn_partial_floats,
                                       long long M, int cout, int cin, long long pitch_x, void* stream);
-/* Several stride-1 SAME depthwise layers of one activation shape in one launch (the five mutually independent branch
- * convolutions of a NASNet normal cell): forward y[j] = dwconv(f(x[j]), w[j]) with kernel size k[j] in {3,5,7}; backward:
- * dxin[u] = gradient of the u-th DISTINCT input summed over the jobs reading it (input_of[j]), partials[j] = the
- * weight-gradient partials of job j (layout / count as xpt_dwconv_bwd_weight_partials). n <= 6. */
-int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* const* y, const int* k, int n, int B, int H,
-                         int W, int C, int relu_in, int dtype, void* stream);
+/* Several depthwise layers of one activation shape and stride in one launch (the mutually independent branch
+ * convolutions of a NASNet cell stage): forward y[j] = dwconv(f(x[j]), w[j]) with kernel size k[j] in {3,5,7} and leading
+ * padding (pad_t[j], pad_l[j]); backward: dxin[u] = gradient of the u-th DISTINCT input summed over the jobs reading it
+ * (input_of[j]), partials[j] = the weight-gradient partials of job j (layout / count as
+ * xpt_dwconv_bwd_weight_partials). n <= 6. */
+int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* const* y, const int* k, const int* pad_t,
+                         const int* pad_l, int n, int B, int H, int W, int C, int stride, int OH, int OW, int relu_in,
+                         int dtype, void* stream);
 int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs, const void* const* dy,
-                         const float* const* w, float* const* partials, const int* k, const int* input_of, int n, int B,
-                         int H, int W, int C, int relu_in, int dtype, void* stream);
+                         const float* const* w, float* const* partials, const int* k, const int* pad_t,
+                         const int* pad_l, const int* input_of, int n, int B, int H, int W, int C, int stride, int OH,
+                         int OW, int relu_in, int dtype, void* stream);
 int xpt_conv1x1_bwd_weight_splits(long long M, int cout, int cin);
 /* conv1x1 -> BatchNormalization backward in ONE launch (the BN layer that follows every pointwise convolution of a
  * NASNet cell, keras nasnet._separable_conv_block / _adjust_block / cell heads): dy = gradient of the BN output,

@@ -92,24 +92,26 @@ struct DwMultiFwd {
   const void* x[DW_MAX_JOBS];
   const float* w[DW_MAX_JOBS];
   void* y[DW_MAX_JOBS];
-  int k[DW_MAX_JOBS];
+  int k[DW_MAX_JOBS], pad_t[DW_MAX_JOBS], pad_l[DW_MAX_JOBS];
 };
 
-template <typename T>
+template <typename T, int S>
 __global__ __launch_bounds__(256) void dw_multi_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, int blocks_per_job) {
+  constexpr int OXT = (S == 1) ? 4 : 2;
   const int job = blockIdx.x / blocks_per_job, blk = blockIdx.x - job * blocks_per_job;
   const int k = m.k[job];
   DwDims dj = d;
-  dj.pad_t = dj.pad_l = k / 2;
+  dj.pad_t = m.pad_t[job];
+  dj.pad_l = m.pad_l[job];
   const T* x = (const T*)m.x[job];
   const float* w = m.w[job];
   T* y = (T*)m.y[job];
   if (k == 3)
-    dw_fwd_body<T, 3, 1, 4>(x, w, y, dj, relu_in, blk, blocks_per_job);
+    dw_fwd_body<T, 3, S, OXT>(x, w, y, dj, relu_in, blk, blocks_per_job);
   else if (k == 5)
-    dw_fwd_body<T, 5, 1, 4>(x, w, y, dj, relu_in, blk, blocks_per_job);
+    dw_fwd_body<T, 5, S, OXT>(x, w, y, dj, relu_in, blk, blocks_per_job);
   else
-    dw_fwd_body<T, 7, 1, 4>(x, w, y, dj, relu_in, blk, blocks_per_job);
+    dw_fwd_body<T, 7, S, OXT>(x, w, y, dj, relu_in, blk, blocks_per_job);
 }
 
 // ---------------------------------------------------------------- vectorised stencil (forward, stride-1 data gradient)
@@ -404,12 +406,12 @@ struct DwMultiBwd {
   const void* dy[DW_MAX_JOBS];      // per job
   const float* w[DW_MAX_JOBS];
   float* part[DW_MAX_JOBS];
-  int k[DW_MAX_JOBS];
+  int k[DW_MAX_JOBS], pad_t[DW_MAX_JOBS], pad_l[DW_MAX_JOBS];
   int input_of[DW_MAX_JOBS];
   int n, n_inputs;
 };
 
-template <typename T>
+template <typename T, int S>
 __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims d, int relu_in, int RG, int GRP,
                                                            int data_blocks, int cchunks, int wblocks_per_job) {
   const int ndata = m.n_inputs * data_blocks;
@@ -428,14 +430,15 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims 
       for (int j = 0; j < m.n; ++j) {
         if (m.input_of[j] != u) continue;
         DwDims dj = d;
-        dj.pad_t = dj.pad_l = m.k[j] / 2;
+        dj.pad_t = m.pad_t[j];
+        dj.pad_l = m.pad_l[j];
         const T* dy = (const T*)m.dy[j];
         if (m.k[j] == 3)
-          acc += dw_bwd_data_value<T, 3, 1>(m.w[j], dy, dj, c, iy, ix, b);
+          acc += dw_bwd_data_value<T, 3, S>(m.w[j], dy, dj, c, iy, ix, b);
         else if (m.k[j] == 5)
-          acc += dw_bwd_data_value<T, 5, 1>(m.w[j], dy, dj, c, iy, ix, b);
+          acc += dw_bwd_data_value<T, 5, S>(m.w[j], dy, dj, c, iy, ix, b);
         else
-          acc += dw_bwd_data_value<T, 7, 1>(m.w[j], dy, dj, c, iy, ix, b);
+          acc += dw_bwd_data_value<T, 7, S>(m.w[j], dy, dj, c, iy, ix, b);
       }
       if (relu_in && !(ldf<T>(x + idx) > 0.f)) acc = 0.f;
       stf<T>(dx + idx, acc);
@@ -445,15 +448,16 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims 
   const int t = (int)blockIdx.x - ndata;
   const int job = t / wblocks_per_job, tt = t - job * wblocks_per_job;
   DwDims dj = d;
-  dj.pad_t = dj.pad_l = m.k[job] / 2;
+  dj.pad_t = m.pad_t[job];
+  dj.pad_l = m.pad_l[job];
   const T* x = (const T*)m.xin[m.input_of[job]];
   const T* dy = (const T*)m.dy[job];
   if (m.k[job] == 3)
-    dw_bwd_weight_body<T, 3, 1>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
+    dw_bwd_weight_body<T, 3, S>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
   else if (m.k[job] == 5)
-    dw_bwd_weight_body<T, 5, 1>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
+    dw_bwd_weight_body<T, 5, S>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
   else
-    dw_bwd_weight_body<T, 7, 1>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
+    dw_bwd_weight_body<T, 7, S>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
 }
 
 // dw[i] = sum_k part[k][i]: 64 threads per output (few dependent round trips), fixed tree -> deterministic.
@@ -687,42 +691,45 @@ int xpt_dwconv_bwd_both(const void* x, const float* w, const void* dy, void* dx,
   DW_DISPATCH(launch_bwd_both, x, w, dy, dx, partials, d, relu_in, (hipStream_t)stream);
 }
 
-/* n (<= 6) stride-1 SAME depthwise layers of one activation shape in one launch: y[j] = dwconv(f(x[j]), w[j]), kernel
- * size k[j] in {3, 5, 7}; inputs may repeat. */
-int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* const* y, const int* k, int n, int B, int H,
-                         int W, int C, int relu_in, int dtype, void* stream) {
-  XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(y); XPT_CHECK_PTR(k);
+/* n (<= 6) depthwise layers of one activation shape and stride in one launch: y[j] = dwconv(f(x[j]), w[j]), kernel
+ * size k[j] in {3, 5, 7}, leading padding (pad_t[j], pad_l[j]); inputs may repeat. */
+int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* const* y, const int* k, const int* pad_t,
+                         const int* pad_l, int n, int B, int H, int W, int C, int stride, int OH, int OW, int relu_in,
+                         int dtype, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(y); XPT_CHECK_PTR(k); XPT_CHECK_PTR(pad_t); XPT_CHECK_PTR(pad_l);
   if (n < 1 || n > DW_MAX_JOBS) return XPT_ERR_ARG;
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return XPT_ERR_SHAPE;
-  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
   DwMultiFwd m{};
   for (int j = 0; j < n; ++j) {
     if (!x[j] || !w[j] || !y[j]) return XPT_ERR_NULL;
-    if (k[j] != 3 && k[j] != 5 && k[j] != 7) return XPT_ERR_ARG;
-    m.x[j] = x[j]; m.w[j] = w[j]; m.y[j] = y[j]; m.k[j] = k[j];
+    const int rc = check_dims(B, H, W, C, k[j], stride, pad_t[j], pad_l[j], OH, OW, dtype);
+    if (rc != XPT_OK) return rc;
+    m.x[j] = x[j]; m.w[j] = w[j]; m.y[j] = y[j]; m.k[j] = k[j]; m.pad_t[j] = pad_t[j]; m.pad_l[j] = pad_l[j];
   }
-  const DwDims d{B, H, W, C, H, W, 0, 0};
-  const int bpj = (int)grid_for((long long)B * H * ((W + 3) / 4) * C);
+  const DwDims d{B, H, W, C, OH, OW, 0, 0};
+  const int oxt = stride == 1 ? 4 : 2;
+  const int bpj = (int)grid_for((long long)B * OH * ((OW + oxt - 1) / oxt) * C);
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
-  if (dtype == 0)
-    hipLaunchKernelGGL(dw_multi_fwd_kernel<float>, dim3(bpj * n), dim3(256), 0, s, m, d, relu_in, bpj);
-  else
-    hipLaunchKernelGGL(dw_multi_fwd_kernel<__hip_bfloat16>, dim3(bpj * n), dim3(256), 0, s, m, d, relu_in, bpj);
+#define XPT_MULTI(T, S) hipLaunchKernelGGL((dw_multi_fwd_kernel<T, S>), dim3(bpj * n), dim3(256), 0, s, m, d, relu_in, bpj)
+  if (dtype == 0) {
+    if (stride == 1) XPT_MULTI(float, 1); else XPT_MULTI(float, 2);
+  } else {
+    if (stride == 1) XPT_MULTI(__hip_bfloat16, 1); else XPT_MULTI(__hip_bfloat16, 2);
+  }
+#undef XPT_MULTI
   return xpt_launch_status();
 }
 
 /* Backward of xpt_dwconv_multi_fwd in one launch.  xin / dxin: the n_inputs distinct inputs and their gradients (each
- * the sum over the jobs reading it); per job j: dy[j], w[j], k[j], input_of[j] (index into xin) and partials[j]
- * (xpt_dwconv_bwd_weight_chunks(B, H, W, C, k[j], 1) * C * k[j]^2 floats, finished by xpt_reduce_partials). */
+ * the sum over the jobs reading it); per job j: dy[j], w[j], k[j], pads, input_of[j] (index into xin) and partials[j]
+ * (xpt_dwconv_bwd_weight_chunks(B, OH, OW, C, k[j], stride) * C * k[j]^2 floats, finished by xpt_reduce_partials). */
 int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs, const void* const* dy,
-                         const float* const* w, float* const* partials, const int* k, const int* input_of, int n, int B,
-                         int H, int W, int C, int relu_in, int dtype, void* stream) {
+                         const float* const* w, float* const* partials, const int* k, const int* pad_t,
+                         const int* pad_l, const int* input_of, int n, int B, int H, int W, int C, int stride, int OH,
+                         int OW, int relu_in, int dtype, void* stream) {
   XPT_CHECK_PTR(xin); XPT_CHECK_PTR(dxin); XPT_CHECK_PTR(dy); XPT_CHECK_PTR(w); XPT_CHECK_PTR(partials);
-  XPT_CHECK_PTR(k); XPT_CHECK_PTR(input_of);
+  XPT_CHECK_PTR(k); XPT_CHECK_PTR(pad_t); XPT_CHECK_PTR(pad_l); XPT_CHECK_PTR(input_of);
   if (n < 1 || n > DW_MAX_JOBS || n_inputs < 1 || n_inputs > n) return XPT_ERR_ARG;
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return XPT_ERR_SHAPE;
-  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
   DwMultiBwd m{};
   m.n = n; m.n_inputs = n_inputs;
   for (int u = 0; u < n_inputs; ++u) {
@@ -731,11 +738,15 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
   }
   for (int j = 0; j < n; ++j) {
     if (!dy[j] || !w[j] || !partials[j]) return XPT_ERR_NULL;
-    if ((k[j] != 3 && k[j] != 5 && k[j] != 7) || input_of[j] < 0 || input_of[j] >= n_inputs) return XPT_ERR_ARG;
-    m.dy[j] = dy[j]; m.w[j] = w[j]; m.part[j] = partials[j]; m.k[j] = k[j]; m.input_of[j] = input_of[j];
+    const int rc = check_dims(B, H, W, C, k[j], stride, pad_t[j], pad_l[j], OH, OW, dtype);
+    if (rc != XPT_OK) return rc;
+    if (input_of[j] < 0 || input_of[j] >= n_inputs) return XPT_ERR_ARG;
+    m.dy[j] = dy[j]; m.w[j] = w[j]; m.part[j] = partials[j]; m.k[j] = k[j]; m.pad_t[j] = pad_t[j]; m.pad_l[j] = pad_l[j];
+    m.input_of[j] = input_of[j];
   }
-  const DwDims d{B, H, W, C, H, W, 0, 0};
-  const long long ngrp = (long long)B * H * ((W + 3) / 4);
+  const DwDims d{B, H, W, C, OH, OW, 0, 0};
+  const int oxt = stride == 1 ? 4 : 2;
+  const long long ngrp = (long long)B * OH * ((OW + oxt - 1) / oxt);
   const int GRP = wrw_groups(ngrp, C);
   const int nchunk = (int)((ngrp + GRP - 1) / GRP);
   const int RG = (C <= 32) ? (64 / C > GRP / 4 ? (GRP / 4 > 0 ? GRP / 4 : 1) : 64 / C) : 1;
@@ -745,11 +756,14 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
   const dim3 grid(n_inputs * data_blocks + n * wbpj);
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
-  if (dtype == 0)
-    hipLaunchKernelGGL(dw_multi_bwd_kernel<float>, grid, dim3(256), 0, s, m, d, relu_in, RG, GRP, data_blocks, cchunks, wbpj);
-  else
-    hipLaunchKernelGGL(dw_multi_bwd_kernel<__hip_bfloat16>, grid, dim3(256), 0, s, m, d, relu_in, RG, GRP, data_blocks,
-                       cchunks, wbpj);
+#define XPT_MULTI(T, S) \
+  hipLaunchKernelGGL((dw_multi_bwd_kernel<T, S>), grid, dim3(256), 0, s, m, d, relu_in, RG, GRP, data_blocks, cchunks, wbpj)
+  if (dtype == 0) {
+    if (stride == 1) XPT_MULTI(float, 1); else XPT_MULTI(float, 2);
+  } else {
+    if (stride == 1) XPT_MULTI(__hip_bfloat16, 1); else XPT_MULTI(__hip_bfloat16, 2);
+  }
+#undef XPT_MULTI
   return xpt_launch_status();
 }
 

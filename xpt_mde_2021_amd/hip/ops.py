@@ -484,29 +484,35 @@ def depthwise_conv2d(x, weight, stride=1, padding=(0, 0, 0, 0), relu_in=False):
 
 
 class _MultiDepthwise(torch.autograd.Function):
-    """n stride-1 SAME depthwise convolutions of one activation shape in one launch forward and one backward
-    (xpt_dwconv_multi_fwd / _bwd).  args = (relu_in, x_0..x_{n-1}, w_0..w_{n-1}); inputs may repeat: the gradient of a
-    repeated input is returned once, already summed over its jobs."""
+    """n depthwise convolutions of one activation shape and stride in one launch forward and one backward
+    (xpt_dwconv_multi_fwd / _bwd).  args = (relu_in, stride, pads, x_0..x_{n-1}, w_0..w_{n-1}); pads = per-layer
+    (top, bottom, left, right); inputs may repeat: the gradient of a repeated input is returned once, already summed
+    over its jobs."""
 
     @staticmethod
-    def forward(ctx, relu_in, *tensors):
+    def forward(ctx, relu_in, stride, pads, *tensors):
         import ctypes
         lib = _lib.load()
         n = len(tensors) // 2
         xs = [_nhwc(t, "x") for t in tensors[:n]]
         ws = [t.detach().contiguous() for t in tensors[n:]]
         B, C, H, W = xs[0].shape
+        ks = [int(w.shape[-1]) for w in ws]
+        outs = {((H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1) for k, (pt, pb, pl, pr) in zip(ks, pads)}
         for x, w in zip(xs, ws):
             if x.shape != xs[0].shape or x.dtype != xs[0].dtype or w.dtype != torch.float32 or w.numel() != C * w.shape[-1] ** 2:
                 raise _lib.XptHipError("multi_depthwise: all inputs need one shape / dtype, weights [C,1,k,k] float32")
-        ys = [torch.empty((B, C, H, W), dtype=xs[0].dtype, device=xs[0].device, memory_format=torch.channels_last)
+        if len(outs) != 1:
+            raise _lib.XptHipError(f"multi_depthwise: the layers disagree on the output size: {outs}")
+        OH, OW = outs.pop()
+        ys = [torch.empty((B, C, OH, OW), dtype=xs[0].dtype, device=xs[0].device, memory_format=torch.channels_last)
               for _ in range(n)]
-        ks = [int(w.shape[-1]) for w in ws]
+        pts, pls = [int(p[0]) for p in pads], [int(p[2]) for p in pads]
         dt = 0 if xs[0].dtype == torch.float32 else 1
         P, I = ctypes.c_void_p * n, ctypes.c_int * n
         _lib.check(lib.xpt_dwconv_multi_fwd(P(*[x.data_ptr() for x in xs]), P(*[w.data_ptr() for w in ws]),
-                                            P(*[y.data_ptr() for y in ys]), I(*ks), n, B, H, W, C, int(relu_in), dt,
-                                            _stream()), "xpt_dwconv_multi_fwd")
+                                            P(*[y.data_ptr() for y in ys]), I(*ks), I(*pts), I(*pls), n, B, H, W, C,
+                                            int(stride), OH, OW, int(relu_in), dt, _stream()), "xpt_dwconv_multi_fwd")
         # distinct inputs (by storage), in order of first use
         ptrs, input_of = [], []
         for x in xs:
@@ -515,7 +521,7 @@ class _MultiDepthwise(torch.autograd.Function):
             input_of.append(ptrs.index(x.data_ptr()))
         first = [input_of.index(u) for u in range(len(ptrs))]
         ctx.save_for_backward(*[xs[j] for j in first], *ws)
-        ctx.cfg = (n, ks, input_of, first, int(relu_in), dt, (B, C, H, W))
+        ctx.cfg = (n, ks, pts, pls, input_of, first, int(relu_in), int(stride), dt, (B, C, H, W, OH, OW))
         ctx.sinks = [t.flat_grad if grad_sink.wants(t) else None for t in tensors[n:]]
         return tuple(ys)
 
@@ -523,16 +529,24 @@ class _MultiDepthwise(torch.autograd.Function):
     def backward(ctx, *dys):
         import ctypes
         lib = _lib.load()
-        n, ks, input_of, first, relu_in, dt, (B, C, H, W) = ctx.cfg
+        n, ks, pts, pls, input_of, first, relu_in, stride, dt, (B, C, H, W, OH, OW) = ctx.cfg
         nu = len(first)
         saved = ctx.saved_tensors
         xin, ws = saved[:nu], saved[nu:]
         dtype = xin[0].dtype
-        dys = [(_nhwc(dy.to(dtype), "dy") if dy is not None else torch.zeros_like(xin[0])) for dy in dys]
+        zero = None
+        prepared = []
+        for dy in dys:
+            if dy is None:
+                if zero is None:
+                    zero = torch.zeros((B, C, OH, OW), dtype=dtype, device=xin[0].device, memory_format=torch.channels_last)
+                prepared.append(zero)
+            else:
+                prepared.append(_nhwc(dy.to(dtype), "dy"))
         dxin = [torch.empty_like(x, memory_format=torch.channels_last) for x in xin]
         parts, later = [], []
         for j in range(n):
-            nchunk = lib.xpt_dwconv_bwd_weight_chunks(B, H, W, C, ks[j], 1)
+            nchunk = lib.xpt_dwconv_bwd_weight_chunks(B, OH, OW, C, ks[j], stride)
             nfl = C * ks[j] * ks[j]
             if ctx.sinks[j] is not None:
                 buf = grad_sink.partials(ctx.sinks[j], "dw", nchunk * nfl)
@@ -543,24 +557,30 @@ class _MultiDepthwise(torch.autograd.Function):
             parts.append(buf)
         PU, PN, IN_ = ctypes.c_void_p * nu, ctypes.c_void_p * n, ctypes.c_int * n
         _lib.check(lib.xpt_dwconv_multi_bwd(PU(*[x.data_ptr() for x in xin]), PU(*[d.data_ptr() for d in dxin]), nu,
-                                            PN(*[d.data_ptr() for d in dys]), PN(*[w.data_ptr() for w in ws]),
-                                            PN(*[p.data_ptr() for p in parts]), IN_(*ks), IN_(*input_of), n, B, H, W, C,
-                                            relu_in, dt, _stream()), "xpt_dwconv_multi_bwd")
+                                            PN(*[d.data_ptr() for d in prepared]), PN(*[w.data_ptr() for w in ws]),
+                                            PN(*[p.data_ptr() for p in parts]), IN_(*ks), IN_(*pts), IN_(*pls),
+                                            IN_(*input_of), n, B, H, W, C, stride, OH, OW, relu_in, dt, _stream()),
+                   "xpt_dwconv_multi_bwd")
         gx = [None] * n
         for u, j in enumerate(first):
             gx[j] = dxin[u]                       # repeated inputs: autograd adds None for the other uses
         gw = [None] * n
         for j, buf, nchunk, nfl in later:         # weights outside the gradient sink: finish here
             gw[j] = buf.view(nchunk, nfl).sum(0).view(ws[j].shape)
-        return (None, *gx, *gw)
+        return (None, None, None, *gx, *gw)
 
 
-def multi_depthwise(inputs, weights, relu_in=True):
-    """[dwconv_same(f(x_j), w_j)] for up to 6 (input, weight) pairs of one activation shape, kernel sizes 3 / 5 / 7, in
-    one launch; `inputs` may contain the same tensor several times."""
+def multi_depthwise(inputs, weights, relu_in=True, stride=1, pads=None):
+    """[dwconv(f(x_j), w_j)] for up to 6 (input, weight) pairs of one activation shape and stride, kernel sizes 3 / 5 / 7,
+    in one launch; `inputs` may contain the same tensor several times.  pads: per-layer (top, bottom, left, right),
+    default SAME for stride 1 (k // 2 on every side)."""
     if not 1 <= len(inputs) <= 6 or len(inputs) != len(weights):
         raise _lib.XptHipError("multi_depthwise: 1..6 (input, weight) pairs")
-    return list(_MultiDepthwise.apply(relu_in, *inputs, *weights))
+    if pads is None:
+        if stride != 1:
+            raise _lib.XptHipError("multi_depthwise: explicit pads needed for stride 2")
+        pads = [(int(w.shape[-1]) // 2,) * 4 for w in weights]
+    return list(_MultiDepthwise.apply(relu_in, int(stride), tuple(tuple(p) for p in pads), *inputs, *weights))
 
 
 # ------------------------------------------------------------------------------- per-channel conv epilogues

@@ -187,6 +187,34 @@ class _StepGraph:
         for t, s in zip(state, saved):
             t.copy_(s)
         self.signature = sig
+        if state and not self._replays_are_sane(state, saved):
+            # Some library convolution solvers return garbage from the second replay of a captured graph on this stack
+            # (DESIGN.md section 6); which solver MIOpen's find picks can vary from process to process.  Fall back to
+            # the immediate-mode heuristics (whose choices are covered by tests/test_graph_replay.py) and recapture.
+            if torch.backends.cudnn.benchmark:
+                import sys
+                print("[StepGraph] captured step produced non-finite state on replay: MIOpen find off, recapturing",
+                      file=sys.stderr, flush=True)
+                torch.backends.cudnn.benchmark = False
+                opts.MIOPEN_FIND = False
+                self.graph = None
+                return self._capture(features, sig)
+            raise RuntimeError("captured training step produces non-finite parameters / moments when replayed")
+
+    def _replays_are_sane(self, state, saved, replays=3):
+        """Replays the fresh graph a few times from the saved state and checks that parameters, moments and gradients
+        stay finite and bounded (the library failure this guards against yields 1e25 ... inf from the second replay)."""
+        ok = True
+        for _ in range(replays):
+            self.graph.replay()
+            torch.cuda.synchronize()
+            for t in state:
+                if t.is_floating_point() and not (bool(torch.isfinite(t).all()) and float(t.abs().max()) < 1e8):
+                    ok = False
+            for t, s in zip(state, saved):
+                t.copy_(s)
+        torch.cuda.synchronize()
+        return ok
 
 
 class ModelTrainerGraph(ModelTrainer):
