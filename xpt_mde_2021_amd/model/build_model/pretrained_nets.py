@@ -499,20 +499,29 @@ class ReductionCell(nn.Module):
         h3 = zero_pad(h, correct_pad(h.shape[2], h.shape[3], 3))
         mp = F.max_pool2d(h3, 3, 2)                      # MaxPooling2D of h feeds x2 and x5: pooled once
         mp1, mp2 = _ops.fan_out(mp, 2)
-        blocks = (self.left1, self.right1, self.right2, self.right3)
+        def tapped(b):
+            return taps.wants(b.act_id1) or taps.wants(b.act_id2)
+
         if (h.is_cuda and not _DISABLE_HIP_DWCONV and _WIDE_CELL and h.shape == p.shape
-                and not any(taps.wants(b.act_id1) or taps.wants(b.act_id2) for b in blocks + (self.left4,))):
-            # the four stride-2 separable-conv branches stage by stage, as in the normal cell (left4 follows on x1)
+                and not any(tapped(b) for b in (self.left1, self.right1, self.right2, self.left4))):
+            # the stride-2 separable-conv branches stage by stage, as in the normal cell (left4 follows on x1); right3
+            # carries one of the decoder's skip taps in every reduction cell and then runs on its own
+            wide3 = not tapped(self.right3)
+            blocks = (self.left1, self.right1, self.right2) + ((self.right3,) if wide3 else ())
             H, W = h.shape[2], h.shape[3]
             pads = []
             for b in blocks:
                 (pt, pb), (pl, pr) = correct_pad(H, W, b.conv1.k)
                 pads.append((pt, pb, pl, pr))
-            y1 = _ops.multi_depthwise([h, p, p, p], [b.conv1.depthwise.weight for b in blocks], stride=2, pads=pads)
+            y1 = _ops.multi_depthwise([h] + [p] * (len(blocks) - 1), [b.conv1.depthwise.weight for b in blocks],
+                                      stride=2, pads=pads)
             z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
             y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
-            r1, x2, x3 = multi_conv1x1_bn(y2[1:], [b.conv2.pointwise.weight for b in blocks[1:]],
-                                          [b.bn2 for b in blocks[1:]], [None, mp1, F.avg_pool2d(h3, 3, 2)])
+            ap = F.avg_pool2d(h3, 3, 2)
+            outs = multi_conv1x1_bn(y2[1:], [b.conv2.pointwise.weight for b in blocks[1:]], [b.bn2 for b in blocks[1:]],
+                                    [None, mp1] + ([ap] if wide3 else []))
+            r1, x2 = outs[0], outs[1]
+            x3 = outs[2] if wide3 else self.right3(p, taps, residual=ap)
             x1 = conv1x1_bn(y2[0], self.left1.conv2.pointwise.weight, self.left1.bn2, residual=r1)
             x1a, x1b = _ops.fan_out(x1, 2)
             x2a, x2b = _ops.fan_out(x2, 2)
