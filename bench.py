@@ -132,6 +132,9 @@ def main():
         elapsed = float(t.item())
 
     result = None
+    step_graph = getattr(trainer, "_graph", None)
+    if step_graph is not None and getattr(step_graph, "eager_fallback", False):
+        mode += " (eager fallback: no captured step passed the replay check)"
     if rank == 0:
         global_batch = args.batch * world
         result = {

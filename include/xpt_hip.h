@@ -117,6 +117,8 @@ int xpt_photo_bwd(int method, const float* synth, const float* target, const flo
 /* launch-plan knobs (process-wide, for benchmarking): the row chunks (32, 16, 8 ... min_rows) shrink until the launch has
  * at least this many waves */
 int xpt_photo_fused_tune(int fwd_min_waves, int bwd_min_waves, int min_rows);
+/* forward variant (process-wide): 1 = hand-pipelined row loop (default), 0 = compiler-scheduled; same results */
+int xpt_photo_fused_variant(int pipelined);
 size_t xpt_photo_fused_workspace_floats(int B, int N, int h, int w);
 int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, const float* K, const float* target,
                         float* synth, float* loss_l1, float* loss_ssim, float* workspace, size_t workspace_floats,

@@ -140,6 +140,52 @@ def test_train_step_runs_and_learns(gpu_device):
         opts.IMAGE_SIZES.update(saved[3])
 
 
+def test_step_leaves_no_autograd_graph_behind(gpu_device):
+    """No tensor with a grad_fn may survive a training step (a module attribute holding one keeps the whole autograd
+    graph and its AccumulateGrad nodes -- created on the warm-up stream -- alive into the hipGraph capture), the
+    capture must not trip autograd's AccumulateGrad stream-mismatch warning, and the graph trainer must not have
+    fallen back to eager execution."""
+    import gc
+    import warnings
+    from xpt_mde_2021_amd.model import model_main as mm
+    from xpt_mde_2021_amd.model import train_val as tv
+    saved = (opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE, dict(opts.IMAGE_SIZES))
+    opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 2
+    opts.IMAGE_SIZES["kitti_raw"] = (64, 192)
+    opts.CONV_DTYPE = "bf16"
+    try:
+        dataset, cfg, _ = mm.get_dataset("synthetic", "train", True)
+        model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, opts.LOSS_RIGID_T1,
+                                                                      opts.SCALE_WEIGHT_T1, opts.RIGID_NET,
+                                                                      ckpt_name="__test__")
+        trainer, _ = tv.train_val_factory("eager", model, loss_object, 0, False, None, optimizer)
+        gc.collect()
+        trainer.run_a_batch(dataset.batches[0])
+        torch.cuda.synchronize()
+        alive = []
+        for o in gc.get_objects():
+            try:
+                if torch.is_tensor(o) and o.grad_fn is not None:
+                    alive.append((tuple(o.shape), type(o.grad_fn).__name__))
+            except ReferenceError:
+                pass
+        assert not alive, f"tensors keeping the step's autograd graph alive: {alive[:8]}"
+
+        trainer, _ = tv.train_val_factory("graph", model, loss_object, 0, False, None, optimizer)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            for _ in range(3):
+                trainer.run_a_batch(dataset.batches[0])
+            torch.cuda.synchronize()
+        stale = [str(w.message)[:120] for w in caught if "AccumulateGrad" in str(w.message)]
+        assert not stale, stale
+        assert not trainer._graph.eager_fallback
+    finally:
+        opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
+        opts.IMAGE_SIZES.clear()
+        opts.IMAGE_SIZES.update(saved[3])
+
+
 def test_stereo_train_step_in_graph(gpu_device):
     """configs[4]-style step (stereo feature dict, LOSS_RIGID_T2: mono + stereo L1/SSIM + stereoPose) captured as a
     hipGraph: nothing in it may synchronise with the host (the pose inverses are closed-form), every layer is applied

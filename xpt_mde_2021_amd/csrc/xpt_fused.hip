@@ -124,7 +124,14 @@ __device__ inline float window_rcp(int r, int h, float cnt_c) {
 
 // ------------------------------------------------------------------------------------------------ forward
 // part[16 * wave + {0,1}] = (sum of L1 terms, sum of SSIM terms) over the wave's output pixels (3 channels each).
-template <bool EMIT_SYNTH>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+
+// PIPE (only without EMIT_SYNTH): every vector load of the row loop is issued by hand (inline asm) with hand-placed
+// s_waitcnt, so that the streaming loads of row r+1 (depth, target) are in flight BEHIND the gathers of row r and are
+// only waited for when row r's arithmetic is done -- the compiler's own waitcnt insertion cannot express that (vector
+// memory returns in order and loop-carried load destinations are waited for conservatively).
+template <bool EMIT_SYNTH, bool PIPE>
 __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
                                                         const float* __restrict__ T, const float* __restrict__ K,
                                                         const float* __restrict__ target, float* __restrict__ synth,
@@ -238,12 +245,97 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
   // rows r0-1 .. r1 (one halo row above and below the chunk), three-way rotation keeps the history in registers
   int r = r0 - 1;
   const int rend = r1;          // inclusive
-  while (r <= rend) {
-    body(r, hA, hC, hB); ++r;
-    if (r > rend) break;
-    body(r, hB, hA, hC); ++r;
-    if (r > rend) break;
-    body(r, hC, hB, hA); ++r;
+  if constexpr (!PIPE) {
+    while (r <= rend) {
+      body(r, hA, hC, hB); ++r;
+      if (r > rend) break;
+      body(r, hB, hA, hC); ++r;
+      if (r > rend) break;
+      body(r, hC, hB, hA); ++r;
+    }
+  } else {
+    // ---- hand-pipelined march (branch-free per row: out-of-image rows / columns read a clamped address, are zeroed)
+    const int col_c = min(max(col, 0), d.w - 1);
+    float nd;
+    f32x3 nx;
+    bool nvalid;
+    auto prefetch = [&](int rr) {                  // 2 loads: depth and target pixel of row rr
+      nvalid = rr >= 0 && rr < d.h && col_in;      // rr is wave-uniform
+      const int p = min(max(rr, 0), d.h - 1) * d.w + col_c;
+      const float* pd = dimg + p;
+      const float* pt = timg + 3 * p;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(nd) : "v"(pd) : "memory");
+      asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(nx) : "v"(pt) : "memory");
+    };
+    auto pbody = [&](int r, float (&cur)[15], const float (&m1)[15], const float (&m2)[15]) {
+      // the prefetched depth / target of this row have been waited for (end of the previous body or below)
+      const bool valid = nvalid;
+      const float dd = valid ? nd : 0.f;
+      const float x[3] = {valid ? nx.x : 0.f, valid ? nx.y : 0.f, valid ? nx.z : 0.f};
+      const float fr = (float)r;
+      const float q0 = (M[1] * fr + m_c[0]) * dd + kt[0];
+      const float q1 = (M[4] * fr + m_c[1]) * dd + kt[1];
+      const float q2 = (M[7] * fr + m_c[2]) * dd + kt[2];
+      const float zinv = rcpf(q2 + 1e-10f);
+      const float up = q0 * zinv, vp = q1 * zinv;
+      const float fu = floorf(up), fv = floorf(vp);
+      const bool ok = valid && (fu >= 0.f) && (fu <= fu_max) && (fv >= 0.f) && (fv <= fv_max) && (dd != 0.f);
+      const int off = ok ? ((int)fv * d.w + (int)fu) * 3 : 0;
+      const float wuf = (fu + 1.f) - up, wuc = up - fu, wvf = (fv + 1.f) - vp, wvc = vp - fv;
+      const float wff = wuf * wvf, wfc = wuf * wvc, wcf = wuc * wvf, wcc = wuc * wvc;
+      const float* t0 = simg + off;
+      const float* t1 = t0 + row3;
+      f32x4 a0, a1;
+      f32x2 b0, b1;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a0) : "v"(t0) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=v"(b0) : "v"(t0) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(a1) : "v"(t1) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, off offset:16" : "=v"(b1) : "v"(t1) : "memory");
+      prefetch(r + 1);                             // behind the gathers
+      asm volatile("s_waitcnt vmcnt(2)" : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1) : : "memory");   // gathers landed
+      const f32x2 v01 = ((f32x2{a0.x, a0.y} * wff + f32x2{a1.x, a1.y} * wfc) + f32x2{a0.w, b0.x} * wcf) +
+                        f32x2{a1.w, b1.x} * wcc;
+      const float v2 = ((a0.z * wff + a1.z * wfc) + b0.y * wcf) + b1.y * wcc;
+      const float y[3] = {ok ? v01.x : 0.f, ok ? v01.y : 0.f, ok ? v2 : 0.f};
+      const bool black = ((y[0] + y[1]) + y[2]) == 0.f;
+      if (out_lane && r >= r0 && r < r1 && !black)
+        acc_l1 += (fabsf(y[0] - x[0]) + fabsf(y[1] - x[1])) + fabsf(y[2] - x[2]);
+      {
+        const f32x2 x01{x[0], x[1]}, y01{y[0], y[1]}, xy2{x[2], y[2]};
+        const f32x2 xx01 = x01 * x01, yy01 = y01 * y01, xy01 = x01 * y01, sq2 = xy2 * xy2;
+        const float p[15] = {x[0], x[1], x[2], y[0], y[1], y[2], xx01.x, xx01.y, sq2.x, yy01.x, yy01.y, sq2.y,
+                             xy01.x, xy01.y, x[2] * y[2]};
+#pragma unroll
+        for (int i = 0; i < 15; ++i) cur[i] = hsum3(p[i]);
+      }
+      const int rc = r - 1;
+      if (rc >= r0 && rc < r1) {
+        const float ic = window_rcp(rc, d.h, cnt_c);
+        f32x2 W[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q)
+          W[q] = (f32x2{m2[3 * q], m2[3 * q + 1]} + f32x2{m1[3 * q], m1[3 * q + 1]}) + f32x2{cur[3 * q], cur[3 * q + 1]};
+        const f32x2 l01 = ssim_loss2(W[0], W[1], W[2], W[3], W[4], ic);
+        const f32x2 Wa = (f32x2{m2[2], m2[5]} + f32x2{m1[2], m1[5]}) + f32x2{cur[2], cur[5]};
+        const f32x2 Wb = (f32x2{m2[8], m2[11]} + f32x2{m1[8], m1[11]}) + f32x2{cur[8], cur[11]};
+        const float l2 = ssim_loss(Wa.x, Wa.y, Wb.x, Wb.y, m2[14] + m1[14] + cur[14], ic);
+        const float sum = (l01.x + l01.y) + l2;
+        if (out_lane && !black_prev) acc_ss += sum;
+      }
+      black_prev = black;
+      // the next row's depth / target: waited for here (end of this row's arithmetic).  Always before leaving the body,
+      // so that no register with a load in flight crosses a loop edge or a register copy.
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(nd), "+v"(nx) : : "memory");
+    };
+    prefetch(r);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(nd), "+v"(nx) : : "memory");
+    while (r <= rend) {
+      pbody(r, hA, hC, hB); ++r;
+      if (r > rend) break;
+      pbody(r, hB, hA, hC); ++r;
+      if (r > rend) break;
+      pbody(r, hC, hB, hA); ++r;
+    }
   }
   acc_l1 = wave_sum_all(acc_l1);
   acc_ss = wave_sum_all(acc_ss);
@@ -495,7 +587,7 @@ inline FusedDims make_dims(int B, int N, int h, int w, float scale, int rows_per
   return d;
 }
 
-int g_fwd_min_waves = 4096, g_bwd_min_waves = 1536, g_min_rows = 8;
+int g_fwd_min_waves = 4096, g_bwd_min_waves = 1536, g_min_rows = 8, g_fwd_pipe = 1;
 
 // Rows per chunk: enough waves to cover 256 CUs x 4 SIMDs a few times over, as few halo rows as possible.
 inline int pick_rows(int B, int N, int h, int w, long long min_waves) {
@@ -515,6 +607,13 @@ int xpt_photo_fused_tune(int fwd_min_waves, int bwd_min_waves, int min_rows) {
   g_fwd_min_waves = fwd_min_waves;
   g_bwd_min_waves = bwd_min_waves;
   g_min_rows = min_rows;
+  return XPT_OK;
+}
+
+/* 1: the hand-pipelined forward (asm loads, explicit s_waitcnt); 0: the compiler-scheduled one */
+int xpt_photo_fused_variant(int pipelined) {
+  if (pipelined != 0 && pipelined != 1) return XPT_ERR_ARG;
+  g_fwd_pipe = pipelined;
   return XPT_OK;
 }
 
@@ -538,9 +637,14 @@ int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, co
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
   if (synth)
-    hipLaunchKernelGGL(fused_fwd_kernel<true>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth, workspace, d);
+    hipLaunchKernelGGL((fused_fwd_kernel<true, false>), dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth,
+                       workspace, d);
+  else if (g_fwd_pipe)
+    hipLaunchKernelGGL((fused_fwd_kernel<false, true>), dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth,
+                       workspace, d);
   else
-    hipLaunchKernelGGL(fused_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth, workspace, d);
+    hipLaunchKernelGGL((fused_fwd_kernel<false, false>), dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth,
+                       workspace, d);
   if (loss_l1)
     hipLaunchKernelGGL(fused_reduce_kernel, dim3(B), dim3(64), 0, s, workspace, loss_l1, loss_ssim, d.S * d.CH * d.N,
                        1.0f / ((float)N * (float)h * (float)w * 3.0f));

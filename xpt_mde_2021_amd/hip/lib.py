@@ -38,6 +38,7 @@ SIGNATURES = {
     "xpt_photo_fwd": (_i, [_i, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     "xpt_photo_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     "xpt_photo_fused_tune": (_i, [_i, _i, _i]),
+    "xpt_photo_fused_variant": (_i, [_i]),
     "xpt_photo_fused_workspace_floats": (_z, [_i, _i, _i, _i]),
     "xpt_photo_fused_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _f, _p]),
     "xpt_photo_fused_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _f, _p]),
@@ -120,6 +121,9 @@ def load():
             raise XptHipError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
         fn.restype = restype
         fn.argtypes = argtypes
+    variant = os.environ.get("XPT_FUSED_FWD_PIPE")
+    if variant is not None:                      # A/B switch of the fused forward's row loop (default: the library's)
+        lib.xpt_photo_fused_variant(int(variant))
     _lib = lib
     return lib
 

@@ -93,7 +93,10 @@ class DepthNetPretrained(nn.Module):
 
         out = {"depth_ms": [nhwc1(depth0), nhwc1(depth1), nhwc1(depth2), nhwc1(depth3)],
                "debug_out": [dpconv0, upconv0, dpconv3, upconv3]}
-        disps = [h.last_disp for h in (self.depth0, self.depth1, self.depth2, self.depth3)]
+        heads = (self.depth0, self.depth1, self.depth2, self.depth3)
+        disps = [h.last_disp for h in heads]
+        for h in heads:        # hand the tensors over: a module attribute would keep this step's autograd graph (and its
+            h.last_disp = None  # AccumulateGrad nodes with their stream) alive into the next step / a hipGraph capture
         if all(d is not None for d in disps):      # model_wrappers.py:48-49 would compute it with four more elementwise ops per scale
             out["disp_ms"] = [nhwc1(d) for d in disps]
         return out

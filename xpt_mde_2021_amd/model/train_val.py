@@ -155,15 +155,20 @@ class _StepGraph:
         self.static_in = None
         self.static_out = None
         self.signature = None
+        self.eager_fallback = False            # set when no capture of the step survives the replay check
 
     @staticmethod
     def _sig(features):
         return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in features.items() if torch.is_tensor(v)))
 
     def __call__(self, features):
+        if self.eager_fallback:
+            return self.fn(features)
         sig = self._sig(features)
         if self.graph is None or sig != self.signature:
             self._capture(features, sig)
+            if self.eager_fallback:
+                return self.fn(features)
         else:
             for k, v in self.static_in.items():
                 v.copy_(features[k], non_blocking=True)
@@ -187,34 +192,42 @@ class _StepGraph:
         for t, s in zip(state, saved):
             t.copy_(s)
         self.signature = sig
-        if state and not self._replays_are_sane(state, saved):
+        report = self._replay_report(state, saved) if state else None
+        if report is not None:
             # Some library convolution solvers return garbage from the second replay of a captured graph on this stack
             # (DESIGN.md section 6); which solver MIOpen's find picks can vary from process to process.  Fall back to
-            # the immediate-mode heuristics (whose choices are covered by tests/test_graph_replay.py) and recapture.
+            # the immediate-mode heuristics (whose choices are covered by tests/test_graph_replay.py) and recapture;
+            # if that capture fails the check too, run the step eagerly rather than train on garbage.
+            import sys
             if torch.backends.cudnn.benchmark:
-                import sys
-                print("[StepGraph] captured step produced non-finite state on replay: MIOpen find off, recapturing",
+                print(f"[StepGraph] captured step fails the replay check ({report}): MIOpen find off, recapturing",
                       file=sys.stderr, flush=True)
                 torch.backends.cudnn.benchmark = False
                 opts.MIOPEN_FIND = False
                 self.graph = None
                 return self._capture(features, sig)
-            raise RuntimeError("captured training step produces non-finite parameters / moments when replayed")
+            print(f"[StepGraph] captured step fails the replay check again ({report}): running the step EAGERLY "
+                  f"(about 3x slower) -- please report the shapes", file=sys.stderr, flush=True)
+            self.graph = None
+            self.eager_fallback = True
 
-    def _replays_are_sane(self, state, saved, replays=3):
+    def _replay_report(self, state, saved, replays=3):
         """Replays the fresh graph a few times from the saved state and checks that parameters, moments and gradients
-        stay finite and bounded (the library failure this guards against yields 1e25 ... inf from the second replay)."""
-        ok = True
-        for _ in range(replays):
+        stay finite and bounded (the library failure this guards against yields 1e25 ... inf from the second replay).
+        Returns None when they do, else a short description of what went wrong."""
+        report = None
+        for rep in range(replays):
             self.graph.replay()
             torch.cuda.synchronize()
-            for t in state:
-                if t.is_floating_point() and not (bool(torch.isfinite(t).all()) and float(t.abs().max()) < 1e8):
-                    ok = False
+            for i, t in enumerate(state):
+                if report is None and t.is_floating_point():
+                    bad = ~torch.isfinite(t) | (t.abs() >= 1e8)
+                    if bool(bad.any()):
+                        report = f"replay {rep}: {int(bad.sum())} of {t.numel()} elements of state tensor {i} non-finite"
             for t, s in zip(state, saved):
                 t.copy_(s)
         torch.cuda.synchronize()
-        return ok
+        return report
 
 
 class ModelTrainerGraph(ModelTrainer):
