@@ -23,14 +23,16 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+CODEGEN_FLAGS = ["-O3", "-fno-slp-vectorize", f"--offload-arch={ARCH}", "-std=c++17"]     # also used by tests/test_pipelined_isa.py
+
+
 def build(force=False, verbose=True, extra_flags=()):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libxpt_hip.so")
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc, "-O3", "-fno-slp-vectorize", f"--offload-arch={ARCH}", "-std=c++17", "-shared", "-fPIC", "-Wall", "-Wno-unused-function",
-           "-o", OUT] + list(extra_flags) + sources()
+    cmd = [hipcc, *CODEGEN_FLAGS, "-shared", "-fPIC", "-Wall", "-Wno-unused-function", "-o", OUT] + list(extra_flags) + sources()
     if verbose:
         print("[xpt build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
