@@ -232,6 +232,19 @@ int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const fl
 int xpt_depth_head_fwd(const float* x, float* depth, float* disp, long long n, void* stream);
 int xpt_depth_head_bwd(const float* x, const float* g_depth, const float* g_disp, float* gx, long long n, void* stream);
 
+/* ------------------------------------------------------------------ f-4: PWC-Net correlation cost volume
+ * tfa.layers.CorrelationCost(kernel_size=1, max_displacement=md, stride_1=1, stride_2=s2, pad=md, channels_last)
+ * as called by PWCNet.correlation (model/build_model/flow_net.py:181-196; md = 128 >> level, s2 = max(md / 4, 1)):
+ *   out[b,y,x, ty*D + tx] = (1/C) sum_c left[b,y,x,c] * right[b, y + (ty-rad)*s2, x + (tx-rad)*s2, c],  rad = md / s2,
+ *   D = 2 rad + 1, zero where the displaced pixel is outside the image.  left / right [B,H,W,C] dense NHWC,
+ *   out [B,H,W,D*D]; dtype 0 float32 / 1 bfloat16 (all three tensors), fp32 accumulation.
+ * bwd: dleft, dright [B,H,W,C] from gout [B,H,W,D*D] (gathers, deterministic).  D*D <= 256; bwd: C <= 256. */
+int xpt_corr_cost_channels(int max_disp, int stride2);
+int xpt_corr_cost_fwd(const void* left, const void* right, void* out, int B, int H, int W, int C, int max_disp,
+                      int stride2, int dtype, void* stream);
+int xpt_corr_cost_bwd(const void* left, const void* right, const void* gout, void* dleft, void* dright, int B, int H,
+                      int W, int C, int max_disp, int stride2, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ a2: the cells' 3x3 average pooling
  * keras AveragePooling2D((3,3), strides (1,1), padding='same') inside NASNetMobile (divisor = number of in-image taps),
  * times `scale` (add([avg(p), avg(p)]) of the normal cell = scale 2).  in [B,H,W,C] NHWC with row pitch in_pitch >= C

@@ -1,0 +1,183 @@
+"""FlowNet branch on the GPU: the correlation cost kernels against the oracle, the flow-warped targets
+and the flow-aided losses against the oracle, and training steps of the flow net / the joint net (eager and hipGraph)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_flow, ref_loss
+from tests.util import frac_close
+from xpt_mde_2021_amd.config import opts
+from xpt_mde_2021_amd.utils import synthetic_data as sd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C,md,s2", [(2, 2, 3, 196, 2, 1), (2, 4, 6, 128, 4, 1), (1, 8, 12, 96, 8, 2),
+                                           (1, 16, 24, 64, 16, 4), (2, 16, 48, 32, 32, 8), (1, 5, 7, 10, 4, 1),
+                                           (1, 3, 2, 7, 2, 1)])
+def test_correlation_cost_fwd_bwd(gpu_device, dtype, B, H, W, C, md, s2):
+    """xpt_corr_cost_{fwd,bwd} == the restated tfa.layers.CorrelationCost and its autograd gradients."""
+    from xpt_mde_2021_amd.hip import ops
+    g = torch.Generator().manual_seed(11 * C + md)
+    left = torch.randn((B, H, W, C), generator=g)
+    right = torch.randn((B, H, W, C), generator=g)
+    if dtype == torch.bfloat16:                       # same rounded inputs on both sides: only the accumulation differs
+        left, right = left.bfloat16().float(), right.bfloat16().float()
+    lr, rr = left.double().requires_grad_(True), right.double().requires_grad_(True)
+    ref = ref_flow.correlation_cost(lr, rr, md, s2)
+    gout = torch.randn(ref.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gout = gout.bfloat16().float()
+    (ref * gout.double()).sum().backward()
+
+    ld = left.permute(0, 3, 1, 2).to(gpu_device, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rd = right.permute(0, 3, 1, 2).to(gpu_device, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = ops.correlation_cost(ld, rd, md, s2)
+    assert out.shape == (B, (2 * (md // s2) + 1) ** 2, H, W) and out.dtype == dtype
+    (out.float() * gout.permute(0, 3, 1, 2).to(gpu_device)).sum().backward()
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    frac_close(out.float().permute(0, 2, 3, 1), ref, tol, rtol=tol, what="corr")
+    frac_close(ld.grad.float().permute(0, 2, 3, 1), lr.grad, tol * 3, rtol=tol, what="dleft")
+    frac_close(rd.grad.float().permute(0, 2, 3, 1), rr.grad, tol * 3, rtol=tol, what="dright")
+    # gathers only: bit-repeatable
+    out2 = ops.correlation_cost(ld.detach(), rd.detach(), md, s2)
+    assert torch.equal(out2, out.detach())
+
+
+def _flow_case(B, N, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    feats = sd.make_features(B, H, W, N + 1, seed)
+    image5d = feats["image5d"]
+    source, target = image5d[:, :-1].contiguous(), image5d[:, -1].contiguous()
+    flow_ms = [(torch.randn((B, N, H // s, W // s, 2), generator=g) * 1.5) for s in (4, 8, 16, 32)]
+    flow_ms[0][0, 0, :2] += 40.0                      # some samples far outside the image
+    return source, target, flow_ms
+
+
+def test_flow_warp_and_flow_losses(gpu_device):
+    """FlowWarpMultiScale, multi_scale_like_flow, FlowWarpLossMultiScale("L2") and their gradient w.r.t. the flows."""
+    from xpt_mde_2021_amd.model.loss_and_metric import losses as lm
+    from xpt_mde_2021_amd.model.synthesize.flow_warping import FlowWarpMultiScale
+    from xpt_mde_2021_amd.utils import util_funcs as uf
+    B, N, H, W = 2, 4, 64, 128
+    source, target, flow_ms = _flow_case(B, N, H, W, 5)
+    sw = np.ones((4, 1), dtype=np.float32)
+    f_ref = [f.clone().double().requires_grad_(True) for f in flow_ms]
+    warped_ref = ref_flow.flow_warp_multi_scale(source.double(), f_ref)
+    tgt_ref = ref_flow.multi_scale_like_flow(target.double(), f_ref)
+    loss_ref = ref_flow.flow_warp_loss_multi_scale("L2", warped_ref, tgt_ref, sw)
+    loss_ref.sum().backward()
+
+    f_dev = [f.to(gpu_device).requires_grad_(True) for f in flow_ms]
+    warped = FlowWarpMultiScale()(source.to(gpu_device), f_dev)
+    tgt_ms = uf.multi_scale_like_flow(target.to(gpu_device), f_dev)
+    for a, b in zip(tgt_ms, tgt_ref):
+        frac_close(a, b, 1e-5, what="flow target pyramid")
+    for a, b in zip(warped, warped_ref):
+        frac_close(a, b, 1e-4, max_bad_frac=2e-3, what="flow-warped target")
+    obj = lm.FlowWarpLossMultiScale("L2", sw)
+    loss = obj(None, None, {"flow_target_ms": tgt_ms, "warped_target_ms": warped})
+    frac_close(loss.reshape(-1), loss_ref.reshape(-1), 1e-5, rtol=1e-4, what="flowL2")
+    loss.sum().backward()
+    for a, b in zip(f_dev, f_ref):
+        scale = float(b.grad.abs().max())
+        frac_close(a.grad, b.grad, 2e-4 * scale, rtol=2e-3, max_bad_frac=2e-3, what="d flowL2 / d flow")
+
+
+@pytest.mark.parametrize("method", ["L1", "SSIM"])
+def test_combined_loss(gpu_device, method):
+    """CombinedLossMultiScale (losses.py:235-279) against the oracle, value and gradient w.r.t. the synthesized views."""
+    from xpt_mde_2021_amd.model.loss_and_metric import losses as lm
+    B, N, H, W = 2, 4, 32, 64
+    g = torch.Generator().manual_seed(21)
+    target = (sd.smooth_noise((B, H, W, 3), g)).clamp(-1, 1).contiguous()
+    synth_ms = [(target[:, None, ::s, ::s] * 0.8 + 0.2 * sd.smooth_noise((B * N, H // s, W // s, 3), g).reshape(B, N, H // s, W // s, 3)).contiguous()
+                for s in (1, 2, 4, 8)]
+    synth_ms[0][0, 1, :3] = 0.0                        # black (invalid) pixels
+    warped_ms = [(target[:, None, ::s, ::s] * 0.8 + 0.2 * sd.smooth_noise((B * N, H // s, W // s, 3), g).reshape(B, N, H // s, W // s, 3)).contiguous()
+                 for s in (4, 8, 16, 32)]
+    sw = np.array([[1.0], [0.5], [0.25], [2.0]], dtype=np.float32)
+    s_ref = [s.clone().double().requires_grad_(True) for s in synth_ms]
+    loss_ref = ref_flow.combined_loss_multi_scale(method, s_ref, [w.double() for w in warped_ms], target.double(), sw)
+    loss_ref.sum().backward()
+    s_dev = [s.to(gpu_device).requires_grad_(True) for s in synth_ms]
+    obj = lm.CombinedLossMultiScale(method, sw)
+    loss = obj(None, None, {"synth_target_ms": s_dev, "warped_target_ms": [w.to(gpu_device) for w in warped_ms],
+                            "target": target.to(gpu_device)})
+    frac_close(loss.reshape(-1), loss_ref.reshape(-1), 2e-5, rtol=2e-4, what=f"cmb{method}")
+    loss.sum().backward()
+    for a, b in zip(s_dev, s_ref):
+        scale = float(b.grad.abs().max())
+        # pixels where static ~ flow loss flip the mask under fp32 rounding
+        frac_close(a.grad, b.grad, 2e-4 * scale, rtol=2e-3, max_bad_frac=2e-3, what=f"d cmb{method}")
+
+
+def _train(mode, dtype, net_names, loss_weights, steps=6, hw=(64, 128)):
+    from xpt_mde_2021_amd.model import model_main as mm
+    from xpt_mde_2021_amd.model import train_val as tv
+    opts.CONV_DTYPE = dtype
+    torch.manual_seed(0)
+    dataset, cfg, _ = mm.get_dataset("synthetic", "train", True)
+    model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, loss_weights, opts.SCALE_WEIGHT_T1,
+                                                                  net_names, ckpt_name="__test__")
+    trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, False, None, optimizer)
+    feats = dataset.batches[0]
+    hist, types = [], None
+    model.before = {name: [p.detach().clone() for p in net.parameters()] for name, net in model.models.items()}
+    for _ in range(steps):
+        _, loss, by_type = trainer.run_a_batch(feats)
+        hist.append(float(loss))
+        types = {k: float(v) for k, v in by_type.items()}
+    if mode == "graph":
+        assert not trainer._graph.eager_fallback
+    return hist, types, model, optimizer
+
+
+@pytest.fixture
+def small_shapes():
+    saved = (opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE, dict(opts.IMAGE_SIZES))
+    opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 2
+    opts.IMAGE_SIZES["kitti_raw"] = (64, 128)
+    yield
+    opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
+    opts.IMAGE_SIZES.clear()
+    opts.IMAGE_SIZES.update(saved[3])
+
+
+def test_flow_net_trains(gpu_device, small_shapes):
+    """FLOW_NET with LOSS_FLOW (flowL2 + flow_reg, config-example.py:110-113): eager == hipGraph, loss decreases, the
+    L2 term reports sum(w^2) / 2 and its gradient reaches the weights through the optimizer."""
+    losses = {}
+    for mode, dtype in (("eager", "fp32"), ("graph", "fp32"), ("graph", "bf16")):
+        hist, types, model, optimizer = _train(mode, dtype, opts.FLOW_NET, opts.LOSS_FLOW)
+        assert all(np.isfinite(hist)), (mode, dtype, hist)
+        # the first update moves the (initially ~1e-6) flows off the exact pixel grid, which flips the sampler's border
+        # validity and so the number of pixels that count: judge the descent from the third step on
+        assert hist[-1] < hist[3] < hist[2], (mode, dtype, hist)
+        assert set(types) == {"flowL2", "flow_reg"}
+        want = sum(float(p.detach().float().square().sum()) for p in model.weights_to_regularize()) / 2
+        assert abs(types["flow_reg"] - want) < 2e-3 * want, (types, want)     # the value before the last update
+        losses[(mode, dtype)] = hist
+    a, b, c = losses[("eager", "fp32")], losses[("graph", "fp32")], losses[("graph", "bf16")]
+    assert abs(a[0] - b[0]) < 1e-5 * abs(a[0]) and abs(a[-1] - b[-1]) < 2e-3 * abs(a[-1]), (a, b)
+    assert abs(a[0] - c[0]) < 5e-2 * abs(a[0]), (a, c)
+
+
+def test_joint_net_step_with_combined_loss(gpu_device, small_shapes):
+    """JOINT_NET (DepthNet + PoseNet + PWCNet) with the mono part of LOSS_RIGID_COMB (config-example.py:90-96): the
+    flow net only gates the static loss (no gradient reaches it), depth / pose nets learn; eager == hipGraph."""
+    weights = {"cmbL1": 5.0, "cmbSSIM": 0.5, "smoothe": 1.0}
+    losses = {}
+    for mode in ("eager", "graph"):
+        hist, types, model, optimizer = _train(mode, "fp32", opts.JOINT_NET, weights)
+        # not a descent test: with an untrained flow net every pixel whose static loss improves below the flow loss
+        # ENTERS the masked mean, so the combined loss may grow while the static loss falls
+        assert all(np.isfinite(hist)), (mode, hist)
+        assert set(types) == set(weights)
+        moved = {name: max(float((p.detach() - q).abs().max()) for p, q in zip(net.parameters(), model.before[name]))
+                 for name, net in model.models.items()}
+        assert moved["depthnet"] > 0 and moved["posenet"] > 0 and moved["flownet"] == 0, moved
+        losses[mode] = hist
+    a, b = losses["eager"], losses["graph"]
+    assert abs(a[0] - b[0]) < 1e-5 * abs(a[0]) and abs(a[-1] - b[-1]) < 5e-3 * abs(a[-1]), (a, b)

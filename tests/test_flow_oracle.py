@@ -1,0 +1,116 @@
+"""FlowNet branch, CPU side: the oracle against the reference's known-answer tests, the host-side torch
+paths of the product (used for CPU tensors) against the oracle, PWCNet's structure and the optimizer's L2 term."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_flow
+
+
+def test_warp_simple_known_answer():
+    """flow_net.py:225-262 (test_warp_simple): for a constant flow dense_image_warp == FlowBilinearInterpolation ==
+    the hand-interpolated image in the interior [ceil(dy):, ceil(dx):]."""
+    g = torch.Generator().manual_seed(7)
+    batch, height, width, channel = 2, 20, 30, 3
+    im = torch.rand((batch, height, width, channel), generator=g) * 4 - 2
+    dy, dx = 3.5, 1.5
+    dyd, dyu, dxd, dxu = int(np.floor(dy)), int(np.ceil(dy)), int(np.floor(dx)), int(np.ceil(dx))
+    warp_vu = torch.stack([torch.full((batch, height, width), dy), torch.full((batch, height, width), dx)], dim=-1)
+    warp_uv = torch.stack([torch.full((batch, height, width), dx), torch.full((batch, height, width), dy)], dim=-1)
+    warp_tfa = ref_flow.dense_image_warp(im, warp_vu)
+    warp_ian = ref_flow.flow_bilinear_interpolation(im, warp_uv)
+    im_np = im[1, :, :, 1].numpy()
+    temp = (im_np[:-dyu, :-dxu] + im_np[1:-dyd, :-dxu] + im_np[:-dyu, 1:-dxd] + im_np[1:-dyd, 1:-dxd]) / 4.
+    manual = np.zeros((height, width), dtype=np.float32)
+    manual[dyu:, dxu:] += temp
+    assert np.allclose(warp_tfa[1, dyu:, dxu:, 1].numpy(), warp_ian[1, dyu:, dxu:, 1].numpy(), atol=1e-6)
+    assert np.allclose(manual[dyu:, dxu:], warp_ian[1, dyu:, dxu:, 1].numpy(), atol=1e-6)
+    # outside the interior the two samplers differ by design: zeros (reference sampler) vs the replicated border (tfa)
+    assert torch.all(warp_ian[:, :dyd, :, :] == 0)
+    assert torch.allclose(warp_tfa[:, 0, dxu:, :], warp_tfa[:, dyd, dxu:, :])
+
+
+@pytest.mark.parametrize("level,channels", [(2, 81), (3, 81), (4, 81), (5, 81), (6, 25)])
+def test_correlation_channel_counts(level, channels):
+    """flow_net.py:204-222 (test_correlation): max_displacement = 128 >> level, stride_2 = max(md // 4, 1)."""
+    md = 128 // 2 ** level
+    stride_2 = max(md // 4, 1)
+    g = torch.Generator().manual_seed(level)
+    cl, cr = torch.rand((1, 6, 9, 5), generator=g), torch.rand((1, 6, 9, 5), generator=g)
+    corr = ref_flow.correlation_cost(cl, cr, md, stride_2)
+    assert corr.shape == (1, 6, 9, channels)
+    rad = md // stride_2
+    centre = rad * (2 * rad + 1) + rad
+    assert torch.allclose(corr[..., centre], (cl * cr).mean(dim=-1))                 # zero displacement
+    if level == 6:                                                                    # (dy, dx) = (-2, 1) by hand
+        t = (0 * 5) + (rad + 1)
+        want = (cl[0, 3, 4] * cr[0, 1, 5]).mean()
+        assert torch.allclose(corr[0, 3, 4, t], want)
+        assert corr[0, 0, 4, t] == 0                                                  # row -2: zero padding
+
+
+def test_host_paths_match_oracle():
+    """The torch paths the product takes for CPU tensors (structure tests, gloo ranks) restate the same operators."""
+    from xpt_mde_2021_amd.model.build_model import flow_net as fn
+    g = torch.Generator().manual_seed(3)
+    cl, cr = torch.randn((2, 7, 10, 12), generator=g), torch.randn((2, 7, 10, 12), generator=g)
+    for md, s2 in ((2, 1), (4, 1), (8, 2)):
+        got = fn.correlation_cost(cl.permute(0, 3, 1, 2), cr.permute(0, 3, 1, 2), md, s2).permute(0, 2, 3, 1)
+        assert torch.allclose(got, ref_flow.correlation_cost(cl, cr, md, s2), atol=1e-6)
+    flow = torch.randn((2, 7, 10, 2), generator=g) * 4                               # well past the borders
+    got = fn.dense_image_warp(cl.permute(0, 3, 1, 2), flow.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    assert torch.allclose(got, ref_flow.dense_image_warp(cl, flow), atol=1e-5)
+
+
+def test_pwcnet_structure():
+    """flow_net.py:19-50: two encoders, five estimators, context network; flow_ms = [flow2..flow5] as
+    [batch, numsrc, H/2^p, W/2^p, 2]; sizes must be divisible by 64."""
+    from xpt_mde_2021_amd.model.build_model.model_factory import ModelFactory
+    from xpt_mde_2021_amd.utils.util_class import WrongInputException
+    model = ModelFactory({"imshape": (5, 64, 128, 3)}, global_batch=1, net_names={"flow": "PWCNet"}).get_model()
+    net = model.models["flownet"]
+    # conv kernels + biases: 2 encoders x 18 convs, estimators 5 x 6 convs (+ 4 x 2 transposed), context 7
+    params = list(net.parameters())
+    assert len(params) == 2 * (2 * 18 + 5 * 6 + 4 * 2 + 7)
+    assert [net.corr_channels(p) for p in (2, 3, 4, 5, 6)] == [81, 81, 81, 81, 25]
+    assert net.flow5.convs[0].conv.in_channels == 81 + 128 + 2 + 2
+    assert net.flow2.last.conv.in_channels == 81 + 32 + 4 + 128 + 128 + 96 + 64
+    assert [c.conv.dilation[0] for c in net.context] == [1, 2, 4, 8, 16, 1, 1]
+    out = model({"image5d": torch.rand(1, 5, 64, 128, 3) * 2 - 1})
+    assert [tuple(f.shape) for f in out["flow_ms"]] == [(1, 4, 16, 32, 2), (1, 4, 8, 16, 2), (1, 4, 4, 8, 2), (1, 4, 2, 4, 2)]
+    assert model.weights_to_regularize() is not None and len(model.weights_to_regularize()) == len(params)
+    with pytest.raises(WrongInputException):
+        net(torch.rand(1, 5, 64, 96, 3))
+
+
+def test_same_padding_with_dilation():
+    """Conv2D(padding="same", dilation_rate=d) keeps the size; pad = d (k - 1) / 2 per side for k = 3."""
+    from xpt_mde_2021_amd.model.model_util import layer_ops as lo
+    assert lo.same_pad(13, 3, 1, 16) == (16, 16)
+    assert lo.same_pad(8, 3, 2) == (0, 1)
+    conv = lo.CustomConv2D(activation="linear")(3, 4, 3, dilation_rate=4)
+    x = torch.randn(1, 3, 9, 11)
+    assert conv(x).shape == (1, 4, 9, 11)
+    ref = torch.nn.functional.conv2d(x, conv.conv.weight, conv.conv.bias, 1, 4, 4)
+    assert torch.allclose(conv(x), ref, atol=1e-6)
+
+
+def test_l2_term_in_optimizer():
+    """flow_reg (losses.py:522-533): the optimizer adds coefficient * w to the gradient of the regularised run."""
+    from xpt_mde_2021_amd.model.model_util.optimizers import KerasAdam
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(3, 5)), torch.nn.Parameter(torch.randn(7))]
+    b = [torch.nn.Parameter(torch.randn(4, 2, 3, 3)), torch.nn.Parameter(torch.randn(4))]
+    opt = KerasAdam(1e-3)
+    flat = opt.bind(a + b)
+    opt.add_l2(b, 0.25)
+    before = flat.data.clone()
+    flat.grad.zero_()
+    opt.apply_gradients(zero_grad=False)
+    for p, off in zip(flat.params[:2], flat.offsets[:2]):
+        assert torch.all(flat.grad[off:off + p.numel()] == 0)
+    for p, off in zip(flat.params[2:], flat.offsets[2:]):
+        assert torch.allclose(flat.grad[off:off + p.numel()], 0.25 * before[off:off + p.numel()])
+    with pytest.raises(Exception):
+        opt.add_l2([a[0], b[1]], 1.0)
+        opt._ranges()

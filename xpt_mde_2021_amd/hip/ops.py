@@ -851,3 +851,41 @@ def conv1x1_weight_grad_deferred(dy2, x2, dst):
     _lib.check(lib.xpt_conv1x1_bwd_weight_partials(_ptr(dy2), _ptr(x2), _ptr(ws), ws.numel(), M, cout, cin, pitch_dy,
                                                    pitch_x, _stream()), "xpt_conv1x1_bwd_weight_partials")
     grad_sink.add(dst, ws, 0, cout * cin, nsplit, cout * cin)
+
+
+# ------------------------------------------------------------------------------- PWC-Net correlation cost volume
+class _CorrelationCost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, left, right, max_disp, stride2):
+        lib = _lib.load()
+        left, right = _nhwc(left, "left"), _nhwc(right, "right")
+        if left.shape != right.shape or left.dtype != right.dtype:
+            raise _lib.XptHipError(f"correlation_cost: left {tuple(left.shape)} {left.dtype} vs right "
+                                   f"{tuple(right.shape)} {right.dtype}")
+        B, C, H, W = left.shape
+        DD = lib.xpt_corr_cost_channels(max_disp, stride2)
+        out = torch.empty((B, DD, H, W), dtype=left.dtype, device=left.device, memory_format=torch.channels_last)
+        dt = 0 if left.dtype == torch.float32 else 1
+        _lib.check(lib.xpt_corr_cost_fwd(_ptr(left), _ptr(right), _ptr(out), B, H, W, C, max_disp, stride2, dt, _stream()),
+                   "xpt_corr_cost_fwd")
+        ctx.save_for_backward(left, right)
+        ctx.cfg = (max_disp, stride2, dt)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = _lib.load()
+        left, right = ctx.saved_tensors
+        max_disp, stride2, dt = ctx.cfg
+        B, C, H, W = left.shape
+        gout = _nhwc(gout.to(left.dtype), "gout")
+        dleft, dright = torch.empty_like(left), torch.empty_like(right)       # channels_last like the inputs
+        _lib.check(lib.xpt_corr_cost_bwd(_ptr(left), _ptr(right), _ptr(gout), _ptr(dleft), _ptr(dright), B, H, W, C,
+                                         max_disp, stride2, dt, _stream()), "xpt_corr_cost_bwd")
+        return dleft, dright, None, None
+
+
+def correlation_cost(left, right, max_disp, stride2):
+    """tfa.layers.CorrelationCost(kernel_size=1, max_displacement, stride_1=1, stride_2, pad=max_displacement) on
+    NCHW-indexed (channels_last) feature maps -> [B, (2 (max_disp // stride2) + 1)^2, H, W]  (flow_net.py:181-196)."""
+    return _CorrelationCost.apply(left, right, int(max_disp), int(stride2))

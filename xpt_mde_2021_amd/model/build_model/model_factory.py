@@ -6,6 +6,7 @@ from ...utils import util_funcs as uf
 from ...utils.util_class import WrongInputException
 from ..model_util import layer_ops as lo
 from . import depth_net as dn
+from . import flow_net as fn
 from . import model_wrappers as mw
 from . import pose_net as pn
 
@@ -37,7 +38,7 @@ class ModelFactory:
         if "camera" in self.net_names:
             models["posenet"] = self.pose_net_factory(self.net_names["camera"], self.conv2d_factory(opts.POSE_CONV_ARGS))
         if "flow" in self.net_names and self.net_names.get("flow"):
-            print("[ModelFactory] FlowNet (PWCNet) is outside this build's hot path: skipped")
+            models["flownet"] = self.flow_net_factory(self.net_names["flow"], self.conv2d_factory(opts.FLOW_CONV_ARGS))
 
         if ("stereo_T_LR" in self.dataset_cfg) and ("depth" in self.net_names):
             return mw.StereoPoseModelWrapper(models)
@@ -76,6 +77,12 @@ class ModelFactory:
         if net_name == "PoseNetImproved":
             return pn.PoseNetImproved(self.bshwc_shape, self.global_batch, conv2d_p, self.high_res)
         raise WrongInputException("[pose_net_factory] pose net outside this build's hot path: " + net_name)
+
+    def flow_net_factory(self, net_name, conv2d_f):
+        """model_factory.py:126-131."""
+        if net_name == "PWCNet":
+            return fn.PWCNet(self.bshwc_shape, self.global_batch, conv2d_f)
+        raise WrongInputException("[flow_net_factory] wrong flow net name: " + net_name)
 
 
 class InverseSigmoidActivation:

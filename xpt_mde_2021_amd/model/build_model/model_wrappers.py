@@ -94,6 +94,8 @@ class ModelWrapper:
             outputs["depth_gt" + suffix].append(features["depth_gt" + suffix].cpu().numpy())
             outputs["depth" + suffix].append(predictions["depth_ms" + suffix][0].float().cpu().numpy())
             outputs["intrinsic" + suffix].append(features["intrinsic" + suffix].cpu().numpy())
+        if "flow" + suffix in outputs:                                       # model_wrappers.py:72-78 (no flow_gt yet)
+            outputs["flow" + suffix].append(predictions["flow_ms" + suffix][0].float().cpu().numpy())
         return outputs
 
     def set_trainable(self, name, trainable):
@@ -106,6 +108,9 @@ class ModelWrapper:
         return [p for model in self.models.values() for p in model.parameters() if p.requires_grad]
 
     def weights_to_regularize(self):
+        """model_wrappers.py:95-99: the FlowNet's trainable weights (for the flow_reg L2 term), else None."""
+        if "flownet" in self.models:
+            return [p for p in self.models["flownet"].parameters() if p.requires_grad]
         return None
 
     def save_weights(self, ckpt_dir_path, suffix):

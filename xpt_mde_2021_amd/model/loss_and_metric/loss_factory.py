@@ -5,8 +5,6 @@ from ...config import opts
 from ...utils.util_class import WrongInputException
 from . import losses as lm
 
-_OUT_OF_SCOPE = ("cmbL1", "cmbL1_R", "cmbSSIM", "cmbSSIM_R", "flowL2", "flowL2_R", "flow_reg")
-
 
 def loss_factory(dataset_cfg, loss_weights, scale_weights, stereo=None, weights_to_regularize=None, batch_size=None):
     """Builds TotalLoss from a {name: weight} dict.  Zero-weight losses and losses whose dataset keys are missing
@@ -30,8 +28,14 @@ def loss_factory(dataset_cfg, loss_weights, scale_weights, stereo=None, weights_
             return lm.StereoDepthLoss(name[6:], sw)
         if name == "stereoPose":
             return lm.StereoPoseLoss()
-        if name in _OUT_OF_SCOPE:
-            raise WrongInputException(f"loss '{name}' needs FlowNet, which is outside this build's hot path")
+        if base in ("cmbL1", "cmbSSIM"):
+            return lm.CombinedLossMultiScale(base[3:], sw, key_suffix=sfx)
+        if base == "flowL2":
+            return lm.FlowWarpLossMultiScale("L2", sw, key_suffix=sfx)
+        if name == "flow_reg":
+            if not weights_to_regularize:
+                raise WrongInputException("loss 'flow_reg' needs a FlowNet in the model (weights_to_regularize is empty)")
+            return lm.L2Regularizer(weights_to_regularize)
         raise WrongInputException(f"unknown loss name '{name}'")
 
     losses, weights = dict(), dict()
@@ -48,8 +52,9 @@ def loss_factory(dataset_cfg, loss_weights, scale_weights, stereo=None, weights_
 
 
 _DEPENDENCY = [
-    (("L1", "SSIM", "smoothe", "md2L1", "md2SSIM", "flowL2", "flow_reg"), ("image", "intrinsic")),
-    (("L1_R", "SSIM_R", "smoothe_R", "md2L1_R", "md2SSIM_R", "flowL2_R"), ("image_R", "intrinsic_R")),
+    (("L1", "SSIM", "smoothe", "md2L1", "md2SSIM", "cmbL1", "cmbSSIM", "flowL2", "flow_reg"), ("image", "intrinsic")),
+    (("L1_R", "SSIM_R", "smoothe_R", "md2L1_R", "md2SSIM_R", "cmbL1_R", "cmbSSIM_R", "flowL2_R"),
+     ("image_R", "intrinsic_R")),
     (("stereoL1", "stereoSSIM", "stereoPose", "moaL1", "moaSSIM", "moaL1_R", "moaSSIM_R"),
      ("image", "intrinsic", "image_R", "intrinsic_R", "stereo_T_LR")),
 ]

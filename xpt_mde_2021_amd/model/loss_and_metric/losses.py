@@ -3,7 +3,7 @@
 orchestration of losses.py:26-140 (which tensors are synthesized, how scales / types are merged).
 
 In scope: L1, SSIM, smoothe (+ _R), stereoL1, stereoSSIM, stereoPose, and the "next" row
-md2*/moa* min-over-sources variants.  The flow-aided losses (cmb*, flowL2, flow_reg) need FlowNet: out of scope.
+md2*/moa* min-over-sources variants and the flow-aided losses (cmb*, flowL2, flow_reg; losses.py:235-279, 497-533).
 """
 import numpy as np
 import torch
@@ -13,6 +13,7 @@ from ...hip import ops as _ops
 from ...utils import convert_pose as cp
 from ...utils import util_funcs as uf
 from ...utils.util_class import WrongInputException
+from ..synthesize.flow_warping import FlowWarpMultiScale
 from ..synthesize.synthesize_base import SynthesizeMultiScale
 from . import loss_util as lsu
 
@@ -112,6 +113,11 @@ class TotalLoss:
             else:
                 augm_data["synth_target_ms" + suffix] = SynthesizeMultiScale()(source_image, intrinsic,
                                                                                 pred_depth_ms, pred_pose)
+        if "flow_ms" + suffix in predictions:                     # losses.py:94-101
+            pred_flow_ms = predictions["flow_ms" + suffix]
+            # flows have a lower resolution than the depths: the targets are resized like the flows
+            augm_data["flow_target_ms" + suffix] = uf.multi_scale_like_flow(target_image, pred_flow_ms)
+            augm_data["warped_target_ms" + suffix] = FlowWarpMultiScale()(source_image, pred_flow_ms)
         return augm_data
 
     def synethesize_stereo(self, features, predictions, augm_data):
@@ -213,6 +219,54 @@ class MonoDepth2LossMultiScale(PhotometricLoss):
             loss = torch.min(loss, dim=1).values
             losses.append(torch.mean(loss, dim=[1, 2, 3]))
         return self.merge_multi_scale_losses(losses)
+
+
+class CombinedLossMultiScale(PhotometricLoss):
+    """losses.py:235-279: the static (depth + pose) per-pixel loss counts only where it is BELOW the optical-flow
+    loss of the finest flow scale (both compared at the original resolution); mean over everything."""
+
+    def __call__(self, features, predictions, augm_data):
+        synth_ms = augm_data["synth_target_ms" + self.key_suffix]
+        warped_ms = augm_data["warped_target_ms" + self.key_suffix]
+        original_target = augm_data["target" + self.key_suffix]
+        Ho, Wo = original_target.shape[1:3]
+        flow_loss = self.photometric_loss(resize_bilinear(warped_ms[0], (Ho, Wo)), original_target, False)
+        losses = []
+        for synt in synth_ms:
+            static_loss = self.photometric_loss(resize_bilinear(synt, (Ho, Wo)), original_target, False)
+            mask = (static_loss < flow_loss).to(static_loss.dtype)          # tf.cast(static < flow): no gradient
+            losses.append(torch.mean(static_loss * mask, dim=[1, 2, 3, 4]))
+        return self.merge_multi_scale_losses(losses)
+
+
+class FlowWarpLossMultiScale(PhotometricLoss):
+    """losses.py:497-519: photometric loss between the flow-warped sources and the target at every flow scale."""
+
+    def __call__(self, features, predictions, augm_data):
+        flow_target_ms = augm_data["flow_target_ms" + self.key_suffix]
+        warped_target_ms = augm_data["warped_target_ms" + self.key_suffix]
+        losses = [self.photometric_loss(warp, orig) for warp, orig in zip(warped_target_ms, flow_target_ms)]
+        return self.merge_multi_scale_losses(losses)
+
+
+class L2Regularizer(LossBase):
+    """losses.py:522-533: sum over the given weights of tf.nn.l2_loss(w) = sum(w^2) / 2, tiled to [batch].
+
+    The VALUE is computed here (two multi-tensor launches over the ~110 FlowNet weights); its gradient, weight * w, is
+    added to the flat gradient buffer by the optimizer (`KerasAdam.add_l2`, wired up in
+    model_main.create_training_parts) in one launch instead of ~110 per-weight autograd nodes -- and because the
+    deferred parameter gradients (hip/ops.py GradSink) are written, not accumulated, into that buffer."""
+
+    def __init__(self, weights_to_regularize):
+        self.weights = list(weights_to_regularize)
+        self.scale_weights = None
+
+    def __call__(self, features, predictions, augm_data):
+        with torch.no_grad():
+            norms = torch._foreach_norm([w.detach() for w in self.weights])
+            loss = torch.stack(norms).float().square().sum() * 0.5
+        batch = features["image5d"].shape[0]
+        return loss.reshape(1).expand(batch)
 
 
 class MoALossMultiScale(PhotometricLoss):

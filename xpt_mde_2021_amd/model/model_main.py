@@ -94,6 +94,8 @@ def create_training_parts(initial_epoch, tfr_config, learning_rate, loss_weights
     loss_object = loss_factory(tfr_config, loss_weights, scale_weights, opts.STEREO,
                                weights_to_regularize=model.weights_to_regularize(), batch_size=opts.BATCH_SIZE)
     optimizer = optimizer_factory(opts.OPTIMIZER, learning_rate, initial_epoch)
+    if "flow_reg" in loss_object.loss_weights:       # gradient of the L2 regulariser: one launch in the optimizer
+        optimizer.add_l2(model.weights_to_regularize(), loss_object.loss_weights["flow_reg"])
     return model, augmenter, loss_object, optimizer
 
 

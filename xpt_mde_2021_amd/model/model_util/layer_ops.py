@@ -13,9 +13,9 @@ import torch.nn.functional as F
 from ...hip import ops as _ops
 
 
-def same_pad(n, k, s):
-    """TF "SAME": total = max((ceil(n/s) - 1) * s + k - n, 0); before = total // 2, after = the rest."""
-    total = max((math.ceil(n / s) - 1) * s + k - n, 0)
+def same_pad(n, k, s, d=1):
+    """TF "SAME": total = max((ceil(n/s) - 1) * s + k_eff - n, 0), k_eff = (k - 1) d + 1; before = total // 2, after = the rest."""
+    total = max((math.ceil(n / s) - 1) * s + (k - 1) * d + 1 - n, 0)
     return total // 2, total - total // 2
 
 
@@ -39,30 +39,30 @@ class _ConvFp32WeightGrad(torch.autograd.Function):
     for that one call (the gradient is wanted in fp32 for the flat Adam buffers anyway)."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, compute_dtype):
+    def forward(ctx, x, weight, stride, padding, compute_dtype, dilation=1):
         w = _low_precision_weight(weight, compute_dtype)
         xc = x.to(compute_dtype)
         with torch.autocast(device_type=x.device.type, enabled=False):
-            y = F.conv2d(xc, w, None, stride, padding)
+            y = F.conv2d(xc, w, None, stride, padding, dilation)
         ctx.save_for_backward(xc, weight)
-        ctx.cfg = (stride, padding, compute_dtype)
+        ctx.cfg = (stride, padding, compute_dtype, dilation)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xc, weight = ctx.saved_tensors
-        stride, padding, compute_dtype = ctx.cfg
-        s2, p2 = [stride, stride], list(padding)
+        stride, padding, compute_dtype, dilation = ctx.cfg
+        s2, p2, d2 = [stride, stride], list(padding), [dilation, dilation]
         dx = dw = None
         with torch.autocast(device_type=dy.device.type, enabled=False):
             if ctx.needs_input_grad[0]:
                 dx = torch.ops.aten.convolution_backward(dy.to(compute_dtype), xc,
                                                          _low_precision_weight(weight, compute_dtype), None, s2, p2,
-                                                         [1, 1], False, [0, 0], 1, [True, False, False])[0]
+                                                         d2, False, [0, 0], 1, [True, False, False])[0]
             if ctx.needs_input_grad[1]:
-                dw = torch.ops.aten.convolution_backward(dy.float(), xc.float(), weight.float(), None, s2, p2, [1, 1],
+                dw = torch.ops.aten.convolution_backward(dy.float(), xc.float(), weight.float(), None, s2, p2, d2,
                                                          False, [0, 0], 1, [False, True, False])[1]
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
 def _low_precision_weight(weight, dtype):
@@ -73,22 +73,24 @@ def _low_precision_weight(weight, dtype):
     return weight.to(dtype)
 
 
-def conv2d_library(x, weight, stride, padding):
+def conv2d_library(x, weight, stride, padding, dilation=1):
     """Dense (groups = 1) convolution without bias through MIOpen; see _ConvFp32WeightGrad for the backward."""
     if x.is_cuda and torch.is_autocast_enabled():
         return _ConvFp32WeightGrad.apply(x, weight, int(stride), (int(padding[0]), int(padding[1])),
-                                         torch.get_autocast_dtype("cuda"))
-    return F.conv2d(x, weight, None, stride, padding)
+                                         torch.get_autocast_dtype("cuda"), int(dilation))
+    return F.conv2d(x, weight, None, stride, padding, dilation)
 
 
 class Conv2DSame(nn.Module):
     """keras.layers.Conv2D(filters, k, strides, padding="same", activation=...) on NCHW tensors."""
 
     def __init__(self, in_channels, filters, kernel_size=3, strides=1, activation="leaky_relu", activation_param=0.1,
-                 kernel_initializer="truncated_normal", kernel_initializer_param=0.025, use_bias=True, groups=1):
+                 kernel_initializer="truncated_normal", kernel_initializer_param=0.025, use_bias=True, groups=1,
+                 dilation_rate=1):
         super().__init__()
-        self.k, self.s = int(kernel_size), int(strides)
-        self.conv = nn.Conv2d(in_channels, filters, self.k, self.s, padding=0, bias=use_bias, groups=groups)
+        self.k, self.s, self.d = int(kernel_size), int(strides), int(dilation_rate)
+        self.conv = nn.Conv2d(in_channels, filters, self.k, self.s, padding=0, dilation=self.d, bias=use_bias,
+                              groups=groups)
         self.act = make_activation(activation, activation_param)
         # negative-side slope of the activation for the fused epilogue (1 = linear, 0 = ReLU)
         self.slope = {None: 1.0, "linear": 1.0, "relu": 0.0,
@@ -104,8 +106,8 @@ class Conv2DSame(nn.Module):
             nn.init.zeros_(self.conv.bias)
 
     def forward(self, x):
-        ph = same_pad(x.shape[2], self.k, self.s)
-        pw = same_pad(x.shape[3], self.k, self.s)
+        ph = same_pad(x.shape[2], self.k, self.s, self.d)
+        pw = same_pad(x.shape[3], self.k, self.s, self.d)
         # on the GPU the bias add + activation (and the bias gradient) run in one gfx950 epilogue kernel
         fused = x.is_cuda and self.conv.bias is not None and self.slope is not None
         bias = None if fused else self.conv.bias
@@ -113,9 +115,9 @@ class Conv2DSame(nn.Module):
             x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
             ph, pw = (0, 0), (0, 0)
         if fused and self.conv.groups == 1:
-            y = conv2d_library(x, self.conv.weight, self.s, (ph[0], pw[0]))
+            y = conv2d_library(x, self.conv.weight, self.s, (ph[0], pw[0]), self.d)
         else:
-            y = F.conv2d(x, self.conv.weight, bias, self.s, (ph[0], pw[0]), 1, self.conv.groups)
+            y = F.conv2d(x, self.conv.weight, bias, self.s, (ph[0], pw[0]), self.d, self.conv.groups)
         if fused:
             return _ops.bias_act(y, self.conv.bias, self.slope)
         return self.act(y)
@@ -134,12 +136,12 @@ class CustomConv2D:
         self.kernel_initializer = kernel_initializer
         self.kernel_initializer_param = kernel_initializer_param
 
-    def __call__(self, in_channels, filters, kernel_size=None, strides=None, activation=None, name=""):
+    def __call__(self, in_channels, filters, kernel_size=None, strides=None, activation=None, name="", dilation_rate=1):
         return Conv2DSame(in_channels, filters,
                           self.kernel_size if kernel_size is None else kernel_size,
                           self.strides if strides is None else strides,
                           self.activation if activation is None else activation, self.activation_param,
-                          self.kernel_initializer, self.kernel_initializer_param)
+                          self.kernel_initializer, self.kernel_initializer_param, dilation_rate=dilation_rate)
 
 
 def resize_image(src, dst_height, dst_width):

@@ -83,6 +83,31 @@ class KerasAdam:
         self.lr, self.b1, self.b2, self.eps = float(learning_rate), beta_1, beta_2, epsilon
         self.flat = None
         self.m = self.v = self.step_count = None
+        self.l2_terms = []            # (parameters, coefficient): gradient coefficient * w added before the update
+        self._l2_ranges = None
+
+    def add_l2(self, params, coefficient):
+        """Gradient of coefficient * sum_w l2_loss(w) (= coefficient * w) for a run of parameters that is contiguous in
+        the flat buffers (one network): added to the flat gradient by ONE launch per step, just before the update
+        (the `flow_reg` loss, losses.py:522-533; its value is reported by L2Regularizer)."""
+        params = [p for p in params if p.requires_grad]
+        if params and coefficient:
+            self.l2_terms.append((params, float(coefficient)))
+            self._l2_ranges = None
+
+    def _ranges(self):
+        if self._l2_ranges is None:
+            f = self.flat
+            index = {id(p): i for i, p in enumerate(f.params)}
+            ranges = []
+            for params, coef in self.l2_terms:
+                idx = sorted(index[id(p)] for p in params)
+                if idx != list(range(idx[0], idx[0] + len(idx))):
+                    raise WrongInputException("add_l2: the parameters are not a contiguous run of the flat buffer")
+                last = f.params[idx[-1]]
+                ranges.append((f.offsets[idx[0]], f.offsets[idx[-1]] + last.numel(), coef))   # alignment gaps hold zeros
+            self._l2_ranges = ranges
+        return self._l2_ranges
 
     def bind(self, params):
         self.flat = params if isinstance(params, FlatParameters) else FlatParameters(list(params))
@@ -95,6 +120,8 @@ class KerasAdam:
         """optimizer.apply_gradients (train_val.py:86) on the flat buffers; hipGraph-capturable."""
         f = self.flat
         self.step_count += 1
+        for a, b, coef in self._ranges():
+            f.grad[a:b].add_(f.data[a:b], alpha=coef / float(grad_scale))
         if f.data.is_cuda:
             lib = _lib.load()
             _lib.check(lib.xpt_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),

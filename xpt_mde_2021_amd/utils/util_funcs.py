@@ -61,6 +61,20 @@ def multi_scale_like_depth(image, depth_ms):
     return out
 
 
+def resize_like_size(image, hs, ws):
+    """TF2 bilinear resize of input images [M,H,W,3] (no gradient) to (hs, ws): the gfx950 pyramid kernel for exact even
+    integer down-scales of device images, the generic resize otherwise."""
+    H, W = image.shape[1:3]
+    if image.is_cuda and H % hs == 0 and W % ws == 0 and H // hs == W // ws and (H // hs == 1 or (H // hs) % 2 == 0):
+        return _ops.resize_down(image, H // hs)
+    return resize_bilinear_tf(image, (hs, ws))
+
+
+def multi_scale_like_flow(image, flow_ms):
+    """util_funcs.py:178-190: image [B,H,W,3] resized to the resolution of every flow [B,N,h,w,2]."""
+    return [resize_like_size(image, flow.shape[2], flow.shape[3]) for flow in flow_ms]
+
+
 def read_tfrecords_info(dataset_dir):
     """util_funcs.py:112-116."""
     with open(op.join(opts.DATAPATH_TFR, dataset_dir, "tfr_config.txt"), "r") as fr:
