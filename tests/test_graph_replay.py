@@ -15,19 +15,21 @@ from xpt_mde_2021_amd.config import opts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
-def test_graph_replays_match_eager(gpu_device, dtype):
+@pytest.mark.parametrize("nets,dtype", [("rigid", "bf16"), ("rigid", "fp32"), ("flow", "bf16")])
+def test_graph_replays_match_eager(gpu_device, nets, dtype):
     from xpt_mde_2021_amd.model import model_main as mm
     from xpt_mde_2021_amd.model import train_val as tv
     saved = (opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE, dict(opts.IMAGE_SIZES))
     opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 8           # the benchmark shape: the failure needs PoseNet's 4x13 / 2x7 maps
-    opts.IMAGE_SIZES["kitti_raw"] = (128, 416)
+    # (PWC-Net: the 2x6 ... 8x24 pyramid levels at 128x384 -- its sizes must be divisible by 64)
+    opts.IMAGE_SIZES["kitti_raw"] = (128, 416) if nets == "rigid" else (128, 384)
     opts.CONV_DTYPE = dtype
+    net_names, loss_weights = {"rigid": (opts.RIGID_NET, opts.LOSS_RIGID_T1), "flow": (opts.FLOW_NET, opts.LOSS_FLOW)}[nets]
     try:
         torch.manual_seed(0)
         dataset, cfg, _ = mm.get_dataset("synthetic", "train", True)
-        model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, opts.LOSS_RIGID_T1,
-                                                                      opts.SCALE_WEIGHT_T1, opts.RIGID_NET,
+        model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, loss_weights,
+                                                                      opts.SCALE_WEIGHT_T1, net_names,
                                                                       ckpt_name="__test__")
         trainer, _ = tv.train_val_factory("eager", model, loss_object, 0, False, None, optimizer)   # no random augmentation
         flat = optimizer.flat

@@ -19,6 +19,7 @@ import torch.nn.functional as F
 
 from ...hip import ops as _ops
 from ...utils.util_class import WrongInputException
+from ..model_util import layer_ops as lo
 
 
 def correlation_cost(cl, cr, max_disp, stride2):
@@ -48,6 +49,24 @@ def dense_image_warp(image, flow):
     return out.to(image.dtype)
 
 
+class _UpConvFp32(torch.autograd.Function):
+    """conv_transpose2d(x, W, stride 2, padding 1) in fp32 with a replay-safe weight gradient: the transposed
+    convolution is the adjoint of z = conv2d(u, W, stride 2, padding 1), so dW is that convolution's weight gradient
+    with (dz, u) = (x, dy) -- one GEMM on the unfolded dy (layer_ops.unfolded_weight_grad)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.conv_transpose2d(x, weight, None, 2, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx = F.conv2d(dy, weight, None, 2, 1) if ctx.needs_input_grad[0] else None
+        dw = lo.unfolded_weight_grad(x, dy, weight.shape, 2, 1, 1) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
 class _UpConv(nn.Module):
     """layers.Conv2DTranspose(filters, kernel_size=4, strides=2, padding="same") (flow_net.py:145-148): with k = 4, s = 2
     TF's SAME padding is symmetric (1, 1), i.e. exactly conv_transpose2d(padding=1); Keras defaults: bias, linear,
@@ -62,7 +81,7 @@ class _UpConv(nn.Module):
 
     def forward(self, x):
         with torch.autocast(device_type=x.device.type, enabled=False):
-            y = F.conv_transpose2d(x.float(), self.weight, None, 2, 1)
+            y = _UpConvFp32.apply(x.float(), self.weight)
             if y.is_cuda:
                 return _ops.bias_act(y.contiguous(memory_format=torch.channels_last), self.bias, 1.0)
             return y + self.bias.view(1, -1, 1, 1)

@@ -29,14 +29,23 @@ def make_activation(name, param=None):
     raise ValueError(f"unknown activation {name}")
 
 
+# Weight gradients of convolutions whose output map has at most this many pixels (OH x OW) are evaluated as ONE fp32
+# GEMM on the unfolded input instead of a library weight-gradient solver (see _ConvFp32WeightGrad): PWC-Net's 2x6 and
+# 4x12 levels, PoseNet's 4x13 / 2x7 maps.  (Larger maps pass tests/test_graph_replay.py with the library solvers, and
+# unfolding them costs tens of MB per layer.)
+SMALL_MAP_AREA = 64
+
+
 class _ConvFp32WeightGrad(torch.autograd.Function):
     """Library convolution (MIOpen) whose WEIGHT gradient is always evaluated in fp32.
 
     Forward and data gradient run in the activation dtype (bf16 under autocast).  MIOpen's bf16 weight-gradient
     solvers accumulate in an fp32 workspace and cast; replayed from a hipGraph on ROCm 7.0 / torch 2.10 that path
     returns garbage from the second replay on (tests/test_graph_replay.py), and its deterministic replacements are
-    ~25x slower naive kernels.  The fp32 weight-gradient solvers are correct under replay, so x and dy are up-cast
-    for that one call (the gradient is wanted in fp32 for the flat Adam buffers anyway)."""
+    ~25x slower naive kernels.  The fp32 weight-gradient solvers are correct under replay for the larger maps, so x
+    and dy are up-cast for that one call (the gradient is wanted in fp32 for the flat Adam buffers anyway).  For SMALL
+    maps (PoseNet's and PWC-Net's 2x6 ... 8x24 levels) the fp32 solvers show the same defect (found with the 196 -> 196
+    3x3 convolution of PWC-Net's level 6 on [32, 196, 2, 6]): there dW = dy^T . unfold(x) is one rocBLAS GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight, stride, padding, compute_dtype, dilation=1):
@@ -60,9 +69,27 @@ class _ConvFp32WeightGrad(torch.autograd.Function):
                                                          _low_precision_weight(weight, compute_dtype), None, s2, p2,
                                                          d2, False, [0, 0], 1, [True, False, False])[0]
             if ctx.needs_input_grad[1]:
-                dw = torch.ops.aten.convolution_backward(dy.float(), xc.float(), weight.float(), None, s2, p2, d2,
-                                                         False, [0, 0], 1, [False, True, False])[1]
+                if dy.shape[2] * dy.shape[3] <= SMALL_MAP_AREA:
+                    dw = unfolded_weight_grad(dy, xc, weight.shape, stride, padding, dilation)
+                else:
+                    dw = torch.ops.aten.convolution_backward(dy.float(), xc.float(), weight.float(), None, s2, p2, d2,
+                                                             False, [0, 0], 1, [False, True, False])[1]
         return dx, dw, None, None, None, None
+
+
+def unfolded_weight_grad(dy, x, weight_shape, stride, padding, dilation):
+    """dW[co, ci, kh, kw] = sum_p dy[p, co] * patches(x)[p, (ci, kh, kw)] in fp32: the patches are strided VIEWS of the
+    padded input (Tensor.unfold), gathered by one copy launch, then one GEMM -- F.unfold would launch one im2col kernel
+    per batch element."""
+    cout, cin, kh, kw = weight_shape
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    xp = F.pad(x.float(), (pw, pw, ph, ph)) if (ph or pw) else x.float()
+    B, _, OH, OW = dy.shape
+    win = xp.unfold(2, (kh - 1) * dilation + 1, stride).unfold(3, (kw - 1) * dilation + 1, stride)
+    win = win[:, :, :OH, :OW, ::dilation, ::dilation]                            # [B, cin, OH, OW, kh, kw]
+    cols = win.permute(0, 2, 3, 1, 4, 5).reshape(B * OH * OW, cin * kh * kw)     # the one copy
+    dyr = dy.float().permute(0, 2, 3, 1).reshape(B * OH * OW, cout)              # a view for channels_last dy
+    return torch.mm(dyr.t(), cols).view(cout, cin, kh, kw)
 
 
 def _low_precision_weight(weight, dtype):
@@ -75,9 +102,9 @@ def _low_precision_weight(weight, dtype):
 
 def conv2d_library(x, weight, stride, padding, dilation=1):
     """Dense (groups = 1) convolution without bias through MIOpen; see _ConvFp32WeightGrad for the backward."""
-    if x.is_cuda and torch.is_autocast_enabled():
-        return _ConvFp32WeightGrad.apply(x, weight, int(stride), (int(padding[0]), int(padding[1])),
-                                         torch.get_autocast_dtype("cuda"), int(dilation))
+    if x.is_cuda:
+        dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+        return _ConvFp32WeightGrad.apply(x, weight, int(stride), (int(padding[0]), int(padding[1])), dtype, int(dilation))
     return F.conv2d(x, weight, None, stride, padding, dilation)
 
 

@@ -129,6 +129,29 @@ class ModelTrainer(TrainValBase):
     def reduce_gradients(self):
         pass
 
+    def describe_state(self, index, bad):
+        """Names the parameters behind the flagged elements of a flat state tensor (for the replay-check message)."""
+        flat = self.optimizer.flat
+        if bad.numel() != flat.numel:
+            return ""
+        import bisect
+        names = {id(q): f"{net}.{n}" for net, m in self.model.models.items() for n, q in m.named_parameters()}
+        label = ["value", "gradient", "first moment", "second moment"][index] if index < 4 else f"state {index}"
+        hits = {}
+        for off in torch.nonzero(bad.reshape(-1))[:, 0].tolist()[::max(int(bad.sum()) // 4096, 1)]:
+            i = bisect.bisect_right(flat.offsets, off) - 1
+            key = names.get(id(flat.params[i]), f"param {i}")
+            hits[key] = hits.get(key, 0) + 1
+        return f" [{label} of " + ", ".join(f"{k}{tuple(self._shape(k, names, flat))}" for k in list(hits)[:6]) + \
+               (" ..." if len(hits) > 6 else "") + "]"
+
+    @staticmethod
+    def _shape(name, names, flat):
+        for p in flat.params:
+            if names.get(id(p)) == name:
+                return p.shape
+        return ()
+
     def optimizer_state(self):
         opt = self.optimizer
         state = [opt.flat.data, opt.flat.grad, opt.m, opt.v, opt.step_count]
@@ -147,10 +170,11 @@ class ModelTrainer(TrainValBase):
 class _StepGraph:
     """Captures fn(static_features) into a hipGraph; replays it after copying a new batch into the static buffers."""
 
-    def __init__(self, fn, warmup=3, state=None):
+    def __init__(self, fn, warmup=3, state=None, describe=None):
         self.fn = fn
         self.warmup = warmup
         self.state = state                     # callable -> list of tensors the warm-up runs must not change
+        self.describe = describe               # (state index, bad-element mask) -> text for the replay-check message
         self.graph = None
         self.static_in = None
         self.static_out = None
@@ -224,6 +248,8 @@ class _StepGraph:
                     bad = ~torch.isfinite(t) | (t.abs() >= 1e8)
                     if bool(bad.any()):
                         report = f"replay {rep}: {int(bad.sum())} of {t.numel()} elements of state tensor {i} non-finite"
+                        if self.describe is not None:
+                            report += self.describe(i, bad)
             for t, s in zip(state, saved):
                 t.copy_(s)
         torch.cuda.synchronize()
@@ -234,7 +260,7 @@ class ModelTrainerGraph(ModelTrainer):
     def __init__(self, model, loss_object, steps_per_epoch, stereo, augmenter, optimizer):
         super().__init__(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
         self.set_name("Train (graph)")
-        self._graph = _StepGraph(self.train_a_step, state=self.optimizer_state)
+        self._graph = _StepGraph(self.train_a_step, state=self.optimizer_state, describe=self.describe_state)
 
     def run_a_batch(self, features):
         if not features["image5d"].is_cuda:
@@ -252,7 +278,7 @@ class ModelTrainerDistrib(ModelTrainer):
         self.strategy = DistributionStrategy.get_strategy()
         if self.strategy is not None:
             self.strategy.broadcast_parameters(self.optimizer.flat.data)
-        self._graph = _StepGraph(self.forward_backward, state=self.optimizer_state) \
+        self._graph = _StepGraph(self.forward_backward, state=self.optimizer_state, describe=self.describe_state) \
             if getattr(opts, "DISTRIB_GRAPH", True) else None
 
     def reduce_gradients(self):
