@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Which parameter gradients differ between eager execution and hipGraph replays of forward+backward?  Lists every
+parameter whose replayed gradient is non-finite or off by more than the tolerance, in network order, so that the
+deepest affected layer points at the operator whose backward misbehaves under replay.
+
+    python tools/replay_grad_diff.py [rigid|flow|joint] [fp32|bf16] [H W B] [replays]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from xpt_mde_2021_amd.config import opts  # noqa: E402
+from xpt_mde_2021_amd.model import model_main as mm, train_val as tv  # noqa: E402
+
+nets = sys.argv[1] if len(sys.argv) > 1 else "flow"
+dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+H, W, B = (int(v) for v in sys.argv[3:6]) if len(sys.argv) > 5 else (64, 128, 2)
+replays = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+net_names, loss_weights = {"rigid": (opts.RIGID_NET, opts.LOSS_RIGID_T1), "flow": (opts.FLOW_NET, opts.LOSS_FLOW),
+                           "joint": (opts.JOINT_NET, {"cmbL1": 5.0, "cmbSSIM": 0.5, "smoothe": 1.0})}[nets]
+opts.CONV_DTYPE = dtype
+opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = B
+opts.IMAGE_SIZES["kitti_raw"] = (H, W)
+torch.manual_seed(0)
+dataset, cfg, _ = mm.get_dataset("synthetic", "train", True)
+model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, loss_weights, opts.SCALE_WEIGHT_T1, net_names,
+                                                              ckpt_name="__diff__")
+trainer, _ = tv.train_val_factory("eager", model, loss_object, 0, False, None, optimizer)
+flat = optimizer.flat
+names = [(f"{net}.{n}", p) for net, m in model.models.items() for n, p in m.named_parameters() if p.requires_grad]
+feats = dataset.batches[0]
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    flat.grad.zero_()
+    _, loss, _ = trainer.forward_backward(feats)
+    ref, loss_ref = flat.grad.clone(), float(loss)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+graph = tv._StepGraph(trainer.forward_backward)
+tol = 5e-1 if dtype == "bf16" else 5e-3
+for it in range(replays):
+    flat.grad.zero_()
+    _, loss, _ = graph(feats)
+    torch.cuda.synchronize()
+    bad = []
+    for (name, p), off in zip(names, flat.offsets):
+        a, b = flat.grad[off:off + p.numel()], ref[off:off + p.numel()]
+        scale = max(float(b.abs().max()), 1e-5)
+        if not bool(torch.isfinite(a).all()):
+            bad.append(f"{name}{tuple(p.shape)}:nonfinite")
+        elif float((a - b).abs().max()) / scale > tol:
+            bad.append(f"{name}{tuple(p.shape)}:{float((a - b).abs().max()) / scale:.1e}")
+    print(f"[diff] replay {it}: loss {float(loss):.6f} (eager {loss_ref:.6f}); {len(bad)} of {len(names)} gradients off"
+          + (": " + " ".join(bad[:4]) + " ... " + " ".join(bad[-4:]) if bad else ""), flush=True)

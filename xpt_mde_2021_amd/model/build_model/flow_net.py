@@ -49,6 +49,9 @@ def dense_image_warp(image, flow):
     return out.to(image.dtype)
 
 
+_LIBRARY_UPCONV = __import__("os").environ.get("XPT_DEBUG_LIBRARY_UPCONV", "0") == "1"      # A/B switch
+
+
 class _UpConvFp32(torch.autograd.Function):
     """conv_transpose2d(x, W, stride 2, padding 1) in fp32 with a replay-safe weight gradient: the transposed
     convolution is the adjoint of z = conv2d(u, W, stride 2, padding 1), so dW is that convolution's weight gradient
@@ -81,7 +84,8 @@ class _UpConv(nn.Module):
 
     def forward(self, x):
         with torch.autocast(device_type=x.device.type, enabled=False):
-            y = _UpConvFp32.apply(x.float(), self.weight)
+            y = F.conv_transpose2d(x.float(), self.weight, None, 2, 1) if _LIBRARY_UPCONV else \
+                _UpConvFp32.apply(x.float(), self.weight)
             if y.is_cuda:
                 return _ops.bias_act(y.contiguous(memory_format=torch.channels_last), self.bias, 1.0)
             return y + self.bias.view(1, -1, 1, 1)
@@ -134,6 +138,9 @@ class PWCNet(nn.Module):
                                       conv2d(128, 128, 3, dilation_rate=4), conv2d(128, 96, 3, dilation_rate=8),
                                       conv2d(96, 64, 3, dilation_rate=16), conv2d(64, 32, 3, dilation_rate=1),
                                       conv2d(32, 2, 3, activation="linear")])
+        for m in self.modules():            # small pyramid levels: data gradients through forward solvers (layer_ops)
+            if isinstance(m, lo.Conv2DSame):
+                m.replay_safe_dgrad = True
 
     def _encoder(self, conv2d, cin):
         levels = nn.ModuleList()

@@ -33,7 +33,7 @@ def make_activation(name, param=None):
 # GEMM on the unfolded input instead of a library weight-gradient solver (see _ConvFp32WeightGrad): PWC-Net's 2x6 and
 # 4x12 levels, PoseNet's 4x13 / 2x7 maps.  (Larger maps pass tests/test_graph_replay.py with the library solvers, and
 # unfolding them costs tens of MB per layer.)
-SMALL_MAP_AREA = 64
+SMALL_MAP_AREA = int(__import__("os").environ.get("XPT_DEBUG_SMALL_MAP_AREA", "64"))     # A/B: 0 = library solvers everywhere
 
 
 class _ConvFp32WeightGrad(torch.autograd.Function):
@@ -48,33 +48,63 @@ class _ConvFp32WeightGrad(torch.autograd.Function):
     3x3 convolution of PWC-Net's level 6 on [32, 196, 2, 6]): there dW = dy^T . unfold(x) is one rocBLAS GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, padding, compute_dtype, dilation=1):
+    def forward(ctx, x, weight, stride, padding, compute_dtype, dilation=1, safe_dgrad=False):
         w = _low_precision_weight(weight, compute_dtype)
         xc = x.to(compute_dtype)
         with torch.autocast(device_type=x.device.type, enabled=False):
             y = F.conv2d(xc, w, None, stride, padding, dilation)
         ctx.save_for_backward(xc, weight)
-        ctx.cfg = (stride, padding, compute_dtype, dilation)
+        ctx.cfg = (stride, padding, compute_dtype, dilation, safe_dgrad)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         xc, weight = ctx.saved_tensors
-        stride, padding, compute_dtype, dilation = ctx.cfg
+        stride, padding, compute_dtype, dilation, safe_dgrad = ctx.cfg
         s2, p2, d2 = [stride, stride], list(padding), [dilation, dilation]
         dx = dw = None
+        small = dy.shape[2] * dy.shape[3] <= SMALL_MAP_AREA
         with torch.autocast(device_type=dy.device.type, enabled=False):
-            if ctx.needs_input_grad[0]:
+            if ctx.needs_input_grad[0] and small and safe_dgrad:
+                dx = flipped_conv_data_grad(dy.to(compute_dtype), _low_precision_weight(weight, compute_dtype),
+                                            xc.shape, stride, padding, dilation)
+            elif ctx.needs_input_grad[0]:
                 dx = torch.ops.aten.convolution_backward(dy.to(compute_dtype), xc,
                                                          _low_precision_weight(weight, compute_dtype), None, s2, p2,
                                                          d2, False, [0, 0], 1, [True, False, False])[0]
             if ctx.needs_input_grad[1]:
-                if dy.shape[2] * dy.shape[3] <= SMALL_MAP_AREA:
+                if small or getattr(weight, "xpt_safe_wgrad", False):     # the latter: set by the trainer's replay check
                     dw = unfolded_weight_grad(dy, xc, weight.shape, stride, padding, dilation)
                 else:
                     dw = torch.ops.aten.convolution_backward(dy.float(), xc.float(), weight.float(), None, s2, p2, d2,
                                                              False, [0, 0], 1, [False, True, False])[1]
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
+
+
+def flipped_conv_data_grad(dy, weight, x_shape, stride, padding, dilation):
+    """Data gradient of conv2d as a FORWARD convolution: dx = conv2d(zero-stuffed dy, flip(W)^T, padding d (k - 1) - p,
+    dilation d).  Used for small maps of the flow net, where the library's bf16 data-gradient solvers (like its
+    weight-gradient solvers) return garbage from the second hipGraph replay on: first seen on the 96 -> 96 3x3
+    convolutions of PWC-Net's 4x8 level (tools/replay_grad_diff.py); forward solvers replay correctly."""
+    cout, cin, kh, kw = weight.shape
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    B, _, OH, OW = dy.shape
+    H, W = x_shape[2], x_shape[3]
+    if stride > 1:
+        up = dy.new_zeros((B, cout, (OH - 1) * stride + 1, (OW - 1) * stride + 1))
+        up[:, :, ::stride, ::stride] = dy
+        dy = up
+    wt = weight.flip(2, 3).permute(1, 0, 2, 3).contiguous(memory_format=torch.channels_last)
+    fh, fw = dilation * (kh - 1) - ph, dilation * (kw - 1) - pw
+    # rows / columns of x beyond the last window (stride > 1, or explicit extra padding) receive no gradient
+    eh = H - (dy.shape[2] + 2 * fh - dilation * (kh - 1))
+    ew = W - (dy.shape[3] + 2 * fw - dilation * (kw - 1))
+    if fh < 0 or fw < 0 or eh or ew:
+        dy = F.pad(dy, (max(fw, 0), max(fw, 0) + ew, max(fh, 0), max(fh, 0) + eh))
+        if fh < 0 or fw < 0:                    # padding larger than the dilated kernel reach: crop instead of pad
+            dy = dy[:, :, -min(fh, 0):dy.shape[2] + min(fh, 0), -min(fw, 0):dy.shape[3] + min(fw, 0)]
+        fh = fw = 0
+    return F.conv2d(dy.contiguous(memory_format=torch.channels_last), wt, None, 1, (fh, fw), dilation)
 
 
 def unfolded_weight_grad(dy, x, weight_shape, stride, padding, dilation):
@@ -100,11 +130,12 @@ def _low_precision_weight(weight, dtype):
     return weight.to(dtype)
 
 
-def conv2d_library(x, weight, stride, padding, dilation=1):
+def conv2d_library(x, weight, stride, padding, dilation=1, safe_dgrad=False):
     """Dense (groups = 1) convolution without bias through MIOpen; see _ConvFp32WeightGrad for the backward."""
     if x.is_cuda:
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
-        return _ConvFp32WeightGrad.apply(x, weight, int(stride), (int(padding[0]), int(padding[1])), dtype, int(dilation))
+        return _ConvFp32WeightGrad.apply(x, weight, int(stride), (int(padding[0]), int(padding[1])), dtype, int(dilation),
+                                         bool(safe_dgrad))
     return F.conv2d(x, weight, None, stride, padding, dilation)
 
 
@@ -116,6 +147,7 @@ class Conv2DSame(nn.Module):
                  dilation_rate=1):
         super().__init__()
         self.k, self.s, self.d = int(kernel_size), int(strides), int(dilation_rate)
+        self.replay_safe_dgrad = False         # set by nets whose small-map data gradients need the forward-conv path
         self.conv = nn.Conv2d(in_channels, filters, self.k, self.s, padding=0, dilation=self.d, bias=use_bias,
                               groups=groups)
         self.act = make_activation(activation, activation_param)
@@ -142,7 +174,7 @@ class Conv2DSame(nn.Module):
             x = F.pad(x, (pw[0], pw[1], ph[0], ph[1]))
             ph, pw = (0, 0), (0, 0)
         if fused and self.conv.groups == 1:
-            y = conv2d_library(x, self.conv.weight, self.s, (ph[0], pw[0]), self.d)
+            y = conv2d_library(x, self.conv.weight, self.s, (ph[0], pw[0]), self.d, self.replay_safe_dgrad)
         else:
             y = F.conv2d(x, self.conv.weight, bias, self.s, (ph[0], pw[0]), self.d, self.conv.groups)
         if fused:

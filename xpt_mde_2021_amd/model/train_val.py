@@ -129,6 +129,24 @@ class ModelTrainer(TrainValBase):
     def reduce_gradients(self):
         pass
 
+    def repair_flagged(self):
+        """Called when a captured step failed the replay check: the 4-D convolution weights among the parameters the
+        check named get their weight gradient from the patch-gather GEMM (layer_ops.unfolded_weight_grad) instead of a
+        library solver from now on.  Returns the number of newly marked weights (0: nothing left to try)."""
+        marked = 0
+        for p in getattr(self, "_flagged_params", []):
+            if p.dim() == 4 and p.shape[2] * p.shape[3] > 1 and not getattr(p, "xpt_safe_wgrad", False):
+                p.xpt_safe_wgrad = True
+                marked += 1
+        self._flagged_params = []
+        return marked
+
+    def state_segments(self):
+        """Lengths (alignment gaps included) of the parameters inside the flat buffers, for the replay check."""
+        flat = self.optimizer.flat
+        ends = list(flat.offsets[1:]) + [flat.numel]
+        return torch.tensor([e - o for o, e in zip(flat.offsets, ends)], dtype=torch.int64, device=flat.data.device)
+
     def describe_state(self, index, bad):
         """Names the parameters behind the flagged elements of a flat state tensor (for the replay-check message)."""
         flat = self.optimizer.flat
@@ -138,9 +156,12 @@ class ModelTrainer(TrainValBase):
         names = {id(q): f"{net}.{n}" for net, m in self.model.models.items() for n, q in m.named_parameters()}
         label = ["value", "gradient", "first moment", "second moment"][index] if index < 4 else f"state {index}"
         hits = {}
+        self._flagged_params = []
         for off in torch.nonzero(bad.reshape(-1))[:, 0].tolist()[::max(int(bad.sum()) // 4096, 1)]:
             i = bisect.bisect_right(flat.offsets, off) - 1
             key = names.get(id(flat.params[i]), f"param {i}")
+            if key not in hits:
+                self._flagged_params.append(flat.params[i])
             hits[key] = hits.get(key, 0) + 1
         return f" [{label} of " + ", ".join(f"{k}{tuple(self._shape(k, names, flat))}" for k in list(hits)[:6]) + \
                (" ..." if len(hits) > 6 else "") + "]"
@@ -170,11 +191,14 @@ class ModelTrainer(TrainValBase):
 class _StepGraph:
     """Captures fn(static_features) into a hipGraph; replays it after copying a new batch into the static buffers."""
 
-    def __init__(self, fn, warmup=3, state=None, describe=None):
+    def __init__(self, fn, warmup=3, state=None, describe=None, segments=None, repair=None):
         self.fn = fn
         self.warmup = warmup
         self.state = state                     # callable -> list of tensors the warm-up runs must not change
         self.describe = describe               # (state index, bad-element mask) -> text for the replay-check message
+        self.segments = segments               # callable -> int64 lengths of the parameters inside a flat state tensor
+        self.repair = repair                   # callable -> number of layers switched to replay-safe gradients
+        self.repairs = 0
         self.graph = None
         self.static_in = None
         self.static_out = None
@@ -223,6 +247,13 @@ class _StepGraph:
             # the immediate-mode heuristics (whose choices are covered by tests/test_graph_replay.py) and recapture;
             # if that capture fails the check too, run the step eagerly rather than train on garbage.
             import sys
+            marked = self.repair() if (self.repair is not None and self.repairs < 6) else 0
+            if marked:
+                self.repairs += 1
+                print(f"[StepGraph] captured step fails the replay check ({report}): {marked} convolution(s) switched "
+                      f"to the GEMM weight gradient, recapturing", file=sys.stderr, flush=True)
+                self.graph = None
+                return self._capture(features, sig)
             if torch.backends.cudnn.benchmark:
                 print(f"[StepGraph] captured step fails the replay check ({report}): MIOpen find off, recapturing",
                       file=sys.stderr, flush=True)
@@ -236,11 +267,17 @@ class _StepGraph:
             self.eager_fallback = True
 
     def _replay_report(self, state, saved, replays=3):
-        """Replays the fresh graph a few times from the saved state and checks that parameters, moments and gradients
-        stay finite and bounded (the library failure this guards against yields 1e25 ... inf from the second replay).
-        Returns None when they do, else a short description of what went wrong."""
-        report = None
+        """Replays the fresh graph a few times from the saved state AND the same random-generator state and checks that
+        (a) parameters, moments and gradients stay finite and bounded, (b) every later replay reproduces the first one
+        parameter by parameter (the library failures this guards against are correct on the first replay and yield
+        garbage -- 1e25 ... inf, or finite but wrong -- from the second on; identical inputs and random draws must give
+        identical state up to the rounding noise of atomic accumulation).  Returns None when all is well, else a short
+        description of what went wrong."""
+        report, first = None, None
+        cuda_rng = torch.cuda.get_rng_state()
+        lengths = self.segments() if self.segments is not None else None
         for rep in range(replays):
+            torch.cuda.set_rng_state(cuda_rng)
             self.graph.replay()
             torch.cuda.synchronize()
             for i, t in enumerate(state):
@@ -250,17 +287,42 @@ class _StepGraph:
                         report = f"replay {rep}: {int(bad.sum())} of {t.numel()} elements of state tensor {i} non-finite"
                         if self.describe is not None:
                             report += self.describe(i, bad)
+            if report is None and first is None:
+                first = [t.clone() for t in state]
+            elif report is None:
+                report = self._compare_replays(rep, first, state, lengths)
             for t, s in zip(state, saved):
                 t.copy_(s)
+        torch.cuda.set_rng_state(cuda_rng)
         torch.cuda.synchronize()
         return report
+
+    def _compare_replays(self, rep, first, state, lengths, rtol=5e-2):
+        for i, (a, b) in enumerate(zip(first, state)):
+            # gradients and first moments only (indices 1, 2 of the optimizer state): Adam turns a rounding-noise
+            # gradient into a +-lr step, so VALUES of parameters with a ~zero gradient legitimately differ between runs
+            if a.dtype != torch.float32 or a.numel() < 2 or (len(first) > 3 and i not in (1, 2)):
+                continue
+            diff, mag = (a - b).abs().reshape(-1), a.abs().reshape(-1)
+            if lengths is not None and int(lengths.sum()) == a.numel():      # per parameter of the flat buffers
+                seg_diff = torch.segment_reduce(diff, "max", lengths=lengths)
+                seg_mag = torch.segment_reduce(mag, "max", lengths=lengths)
+                bad_seg = seg_diff > rtol * seg_mag + 1e-5 * seg_mag.max() + 1e-12
+                if bool(bad_seg.any()):
+                    bad = torch.repeat_interleave(bad_seg, lengths) & (diff > 0)
+                    text = f"replay {rep} differs from replay 0 in {int(bad_seg.sum())} parameters of state tensor {i}"
+                    return text + (self.describe(i, bad) if self.describe is not None else "")
+            elif bool((diff > rtol * mag.max() + 1e-12).any()):
+                return f"replay {rep} differs from replay 0 in state tensor {i}"
+        return None
 
 
 class ModelTrainerGraph(ModelTrainer):
     def __init__(self, model, loss_object, steps_per_epoch, stereo, augmenter, optimizer):
         super().__init__(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
         self.set_name("Train (graph)")
-        self._graph = _StepGraph(self.train_a_step, state=self.optimizer_state, describe=self.describe_state)
+        self._graph = _StepGraph(self.train_a_step, state=self.optimizer_state, describe=self.describe_state,
+                                 segments=self.state_segments, repair=self.repair_flagged)
 
     def run_a_batch(self, features):
         if not features["image5d"].is_cuda:
@@ -278,7 +340,8 @@ class ModelTrainerDistrib(ModelTrainer):
         self.strategy = DistributionStrategy.get_strategy()
         if self.strategy is not None:
             self.strategy.broadcast_parameters(self.optimizer.flat.data)
-        self._graph = _StepGraph(self.forward_backward, state=self.optimizer_state, describe=self.describe_state) \
+        self._graph = _StepGraph(self.forward_backward, state=self.optimizer_state, describe=self.describe_state,
+                                 segments=self.state_segments, repair=self.repair_flagged) \
             if getattr(opts, "DISTRIB_GRAPH", True) else None
 
     def reduce_gradients(self):
