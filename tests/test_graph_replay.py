@@ -46,7 +46,9 @@ def test_graph_replays_match_eager(gpu_device, nets, dtype):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         flat.grad.zero_()
-        graph = tv._StepGraph(trainer.forward_backward, state=trainer.optimizer_state)
+        # as the graph trainers build it: replay check at capture, flagged convolutions repaired, eager as the last resort
+        graph = tv._StepGraph(trainer.forward_backward, state=trainer.optimizer_state, describe=trainer.describe_state,
+                              segments=trainer.state_segments, repair=trainer.repair_flagged)
         tol = 5e-1 if dtype == "bf16" else 5e-3              # bf16: rounding noise of small gradients; replay garbage is >= 1e3
         for it in range(5):
             flat.grad.zero_()

@@ -19,15 +19,17 @@ dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 H, W, B = (int(v) for v in sys.argv[3:6]) if len(sys.argv) > 5 else (64, 128, 2)
 replays = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 net_names, loss_weights = {"rigid": (opts.RIGID_NET, opts.LOSS_RIGID_T1), "flow": (opts.FLOW_NET, opts.LOSS_FLOW),
+                           "stereo": (opts.RIGID_NET, opts.LOSS_RIGID_T2),
                            "joint": (opts.JOINT_NET, {"cmbL1": 5.0, "cmbSSIM": 0.5, "smoothe": 1.0})}[nets]
+opts.STEREO = nets == "stereo"
 opts.CONV_DTYPE = dtype
 opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = B
 opts.IMAGE_SIZES["kitti_raw"] = (H, W)
 torch.manual_seed(0)
-dataset, cfg, _ = mm.get_dataset("synthetic", "train", True)
+dataset, cfg, _ = mm.get_dataset("synthetic_stereo" if nets == "stereo" else "synthetic", "train", True)
 model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, loss_weights, opts.SCALE_WEIGHT_T1, net_names,
                                                               ckpt_name="__diff__")
-trainer, _ = tv.train_val_factory("eager", model, loss_object, 0, False, None, optimizer)
+trainer, _ = tv.train_val_factory("eager", model, loss_object, 0, opts.STEREO, None, optimizer)
 flat = optimizer.flat
 names = [(f"{net}.{n}", p) for net, m in model.models.items() for n, p in m.named_parameters() if p.requires_grad]
 feats = dataset.batches[0]
@@ -45,7 +47,7 @@ for it in range(replays):
     flat.grad.zero_()
     _, loss, _ = graph(feats)
     torch.cuda.synchronize()
-    bad = []
+    bad, worst = [], []
     for (name, p), off in zip(names, flat.offsets):
         a, b = flat.grad[off:off + p.numel()], ref[off:off + p.numel()]
         scale = max(float(b.abs().max()), 1e-5)
@@ -53,5 +55,9 @@ for it in range(replays):
             bad.append(f"{name}{tuple(p.shape)}:nonfinite")
         elif float((a - b).abs().max()) / scale > tol:
             bad.append(f"{name}{tuple(p.shape)}:{float((a - b).abs().max()) / scale:.1e}")
+        worst.append(float((a - b).abs().max()) / scale if bool(torch.isfinite(a).all()) else float("inf"))
+    ws = sorted(worst)
+    print(f"[diff] replay {it}: relative error per parameter: median {ws[len(ws) // 2]:.1e}, 90 % {ws[len(ws) * 9 // 10]:.1e}, "
+          f"max {ws[-1]:.1e}", flush=True)
     print(f"[diff] replay {it}: loss {float(loss):.6f} (eager {loss_ref:.6f}); {len(bad)} of {len(names)} gradients off"
           + (": " + " ".join(bad[:4]) + " ... " + " ".join(bad[-4:]) if bad else ""), flush=True)
