@@ -89,6 +89,18 @@ def cpu_baseline(args, seconds):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON); everything the model / loss factories print goes to stderr
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        result, world = run()
+    if result is not None:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -158,11 +170,7 @@ def main():
         note("roofline leg done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return (result if rank == 0 else None), world
 
 
 if __name__ == "__main__":

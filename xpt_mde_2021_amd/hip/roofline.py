@@ -110,12 +110,12 @@ def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
     extra["fused_bwd_kernel"] = (b_ms, b_bytes)
     lf_ms, lb_ms, lf_bytes, lb_bytes, lshape = measure_fused(ops, feats, max(repeats // 5, 5), batch=large_batch)
     achieved = f_bytes / (f_ms * 1e-3) / 1e9
-    traffic = _pmc_traffic("fused_fwd_kernel<false>", shape)
+    traffic = _pmc_traffic("fused_fwd_kernel<false, true>", shape)
 
     def gbs(ms_, nbytes):
         return round(nbytes / (ms_ * 1e-3) / 1e9, 2)
 
-    return {"bound": "hbm", "kernel": "fused_fwd_kernel<false> (warp + L1 + SSIM, scale 1)",
+    return {"bound": "hbm", "kernel": "fused_fwd_kernel<false, true> (warp + L1 + SSIM, scale 1; hand-pipelined row loop)",
             "achieved": round(achieved, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(achieved / hbm_peak_gbs, 4),
             "traffic": traffic, "launch_us": round(f_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(f_bytes),
             "bytes_per_warped_pixel": round(f_bytes / (B * N * P), 3), "shape": shape,
