@@ -27,6 +27,9 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+NETS_LABEL = {"rigid": "DepthNet(NASNetMobile)+PoseNetImproved", "flow": "PWCNet",
+              "joint": "DepthNet(NASNetMobile)+PoseNetImproved+PWCNet"}
+LOSS_LABEL = {"flow": "flowL2+flow_reg", "joint": "cmbL1+cmbSSIM+smoothness"}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -41,6 +44,9 @@ def parse():
     ap.add_argument("--mode", default=None, help="eager | graph | distributed (default: graph at N=1, distributed at N>1)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--stereo", action="store_true", help="stereo feature dict + LOSS_RIGID_T2 (configs[4]-style)")
+    ap.add_argument("--nets", default="rigid", choices=["rigid", "flow", "joint"],
+                    help="rigid = DepthNet + PoseNet (the headline workload); flow = PWC-Net with flowL2 + flow_reg; joint = "
+                         "all three with cmbL1 + cmbSSIM + smoothe (SURVEY 8f-4; PWC-Net needs --width divisible by 64)")
     ap.add_argument("--no-miopen-find", action="store_true", help="MIOpen immediate-mode heuristics instead of the fast find")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -66,8 +72,13 @@ def build_step(args, world):
     name = "synthetic_stereo" if args.stereo else "synthetic"
     dataset, tfr_config, _ = mm.get_dataset(name, "train", True)
     loss_weights = opts.LOSS_RIGID_T2 if args.stereo else opts.LOSS_RIGID_T1
+    net_names = opts.RIGID_NET
+    if args.nets == "flow":
+        net_names, loss_weights = opts.FLOW_NET, opts.LOSS_FLOW
+    elif args.nets == "joint":
+        net_names, loss_weights = opts.JOINT_NET, {"cmbL1": 5.0, "cmbSSIM": 0.5, "smoothe": opts.SMOOTHNESS_FACTOR}
     model, augmenter, loss_object, optimizer = mm.create_training_parts(
-        0, tfr_config, 1e-4, loss_weights, opts.SCALE_WEIGHT_T1, opts.RIGID_NET, ckpt_name="__bench__")
+        0, tfr_config, 1e-4, loss_weights, opts.SCALE_WEIGHT_T1, net_names, ckpt_name="__bench__")
     trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, opts.STEREO, augmenter, optimizer)
     return trainer, dataset, mode, loss_object
 
@@ -158,9 +169,9 @@ def run():
             "ms_per_step": round(1000.0 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"DepthNet(NASNetMobile)+PoseNetImproved train step, KITTI-raw-shaped "
+            "config": {"workload": f"{NETS_LABEL[args.nets]} train step, KITTI-raw-shaped "
                                    f"5x{args.height}x{args.width} snippets, batch {args.batch}/GPU, "
-                                   f"{'stereo LOSS_RIGID_T2' if args.stereo else 'mono L1+SSIM+smoothness'}, 4 scales",
+                                   f"{LOSS_LABEL[args.nets] if args.nets != 'rigid' else ('stereo LOSS_RIGID_T2' if args.stereo else 'mono L1+SSIM+smoothness')}, 4 scales",
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "mode": mode,
                        "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
         }
