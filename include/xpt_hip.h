@@ -238,7 +238,7 @@ int xpt_depth_head_bwd(const float* x, const float* g_depth, const float* g_disp
  *   out[b,y,x, ty*D + tx] = (1/C) sum_c left[b,y,x,c] * right[b, y + (ty-rad)*s2, x + (tx-rad)*s2, c],  rad = md / s2,
  *   D = 2 rad + 1, zero where the displaced pixel is outside the image.  left / right [B,H,W,C] dense NHWC,
  *   out [B,H,W,D*D]; dtype 0 float32 / 1 bfloat16 (all three tensors), fp32 accumulation.
- * bwd: dleft, dright [B,H,W,C] from gout [B,H,W,D*D] (gathers, deterministic).  D*D <= 256; bwd: C <= 256. */
+ * bwd: dleft, dright [B,H,W,C] from gout [B,H,W,D*D] (gathers, deterministic).  D*D <= 256; bwd: C <= 1024 (C % 4 == 0) or C <= 256. */
 int xpt_corr_cost_channels(int max_disp, int stride2);
 int xpt_corr_cost_fwd(const void* left, const void* right, void* out, int B, int H, int W, int C, int max_disp,
                       int stride2, int dtype, void* stream);

@@ -8,8 +8,9 @@
 // displacements of levels 2..5, 10 for the 25 of level 6), stages their left vectors in LDS as fp32 (read back as
 // broadcasts) and every thread walks the C channels of ITS displaced right pixel with 8/16-byte loads; the D^2 results
 // of a pixel are consecutive in memory, so the stores of a workgroup are one contiguous run.
-// Backward: one thread per (pixel, channel) of dleft or dright (blockIdx.y), lanes along the channels (coalesced rows),
-// walking the D^2 displacements; both are gathers (dright reads the pixels that looked at it), no atomics.
+// Backward: one thread per (pixel, 4 channels) of dleft or dright (blockIdx.y), lanes along the channels (coalesced rows,
+// 8 / 16-byte loads), walking the D^2 displacements; both are gathers (dright reads the pixels that looked at it), no
+// atomics.
 #include "xpt_common.h"
 
 #include <hip/hip_bf16.h>
@@ -33,6 +34,18 @@ template <> __device__ inline void cv_ld4<__hip_bfloat16>(const __hip_bfloat16* 
   const uint2 q = *reinterpret_cast<const uint2*>(p);
   v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
   v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+}
+
+// 8 consecutive bf16 channels (16-byte load / store)
+__device__ inline void cv_ld8(const __hip_bfloat16* p, float (&v)[8]) {
+  const uint4 q = *reinterpret_cast<const uint4*>(p);
+  const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ inline void cv_ld8(const float* p, float (&v)[8]) {          // (not used: fp32 rows go 4 wide)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = p[i];
 }
 
 struct CorrDims {
@@ -60,7 +73,14 @@ __global__ __launch_bounds__(256) void corr_fwd_kernel(const T* __restrict__ lef
   const T* r = right + p2 * d.C;
   const float* l = lvec + q * d.C;
   float acc = 0.f;
-  if (V == 4) {
+  if constexpr (V == 8) {
+    for (int c = 0; c < d.C; c += 8) {
+      float v[8];
+      cv_ld8(r + c, v);
+      acc += ((l[c] * v[0] + l[c + 1] * v[1]) + (l[c + 2] * v[2] + l[c + 3] * v[3])) +
+             ((l[c + 4] * v[4] + l[c + 5] * v[5]) + (l[c + 6] * v[6] + l[c + 7] * v[7]));
+    }
+  } else if constexpr (V == 4) {
     for (int c = 0; c < d.C; c += 4) {
       float v[4];
       cv_ld4(r + c, v);
@@ -72,20 +92,34 @@ __global__ __launch_bounds__(256) void corr_fwd_kernel(const T* __restrict__ lef
   cv_st(out + p * d.DD + t, ok ? acc / (float)d.C : 0.f);
 }
 
+template <typename T> __device__ inline void cv_st4(T* p, const float (&v)[4]);
+template <> __device__ inline void cv_st4<float>(float* p, const float (&v)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ inline void cv_st4<__hip_bfloat16>(__hip_bfloat16* p, const float (&v)[4]) {
+  __hip_bfloat16 h[4] = {__float2bfloat16(v[0]), __float2bfloat16(v[1]), __float2bfloat16(v[2]), __float2bfloat16(v[3])};
+  *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(h);
+}
+
 // side 0: dleft[p, c]  = (1/C) sum_t g[p, t] * right[p + disp(t), c]
 // side 1: dright[p, c] = (1/C) sum_t g[p - disp(t), t] * left[p - disp(t), c]
-template <typename T>
+// One thread per (pixel, V consecutive channels): V = 4 reads the other map with 8 / 16-byte loads (2-byte loads are
+// address-path-bound on gfx950: one texture-addresser slot per wave load whatever its width).
+template <typename T, int V>
 __global__ __launch_bounds__(256) void corr_bwd_kernel(const T* __restrict__ left, const T* __restrict__ right,
                                                        const T* __restrict__ gout, T* __restrict__ dleft,
                                                        T* __restrict__ dright, CorrDims d, int pix_per_block) {
   const int side = blockIdx.y;
-  const int q = threadIdx.x / d.C, c = threadIdx.x - q * d.C;          // C <= 256 (host splits wider maps)
+  const int cpt = d.C / V;                                               // threads per pixel (<= 256)
+  const int q = threadIdx.x / cpt, c = (threadIdx.x - q * cpt) * V;
   const long long p = (long long)blockIdx.x * pix_per_block + q;
   if (q >= pix_per_block || p >= d.npix) return;
   const int x = (int)(p % d.W), y = (int)((p / d.W) % d.H);
   const T* other = side == 0 ? right : left;
   const int sign = side == 0 ? 1 : -1;
-  float acc = 0.f;
+  float acc[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) acc[i] = 0.f;
   for (int ty = 0; ty < d.D; ++ty) {
     const int y2 = y + sign * (ty - d.rad) * d.s2;
     const bool oky = y2 >= 0 && y2 < d.H;
@@ -94,12 +128,35 @@ __global__ __launch_bounds__(256) void corr_bwd_kernel(const T* __restrict__ lef
       const bool ok = oky && x2 >= 0 && x2 < d.W;
       const long long p2 = ok ? p + (long long)(y2 - y) * d.W + (x2 - x) : p;
       const long long pg = side == 0 ? p : p2;                          // the pixel whose cost volume holds the term
-      const float g = cv_ld(gout + pg * d.DD + ty * d.D + tx);
-      const float v = cv_ld(other + p2 * d.C + c);
-      acc += ok ? g * v : 0.f;
+      const float g = ok ? cv_ld(gout + pg * d.DD + ty * d.D + tx) : 0.f;   // address always valid: select, no branch
+      if constexpr (V == 8) {
+        float v[8];
+        cv_ld8(other + p2 * d.C + c, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += g * v[i];
+      } else if constexpr (V == 4) {
+        float v[4];
+        cv_ld4(other + p2 * d.C + c, v);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += g * v[i];
+      } else {
+        acc[0] += g * cv_ld(other + p2 * d.C + c);
+      }
     }
   }
-  cv_st((side == 0 ? dleft : dright) + p * d.C + c, acc / (float)d.C);
+  const float inv = 1.0f / (float)d.C;
+  T* dst = (side == 0 ? dleft : dright) + p * d.C + c;
+  if constexpr (V == 8) {
+    float lo[4] = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+    float hi[4] = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
+    cv_st4(dst, lo);
+    cv_st4(dst + 4, hi);
+  } else if constexpr (V == 4) {
+    float o[4] = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+    cv_st4(dst, o);
+  } else {
+    cv_st(dst, acc[0] * inv);
+  }
 }
 
 int make_dims(int B, int H, int W, int C, int max_disp, int stride2, CorrDims* d) {
@@ -137,6 +194,7 @@ int xpt_corr_cost_fwd(const void* left, const void* right, void* out, int B, int
   const unsigned blocks = (unsigned)((d.npix + d.PX - 1) / d.PX);
   const int esz = dtype == 0 ? 4 : 2;
   const bool vec = C % 4 == 0 && ((uintptr_t)right) % (size_t)(4 * esz) == 0;
+  const bool vec8 = dtype == 1 && C % 8 == 0 && ((uintptr_t)right) % 16 == 0;
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
 #define XPT_CORR(T, V) \
@@ -144,7 +202,7 @@ int xpt_corr_cost_fwd(const void* left, const void* right, void* out, int B, int
   if (dtype == 0) {
     if (vec) XPT_CORR(float, 4); else XPT_CORR(float, 1);
   } else {
-    if (vec) XPT_CORR(__hip_bfloat16, 4); else XPT_CORR(__hip_bfloat16, 1);
+    if (vec8) XPT_CORR(__hip_bfloat16, 8); else if (vec) XPT_CORR(__hip_bfloat16, 4); else XPT_CORR(__hip_bfloat16, 1);
   }
 #undef XPT_CORR
   return xpt_launch_status();
@@ -157,18 +215,26 @@ int xpt_corr_cost_bwd(const void* left, const void* right, const void* gout, voi
   CorrDims d;
   const int rc = make_dims(B, H, W, C, max_disp, stride2, &d);
   if (rc != XPT_OK) return rc;
-  if (C > 256) return XPT_ERR_SHAPE;                      // PWC-Net's widest pyramid level has 196 channels
-  const int ppb = 256 / C;
+  const int esz = dtype == 0 ? 4 : 2;
+  const bool vec = C % 4 == 0 && ((uintptr_t)left) % (size_t)(4 * esz) == 0 && ((uintptr_t)right) % (size_t)(4 * esz) == 0 &&
+                   ((uintptr_t)dleft) % (size_t)(4 * esz) == 0 && ((uintptr_t)dright) % (size_t)(4 * esz) == 0;
+  const bool vec8 = vec && dtype == 1 && C % 8 == 0 && ((uintptr_t)left) % 16 == 0 && ((uintptr_t)right) % 16 == 0 &&
+                    ((uintptr_t)dleft) % 8 == 0 && ((uintptr_t)dright) % 8 == 0;
+  const int cpt = vec8 ? C / 8 : vec ? C / 4 : C;
+  if (cpt > 256) return XPT_ERR_SHAPE;                    // PWC-Net's widest pyramid level has 196 channels
+  const int ppb = 256 / cpt;
   const unsigned blocks = (unsigned)((d.npix + ppb - 1) / ppb);
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
-  if (dtype == 0)
-    hipLaunchKernelGGL(corr_bwd_kernel<float>, dim3(blocks, 2), dim3(256), 0, s, (const float*)left, (const float*)right,
-                       (const float*)gout, (float*)dleft, (float*)dright, d, ppb);
-  else
-    hipLaunchKernelGGL(corr_bwd_kernel<__hip_bfloat16>, dim3(blocks, 2), dim3(256), 0, s, (const __hip_bfloat16*)left,
-                       (const __hip_bfloat16*)right, (const __hip_bfloat16*)gout, (__hip_bfloat16*)dleft,
-                       (__hip_bfloat16*)dright, d, ppb);
+#define XPT_CORR_BWD(T, V)                                                                                              \
+  hipLaunchKernelGGL((corr_bwd_kernel<T, V>), dim3(blocks, 2), dim3(256), 0, s, (const T*)left, (const T*)right,        \
+                     (const T*)gout, (T*)dleft, (T*)dright, d, ppb)
+  if (dtype == 0) {
+    if (vec) XPT_CORR_BWD(float, 4); else XPT_CORR_BWD(float, 1);
+  } else {
+    if (vec8) XPT_CORR_BWD(__hip_bfloat16, 8); else if (vec) XPT_CORR_BWD(__hip_bfloat16, 4); else XPT_CORR_BWD(__hip_bfloat16, 1);
+  }
+#undef XPT_CORR_BWD
   return xpt_launch_status();
 }
 
