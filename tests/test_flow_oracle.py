@@ -114,3 +114,23 @@ def test_l2_term_in_optimizer():
     with pytest.raises(Exception):
         opt.add_l2([a[0], b[1]], 1.0)
         opt._ranges()
+
+
+def test_flat_parameter_groups_give_strided_stacks():
+    """FlatParameters(groups=...): the members of a group sit equally spaced in the flat buffers (in group order) and
+    pretrained_nets._stacked_view turns their matrices into one strided [n, r, c] view; ungrouped data is untouched."""
+    from xpt_mde_2021_amd.model.build_model.pretrained_nets import _stacked_view
+    from xpt_mde_2021_amd.model.model_util.optimizers import FlatParameters
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(*shape)) for shape in ((6, 5, 1, 1), (3,), (6, 5, 1, 1), (7, 2), (6, 5, 1, 1), (4, 4))]
+    before = [p.detach().clone() for p in ps]
+    flat = FlatParameters(ps, groups=[[ps[4], ps[0], ps[2]], [ps[3], ps[5]]])            # second group: shapes differ -> ignored
+    assert [id(p) for p in flat.params] == [id(ps[i]) for i in (4, 0, 2, 1, 3, 5)]
+    assert all(torch.equal(p.detach(), b) for p, b in zip(ps, before))
+    mats = [ps[i].detach().reshape(6, 5) for i in (4, 0, 2)]
+    stacked = _stacked_view(mats)
+    assert stacked.data_ptr() == mats[0].data_ptr() and stacked.stride(0) == 32           # 30 elements, aligned to 8
+    assert torch.equal(stacked, torch.stack(mats))
+    assert _stacked_view([mats[0], mats[2], mats[1]]).data_ptr() != mats[0].data_ptr()    # not equally spaced: a copy
+    plain = FlatParameters([torch.nn.Parameter(torch.randn(2, 2)) for _ in range(3)])
+    assert len(plain.params) == 3

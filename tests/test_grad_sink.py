@@ -88,7 +88,9 @@ def test_deferred_equals_immediate(gpu_device, dtype, monkeypatch):
         n_deferred = sum(1 for _, p in names if getattr(p, "flat_grad", None) is not None)
         assert n_deferred > 300, n_deferred
         tol = 2e-3 if dtype == "fp32" else 1e-1          # fp32: summation order + run-to-run noise of upstream library gradients; bf16: the library GEMM rounds, ours is exact
-        for (name, p), off in zip(names, flat.offsets):
+        name_of = {id(q): n for n, q in names}      # the flat buffers may group parameters: follow THEIR order
+        for p, off in zip(flat.params, flat.offsets):
+            name = name_of[id(p)]
             x, y = a[off:off + p.numel()], b[off:off + p.numel()]
             scale = float(y.abs().max()) + 1e-12
             err = float((x - y).abs().max()) / scale

@@ -58,7 +58,9 @@ def test_graph_replays_match_eager(gpu_device, nets, dtype):
             assert abs(float(loss) - loss_ref) < 2e-3 * abs(loss_ref), (it, float(loss), loss_ref)
             g = flat.grad
             assert torch.isfinite(g).all(), f"replay {it}: non-finite gradient"
-            for (name, p), off in zip(names, flat.offsets):
+            name_of = {id(q): n for n, q in names}      # the flat buffers may group parameters: follow THEIR order
+            for p, off in zip(flat.params, flat.offsets):
+                name = name_of[id(p)]
                 a, b = g[off:off + p.numel()], g_ref[off:off + p.numel()]
                 scale = max(float(b.abs().max()), 1e-5)       # floor: a bias whose gradient cancels to ~1e-7 is pure rounding noise
                 err = float((a - b).abs().max()) / scale

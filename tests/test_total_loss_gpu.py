@@ -131,7 +131,8 @@ def test_train_step_runs_and_learns(gpu_device):
             assert hist[-1] < hist[0], (mode, dtype, hist)
             losses[(mode, dtype)] = hist
         a, b = losses[("eager", "fp32")], losses[("graph", "fp32")]
-        assert abs(a[0] - b[0]) < 1e-5 and abs(a[-1] - b[-1]) < 2e-3 * abs(a[-1]), (a, b)
+        # (8 Adam steps amplify rounding differences: a repaired convolution uses the GEMM weight gradient in the graph run)
+        assert abs(a[0] - b[0]) < 1e-5 and abs(a[-1] - b[-1]) < 5e-3 * abs(a[-1]), (a, b)
         c = losses[("graph", "bf16")]
         assert abs(a[0] - c[0]) < 5e-2 * abs(a[0]), (a, c)
     finally:

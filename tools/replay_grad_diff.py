@@ -48,7 +48,9 @@ for it in range(replays):
     _, loss, _ = graph(feats)
     torch.cuda.synchronize()
     bad, worst = [], []
-    for (name, p), off in zip(names, flat.offsets):
+    name_of = {id(q): n for n, q in names}      # the flat buffers may group parameters: follow THEIR order
+    for p, off in zip(flat.params, flat.offsets):
+        name = name_of[id(p)]
         a, b = flat.grad[off:off + p.numel()], ref[off:off + p.numel()]
         scale = max(float(b.abs().max()), 1e-5)
         if not bool(torch.isfinite(a).all()):

@@ -107,6 +107,16 @@ class ModelWrapper:
         """model_wrappers.py:89-93."""
         return [p for model in self.models.values() for p in model.parameters() if p.requires_grad]
 
+    def weight_groups(self):
+        """Same-shape weights that a layer consumes as one strided batch (modules expose `stack_groups()`): the flat
+        parameter buffers place them next to each other (optimizers.FlatParameters)."""
+        groups = []
+        for model in self.models.values():
+            for module in model.modules():
+                if hasattr(module, "stack_groups"):
+                    groups.extend(module.stack_groups())
+        return groups
+
     def weights_to_regularize(self):
         """model_wrappers.py:95-99: the FlowNet's trainable weights (for the flow_reg L2 term), else None."""
         if "flownet" in self.models:

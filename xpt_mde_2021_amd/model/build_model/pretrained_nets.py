@@ -251,14 +251,27 @@ class _MultiConv1x1Bn(torch.autograd.Function):
             sink.add(g_dst, bparts[j], cout, cout, nsplit, 2 * cout)
         need = [ctx.needs_input_grad[2 + j] for j in range(n)]
         if n >= 3 and all(need):
-            # data gradients of all layers as ONE strided-batched GEMM (the g_j are already one [n, M, cout] buffer; the
-            # weights are gathered by one stack launch): 2 launches instead of n
-            dx_all = torch.bmm(g_all, torch.stack(list(shadows)))          # [n, M, cin]
+            # data gradients of all layers as ONE strided-batched GEMM: the g_j are already one [n, M, cout] buffer and the
+            # weights sit equally spaced in the flat shadow buffer (FlatParameters groups them: stack_groups()), so the
+            # [n, cout, cin] operand is a strided view; one stack launch otherwise
+            dx_all = torch.bmm(g_all, _stacked_view(shadows))              # [n, M, cin]
             dxs = [dx_all[j].view(B, H, W, cin).permute(0, 3, 1, 2) for j in range(n)]
         else:
             dxs = [torch.mm(g_all[j], shadows[j]).view(B, H, W, cin).permute(0, 3, 1, 2) if need[j] else None
                    for j in range(n)]
         return (None, None, *dxs, *none, *none, *none, *none, *none, *dres)
+
+
+def _stacked_view(mats):
+    """[n, r, c] over n equally spaced contiguous [r, c] matrices of one storage as a strided view (no copy)."""
+    first = mats[0]
+    step = mats[1].data_ptr() - first.data_ptr()
+    esz = first.element_size()
+    if (step > 0 and step % esz == 0 and all(m.is_contiguous() and m.shape == first.shape for m in mats)
+            and all(m.data_ptr() - first.data_ptr() == j * step for j, m in enumerate(mats))
+            and all(m.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() for m in mats)):
+        return torch.as_strided(first, (len(mats), *first.shape), (step // esz, first.shape[1], 1))
+    return torch.stack(list(mats))
 
 
 def multi_conv1x1_bn(xs, weights, bns, residuals=None):
@@ -434,6 +447,12 @@ class NormalCell(nn.Module):
         self.left5 = SepConvBlock(net, filters, filters, 3)
         self.out_channels = p_ch + 5 * filters
 
+    def stack_groups(self):
+        """Pointwise weights the wide cell consumes as one strided batch (order = the multi_conv1x1_bn calls below)."""
+        blocks = (self.left1, self.left5, self.right1, self.left2, self.right2)
+        return [[b.conv1.pointwise.weight for b in blocks],
+                [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight, self.left5.conv2.pointwise.weight]]
+
     def forward(self, ip, p, taps):
         p = self.adjust(p, taps)
         h = shared_relu(ip)
@@ -490,6 +509,9 @@ class ReductionCell(nn.Module):
         self.right3 = SepConvBlock(net, p_ch, filters, 5, 2)
         self.left4 = SepConvBlock(net, filters, filters, 3, 1)
         self.out_channels = 4 * filters
+
+    def stack_groups(self):
+        return [[b.conv1.pointwise.weight for b in (self.left1, self.right1, self.right2)]]
 
     def forward(self, ip, p, taps):
         p = self.adjust(p, taps)

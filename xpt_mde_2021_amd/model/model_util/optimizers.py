@@ -16,10 +16,11 @@ class FlatParameters:
     """Re-homes `params` (list of nn.Parameter) into flat data / grad buffers, preserving each parameter's memory
     format (channels_last conv kernels stay channels_last views)."""
 
-    def __init__(self, params, align=8):       # 8 elements: 16-byte aligned bf16 shadow rows for the matrix-core kernels
+    def __init__(self, params, align=8, groups=None):   # 8 elements: 16-byte aligned bf16 shadow rows for the matrix-core kernels
         params = [p for p in params if p.requires_grad]
         if not params:
             raise WrongInputException("no trainable parameters")
+        params = self._grouped(params, groups)
         self.params = params
         dev, dtype = params[0].device, torch.float32
         offsets, total = [], 0
@@ -48,6 +49,30 @@ class FlatParameters:
         if self.shadow is not None:
             self.shadow.copy_(self.data)
         self.offsets = offsets
+
+    @staticmethod
+    def _grouped(params, groups):
+        """Lays the members of every group (same-shape weights a layer consumes as ONE strided batch, e.g. the pointwise
+        weights of a NASNet cell stage) next to each other, in group order, at the position of the group's first
+        member: equal shapes then mean equal spacing, so [n, cout, cin] is a strided VIEW of the flat buffers."""
+        if not groups:
+            return params
+        present = {id(p) for p in params}
+        leader, member = {}, set()
+        for group in groups:
+            group = [p for p in group if id(p) in present]
+            if len(group) < 2 or any(p.shape != group[0].shape for p in group) or any(id(p) in member for p in group):
+                continue
+            first = min(group, key=lambda q: next(i for i, r in enumerate(params) if r is q))
+            leader[id(first)] = group
+            member.update(id(p) for p in group)
+        out = []
+        for p in params:
+            if id(p) in leader:
+                out.extend(leader[id(p)])
+            elif id(p) not in member:
+                out.append(p)
+        return out
 
     def gather_grads(self):
         """Moves the per-parameter gradients autograd produced into the flat buffer with one multi-tensor copy
@@ -109,8 +134,8 @@ class KerasAdam:
             self._l2_ranges = ranges
         return self._l2_ranges
 
-    def bind(self, params):
-        self.flat = params if isinstance(params, FlatParameters) else FlatParameters(list(params))
+    def bind(self, params, groups=None):
+        self.flat = params if isinstance(params, FlatParameters) else FlatParameters(list(params), groups=groups)
         self.m = torch.zeros_like(self.flat.data)
         self.v = torch.zeros_like(self.flat.data)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=self.flat.data.device)

@@ -107,7 +107,8 @@ class ModelTrainer(TrainValBase):
         super().__init__(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
         self.set_name("Train (eager)")
         if isinstance(optimizer, KerasAdam) and optimizer.flat is None:
-            optimizer.bind(model.trainable_weights())
+            groups = model.weight_groups() if hasattr(model, "weight_groups") else None
+            optimizer.bind(model.trainable_weights(), groups=groups)
 
     def run_a_batch(self, features):
         return self.train_a_step(features)
