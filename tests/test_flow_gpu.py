@@ -113,7 +113,7 @@ def test_combined_loss(gpu_device, method):
         frac_close(a.grad, b.grad, 2e-4 * scale, rtol=2e-3, max_bad_frac=2e-3, what=f"d cmb{method}")
 
 
-def _train(mode, dtype, net_names, loss_weights, steps=6, hw=(64, 128)):
+def _train(mode, dtype, net_names, loss_weights, steps=6):
     from xpt_mde_2021_amd.model import model_main as mm
     from xpt_mde_2021_amd.model import train_val as tv
     opts.CONV_DTYPE = dtype
@@ -140,7 +140,7 @@ def _train(mode, dtype, net_names, loss_weights, steps=6, hw=(64, 128)):
 def small_shapes():
     saved = (opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE, dict(opts.IMAGE_SIZES))
     opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 2
-    opts.IMAGE_SIZES["kitti_raw"] = (64, 128)
+    opts.IMAGE_SIZES["kitti_raw"] = (128, 256)        # PWC-Net's coarsest level is then 2x4 (64x128 would give 1x2 maps)
     yield
     opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
     opts.IMAGE_SIZES.clear()

@@ -58,7 +58,7 @@ for level, C in (() if os.environ.get("SKIP_CORR") == "1" else ((2, 32), (3, 64)
 
 def step_time(net_names, loss_weights, label, steps=20):
     from xpt_mde_2021_amd.model import model_main as mm, train_val as tv
-    opts.CONV_DTYPE = "bf16"
+    opts.CONV_DTYPE = os.environ.get("DTYPE", "bf16")
     opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = B
     opts.IMAGE_SIZES["kitti_raw"] = (H, W)
     mode = os.environ.get("MODE", "graph")

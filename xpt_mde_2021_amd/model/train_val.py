@@ -189,6 +189,9 @@ class ModelTrainer(TrainValBase):
         return out
 
 
+_DEBUG_REPLAY = __import__("os").environ.get("XPT_DEBUG_REPLAY", "0") == "1"
+
+
 class _StepGraph:
     """Captures fn(static_features) into a hipGraph; replays it after copying a new batch into the static buffers."""
 
@@ -276,7 +279,7 @@ class _StepGraph:
         accumulation in library kernels), and for a rectified stereo pair ulp-level differences in the depth flip the
         sampler's validity of whole border rows, which moves individual gradients by tens of percent.
         Returns None when all is well, else a short description of what went wrong."""
-        report, first = None, None
+        report, first, last, last_loss = None, None, None, None
         cuda_rng = torch.cuda.get_rng_state()
         lengths = self.segments() if self.segments is not None else None
         for rep in range(replays):
@@ -293,14 +296,42 @@ class _StepGraph:
             if report is None and first is None:
                 first = [t.clone() for t in state]
             elif report is None:
-                report = self._compare_replays(rep, first, state, lengths)
+                report = self._compare_replays(f"replay {rep} differs from replay 0", first, state, lengths)
+                last, last_loss = [t.clone() for t in state], self._scalar_loss(self.static_out)
+            for t, s in zip(state, saved):
+                t.copy_(s)
+        if report is None and last is not None:
+            # (c) the same step executed EAGERLY from the same state and the same random draws (a replay started from a
+            # saved generator state draws the numbers eager execution draws: tools/rng_align_probe.py): a captured step
+            # whose replays agree with each other can still be wrong -- consistently
+            torch.cuda.set_rng_state(cuda_rng)
+            out = self.fn(self.static_in)
+            torch.cuda.synchronize()
+            ref_loss = self._scalar_loss(out)
+            if _DEBUG_REPLAY:
+                import sys
+                print(f"[StepGraph debug] replay loss {last_loss}, eager loss {ref_loss}, benchmark "
+                      f"{torch.backends.cudnn.benchmark}, weights checksum {float(saved[0].double().abs().sum()):.6f}",
+                      file=sys.stderr, flush=True)
+            if ref_loss is not None and last_loss is not None and \
+                    not abs(last_loss - ref_loss) <= 2e-2 * abs(ref_loss) + 1e-6:
+                report = f"replayed loss {last_loss:.6g} but eager loss {ref_loss:.6g} from the same state"
+            else:
+                report = self._compare_replays("replay differs from the eager step", state, last, lengths)
+            del out
             for t, s in zip(state, saved):
                 t.copy_(s)
         torch.cuda.set_rng_state(cuda_rng)
         torch.cuda.synchronize()
         return report
 
-    def _compare_replays(self, rep, first, state, lengths, rtol=8.0):
+    @staticmethod
+    def _scalar_loss(out):
+        if isinstance(out, (tuple, list)) and len(out) > 1 and torch.is_tensor(out[1]) and out[1].numel() == 1:
+            return float(out[1])
+        return None
+
+    def _compare_replays(self, what, first, state, lengths, rtol=8.0):
         for i, (a, b) in enumerate(zip(first, state)):
             # gradients and first moments only (indices 1, 2 of the optimizer state): Adam turns a rounding-noise
             # gradient into a +-lr step, so VALUES of parameters with a ~zero gradient legitimately differ between runs
@@ -313,10 +344,10 @@ class _StepGraph:
                 bad_seg = seg_diff > rtol * seg_mag + 1e-5 * seg_mag.max() + 1e-12
                 if bool(bad_seg.any()):
                     bad = torch.repeat_interleave(bad_seg, lengths) & (diff > 0)
-                    text = f"replay {rep} differs from replay 0 in {int(bad_seg.sum())} parameters of state tensor {i}"
+                    text = f"{what} in {int(bad_seg.sum())} parameters of state tensor {i}"
                     return text + (self.describe(i, bad) if self.describe is not None else "")
             elif bool((diff > rtol * mag.max() + 1e-12).any()):
-                return f"replay {rep} differs from replay 0 in state tensor {i}"
+                return f"{what} in state tensor {i}"
         return None
 
 
