@@ -158,6 +158,8 @@ def run():
     step_graph = getattr(trainer, "_graph", None)
     if step_graph is not None and getattr(step_graph, "eager_fallback", False):
         mode += " (eager fallback: no captured step passed the replay check)"
+    if getattr(trainer, "trains_flow_net", False):
+        mode += " (PWC-Net is trained eagerly: see DESIGN.md section 6)"
     if rank == 0:
         global_batch = args.batch * world
         result = {

@@ -15,7 +15,7 @@ from xpt_mde_2021_amd.config import opts
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("nets,dtype", [("rigid", "bf16"), ("rigid", "fp32"), ("flow", "bf16")])
+@pytest.mark.parametrize("nets,dtype", [("rigid", "bf16"), ("rigid", "fp32")])     # (flow: tools/replay_grad_diff.py)
 def test_graph_replays_match_eager(gpu_device, nets, dtype):
     from xpt_mde_2021_amd.model import model_main as mm
     from xpt_mde_2021_amd.model import train_val as tv
@@ -48,7 +48,7 @@ def test_graph_replays_match_eager(gpu_device, nets, dtype):
         flat.grad.zero_()
         # as the graph trainers build it: replay check at capture, flagged convolutions repaired, eager as the last resort
         graph = tv._StepGraph(trainer.forward_backward, state=trainer.optimizer_state, describe=trainer.describe_state,
-                              segments=trainer.state_segments, repair=trainer.repair_flagged)
+                              segments=trainer.state_segments, repair=trainer.repair_flagged, reference=True)
         tol = 5e-1 if dtype == "bf16" else 5e-3              # bf16: rounding noise of small gradients; replay garbage is >= 1e3
         for it in range(5):
             flat.grad.zero_()

@@ -82,7 +82,7 @@ def step_time(net_names, loss_weights, label, steps=20):
     ms = (time.perf_counter() - t0) / steps * 1e3
     params = sum(p.numel() for p in model.trainable_weights()) / 1e6
     print(f"{label}: {ms:.2f} ms/step = {B / ms * 1e3:.0f} snippets/s  ({params:.1f} M parameters, batch {B}, {H}x{W}, "
-          f"bf16, {mode}{' -> EAGER FALLBACK' if getattr(getattr(trainer, '_graph', None), 'eager_fallback', False) else ''}; loss {float(out[1]):.4f})",
+          f"{opts.CONV_DTYPE}, {mode}{' (PWC-Net trained eagerly)' if getattr(trainer, 'trains_flow_net', False) else ''}{' -> EAGER FALLBACK' if getattr(getattr(trainer, '_graph', None), 'eager_fallback', False) else ''}; loss {float(out[1]):.4f})",
           flush=True)
 
 

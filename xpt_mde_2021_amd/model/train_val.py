@@ -195,7 +195,7 @@ _DEBUG_REPLAY = __import__("os").environ.get("XPT_DEBUG_REPLAY", "0") == "1"
 class _StepGraph:
     """Captures fn(static_features) into a hipGraph; replays it after copying a new batch into the static buffers."""
 
-    def __init__(self, fn, warmup=3, state=None, describe=None, segments=None, repair=None):
+    def __init__(self, fn, warmup=3, state=None, describe=None, segments=None, repair=None, reference=False):
         self.fn = fn
         self.warmup = warmup
         self.state = state                     # callable -> list of tensors the warm-up runs must not change
@@ -203,6 +203,7 @@ class _StepGraph:
         self.segments = segments               # callable -> int64 lengths of the parameters inside a flat state tensor
         self.repair = repair                   # callable -> number of layers switched to replay-safe gradients
         self.repairs = 0
+        self.reference = reference             # the step draws no random numbers: compare the replays with an eager step
         self.graph = None
         self.static_in = None
         self.static_out = None
@@ -271,7 +272,7 @@ class _StepGraph:
             self.eager_fallback = True
 
     def _replay_report(self, state, saved, replays=3):
-        """Replays the fresh graph a few times from the saved state AND the same random-generator state and checks that
+        """Replays the fresh graph a few times from the saved state and checks that
         (a) parameters, moments and gradients stay finite and bounded, (b) every later replay reproduces the first one
         parameter by parameter in MAGNITUDE (the library failures this guards against are correct on the first replay and
         yield garbage -- typically 1e25 ... inf, sometimes finite -- from the second on).  The comparison is deliberately
@@ -280,10 +281,8 @@ class _StepGraph:
         sampler's validity of whole border rows, which moves individual gradients by tens of percent.
         Returns None when all is well, else a short description of what went wrong."""
         report, first, last, last_loss = None, None, None, None
-        cuda_rng = torch.cuda.get_rng_state()
         lengths = self.segments() if self.segments is not None else None
         for rep in range(replays):
-            torch.cuda.set_rng_state(cuda_rng)
             self.graph.replay()
             torch.cuda.synchronize()
             for i, t in enumerate(state):
@@ -300,11 +299,12 @@ class _StepGraph:
                 last, last_loss = [t.clone() for t in state], self._scalar_loss(self.static_out)
             for t, s in zip(state, saved):
                 t.copy_(s)
-        if report is None and last is not None:
-            # (c) the same step executed EAGERLY from the same state and the same random draws (a replay started from a
-            # saved generator state draws the numbers eager execution draws: tools/rng_align_probe.py): a captured step
-            # whose replays agree with each other can still be wrong -- consistently
-            torch.cuda.set_rng_state(cuda_rng)
+        if report is None and last is not None and self.reference:
+            # (c) steps without random draws (no augmenter): the same step executed EAGERLY from the same state must give
+            # the same loss and gradients of the same magnitude -- a captured step whose replays agree with each other can
+            # still be wrong, consistently.  (With an augmenter the draws of a replay and of an eager run only line up if
+            # the generator state is reset in between -- tools/rng_align_probe.py -- and torch.cuda.set_rng_state() after a
+            # capture leaves the captured graph drawing the SAME numbers on every later replay, so that is not done.)
             out = self.fn(self.static_in)
             torch.cuda.synchronize()
             ref_loss = self._scalar_loss(out)
@@ -321,7 +321,6 @@ class _StepGraph:
             del out
             for t, s in zip(state, saved):
                 t.copy_(s)
-        torch.cuda.set_rng_state(cuda_rng)
         torch.cuda.synchronize()
         return report
 
@@ -355,11 +354,19 @@ class ModelTrainerGraph(ModelTrainer):
     def __init__(self, model, loss_object, steps_per_epoch, stereo, augmenter, optimizer):
         super().__init__(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
         self.set_name("Train (graph)")
+        # Training PWC-Net itself (flowL2 / flow_reg) stays eager: the backward of its small pyramid levels goes through
+        # library solvers that do not survive hipGraph replay on this stack -- the replay check below catches them, but
+        # intermittently the step was found corrupted even after the fallback -- and the step is
+        # bound by MIOpen's dense convolutions, not by launches (24.1 ms captured vs 24.0 ms eager at batch 8, 128x384).
+        # JOINT_NET steps with the combined loss only run PWC-Net forward and are captured like the rigid step.
+        weights = getattr(loss_object, "loss_weights", None) or {}
+        self.trains_flow_net = "flownet" in getattr(model, "models", {}) and any(k.startswith("flow") for k in weights)
         self._graph = _StepGraph(self.train_a_step, state=self.optimizer_state, describe=self.describe_state,
-                                 segments=self.state_segments, repair=self.repair_flagged)
+                                 segments=self.state_segments, repair=self.repair_flagged,
+                                 reference=self.augmenter is None)
 
     def run_a_batch(self, features):
-        if not features["image5d"].is_cuda:
+        if not features["image5d"].is_cuda or self.trains_flow_net:
             return self.train_a_step(features)
         return self._graph(features)
 
@@ -374,8 +381,11 @@ class ModelTrainerDistrib(ModelTrainer):
         self.strategy = DistributionStrategy.get_strategy()
         if self.strategy is not None:
             self.strategy.broadcast_parameters(self.optimizer.flat.data)
+        weights = getattr(loss_object, "loss_weights", None) or {}           # see ModelTrainerGraph
+        self.trains_flow_net = "flownet" in getattr(model, "models", {}) and any(k.startswith("flow") for k in weights)
         self._graph = _StepGraph(self.forward_backward, state=self.optimizer_state, describe=self.describe_state,
-                                 segments=self.state_segments, repair=self.repair_flagged) \
+                                 segments=self.state_segments, repair=self.repair_flagged,
+                                 reference=self.augmenter is None) \
             if getattr(opts, "DISTRIB_GRAPH", True) else None
 
     def reduce_gradients(self):
@@ -383,7 +393,7 @@ class ModelTrainerDistrib(ModelTrainer):
             self.strategy.all_reduce_gradients(self.optimizer.flat.grad)
 
     def run_a_batch(self, features):
-        if self._graph is not None and features["image5d"].is_cuda:
+        if self._graph is not None and features["image5d"].is_cuda and not self.trains_flow_net:
             out = self._graph(features)
         else:
             out = self.forward_backward(features)
