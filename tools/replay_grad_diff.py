@@ -41,8 +41,10 @@ with torch.cuda.stream(side):
     ref, loss_ref = flat.grad.clone(), float(loss)
 torch.cuda.current_stream().wait_stream(side)
 torch.cuda.synchronize()
-graph = tv._StepGraph(trainer.forward_backward)
+graph = tv._StepGraph(trainer.forward_backward, state=trainer.optimizer_state, describe=trainer.describe_state,
+                      segments=trainer.state_segments, repair=trainer.repair_flagged, reference=True)   # as the trainers build it
 tol = 5e-1 if dtype == "bf16" else 5e-3
+total_bad = 0
 for it in range(replays):
     flat.grad.zero_()
     _, loss, _ = graph(feats)
@@ -61,5 +63,9 @@ for it in range(replays):
     ws = sorted(worst)
     print(f"[diff] replay {it}: relative error per parameter: median {ws[len(ws) // 2]:.1e}, 90 % {ws[len(ws) * 9 // 10]:.1e}, "
           f"max {ws[-1]:.1e}", flush=True)
+    total_bad += len(bad)
     print(f"[diff] replay {it}: loss {float(loss):.6f} (eager {loss_ref:.6f}); {len(bad)} of {len(names)} gradients off"
           + (": " + " ".join(bad[:4]) + " ... " + " ".join(bad[-4:]) if bad else ""), flush=True)
+print(f"[diff] RESULT: {total_bad} gradient mismatches over {replays} replays; eager fallback: {graph.eager_fallback}; "
+      f"repairs: {graph.repairs}", flush=True)
+sys.exit(4 if total_bad else 0)
