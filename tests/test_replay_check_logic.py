@@ -1,0 +1,59 @@
+"""Host logic of the hipGraph replay check (train_val._StepGraph._compare_replays / ModelTrainer.repair_flagged) on the
+CPU: which differences between two runs of a step count as a defective capture, and which convolutions get repaired."""
+import torch
+
+from xpt_mde_2021_amd.model import train_val as tv
+
+
+def _state(grads):
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    return [flat.clone(), flat.clone(), flat.clone(), flat.clone().abs(), torch.ones(1), flat.clone().bfloat16()]
+
+
+def test_compare_replays_is_coarse_but_catches_garbage():
+    torch.manual_seed(0)
+    grads = [torch.randn(40) * 1e-3, torch.randn(8) * 1e-6, torch.randn(100), torch.zeros(16)]
+    lengths = torch.tensor([g.numel() for g in grads])
+    graph = tv._StepGraph(fn=None)
+    first = _state(grads)
+    # run-to-run noise of tens of percent (rectified stereo borders, atomics): accepted
+    noisy = _state([g * (1 + 0.4 * torch.rand_like(g)) for g in grads])
+    assert graph._compare_replays("replay 1 differs from replay 0", first, noisy, lengths) is None
+    # parameter VALUES (index 0) are not compared: Adam turns rounding noise into +-lr steps
+    moved = [t.clone() for t in first]
+    moved[0] = moved[0] + 1.0
+    assert graph._compare_replays("x", first, moved, lengths) is None
+    # a gradient 100x its first-replay magnitude in ONE parameter: flagged, and only that parameter is named
+    bad = [t.clone() for t in first]
+    bad[2][40:48] *= 100.0
+    seen = {}
+    graph.describe = lambda i, mask: seen.setdefault("hit", (i, torch.nonzero(mask)[:, 0].tolist())) and ""
+    report = graph._compare_replays("replay 1 differs from replay 0", first, bad, lengths)
+    assert report is not None and "1 parameters of state tensor 2" in report
+    assert seen["hit"][0] == 2 and set(seen["hit"][1]) <= set(range(40, 48))
+    # without segment information: one global magnitude
+    graph.describe = None
+    assert graph._compare_replays("y", first[1:3], [bad[1], bad[2]], None) is None        # only two tensors: all compared
+    huge = first[2].clone()
+    huge[140] = 1e6
+    assert graph._compare_replays("y", [first[2]], [huge], None) is not None
+
+
+def test_scalar_loss_extraction():
+    assert tv._StepGraph._scalar_loss(({"pose": torch.zeros(2, 4, 6)}, torch.tensor(0.25), {})) == 0.25
+    assert tv._StepGraph._scalar_loss(torch.zeros(3)) is None
+
+
+def test_repair_marks_only_dense_conv_weights():
+    class Trainer(tv.ModelTrainer):
+        def __init__(self):                      # no model / optimizer needed for this method
+            pass
+
+    t = Trainer()
+    conv, conv1x1, bias = (torch.nn.Parameter(torch.zeros(8, 4, 3, 3)), torch.nn.Parameter(torch.zeros(8, 4, 1, 1)),
+                           torch.nn.Parameter(torch.zeros(8)))
+    t._flagged_params = [conv, conv1x1, bias]
+    assert t.repair_flagged() == 1 and getattr(conv, "xpt_safe_wgrad", False) is True
+    assert not hasattr(conv1x1, "xpt_safe_wgrad") and not hasattr(bias, "xpt_safe_wgrad")
+    t._flagged_params = [conv]
+    assert t.repair_flagged() == 0               # nothing new to try: the caller moves on to its next fallback
