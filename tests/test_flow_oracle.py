@@ -134,3 +134,35 @@ def test_flat_parameter_groups_give_strided_stacks():
     assert _stacked_view([mats[0], mats[2], mats[1]]).data_ptr() != mats[0].data_ptr()    # not equally spaced: a copy
     plain = FlatParameters([torch.nn.Parameter(torch.randn(2, 2)) for _ in range(3)])
     assert len(plain.params) == 3
+
+
+def test_flow_losses_hand_cases():
+    """Hand-checkable cases of the restated flow losses (there are no golden values for them in the reference)."""
+    import numpy as np
+    from oracle import ref_loss
+    g = torch.Generator().manual_seed(5)
+    B, N, H, W = 2, 3, 16, 32
+    target = torch.rand((B, H, W, 3), generator=g) * 1.6 - 0.8
+    other = torch.rand((B, N, H, W, 3), generator=g) * 1.6 - 0.8
+    same = target.unsqueeze(1).expand(B, N, H, W, 3).contiguous()
+    sw = np.ones((4, 1), dtype=np.float32)
+    # the synthesized view equals the target at full resolution: static loss 0 everywhere -> first-scale term 0
+    full = ref_flow.combined_loss_multi_scale("L1", [same], [other], target, sw[:1])
+    assert torch.allclose(full, torch.zeros_like(full))
+    # the flow-warped view equals the target: flow loss 0, so no pixel has static < flow -> the whole loss is masked out
+    masked = ref_flow.combined_loss_multi_scale("L1", [other], [same], target, sw[:1])
+    assert torch.allclose(masked, torch.zeros_like(masked))
+    # flowL2 of a zero flow = L2 photometric loss between the resized sources and the resized target, per scale
+    zero_flow = [torch.zeros((B, N, H // s, W // s, 2)) for s in (4, 8)]
+    warped = ref_flow.flow_warp_multi_scale(other, zero_flow)
+    tgt = ref_flow.multi_scale_like_flow(target, zero_flow)
+    want = sum(ref_loss.photometric_loss_l2(w, t) for w, t in zip(warped, tgt))
+    got = ref_flow.flow_warp_loss_multi_scale("L2", warped, tgt, sw[:2]).reshape(-1)
+    assert torch.allclose(got, want)
+    # zero flow samples the grid itself: interior pixels reproduce the resized source, the last row / column is invalid
+    src4 = ref_flow.tf_resize_bilinear(other.reshape(B * N, H, W, 3), (H // 4, W // 4)).reshape(B, N, H // 4, W // 4, 3)
+    assert torch.allclose(warped[0][:, :, :-1, :-1], src4[:, :, :-1, :-1], atol=1e-6)
+    assert torch.all(warped[0][:, :, -1] == 0) and torch.all(warped[0][:, :, :, -1] == 0)
+    # the L2 regulariser: sum(w^2) / 2 over all weights, tiled to the batch
+    ws = [torch.full((2, 3), 2.0), torch.full((4,), -1.0)]
+    assert torch.allclose(ref_flow.l2_regularizer(ws, 3), torch.full((3,), (6 * 4 + 4 * 1) / 2))
