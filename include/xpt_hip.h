@@ -225,6 +225,54 @@ int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const fl
                       const float* var, float eps, const void* residual, void* ypre, void* y, long long M, int cin,
                       int cout, long long pitch_x, void* stream);
 
+/* ------------------------------------------------------------------ a2/a3: dense k x k convolutions (implicit GEMM, bf16 matrix cores)
+ * replaces keras Conv2D(filters, k, strides, padding="same") + bias + LeakyReLU as built by CustomConv2D
+ * (model/model_util/layer_ops.py:5-36) for PoseNetImproved (model/build_model/pose_net.py:57-91) and the depth decoder
+ * (model/build_model/depth_net.py:101-109, 137-167), the UpSampling2D(2, "nearest") in front of the decoder's first
+ * convolution of each level (depth_net.py:76-84), and tape.gradient of those layers (model/train_val.py:85-86).
+ * All activations NHWC bf16 with a pixel pitch (in elements) so that channel slices / padded tensors are used in place.
+ *
+ * xpt_conv_pack_weights: ONE launch converts the fp32 master weights into the kernels' bf16 operand layouts,
+ *   fwd [N][KH*KW][Cp] (Cp = C rounded up to 8, zero filled) and bwd [Cp][KH*KW][Np] (Np = N rounded up to 8).
+ *   jobs = device array of xpt_conv_pack_job (first_block = running sum of ceil((N*T*Cp + Cp*T*Np) / 256) over the
+ *   preceding jobs; nblocks = the total).
+ * xpt_conv2d_fwd: y[b,oh,ow,n] = act(bias[n] + sum_{kh,kw,c} x[b, oh*stride + kh - pad_t, ow*stride + kw - pad_l, c] w[n,kh,kw,c]),
+ *   zero outside the input (TF SAME: asymmetric pads are given explicitly), act = LeakyReLU(slope) (1 = linear);
+ *   x has PH x PW physical pixels of C channels (C % 8 == 0, pad channels must be finite); upsample = 1: the taps index
+ *   the nearest-2x up-sampling of x (2PH x 2PW) without materialising it.
+ * xpt_conv2d_bwd_data: dx[b,ih,iw,c] = sum_{kh,kw,n} g[b,(ih+pad_t-kh)/stride,(iw+pad_l-kw)/stride,n] w[n,kh,kw,c]
+ *   (integral, in-range positions only; stride 1 or 2); g has Np readable channels; fold2x2 = 1: x was consumed through
+ *   upsample = 1, the gradients of the four children of a pixel are summed (IH x IW = physical extent).
+ * xpt_conv2d_bwd_weight_partials: split-K partial sums [splits][N][KH][KW][Cr] fp32 of
+ *   dw[n,kh,kw,c] = sum_{b,oh,ow} g[b,oh,ow,n] x[b, oh*stride+kh-pad_t, ow*stride+kw-pad_l, c]  (c < Cr <= C);
+ *   splits = xpt_conv2d_bwd_weight_splits(...); finished by xpt_reduce_partials.  N % 8 == 0, C % 8 == 0.
+ * xpt_restack_bf16: restack_on_channels (pose_net.py:44-50): image5d [B,S,H,W,3] fp32 -> [B,H,W,Cp] bf16,
+ *   channel = frame*3 + c, channels >= 3S zero.
+ * xpt_conv2d_tune / xpt_conv2d_bwd_weight_tune: launch-plan knobs (process-wide, benchmarking). */
+typedef struct xpt_conv_pack_job {
+  const float* src;          /* element (n,kh,kw,c) at n*sn + kh*sh + kw*sw + c*sc */
+  void* fwd;
+  void* bwd;                 /* may be NULL */
+  long long sn, sc, sh, sw;
+  int N, T, KW, C, Cp, Np;
+  long long first_block;
+} xpt_conv_pack_job;
+int xpt_conv_pack_job_bytes(void);
+int xpt_conv_pack_weights(const void* jobs, int njobs, long long nblocks, void* stream);
+int xpt_conv2d_tune(int plan);
+int xpt_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int PH, int PW, int C,
+                   long long xpitch, int N, int KH, int KW, int stride, int pad_t, int pad_l, int OH, int OW,
+                   long long ypitch, int upsample, float slope, void* stream);
+int xpt_conv2d_bwd_data(const void* g, const void* wb, void* dx, int B, int OH, int OW, int Np, long long gpitch,
+                        int C, int KH, int KW, int stride, int pad_t, int pad_l, int IH, int IW, long long dxpitch,
+                        int fold2x2, void* stream);
+int xpt_conv2d_bwd_weight_tune(int max_partial_mib, int target_blocks);
+int xpt_conv2d_bwd_weight_splits(int B, int C, int N, int KH, int KW, int stride, int OH, int OW);
+int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, float* partials, size_t partial_floats, int B, int PH,
+                                   int PW, int C, int Cr, long long xpitch, int N, long long gpitch, int KH, int KW,
+                                   int stride, int pad_t, int pad_l, int OH, int OW, int upsample, void* stream);
+int xpt_restack_bf16(const float* image5d, void* out, int B, int S, int H, int W, int Cp, void* stream);
+
 /* ------------------------------------------------------------------ a2/a4: depth head activation
  * InverseSigmoid (model/build_model/model_factory.py:134-138) and safe_reciprocal_number (utils/util_funcs.py:157-160):
  *   depth = safe_rcp(sigmoid(x) + 0.01), disp = safe_rcp(depth), safe_rcp(v) = (1 / v) [v > 1e-5]; float32, n elements.

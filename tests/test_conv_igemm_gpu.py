@@ -1,0 +1,119 @@
+"""The matrix-core convolutions (csrc/xpt_conv.hip, xpt_conv_wgrad.hip) against a plain fp32 PyTorch reference of the
+same op on the same bf16-rounded operands: forward (+ bias + LeakyReLU, TF-SAME padding, nearest-2x input), data
+gradient (+ 2x2 fold, stride-2 residue classes) and weight / bias gradients, over every layer shape of PoseNetImproved
+(model/build_model/pose_net.py:57-91) and of the depth decoder (model/build_model/depth_net.py:101-109, 137-167).
+
+Tolerances: products of bf16 operands are exact in fp32, both sides accumulate in fp32 -> the forward differs only by
+the final bf16 rounding of y (2^-8 relative) and the summation order; gradients see one more bf16 rounding (g)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def same_pad(n, k, s):
+    total = max((math.ceil(n / s) - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def reference(x, w, b, stride, slope, upsample, valid=False):
+    """fp32 CPU-style reference: F.pad (TF SAME, asymmetric) + conv2d + bias + leaky_relu."""
+    if upsample:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    k = w.shape[-1]
+    if not valid:
+        (pt, pb), (pl, pr) = same_pad(x.shape[2], k, stride), same_pad(x.shape[3], k, stride)
+        x = F.pad(x, (pl, pr, pt, pb))
+    y = F.conv2d(x, w, b, stride)
+    return F.leaky_relu(y, slope) if slope != 1.0 else y
+
+
+# (cin, cout, k, stride, H, W, upsample): PoseNet c0..c7 + 1x1 head, decoder up4..up0 first / second convolutions
+SHAPES = [
+    (15, 32, 5, 2, 128, 416, False), (32, 32, 5, 2, 64, 208, False), (32, 64, 3, 2, 32, 104, False),
+    (64, 128, 3, 2, 16, 52, False), (128, 256, 3, 2, 8, 26, False), (256, 256, 3, 2, 4, 13, False),
+    (256, 256, 3, 1, 2, 7, False), (256, 24, 1, 1, 2, 7, False),
+    (1056, 256, 3, 1, 4, 13, True), (432, 256, 3, 1, 8, 26, False), (256, 128, 3, 1, 8, 26, True),
+    (216, 128, 3, 1, 16, 52, False), (128, 64, 3, 1, 16, 52, True), (87, 64, 3, 1, 32, 104, False),
+    (64, 32, 3, 1, 32, 104, True), (65, 32, 3, 1, 64, 208, False), (32, 16, 3, 1, 64, 208, True),
+    (17, 16, 3, 1, 128, 416, False),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,ups", SHAPES)
+@pytest.mark.parametrize("batch", [2])
+def test_conv_fwd_bwd_matches_fp32_reference(gpu_device, cin, cout, k, stride, H, W, ups, batch):
+    from xpt_mde_2021_amd.hip import conv as xc
+    dev = gpu_device
+    g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k)
+    cp = xc.round_up(cin, 8)
+    x = torch.randn(batch, cin, H, W, generator=g).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).to(torch.bfloat16).float()
+    b = 0.1 * torch.randn(cout, generator=g)
+    slope = 0.1 if cout != 24 else 1.0
+    # reference on the CPU in fp32 (operands already rounded to bf16)
+    xr = x.float().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = reference(xr, wr, br, stride, slope, ups)
+    gy = torch.randn(yr.shape, generator=g).to(torch.bfloat16)
+    (yr * gy.float()).sum().backward()
+    # device
+    xd = F.pad(x, (0, 0, 0, 0, 0, cp - cin)).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    yd = xc.conv2d_same(xd, wd, bd, stride, slope, ups)
+    assert yd.shape == yr.shape and yd.dtype == torch.bfloat16
+    (yd.float() * gy.to(dev).float()).sum().backward()
+    torch.cuda.synchronize()
+
+    def close(a, ref, rtol, what):
+        a, ref = a.detach().float().cpu(), ref.detach().float()
+        scale = ref.abs().max().item() + 1e-12
+        err = (a - ref).abs().max().item() / scale
+        assert err < rtol, f"{what}: max error {err:.3e} of the largest magnitude (allowed {rtol})"
+
+    close(yd, yr, 6e-3, "forward")                    # bf16 output rounding (2^-8) + accumulation order
+    close(xd.grad[:, :cin], xr.grad, 1.5e-2, "data gradient")
+    assert float(xd.grad[:, cin:].abs().max()) == 0.0 if cp > cin else True
+    close(wd.grad, wr.grad, 1.5e-2, "weight gradient")
+    close(bd.grad, br.grad, 1.5e-2, "bias gradient")
+
+
+def test_conv_valid_stem_and_channel_slice_input(gpu_device):
+    """keras padding="valid" stride-2 stem (3 -> 32 channels on a 130x418 image) and an input that is a channel slice of a
+    wider tensor (consumed through its pixel pitch, no copy)."""
+    from xpt_mde_2021_amd.hip import conv as xc
+    dev = gpu_device
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 66, 98, generator=g).to(torch.bfloat16)
+    w = (0.2 * torch.randn(32, 3, 3, 3, generator=g)).to(torch.bfloat16).float()
+    yr = reference(x.float(), w, None, 2, 1.0, False, valid=True)
+    xd = F.pad(x, (0, 0, 0, 0, 0, 5)).to(dev).contiguous(memory_format=torch.channels_last)
+    yd = xc.conv2d_same(xd, w.to(dev), None, 2, 1.0, valid=True)
+    assert yd.shape == yr.shape
+    assert (yd.float().cpu() - yr).abs().max().item() < 6e-3 * yr.abs().max().item()
+    # slice input: channels 8..39 of a 48-channel tensor
+    wide = torch.randn(2, 48, 12, 20, generator=g).to(torch.bfloat16)
+    w2 = (0.1 * torch.randn(16, 32, 3, 3, generator=g)).to(torch.bfloat16).float()
+    yr2 = reference(wide[:, 8:40].float(), w2, None, 1, 0.1, False)
+    wd = wide.to(dev).contiguous(memory_format=torch.channels_last)
+    yd2 = xc.conv2d_same(wd[:, 8:40], w2.to(dev), None, 1, 0.1)
+    assert (yd2.float().cpu() - yr2).abs().max().item() < 6e-3 * yr2.abs().max().item()
+
+
+def test_packer_tracks_weight_updates(gpu_device):
+    """The packed bf16 operands follow the fp32 master after packer.pack() (what every model forward launches first)."""
+    from xpt_mde_2021_amd.hip import conv as xc
+    dev = gpu_device
+    w = torch.randn(16, 8, 3, 3, device=dev)
+    x = torch.randn(1, 8, 6, 10, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y0 = xc.conv2d_same(x, w, None, 1, 1.0).float()
+    w.mul_(2.0)
+    xc.packer.pack()
+    y1 = xc.conv2d_same(x, w, None, 1, 1.0).float()
+    torch.cuda.synchronize()
+    assert torch.allclose(y1, 2 * y0, rtol=2e-2, atol=1e-3)

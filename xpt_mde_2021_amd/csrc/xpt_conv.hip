@@ -1,0 +1,453 @@
+// xpt_conv.hip -- the dense k x k convolutions of PoseNetImproved and of the depth decoder as implicit GEMMs on the
+// gfx950 bf16 matrix cores: forward (+ bias + LeakyReLU, TF-SAME asymmetric zero padding, nearest-2x up-sampled input,
+// output written into a channel slice of a wider tensor), data gradient (the same kernel in its transposed mode, + the
+// 2x2 fold of a nearest-2x input) and a per-step weight packer.  The weight gradient lives in xpt_conv_wgrad.hip.
+//
+// Replaces keras Conv2D(padding="same") as built by CustomConv2D (model/model_util/layer_ops.py:5-36) for
+// PoseNetImproved (model/build_model/pose_net.py:57-91) and DepthNetNoResize's decoder
+// (model/build_model/depth_net.py:101-109, 137-167: UpSampling2D(2, "nearest") -> conv -> concat -> conv), and the
+// tape.gradient of those layers w.r.t. their inputs (model/train_val.py:85-86).
+//
+// Why own kernels: no library workspace (MIOpen's bf16 backward solvers accumulate in an fp32 workspace handed out by
+// the capture allocator; inside the captured training step that path returned one 64-channel tile of garbage from the
+// second replay on -- DESIGN.md section 6), and the pad / up-sample / concat / bias / activation launches around a
+// library convolution disappear.
+//
+// GEMM view.  D[n][m] = sum_{tap, c} Wp[n][tap][c] * X[pixel(m, tap)][c]: A = packed weights (rows n, k-contiguous),
+// B = NHWC activations (columns = pixels, k-contiguous channels) -- both operands are k-contiguous, which is the operand
+// layout of v_mfma_f32_32x32x16_bf16 (lane (r = lane & 31, h = lane >> 5) holds A[row r][8h..8h+7] and B[8h..8h+7][col r]),
+// so every fragment is ONE 16-byte global load with no LDS staging and no transposition.  The accumulator of a lane is
+// 4 groups of 4 CONSECUTIVE output channels of one pixel: 8-byte bf16 stores into the NHWC output.
+// A wave owns RM x RN tiles of 32 x 32; the K loop keeps G k-steps of loads in flight ahead of their MFMAs.
+//   large pixel counts: 4 waves of a workgroup stack along the pixel axis (weights shared through the L1);
+//   small pixel counts (the 2x7 ... 8x26 maps): the NKW waves of a workgroup split the K loop of ONE tile and add their
+//   accumulators through LDS, so that even a 112-pixel layer spreads over hundreds of waves.
+// Transposed mode (data gradient of a stride-s convolution): input coordinate t = o + pad - k must be a multiple of s;
+// output pixels are enumerated per residue class (blockIdx.z) so that only the taps that contribute are visited.
+#include "xpt_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline unsigned short f2bf(float f) {   // round to nearest even (inputs are finite or NaN-preserving enough here)
+  return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+
+struct ConvArgs {
+  const unsigned short* x;   // NHWC bf16 activations, physical extent PH x PW, pixel pitch xpitch elements
+  const unsigned short* w;   // packed weights [N][T][C] bf16 (T = KH*KW taps, C = padded reduction channels)
+  const float* bias;         // [N] or null
+  unsigned short* y;         // NHWC bf16 output, pixel pitch ypitch elements
+  long long xpitch, ypitch;
+  int B, PH, PW;             // physical input extent
+  int Hlim, Wlim;            // logical extent the taps index: PH << shift
+  int shift;                 // 0 direct; 1 nearest-2x input (source = t >> 1) or transposed with forward stride 2 (t / 2)
+  int C, N, KH, KW;
+  int so;                    // output -> input step (the forward stride; 1 in transposed mode)
+  int sgn;                   // +1: t = o*so + k + off; -1 (transposed): t = o + off - k
+  int off_h, off_w;          // -pad (forward) / +pad (transposed)
+  int OH, OW;                // pixel grid the kernel enumerates
+  int xs;                    // residue classes per axis (transposed with forward stride 2: 2; else 1)
+  int quad;                  // 1: pixels are enumerated as (parent, child) and the 4 children are summed into the parent
+  float slope;               // LeakyReLU slope of the epilogue (1 = linear)
+};
+
+template <int RM, int RN, int NKW>
+__global__ __launch_bounds__(NKW > 1 ? 64 * NKW : 256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int G = (RM * RN >= 4) ? 4 : 8;      // k-steps whose loads are in flight together
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  // residue class of this part of the grid (transposed stride-2 mode), its pixel grid and its taps
+  const int cls = blockIdx.z, ch = cls / a.xs, cw = cls % a.xs;
+  const int rows_c = (a.OH - ch + a.xs - 1) / a.xs, cols_c = (a.OW - cw + a.xs - 1) / a.xs;
+  const long long Mc = (long long)a.B * rows_c * cols_c;
+  int kh0 = 0, kw0 = 0, kstep = 1;
+  if (a.xs > 1) {
+    kh0 = (ch + a.off_h) % a.xs;
+    kw0 = (cw + a.off_w) % a.xs;
+    kstep = a.xs;
+  }
+  const int nkh = kh0 < a.KH ? (a.KH - kh0 + kstep - 1) / kstep : 0;
+  const int nkw = kw0 < a.KW ? (a.KW - kw0 + kstep - 1) / kstep : 0;
+  const int csteps = (a.C + 15) >> 4;
+  const int nsteps = nkh * nkw * csteps;
+
+  const long long tile_m = (NKW > 1) ? (long long)blockIdx.y : (long long)blockIdx.y * 4 + wave;
+  const long long m0 = tile_m * (32 * RN);
+  const int n0 = blockIdx.x * (32 * RM);
+  if (m0 >= Mc) return;                          // uniform per wave; with NKW > 1 uniform per workgroup
+
+  // ---- per-lane pixel geometry (columns of the B operand)
+  int pb[RN], poh[RN], pow_[RN];
+  bool pok[RN];
+#pragma unroll
+  for (int j = 0; j < RN; ++j) {
+    long long m = m0 + 32 * j + r;
+    pok[j] = m < Mc;
+    if (!pok[j]) m = Mc - 1;
+    int oh, ow, b;
+    if (a.quad) {                                // m = parent * 4 + child over the (OH/2) x (OW/2) parent grid
+      const int child = (int)(m & 3);
+      long long p = m >> 2;
+      const int pw_ = a.OW >> 1, ph_ = a.OH >> 1;
+      const int c = (int)(p % pw_);
+      p /= pw_;
+      const int rr = (int)(p % ph_);
+      b = (int)(p / ph_);
+      oh = 2 * rr + (child >> 1);
+      ow = 2 * c + (child & 1);
+    } else {
+      const int c = (int)(m % cols_c);
+      long long p = m / cols_c;
+      const int rr = (int)(p % rows_c);
+      b = (int)(p / rows_c);
+      oh = rr * a.xs + ch;
+      ow = c * a.xs + cw;
+    }
+    pb[j] = b;
+    poh[j] = oh;
+    pow_[j] = ow;
+  }
+  int base_h[RN], base_w[RN];
+#pragma unroll
+  for (int j = 0; j < RN; ++j) {
+    base_h[j] = poh[j] * a.so + a.off_h;
+    base_w[j] = pow_[j] * a.so + a.off_w;
+  }
+  // ---- weight rows (rows of the A operand)
+  const int T = a.KH * a.KW;
+  const unsigned short* wrow[RM];
+  bool nok[RM];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    const int n = n0 + 32 * i + r;
+    nok[i] = n < a.N;
+    wrow[i] = a.w + (long long)(nok[i] ? n : a.N - 1) * T * a.C;
+  }
+
+  f32x16 acc[RM][RN];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int j = 0; j < RN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // ---- K loop: this wave's range of k-steps (all of them unless the workgroup splits K)
+  int s_begin = 0, s_end = nsteps;
+  if (NKW > 1) {
+    const int per = (nsteps + NKW - 1) / NKW;
+    s_begin = wave * per;
+    s_end = s_begin + per < nsteps ? s_begin + per : nsteps;
+  }
+  // running (tap row, tap column, channel step) of the NEXT step to issue
+  int it = 0, khi = 0, kwi = 0, cs = 0;
+  if (s_begin > 0 && s_begin < nsteps) {
+    it = s_begin / csteps;
+    cs = s_begin % csteps;
+    khi = it / nkw;
+    kwi = it % nkw;
+  }
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  for (int s0 = s_begin; s0 < s_end; s0 += G) {
+    uint4 fa[G][RM], fb[G][RN];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int kh = kh0 + khi * kstep, kw = kw0 + kwi * kstep;
+      const int c0 = cs * 16 + 8 * h;
+      const bool live = (s0 + g < s_end) && (c0 < a.C);        // steps past the range load from offset 0 and are zeroed
+      const int cc = live ? c0 : 0;
+      const long long woff = (long long)(kh * a.KW + kw) * a.C + cc;
+#pragma unroll
+      for (int i = 0; i < RM; ++i) {
+        const uint4 v = *(const uint4*)(wrow[i] + (s0 + g < s_end ? woff : 0));
+        fa[g][i] = (live && nok[i]) ? v : zero4;
+      }
+#pragma unroll
+      for (int j = 0; j < RN; ++j) {
+        const int th = base_h[j] + a.sgn * kh, tw = base_w[j] + a.sgn * kw;
+        const bool ok = live && pok[j] && th >= 0 && th < a.Hlim && tw >= 0 && tw < a.Wlim;
+        const int row = ok ? (th >> a.shift) : 0, col = ok ? (tw >> a.shift) : 0;
+        const long long xoff = (((long long)pb[j] * a.PH + row) * a.PW + col) * a.xpitch + cc;
+        const uint4 v = *(const uint4*)(a.x + (ok ? xoff : 0));
+        fb[g][j] = ok ? v : zero4;
+      }
+      // advance to the next step (scalar state)
+      if (++cs == csteps) {
+        cs = 0;
+        if (++kwi == nkw) {
+          kwi = 0;
+          ++khi;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (s0 + g < s_end) {                                    // wave-uniform
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int j = 0; j < RN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[g][i]),
+                                                                __builtin_bit_cast(bf16x8, fb[g][j]), acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- split-K: add the waves' accumulators through LDS; wave w then owns the register groups q with q % NKW == w
+  __shared__ float red[(NKW > 1) ? NKW * 16 * 64 : 1];
+  if (NKW > 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) red[(wave * 16 + q) * 64 + lane] = acc[0][0][q];
+    __syncthreads();
+    if (wave >= 4) return;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      if (((q >> 2) % (NKW < 4 ? NKW : 4)) != (wave % 4)) continue;      // wave-uniform: only this wave's groups
+      float sum = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < NKW; ++w2) sum += red[(w2 * 16 + q) * 64 + lane];
+      acc[0][0][q] = sum;
+    }
+  }
+
+  // ---- epilogue.  Register q of tile (i, j): channel n0 + 32 i + (q & 3) + 8 (q >> 2) + 4 h, pixel m0 + 32 j + r
+  const bool vec_ok = (a.N % 4 == 0) && (a.ypitch % 4 == 0) && (((uintptr_t)a.y) % 8 == 0);
+#pragma unroll
+  for (int j = 0; j < RN; ++j) {
+    long long opix;
+    bool store = pok[j];
+    if (a.quad) {
+      opix = (m0 + 32 * j + r) >> 2;
+    } else {
+      opix = ((long long)pb[j] * a.OH + poh[j]) * a.OW + pow_[j];
+    }
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+#pragma unroll
+      for (int qg = 0; qg < 4; ++qg) {
+        if (NKW > 1 && (qg % (NKW < 4 ? NKW : 4)) != (wave % 4)) continue;   // wave-uniform: this wave's share
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * qg + e];
+        if (a.quad) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += __shfl_xor(v[e], 1, 64);
+            v[e] += __shfl_xor(v[e], 2, 64);
+          }
+        }
+        const int n = n0 + 32 * i + 8 * qg + 4 * h;
+        if (!store || (a.quad && (r & 3) != 0) || n >= a.N) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (a.bias != nullptr && n + e < a.N) v[e] += a.bias[n + e];
+          v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+        }
+        unsigned short* dst = a.y + opix * a.ypitch + n;
+        if (vec_ok) {
+          uint2 pk;
+          pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          *(uint2*)dst = pk;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < a.N) dst[e] = f2bf(v[e]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight packer
+// One launch per step converts every dense convolution weight from its fp32 master copy (any strides; the flat parameter
+// buffer keeps them in channels_last order [N][KH][KW][C]) into the two bf16 operand layouts of the kernels above:
+//   fwd [N][T][Cp]   (Cp = C rounded up to a multiple of 8, zero filled)
+//   bwd [Cp][T][Np]  (the transposed-mode operand: rows = input channels (rows >= C zero, so that the data gradient of a
+//                     padded channel is written as 0), reduction = output channels, Np = N rounded up to 8, zero filled)
+struct PackJob {
+  const float* src;          // fp32 master weight; element (n, kh, kw, c) at n*sn + kh*sh + kw*sw + c*sc
+  unsigned short* fwd;
+  unsigned short* bwd;       // may be null (layer whose input needs no gradient)
+  long long sn, sc, sh, sw;
+  int N, T, KW, C, Cp, Np;
+  long long first_block;     // first workgroup of this job in the launch
+};
+
+__global__ __launch_bounds__(256) void conv_pack_kernel(const PackJob* __restrict__ jobs, int njobs) {
+  // find the job of this workgroup (jobs are few: linear scan by one thread, broadcast through LDS)
+  __shared__ int sj;
+  if (threadIdx.x == 0) {
+    int j = 0;
+    while (j + 1 < njobs && jobs[j + 1].first_block <= (long long)blockIdx.x) ++j;
+    sj = j;
+  }
+  __syncthreads();
+  const PackJob jb = jobs[sj];
+  const long long local = ((long long)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+  const long long nf = (long long)jb.N * jb.T * jb.Cp;
+  const long long nb = (long long)jb.Cp * jb.T * jb.Np;
+  if (local < nf) {                                            // forward layout: element (n, t, c)
+    const int c = (int)(local % jb.Cp);
+    const long long nt = local / jb.Cp;
+    const int t = (int)(nt % jb.T);
+    const long long n = nt / jb.T;
+    const float v = c < jb.C ? jb.src[n * jb.sn + (t / jb.KW) * jb.sh + (t % jb.KW) * jb.sw + c * jb.sc] : 0.f;
+    jb.fwd[local] = f2bf(v);
+  } else if (local < nf + nb && jb.bwd != nullptr) {           // backward layout: element (c, t, n)
+    const long long l2 = local - nf;
+    const int n = (int)(l2 % jb.Np);
+    const long long ct = l2 / jb.Np;
+    const int t = (int)(ct % jb.T);
+    const int c = (int)(ct / jb.T);
+    const float v = (n < jb.N && c < jb.C) ? jb.src[n * jb.sn + (t / jb.KW) * jb.sh + (t % jb.KW) * jb.sw + c * jb.sc] : 0.f;
+    jb.bwd[l2] = f2bf(v);
+  }
+}
+
+// PoseNet input: restack_on_channels (pose_net.py:44-50) of the fp32 snippet [B,S,H,W,3] into bf16 [B,H,W,Cp]
+// (channel = frame * 3 + c, channels >= 3 S zero) -- the layout the first convolution reads.
+__global__ __launch_bounds__(256) void restack_kernel(const float* __restrict__ img, unsigned short* __restrict__ out,
+                                                      int B, int S, long long HW, int Cp) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread per (pixel, frame-or-pad slot)
+  const int slots = S + ((Cp - 3 * S + 2) / 3);
+  const long long total = (long long)B * HW * slots;
+  if (i >= total) return;
+  const int sl = (int)(i % slots);
+  const long long bp = i / slots;
+  const long long p = bp % HW;
+  const long long b = bp / HW;
+  unsigned short* o = out + bp * Cp + 3 * sl;
+  if (sl < S) {
+    const float* src = img + ((b * S + sl) * HW + p) * 3;
+    o[0] = f2bf(src[0]);
+    o[1] = f2bf(src[1]);
+    o[2] = f2bf(src[2]);
+  } else {
+    for (int c = 3 * sl; c < Cp && c < 3 * sl + 3; ++c) out[bp * Cp + c] = 0;
+  }
+}
+
+template <int RM, int RN, int NKW>
+int launch_igemm(const ConvArgs& a, long long Mmax, int classes, hipStream_t s) {
+  const long long mtiles = (Mmax + 32 * RN - 1) / (32 * RN);
+  const long long gy = NKW > 1 ? mtiles : (mtiles + 3) / 4;
+  if (gy > 65535) return XPT_ERR_SHAPE;
+  const dim3 grid((a.N + 32 * RM - 1) / (32 * RM), (unsigned)gy, classes);
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL((conv_igemm_kernel<RM, RN, NKW>), grid, dim3(NKW > 1 ? 64 * NKW : 256), 0, s, a);
+  return xpt_launch_status();
+}
+
+int g_conv_plan = 0;   // 0 = automatic; otherwise RM*100 + RN*10 + log2(NKW) (benchmarking)
+
+int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
+  const int classes = a.xs * a.xs;
+  // pixels of the largest residue class
+  const long long Mmax = (long long)a.B * ((a.OH + a.xs - 1) / a.xs) * ((a.OW + a.xs - 1) / a.xs);
+  const long long ntile = (a.N + 31) / 32, mtile = (Mmax + 31) / 32;
+  const long long waves11 = ntile * mtile * classes;
+  int rm = 1, rn = 1, nkw = 1;
+  if (g_conv_plan) {
+    rm = g_conv_plan / 100;
+    rn = (g_conv_plan / 10) % 10;
+    nkw = 1 << (g_conv_plan % 10);
+  } else if (waves11 >= 8192) {
+    rm = a.N > 32 ? 2 : 1;
+    rn = 2;
+  } else if (waves11 >= 3072) {
+    rn = 2;
+  } else if (waves11 >= 1024) {
+  } else if (waves11 >= 384) {
+    nkw = 4;
+  } else {
+    nkw = 8;
+  }
+  if (rm == 2 && rn == 2 && nkw == 1) return launch_igemm<2, 2, 1>(a, Mmax, classes, s);
+  if (rm == 1 && rn == 2 && nkw == 1) return launch_igemm<1, 2, 1>(a, Mmax, classes, s);
+  if (rm == 1 && rn == 1 && nkw == 1) return launch_igemm<1, 1, 1>(a, Mmax, classes, s);
+  if (rm == 1 && rn == 1 && nkw == 2) return launch_igemm<1, 1, 2>(a, Mmax, classes, s);
+  if (rm == 1 && rn == 1 && nkw == 4) return launch_igemm<1, 1, 4>(a, Mmax, classes, s);
+  if (rm == 1 && rn == 1 && nkw == 8) return launch_igemm<1, 1, 8>(a, Mmax, classes, s);
+  return XPT_ERR_ARG;
+}
+
+}  // namespace
+
+extern "C" int xpt_conv2d_tune(int plan) {
+  g_conv_plan = plan;
+  return XPT_OK;
+}
+
+extern "C" int xpt_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int B, int PH, int PW, int C,
+                              long long xpitch, int N, int KH, int KW, int stride, int pad_t, int pad_l, int OH, int OW,
+                              long long ypitch, int upsample, float slope, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(y);
+  if (B <= 0 || PH <= 0 || PW <= 0 || C <= 0 || N <= 0 || KH <= 0 || KW <= 0 || OH <= 0 || OW <= 0) return XPT_ERR_SHAPE;
+  if (C % 8 != 0 || xpitch < C || xpitch % 8 != 0 || ypitch < N || ((uintptr_t)x) % 16 != 0 || ((uintptr_t)w) % 16 != 0)
+    return XPT_ERR_ARG;
+  if (stride < 1 || (upsample != 0 && upsample != 1) || pad_t < 0 || pad_l < 0) return XPT_ERR_ARG;
+  ConvArgs a{};
+  a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias; a.y = (unsigned short*)y;
+  a.xpitch = xpitch; a.ypitch = ypitch;
+  a.B = B; a.PH = PH; a.PW = PW; a.shift = upsample; a.Hlim = PH << upsample; a.Wlim = PW << upsample;
+  a.C = C; a.N = N; a.KH = KH; a.KW = KW;
+  a.so = stride; a.sgn = 1; a.off_h = -pad_t; a.off_w = -pad_l;
+  a.OH = OH; a.OW = OW; a.xs = 1; a.quad = 0; a.slope = slope;
+  // the last window must start inside the padded input
+  if ((long long)(OH - 1) * stride - pad_t >= a.Hlim || (long long)(OW - 1) * stride - pad_l >= a.Wlim) return XPT_ERR_SHAPE;
+  return dispatch_igemm(a, (hipStream_t)stream);
+}
+
+/* data gradient: g [B,OH,OW,Np] (gradient at the convolution output, channels padded to Np with zeros or any finite
+ * values times zero weights) -> dx [B,IH,IW,C] where IH x IW is the PHYSICAL input extent; fold2x2 = the forward input
+ * was the nearest-2x up-sampling of x (the gradient of the four children is summed). */
+extern "C" int xpt_conv2d_bwd_data(const void* g, const void* wb, void* dx, int B, int OH, int OW, int Np, long long gpitch,
+                                   int C, int KH, int KW, int stride, int pad_t, int pad_l, int IH, int IW,
+                                   long long dxpitch, int fold2x2, void* stream) {
+  XPT_CHECK_PTR(g); XPT_CHECK_PTR(wb); XPT_CHECK_PTR(dx);
+  if (B <= 0 || OH <= 0 || OW <= 0 || Np <= 0 || C <= 0 || KH <= 0 || KW <= 0 || IH <= 0 || IW <= 0) return XPT_ERR_SHAPE;
+  if (Np % 8 != 0 || gpitch < Np || gpitch % 8 != 0 || dxpitch < C || ((uintptr_t)g) % 16 != 0 || ((uintptr_t)wb) % 16 != 0)
+    return XPT_ERR_ARG;
+  if ((stride != 1 && stride != 2) || (fold2x2 != 0 && fold2x2 != 1) || (fold2x2 && stride != 1)) return XPT_ERR_ARG;
+  ConvArgs a{};
+  a.x = (const unsigned short*)g; a.w = (const unsigned short*)wb; a.bias = nullptr; a.y = (unsigned short*)dx;
+  a.xpitch = gpitch; a.ypitch = dxpitch;
+  a.B = B; a.PH = OH; a.PW = OW;
+  a.shift = stride == 2 ? 1 : 0; a.Hlim = OH * stride; a.Wlim = OW * stride;
+  a.C = Np; a.N = C; a.KH = KH; a.KW = KW;
+  a.so = 1; a.sgn = -1; a.off_h = pad_t; a.off_w = pad_l;
+  a.OH = fold2x2 ? 2 * IH : IH; a.OW = fold2x2 ? 2 * IW : IW;
+  a.xs = stride; a.quad = fold2x2; a.slope = 1.f;
+  return dispatch_igemm(a, (hipStream_t)stream);
+}
+
+extern "C" int xpt_conv_pack_job_bytes(void) { return (int)sizeof(PackJob); }
+
+extern "C" int xpt_conv_pack_weights(const void* jobs, int njobs, long long nblocks, void* stream) {
+  XPT_CHECK_PTR(jobs);
+  if (njobs <= 0 || nblocks <= 0 || nblocks > 0x7fffffffLL) return XPT_ERR_SHAPE;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const PackJob*)jobs,
+                     njobs);
+  return xpt_launch_status();
+}
+
+extern "C" int xpt_restack_bf16(const float* image5d, void* out, int B, int S, int H, int W, int Cp, void* stream) {
+  XPT_CHECK_PTR(image5d); XPT_CHECK_PTR(out);
+  if (B <= 0 || S <= 0 || H <= 0 || W <= 0 || Cp < 3 * S) return XPT_ERR_SHAPE;
+  const long long HW = (long long)H * W;
+  const int slots = S + ((Cp - 3 * S + 2) / 3);
+  const long long total = (long long)B * HW * slots;
+  const long long blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return XPT_ERR_SHAPE;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(restack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, image5d,
+                     (unsigned short*)out, B, S, HW, Cp);
+  return xpt_launch_status();
+}

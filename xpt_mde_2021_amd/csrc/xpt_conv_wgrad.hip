@@ -1,0 +1,257 @@
+// xpt_conv_wgrad.hip -- weight gradient of the dense k x k convolutions (PoseNetImproved, depth decoder) on the gfx950
+// bf16 matrix cores:   dW[n][kh][kw][c] = sum over output pixels m of  g[m][n] * x[pixel(m, kh, kw)][c]
+// (tape.gradient of the Conv2D kernels built by CustomConv2D, model/model_util/layer_ops.py:5-36; model/train_val.py:85-86).
+//
+// The reduction index (pixels) is the SLOW axis of both NHWC operands, the opposite of what an MFMA fragment wants
+// (8 consecutive k per lane).  The tiles are therefore staged row-major in LDS exactly as they lie in memory (16-byte
+// global loads along the channels) and read back TRANSPOSED with ds_read_b64_tr_b16: per 16-lane group the instruction
+// takes 4 pixel rows x 16 channel columns and hands lane i the 4 pixels of channel column i -- two reads give a lane
+// the 8 consecutive pixels of its channel that v_mfma_f32_32x32x16_bf16 expects, for A (= g^T, rows = output channels)
+// and for B (= x, columns = input channels).  Every lane supplies the address of one pixel row, so the shifted
+// windows of the taps and the stride-2 input grid are plain address arithmetic on ONE staged halo tile of x: the input
+// is read from HBM/L2 once per unit, not once per tap.
+//
+// Work decomposition.  A workgroup (4 waves) owns a TNB x TCB (output x input channel) block of dW for all taps and
+// loops over its share of the pixel UNITS (R output rows x CB columns of one image); the waves split the block into
+// 32 x 32 sub-tiles (WN x WC) and, when the block is small, the taps (WT groups of TAPS).  The workgroup's sum over its
+// units is written as one fp32 partial (row-major like the parameter, [N][KH][KW][Cr]); the per-step finishing launch
+// (xpt_reduce_partials) adds the partials of all splits into the flat gradient buffer in a fixed order.
+#include "xpt_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct WgradArgs {
+  const unsigned short* g;   // [B,OH,OW,N] bf16, pixel pitch gpitch
+  const unsigned short* x;   // [B,PH,PW,C] bf16, pixel pitch xpitch (C = channels readable per pixel, multiple of 8)
+  float* part;               // [nsplit][N][T][Cr] fp32
+  long long gpitch, xpitch;
+  int B, PH, PW, shift, Hlim, Wlim;
+  int C, Cr, N, KH, KW, stride, pad_t, pad_l, OH, OW;
+  int R, CB, nseg, nrb, units, nsplit;
+  int WN, WC, WT;
+};
+
+__device__ inline bf16x8 tr_pair(const char* lds, unsigned off0, unsigned off1) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + off1));
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int TNB = 32 * a.WN, TCB = 32 * a.WC;
+  const int T = a.KH * a.KW;
+  const int ntc = (a.C + TCB - 1) / TCB;
+  const int n0 = (blockIdx.x / ntc) * TNB, c0 = (blockIdx.x % ntc) * TCB;
+  const int HR = (a.R - 1) * a.stride + a.KH, Wt = (a.CB - 1) * a.stride + a.KW;
+  char* gs = smem;                                             // [R][CB][TNB] bf16
+  char* xs = smem + (size_t)a.R * a.CB * TNB * 2;              // [HR][Wt][TCB] bf16
+
+  // this wave's sub-tile and taps
+  const int wt = wave % a.WT, wc = (wave / a.WT) % a.WC, wn = wave / (a.WT * a.WC);
+  const int tap0 = wt * TAPS;
+  const bool active = tap0 < T;                                // wave-uniform
+  // lane roles of the transposed reads
+  const int g4 = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, h = g4 >> 1, half = g4 & 1;
+  unsigned a_base[2], b_base[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pc = 8 * h + 4 * i + q;                          // pixel column of this lane's row, read i
+    a_base[i] = (unsigned)((pc * TNB + wn * 32 + 16 * half + 4 * p) * 2);
+    b_base[i] = (unsigned)((pc * a.stride * TCB + wc * 32 + 16 * half + 4 * p) * 2);
+  }
+  unsigned toff[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int tap = tap0 + t < T ? tap0 + t : 0;
+    toff[t] = (unsigned)(((tap / a.KW) * Wt + (tap % a.KW)) * TCB * 2);
+  }
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  const int gchunks = a.R * a.CB * (TNB / 8), xchunks = HR * Wt * (TCB / 8);
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  for (int u = blockIdx.y; u < a.units; u += a.nsplit) {
+    const int seg = u % a.nseg, rb = (u / a.nseg) % a.nrb, b = u / (a.nseg * a.nrb);
+    const int oh0 = rb * a.R, ow0 = seg * a.CB;
+    __syncthreads();                                           // the previous unit's reads are done
+    for (int ck = tid; ck < gchunks; ck += 256) {
+      const int c8 = ck % (TNB / 8), pix = ck / (TNB / 8);
+      const int cc = pix % a.CB, rr = pix / a.CB;
+      const int oh = oh0 + rr, ow = ow0 + cc, n = n0 + 8 * c8;
+      const bool ok = oh < a.OH && ow < a.OW && n < a.N;
+      const long long off = (((long long)b * a.OH + oh) * a.OW + ow) * a.gpitch + n;
+      const uint4 v = *(const uint4*)(a.g + (ok ? off : 0));
+      *(uint4*)(gs + (size_t)ck * 16) = ok ? v : zero4;
+    }
+    for (int ck = tid; ck < xchunks; ck += 256) {
+      const int c8 = ck % (TCB / 8), pix = ck / (TCB / 8);
+      const int wcx = pix % Wt, hr = pix / Wt;
+      const int th = oh0 * a.stride - a.pad_t + hr, tw = ow0 * a.stride - a.pad_l + wcx, c = c0 + 8 * c8;
+      const bool ok = th >= 0 && th < a.Hlim && tw >= 0 && tw < a.Wlim && c < a.C;
+      const long long off = (((long long)b * a.PH + (th >> a.shift)) * a.PW + (tw >> a.shift)) * a.xpitch + c;
+      const uint4 v = *(const uint4*)(a.x + (ok ? off : 0));
+      *(uint4*)(xs + (size_t)ck * 16) = ok ? v : zero4;
+    }
+    __syncthreads();
+    if (active) {
+      for (int rr = 0; rr < a.R; ++rr) {
+        for (int c16 = 0; c16 < a.CB; c16 += 16) {
+          const unsigned ga = (unsigned)((rr * a.CB + c16) * TNB * 2);
+          const unsigned xa = (unsigned)(((rr * a.stride) * Wt + c16 * a.stride) * TCB * 2);
+          const bf16x8 fa = tr_pair(gs, a_base[0] + ga, a_base[1] + ga);
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) {
+            if (tap0 + t < T) {                                // wave-uniform
+              const bf16x8 fb = tr_pair(xs, b_base[0] + xa + toff[t], b_base[1] + xa + toff[t]);
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // partial of this split: register e of tap t -> output channel n0 + 32 wn + (e & 3) + 8 (e >> 2) + 4 h,
+  // input channel c0 + 32 wc + (lane & 31)
+  if (!active) return;
+  const int c = c0 + wc * 32 + (lane & 31);
+  float* dst = a.part + (long long)blockIdx.y * a.N * T * a.Cr;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    if (tap0 + t >= T) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = n0 + wn * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (n < a.N && c < a.Cr) dst[((long long)n * T + tap0 + t) * a.Cr + c] = acc[t][e];
+    }
+  }
+}
+
+struct WgradPlan {
+  int WN, WC, WT, TAPS, R, CB, nseg, nrb, units, nsplit;
+  size_t lds;
+};
+
+int g_wgrad_max_partial_mib = 24, g_wgrad_target_blocks = 768;
+
+bool make_plan(int B, int C, int N, int KH, int KW, int stride, int OH, int OW, WgradPlan& p) {
+  const int T = KH * KW;
+  // wave decomposition: sub-tiles first, taps with what is left of the 4 waves
+  p.WN = N > 32 ? 2 : 1;
+  p.WC = C > 32 ? 2 : 1;
+  if (p.WN * p.WC == 4 && T > 13) p.WC = 1;                   // 5x5 with 13+ taps per wave would not fit the registers
+  p.WT = 4 / (p.WN * p.WC);
+  int taps = (T + p.WT - 1) / p.WT;
+  const int allowed[] = {1, 3, 5, 7, 9, 13};
+  p.TAPS = 0;
+  for (int v : allowed)
+    if (v >= taps) { p.TAPS = v; break; }
+  if (!p.TAPS) return false;
+  const int TNB = 32 * p.WN, TCB = 32 * p.WC;
+  // pixel units: CB columns (multiple of 16) x R rows; about 8+ k-steps per unit within 64 KiB of LDS
+  const int ow16 = (OW + 15) / 16 * 16;
+  p.CB = ow16 < 64 ? ow16 : 64;
+  p.nseg = (OW + p.CB - 1) / p.CB;
+  p.R = 128 / p.CB;
+  if (p.R < 1) p.R = 1;
+  if (p.R > OH) p.R = OH;
+  for (;;) {
+    const int HR = (p.R - 1) * stride + KH, Wt = (p.CB - 1) * stride + KW;
+    p.lds = ((size_t)p.R * p.CB * TNB + (size_t)HR * Wt * TCB) * 2;
+    if (p.lds <= 64 * 1024 || (p.R == 1 && p.CB == 16)) break;
+    if (p.R > 1) p.R = (p.R + 1) / 2;
+    else { p.CB = (p.CB / 2 + 15) / 16 * 16; p.nseg = (OW + p.CB - 1) / p.CB; }
+  }
+  if (p.lds > 160 * 1024) return false;
+  p.nrb = (OH + p.R - 1) / p.R;
+  p.units = B * p.nrb * p.nseg;
+  const long long tiles = (long long)((N + TNB - 1) / TNB) * ((C + TCB - 1) / TCB);
+  long long ns = (g_wgrad_target_blocks + tiles - 1) / tiles;
+  const long long bytes = (long long)N * T * C * 4;
+  const long long cap = ((long long)g_wgrad_max_partial_mib << 20) / (bytes > 0 ? bytes : 1);
+  if (ns > cap) ns = cap;
+  if (ns > p.units) ns = p.units;
+  if (ns < 1) ns = 1;
+  p.nsplit = (int)ns;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int xpt_conv2d_bwd_weight_tune(int max_partial_mib, int target_blocks) {
+  if (max_partial_mib > 0) g_wgrad_max_partial_mib = max_partial_mib;
+  if (target_blocks > 0) g_wgrad_target_blocks = target_blocks;
+  return XPT_OK;
+}
+
+extern "C" int xpt_conv2d_bwd_weight_splits(int B, int C, int N, int KH, int KW, int stride, int OH, int OW) {
+  WgradPlan p;
+  if (B <= 0 || C <= 0 || N <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || OH <= 0 || OW <= 0) return XPT_ERR_SHAPE;
+  if (!make_plan(B, C, N, KH, KW, stride, OH, OW, p)) return XPT_ERR_ARG;
+  return p.nsplit;
+}
+
+/* partials [splits][N][KH][KW][Cr] fp32 of dW = sum_m g[m][n] x[pixel(m,kh,kw)][c]; x has PH x PW physical pixels (the
+ * taps index its nearest-2x up-sampling when upsample = 1) of C readable channels (multiple of 8) of which the first Cr
+ * are real weight channels; g has N channels (multiple of 8). */
+extern "C" int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, float* partials, size_t partial_floats, int B,
+                                              int PH, int PW, int C, int Cr, long long xpitch, int N, long long gpitch,
+                                              int KH, int KW, int stride, int pad_t, int pad_l, int OH, int OW,
+                                              int upsample, void* stream) {
+  XPT_CHECK_PTR(g); XPT_CHECK_PTR(x); XPT_CHECK_PTR(partials);
+  if (B <= 0 || PH <= 0 || PW <= 0 || C <= 0 || Cr <= 0 || Cr > C || N <= 0 || KH <= 0 || KW <= 0 || OH <= 0 || OW <= 0)
+    return XPT_ERR_SHAPE;
+  if (C % 8 != 0 || N % 8 != 0 || xpitch < C || xpitch % 8 != 0 || gpitch < N || gpitch % 8 != 0 ||
+      ((uintptr_t)g) % 16 != 0 || ((uintptr_t)x) % 16 != 0 || stride < 1 || (upsample != 0 && upsample != 1))
+    return XPT_ERR_ARG;
+  WgradPlan p;
+  if (!make_plan(B, C, N, KH, KW, stride, OH, OW, p)) return XPT_ERR_ARG;
+  if (partial_floats < (size_t)p.nsplit * N * KH * KW * Cr) return XPT_ERR_WORKSPACE;
+  WgradArgs a{};
+  a.g = (const unsigned short*)g; a.x = (const unsigned short*)x; a.part = partials;
+  a.gpitch = gpitch; a.xpitch = xpitch;
+  a.B = B; a.PH = PH; a.PW = PW; a.shift = upsample; a.Hlim = PH << upsample; a.Wlim = PW << upsample;
+  a.C = C; a.Cr = Cr; a.N = N; a.KH = KH; a.KW = KW; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
+  a.OH = OH; a.OW = OW;
+  a.R = p.R; a.CB = p.CB; a.nseg = p.nseg; a.nrb = p.nrb; a.units = p.units; a.nsplit = p.nsplit;
+  a.WN = p.WN; a.WC = p.WC; a.WT = p.WT;
+  const int TNB = 32 * p.WN, TCB = 32 * p.WC;
+  const dim3 grid(((N + TNB - 1) / TNB) * ((C + TCB - 1) / TCB), p.nsplit);
+  hipStream_t s = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+#define XPT_WGRAD_CASE(TP)                                                                                         \
+  case TP: {                                                                                                       \
+    if (p.lds > 64 * 1024)                                                                                         \
+      (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<TP>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                (int)p.lds);                                                                       \
+    hipLaunchKernelGGL(conv_wgrad_kernel<TP>, grid, dim3(256), p.lds, s, a);                                       \
+  } break;
+  switch (p.TAPS) {
+    XPT_WGRAD_CASE(1)
+    XPT_WGRAD_CASE(3)
+    XPT_WGRAD_CASE(5)
+    XPT_WGRAD_CASE(7)
+    XPT_WGRAD_CASE(9)
+    XPT_WGRAD_CASE(13)
+    default:
+      return XPT_ERR_ARG;
+  }
+#undef XPT_WGRAD_CASE
+  return xpt_launch_status();
+}

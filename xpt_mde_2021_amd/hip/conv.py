@@ -1,0 +1,257 @@
+"""Dense k x k convolutions on the gfx950 matrix cores (csrc/xpt_conv.hip, csrc/xpt_conv_wgrad.hip) as one autograd op:
+keras Conv2D(padding="same") + bias + LeakyReLU of CustomConv2D (model/model_util/layer_ops.py:5-36), optionally reading
+its input through UpSampling2D(2, "nearest") (model/build_model/depth_net.py:76-84) without materialising it.
+
+Nothing here goes through MIOpen: no library workspace, no find step, hipGraph-replay-safe by construction (every buffer
+a kernel touches is either a tensor of the step or a persistent partial-sum workspace of hip/ops.py GradSink).
+"""
+import ctypes
+import math
+import weakref
+
+import torch
+
+from . import lib as _lib
+from . import ops as _ops
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+def same_pad(n, k, s):
+    """TF "SAME" (model/model_util/layer_ops.py padding="same"): total = max((ceil(n/s)-1)*s + k - n, 0); before = total // 2."""
+    total = max((math.ceil(n / s) - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+# ------------------------------------------------------------------------------- packed bf16 weights
+class ConvWeightPacker:
+    """Keeps, for every registered convolution weight, the two bf16 operand layouts of the kernels (forward
+    [N][T][Cp], data gradient [Cp][T][Np]) and refreshes ALL of them with one launch (`pack()`, called once per model
+    forward, i.e. once per training step and captured with it).  The job table lives on the device and is rebuilt when a
+    weight is added or its master storage moves (FlatParameters re-homes the parameters once)."""
+
+    def __init__(self):
+        self.entries = {}          # id(weight) -> dict(ref, fwd, bwd, geometry)
+        self.signature = None
+        self.table = None
+        self.nblocks = 0
+
+    def get(self, weight, need_bwd=True):
+        e = self.entries.get(id(weight))
+        if e is not None and e["ref"]() is weight:
+            if need_bwd and e["bwd"] is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise _lib.XptHipError("ConvWeightPacker: new operand layout requested during graph capture")
+                e["bwd"] = torch.zeros((e["Cp"], e["T"], e["Np"]), dtype=torch.bfloat16, device=weight.device)
+                self.signature = None
+                self._pack_now()
+            return e
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.XptHipError("ConvWeightPacker: a convolution weight was first used during graph capture "
+                                   "(run one eager step first)")
+        N, C, KH, KW = weight.shape
+        Cp, Np, T = round_up(C, 8), round_up(N, 8), KH * KW
+        e = {"ref": weakref.ref(weight), "N": N, "C": C, "KH": KH, "KW": KW, "T": T, "Cp": Cp, "Np": Np,
+             "fwd": torch.zeros((N, T, Cp), dtype=torch.bfloat16, device=weight.device),
+             "bwd": torch.zeros((Cp, T, Np), dtype=torch.bfloat16, device=weight.device) if need_bwd else None}
+        self.entries[id(weight)] = e
+        self.signature = None
+        self._pack_now()
+        return e
+
+    def _live(self):
+        dead = [k for k, e in self.entries.items() if e["ref"]() is None]
+        for k in dead:
+            del self.entries[k]
+        if dead:
+            self.signature = None
+        return [(e["ref"](), e) for e in self.entries.values()]
+
+    def _pack_now(self):
+        if not torch.cuda.is_current_stream_capturing():
+            self.pack()
+
+    def pack(self):
+        live = self._live()
+        live = [(w, e) for w, e in live if w is not None and w.is_cuda]
+        if not live:
+            return
+        lib = _lib.load()
+        sig = tuple((w.data_ptr(), w.stride(), e["fwd"].data_ptr(), 0 if e["bwd"] is None else e["bwd"].data_ptr())
+                    for w, e in live)
+        if sig != self.signature:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.XptHipError("ConvWeightPacker: the set of convolution weights changed during graph capture")
+            assert lib.xpt_conv_pack_job_bytes() == ctypes.sizeof(_lib.ConvPackJob)
+            jobs = (_lib.ConvPackJob * len(live))()
+            first = 0
+            for j, (w, e) in enumerate(live):
+                if w.dtype != torch.float32:
+                    raise _lib.XptHipError("ConvWeightPacker: master weights must be float32")
+                sn, sc, sh, sw = w.stride()
+                job = jobs[j]
+                job.src, job.fwd, job.bwd = w.data_ptr(), e["fwd"].data_ptr(), (None if e["bwd"] is None else e["bwd"].data_ptr())
+                job.sn, job.sc, job.sh, job.sw = sn, sc, sh, sw
+                job.N, job.T, job.KW, job.C, job.Cp, job.Np = e["N"], e["T"], e["KW"], e["C"], e["Cp"], e["Np"]
+                job.first_block = first
+                first += (e["N"] * e["T"] * e["Cp"] + e["Cp"] * e["T"] * e["Np"] + 255) // 256
+            self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(live[0][0].device)
+            self.nblocks = first
+            self.signature = sig
+        _lib.check(lib.xpt_conv_pack_weights(self.table.data_ptr(), len(live), self.nblocks, _stream()),
+                   "xpt_conv_pack_weights")
+
+
+packer = ConvWeightPacker()
+
+
+# ------------------------------------------------------------------------------- activations as (pointer, pitch)
+def nhwc_view(t, channels=None):
+    """NCHW-indexed bf16 tensor -> (tensor, pixel pitch in elements): dense channels_last tensors and channel slices of
+    them are used in place, anything else is made channels_last first."""
+    if t.dtype != torch.bfloat16 or not t.is_cuda:
+        raise _lib.XptHipError("conv: expected a bfloat16 CUDA/HIP tensor (no CPU fallback)")
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    ok = sc == 1 and sh == W * sw and sb == H * sh and sw >= C and sw % 8 == 0 and t.data_ptr() % 16 == 0
+    if not ok or B * H * W == 1:
+        t = t.contiguous(memory_format=torch.channels_last)
+        if t.stride(1) != 1:                       # [B,C,1,1] and friends: force the NHWC order
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        sw = C
+        if C % 8 != 0:
+            raise _lib.XptHipError(f"conv: {C} channels are not a multiple of 8 (pad the tensor)")
+    return t, sw
+
+
+class _Conv2dSame(torch.autograd.Function):
+    """y = LeakyReLU_slope(conv2d_same(x [nearest-2x up-sampled], weight, stride) + bias)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, slope, upsample, valid):
+        lib = _lib.load()
+        x, xpitch = nhwc_view(x)
+        B, Cx, PH, PW = x.shape
+        need_dx = ctx.needs_input_grad[0]
+        e = packer.get(weight, need_bwd=need_dx)
+        N, C, KH, KW, Cp = e["N"], e["C"], e["KH"], e["KW"], e["Cp"]
+        if Cx != Cp:
+            raise _lib.XptHipError(f"conv: input has {Cx} channels, the packed weight expects {Cp} (= {C} padded to 8)")
+        H, W = PH << upsample, PW << upsample
+        if valid:                                   # keras padding="valid" (the NASNet stem)
+            pt = pl = 0
+            OH, OW = (H - KH) // stride + 1, (W - KW) // stride + 1
+        else:
+            (pt, _), (pl, _) = same_pad(H, KH, stride), same_pad(W, KW, stride)
+            OH, OW = -(-H // stride), -(-W // stride)
+        y = torch.empty((B, N, OH, OW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        b_ = None if bias is None else bias.detach()
+        if b_ is not None and (b_.dtype != torch.float32 or not b_.is_contiguous()):
+            raise _lib.XptHipError("conv: bias must be a contiguous float32 vector")
+        _lib.check(lib.xpt_conv2d_fwd(x.data_ptr(), e["fwd"].data_ptr(), None if b_ is None else b_.data_ptr(),
+                                      y.data_ptr(), B, PH, PW, Cp, xpitch, N, KH, KW, stride, pt, pl, OH, OW, N,
+                                      int(upsample), float(slope), _stream()), "xpt_conv2d_fwd")
+        ctx.save_for_backward(x, y if slope != 1.0 else None, b_)
+        ctx.geom = (B, PH, PW, Cp, C, xpitch, N, KH, KW, stride, pt, pl, OH, OW, int(upsample), float(slope))
+        ctx.weight = weight
+        ctx.sink_w = weight.flat_grad if (_ops.grad_sink.wants(weight) and N % 8 == 0) else None
+        ctx.sink_b = bias.flat_grad if (bias is not None and _ops.grad_sink.wants(bias)) else None
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy_in):
+        lib = _lib.load()
+        x, y, bias = ctx.saved_tensors
+        B, PH, PW, Cp, C, xpitch, N, KH, KW, stride, pt, pl, OH, OW, ups, slope = ctx.geom
+        weight = ctx.weight
+        rows = B * OH * OW
+        # ---- activation / bias backward: g = dy * act'(y) (dense bf16 [rows, N]) and the bias gradient
+        dy, dpitch = _ops._rows_with_pitch(dy_in.to(torch.bfloat16))
+        dbias = None
+        if ctx.has_bias or slope != 1.0:
+            g = torch.empty((B, N, OH, OW), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+            if ctx.sink_b is not None:
+                nblk = lib.xpt_affine_act_bwd_blocks(rows, N)
+                ws = _ops.grad_sink.partials(ctx.sink_b, "affine", nblk * 2 * N)
+                _lib.check(lib.xpt_affine_act_bwd_partials(None, None if y is None else y.data_ptr(), dy.data_ptr(), dpitch,
+                                                           None, bias.data_ptr(), None, None, 0.0, g.data_ptr(),
+                                                           ws.data_ptr(), ws.numel(), rows, N, slope, 0, 1, _stream()),
+                           "xpt_affine_act_bwd_partials")
+                _ops.grad_sink.add(ctx.sink_b, ws, 0, N, nblk, 2 * N)
+            else:
+                beta = bias if bias is not None else torch.zeros(N, dtype=torch.float32, device=dy.device)
+                dbias = torch.empty(N, dtype=torch.float32, device=dy.device)
+                nws = lib.xpt_affine_act_bwd_workspace_floats(rows, N)
+                ws = torch.empty(nws, dtype=torch.float32, device=dy.device)
+                _lib.check(lib.xpt_affine_act_bwd(None, None if y is None else y.data_ptr(), dy.data_ptr(), dpitch, None,
+                                                  beta.data_ptr(), None, None, 0.0, g.data_ptr(), dbias.data_ptr(), None,
+                                                  ws.data_ptr(), nws, rows, N, slope, 0, 1, _stream()), "xpt_affine_act_bwd")
+                if not ctx.has_bias:
+                    dbias = None
+            gpitch = N
+        else:
+            g, gpitch = nhwc_view(dy_in.to(torch.bfloat16))
+        if N % 8 != 0:
+            raise _lib.XptHipError(f"conv backward: {N} output channels are not a multiple of 8")
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            e = packer.get(weight, need_bwd=True)
+            dx = torch.empty((B, Cp, PH, PW), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+            _lib.check(lib.xpt_conv2d_bwd_data(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"], gpitch,
+                                               Cp, KH, KW, stride, pt, pl, PH, PW, Cp, ups, _stream()), "xpt_conv2d_bwd_data")
+        if ctx.needs_input_grad[1]:
+            nsplit = lib.xpt_conv2d_bwd_weight_splits(B, Cp, N, KH, KW, stride, OH, OW)
+            if nsplit < 1:
+                raise _lib.XptHipError(f"xpt_conv2d_bwd_weight_splits failed: {nsplit}")
+            n = N * KH * KW * C
+            if ctx.sink_w is not None:
+                ws = _ops.grad_sink.partials(ctx.sink_w, "convw", nsplit * n)
+            else:
+                ws = torch.empty(nsplit * n, dtype=torch.float32, device=g.device)
+            _lib.check(lib.xpt_conv2d_bwd_weight_partials(g.data_ptr(), x.data_ptr(), ws.data_ptr(), ws.numel(), B, PH, PW,
+                                                          Cp, C, xpitch, N, gpitch, KH, KW, stride, pt, pl, OH, OW, ups,
+                                                          _stream()), "xpt_conv2d_bwd_weight_partials")
+            if ctx.sink_w is not None:
+                _ops.grad_sink.add(ctx.sink_w, ws, 0, n, nsplit, n)
+            else:
+                dw = ws[:nsplit * n].view(nsplit, N, KH, KW, C).sum(0).permute(0, 3, 1, 2)
+        return dx, dw, dbias, None, None, None, None
+
+
+def conv2d_same(x, weight, bias, stride=1, slope=1.0, upsample=False, valid=False):
+    """x [B,Cp,H,W] bf16 (NCHW-indexed, NHWC-stored; Cp = weight's input channels rounded up to 8, pad channels zero),
+    weight [N,C,KH,KW] float32 master, bias [N] float32 or None -> [B,N,ceil(2^u H / stride),ceil(2^u W / stride)] bf16."""
+    return _Conv2dSame.apply(x, weight, bias, int(stride), float(slope), bool(upsample), bool(valid))
+
+
+def usable(x, conv, slope):
+    """Can this Conv2DSame call run on the matrix-core kernels?  (bf16 activations on the GPU, dense, undilated, at most
+    13 taps per wave group: k <= 5; heads with a single output channel go through their own kernels.)"""
+    if not x.is_cuda or slope is None or conv.groups != 1 or conv.dilation != (1, 1):
+        return False
+    dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
+    k = conv.kernel_size
+    return dtype == torch.bfloat16 and k[0] == k[1] and k[0] in (1, 3, 5) and conv.out_channels % 8 == 0 \
+        and conv.weight.dtype == torch.float32
+
+
+def restack_bf16(image5d, channels_padded):
+    """restack_on_channels (pose_net.py:44-50) + cast: [B,S,H,W,3] float32 -> [B,Cp,H,W] bf16 (NHWC storage)."""
+    lib = _lib.load()
+    if not image5d.is_cuda or image5d.dtype != torch.float32:
+        raise _lib.XptHipError("restack_bf16: expected a float32 CUDA/HIP tensor")
+    image5d = image5d.contiguous()
+    B, S, H, W, C = image5d.shape
+    if C != 3:
+        raise _lib.XptHipError("restack_bf16: expected 3 channels per frame")
+    out = torch.empty((B, H, W, channels_padded), dtype=torch.bfloat16, device=image5d.device)
+    _lib.check(lib.xpt_restack_bf16(image5d.data_ptr(), out.data_ptr(), B, S, H, W, channels_padded, _stream()),
+               "xpt_restack_bf16")
+    return out.permute(0, 3, 1, 2)

@@ -83,12 +83,32 @@ SIGNATURES = {
     "xpt_depth_head_bwd": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p]),
     "xpt_sum_rows": (_i, [_p, _p, _i, _p, ctypes.c_longlong, _i, _i, _p]),
     "xpt_crc32c": (ctypes.c_uint32, [_p, _z]),
+    "xpt_conv_pack_job_bytes": (_i, []),
+    "xpt_conv_pack_weights": (_i, [_p, _i, ctypes.c_longlong, _p]),
+    "xpt_conv2d_tune": (_i, [_i]),
+    "xpt_conv2d_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _i, _i,
+                            ctypes.c_longlong, _i, _f, _p]),
+    "xpt_conv2d_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _i, _i,
+                                 ctypes.c_longlong, _i, _p]),
+    "xpt_conv2d_bwd_weight_tune": (_i, [_i, _i]),
+    "xpt_conv2d_bwd_weight_splits": (_i, [_i] * 8),
+    "xpt_conv2d_bwd_weight_partials": (_i, [_p, _p, _p, _z, _i, _i, _i, _i, _i, ctypes.c_longlong, _i, ctypes.c_longlong,
+                                            _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "xpt_restack_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "xpt_affine_act_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, ctypes.c_longlong, _i, _f, _i, _i, _p]),
     "xpt_affine_act_bwd_workspace_floats": (_z, [ctypes.c_longlong, _i]),
     "xpt_affine_act_bwd": (_i, [_p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f, _p, _p, _p, _p, _z, ctypes.c_longlong,
                                 _i, _f, _i, _i, _p]),
 }
 
+
+
+class ConvPackJob(ctypes.Structure):
+    """Mirror of xpt_conv_pack_job (include/xpt_hip.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("fwd", ctypes.c_void_p), ("bwd", ctypes.c_void_p),
+                ("sn", ctypes.c_longlong), ("sc", ctypes.c_longlong), ("sh", ctypes.c_longlong), ("sw", ctypes.c_longlong),
+                ("N", ctypes.c_int), ("T", ctypes.c_int), ("KW", ctypes.c_int), ("C", ctypes.c_int), ("Cp", ctypes.c_int),
+                ("Np", ctypes.c_int), ("first_block", ctypes.c_longlong)]
 
 
 class ReduceJob(ctypes.Structure):

@@ -21,11 +21,23 @@ class UpconvWithSkip(nn.Module):
 
     def forward(self, bef_layer, skips):
         if self.interp == "nearest":
-            up = F.interpolate(bef_layer, scale_factor=2, mode="nearest")        # UpSampling2D(2, "nearest")
+            up = self.conv1(bef_layer, upsample=True)                             # UpSampling2D(2, "nearest") fused into the conv
         else:
-            up = F.interpolate(bef_layer, scale_factor=2, mode="bilinear", align_corners=False)
-        up = self.conv1(up)
-        return self.conv2(torch.cat([up] + [s.to(up.dtype) for s in skips], dim=1))
+            up = self.conv1(F.interpolate(bef_layer, scale_factor=2, mode="bilinear", align_corners=False))
+        parts = [up] + [s.to(up.dtype) for s in skips]
+        total = sum(p.shape[1] for p in parts)
+        if up.is_cuda and up.dtype == torch.bfloat16 and total % 8:
+            # the matrix-core convolution reads 8-channel groups: the concatenation is built with its zero pad channels
+            parts.append(self._zeros(up, -total % 8))
+        return self.conv2(torch.cat(parts, dim=1))
+
+    def _zeros(self, like, channels):
+        key = (like.shape[0], channels, like.shape[2], like.shape[3], like.device)
+        cache = self.__dict__.setdefault("_zero_cache", {})
+        if key not in cache:                       # allocated by the first eager step, reused (also by captured steps)
+            cache[key] = torch.zeros((like.shape[0], channels, like.shape[2], like.shape[3]), dtype=like.dtype,
+                                     device=like.device).contiguous(memory_format=torch.channels_last)
+        return cache[key]
 
 
 class ScaledDepthHead(nn.Module):

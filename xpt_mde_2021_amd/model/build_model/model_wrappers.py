@@ -36,6 +36,11 @@ class ModelWrapper:
     def predict_batch(self, features, suffix=""):
         predictions = dict()
         image5d = features["image5d" + suffix]
+        if image5d.is_cuda and suffix == "":
+            # one launch refreshes the bf16 operand copies of every dense convolution weight from the fp32 masters
+            # (first thing of every step: captured with it, so a replayed step sees the weights Adam just wrote)
+            from ...hip import conv as _conv
+            _conv.packer.pack()
         nets = list(self.models.values())
         if image5d.is_cuda and len(nets) > 1 and getattr(opts, "NET_STREAMS", False):
             # DepthNet and PoseNet are independent until the loss: the small PoseNet runs on a side HIP stream next

@@ -33,7 +33,12 @@ class PoseNetBasic(nn.Module):
         return cin, []
 
     def forward(self, image5d):
-        x = restack_on_channels(image5d)
+        if image5d.is_cuda and image5d.dtype == torch.float32 and torch.is_autocast_enabled() \
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+            from ...hip import conv as _conv           # one launch: restack + cast + zero pad channel(s) for the MFMA conv
+            x = _conv.restack_bf16(image5d, _conv.round_up(image5d.shape[1] * image5d.shape[4], 8))
+        else:
+            x = restack_on_channels(image5d)
         x = self.head(self.convs(x))
         poses = x.float().mean(dim=(2, 3))                     # GlobalAveragePooling2D
         return {"pose": poses.reshape(-1, self.numsrc, 6)}

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from ...hip import ops as _ops
 from ...utils.util_class import WrongInputException
+from ...hip import conv as _conv
 from ..model_util.layer_ops import conv2d_library, same_pad
 
 _LIBRARY_WGRAD = __import__("os").environ.get("XPT_DEBUG_LIBRARY_WGRAD", "0") == "1"     # A/B switch: rocBLAS weight gradient
@@ -636,7 +637,13 @@ class NASNetMobileEncoder(nn.Module):
 
     def forward(self, image):
         taps = _Taps(self.TAP_ACTIVATIONS)
-        x = self.stem_bn(conv2d_library(self.preprocess(image), self.stem_conv.weight, 2, (0, 0)))
+        x = self.preprocess(image)
+        if _conv.usable(x, self.stem_conv, 1.0):          # keras Conv2D(32, 3, strides 2, padding="valid") on the matrix cores
+            x = F.pad(x.to(torch.bfloat16), (0, 0, 0, 0, 0, 5))                   # 3 -> 8 channels (16-byte pixel rows)
+            x = _conv.conv2d_same(x, self.stem_conv.weight, None, 2, 1.0, valid=True)
+        else:
+            x = conv2d_library(x, self.stem_conv.weight, 2, (0, 0))
+        x = self.stem_bn(x)
         p = None
         for cell in self.cells:
             x, p = cell(x, x if p is None else p, taps)

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip import conv as _conv
 from ...hip import ops as _ops
 
 
@@ -165,7 +166,20 @@ class Conv2DSame(nn.Module):
         if use_bias:
             nn.init.zeros_(self.conv.bias)
 
-    def forward(self, x):
+    def forward(self, x, upsample=False):
+        """`upsample`: the input is consumed through UpSampling2D(2, "nearest") (depth_net.py:76-84); on the matrix-core
+        path the up-sampled tensor is never materialised."""
+        if _conv.usable(x, self.conv, self.slope):
+            # gfx950 implicit-GEMM kernels (hip/conv.py): TF-SAME padding, bias, activation (and the up-sampling) fused;
+            # no library call, so nothing in a captured training step depends on MIOpen's solvers or workspaces
+            cp = _conv.round_up(self.conv.in_channels, 8)
+            if x.dtype != torch.bfloat16:
+                x = x.to(torch.bfloat16)
+            if x.shape[1] < cp:
+                x = F.pad(x, (0, 0, 0, 0, 0, cp - x.shape[1]))
+            return _conv.conv2d_same(x, self.conv.weight, self.conv.bias, self.s, self.slope, upsample)
+        if upsample:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
         ph = same_pad(x.shape[2], self.k, self.s, self.d)
         pw = same_pad(x.shape[3], self.k, self.s, self.d)
         # on the GPU the bias add + activation (and the bias gradient) run in one gfx950 epilogue kernel
