@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- train images/sec of the self-supervised depth/pose training step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4|c5]
+    N > 1 works both ways: under an external `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+    --gpus N ...` (RANK / WORLD_SIZE set), or stand-alone -- then this process starts that launcher itself (one fresh
+    child per GPU, before anything here touches the GPU) and relays rank 0's JSON line.
 
 One "step" = one full training step over one batch of synthetic KITTI-shaped snippets already resident in HBM:
-DepthNet(NASNet-Mobile)+PoseNetImproved forward in bf16 (MIOpen / rocBLAS), view synthesis + multi-scale
+DepthNet(NASNet-Mobile)+PoseNetImproved forward in bf16 (gfx950 MFMA kernels of this repo + rocBLAS GEMMs), view synthesis + multi-scale
 L1 + SSIM + smoothness loss in the gfx950 HIP kernels, backward, [RCCL all-reduce of the flat gradient], fused Adam.
 One "image" = one 5-frame 128x416 snippet (BASELINE.json).  Workload at N=1 = BASELINE.json configs[1]
 (batch 8 per GPU); N>1 keeps 8 snippets per GPU (weak scaling, configs[2]).
@@ -47,11 +49,48 @@ def parse():
     ap.add_argument("--nets", default="rigid", choices=["rigid", "flow", "joint"],
                     help="rigid = DepthNet + PoseNet (the headline workload); flow = PWC-Net with flowL2 + flow_reg; joint = "
                          "all three with cmbL1 + cmbSSIM + smoothe (SURVEY 8f-4; PWC-Net needs --width divisible by 64)")
+    ap.add_argument("--config", default=None, choices=["c2", "c4", "c5"],
+                    help="BASELINE.json configs: c2 = batch 8 128x416 (default), c4 = configs[3]: 256x832 batch 4, "
+                         "c5 = configs[4]: stereo + mono losses over the mixed dataset shapes cycled per step")
     ap.add_argument("--no-miopen-find", action="store_true", help="MIOpen immediate-mode heuristics instead of the fast find")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == "c4":
+        args.height, args.width, args.batch = 256, 832, 4
+    elif args.config == "c5":
+        args.stereo = True
+    return args
+
+
+# SURVEY.md 8(d) / config-example.py:25-30: image sizes of the mixed pretrain stream (cityscapes, waymo, a2d2, kitti-odom ...)
+MIXED_SHAPES = [(128, 512), (192, 512), (256, 384), (192, 384)]
+
+
+def launch_children(args):
+    """`python bench.py --gpus N` without a launcher around it: start `torch.distributed.run` with N fresh workers (this
+    process has not touched the GPU), pass rank 0's JSON line through and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for text in proc.stdout.splitlines():
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        else:
+            print(text, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if line is not None or proc.returncode else 1
 
 
 def build_step(args, world):
@@ -80,6 +119,14 @@ def build_step(args, world):
     model, augmenter, loss_object, optimizer = mm.create_training_parts(
         0, tfr_config, 1e-4, loss_weights, opts.SCALE_WEIGHT_T1, net_names, ckpt_name="__bench__")
     trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, opts.STEREO, augmenter, optimizer)
+    if args.config == "c5":
+        # configs[4]: the mixed pretrain stream -- every step another dataset's image size (one captured graph per size)
+        batches = []
+        for hw in MIXED_SHAPES:
+            opts.IMAGE_SIZES["kitti_raw"] = hw
+            batches.append(mm.get_dataset(name, "train", True)[0].batches)
+        dataset.batches = [b[i] for i in range(len(batches[0])) for b in batches]
+        opts.IMAGE_SIZES["kitti_raw"] = (args.height, args.width)
     return trainer, dataset, mode, loss_object
 
 
@@ -100,10 +147,13 @@ def cpu_baseline(args, seconds):
 
 
 def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_children(args))
     # stdout carries exactly ONE line (the JSON); everything the model / loss factories print goes to stderr
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
-        result, world = run()
+        result, world = run(args)
     if result is not None:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -111,11 +161,13 @@ def main():
         dist.destroy_process_group()
 
 
-def run():
-    args = parse()
+def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # every rank keeps its own MIOpen user database (eight ranks tuning into one file is an untested hazard)
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"xpt_miopen_db_rank{rank}"))
+    os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP ops have no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -136,6 +188,8 @@ def run():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     note(f"mode={mode} world={world} batch/GPU={args.batch} {args.height}x{args.width} dtype={args.dtype}")
+    if args.config == "c5":
+        args.warmup = max(args.warmup, len(MIXED_SHAPES))          # every image size is captured before the timed region
     for i in range(args.warmup):
         trainer.run_a_batch(batches[i % len(batches)])
         if i == 0:
@@ -163,7 +217,8 @@ def run():
     if rank == 0:
         global_batch = args.batch * world
         result = {
-            "metric": "train images/sec (5-frame 128x416 snippets)" if (args.height, args.width) == (128, 416)
+            "metric": "train images/sec (5-frame mixed-size snippets: " + ", ".join(f"{h}x{w}" for h, w in MIXED_SHAPES) + ")"
+            if args.config == "c5" else "train images/sec (5-frame 128x416 snippets)" if (args.height, args.width) == (128, 416)
             else f"train images/sec (5-frame {args.height}x{args.width} snippets)",
             "value": round(global_batch * args.steps / elapsed, 3),
             "unit": "images/sec",
@@ -175,7 +230,8 @@ def run():
                                    f"5x{args.height}x{args.width} snippets, batch {args.batch}/GPU, "
                                    f"{LOSS_LABEL[args.nets] if args.nets != 'rigid' else ('stereo LOSS_RIGID_T2' if args.stereo else 'mono L1+SSIM+smoothness')}, 4 scales",
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "mode": mode,
-                       "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
+                       "parallelism": f"dp{world}", "ranks": (dist.get_world_size() if world > 1 else 1),
+                       "final_loss": round(loss, 6)},
         }
     note(f"timed region done: {elapsed:.3f} s")
     if rank == 0 and not args.no_roofline:

@@ -273,6 +273,17 @@ int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, float* partials
                                    int stride, int pad_t, int pad_l, int OH, int OW, int upsample, void* stream);
 int xpt_restack_bf16(const float* image5d, void* out, int B, int S, int H, int W, int Cp, void* stream);
 
+/* ------------------------------------------------------------------ a2: decoder prediction heads
+ * replaces the Conv2D(1, 3, padding="same", activation linear) of get_scaled_depth (model/build_model/depth_net.py:87-92)
+ * and its tape.gradient: pre [B,H,W] fp32 = bias + conv3x3_same(x [B,H,W,C] bf16 with pixel pitch xpitch, w [3][3][C] fp32),
+ * C in {16, 32, 64, 128}.  bwd: g [B,H,W] fp32 -> dx [B,H,W,C] bf16 dense and per-workgroup partials
+ * [xpt_headconv_bwd_blocks()][9 C + 1] fp32 (dW [3][3][C], then dbias), finished by xpt_reduce_partials. */
+int xpt_headconv_bwd_blocks(int B, int H, int W, int C);
+int xpt_headconv_fwd(const void* x, long long xpitch, const float* w, const float* bias, float* pre, int B, int H, int W,
+                     int C, void* stream);
+int xpt_headconv_bwd(const void* x, long long xpitch, const float* w, const float* g, void* dx, float* partials,
+                     size_t partial_floats, int B, int H, int W, int C, void* stream);
+
 /* ------------------------------------------------------------------ a2/a4: depth head activation
  * InverseSigmoid (model/build_model/model_factory.py:134-138) and safe_reciprocal_number (utils/util_funcs.py:157-160):
  *   depth = safe_rcp(sigmoid(x) + 0.01), disp = safe_rcp(depth), safe_rcp(v) = (1 / v) [v > 1e-5]; float32, n elements.

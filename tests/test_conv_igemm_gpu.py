@@ -117,3 +117,29 @@ def test_packer_tracks_weight_updates(gpu_device):
     y1 = xc.conv2d_same(x, w, None, 1, 1.0).float()
     torch.cuda.synchronize()
     assert torch.allclose(y1, 2 * y0, rtol=2e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("C,H,W", [(16, 32, 104), (32, 16, 52), (64, 8, 26), (128, 5, 13)])
+def test_head_conv_fwd_bwd(gpu_device, C, H, W):
+    """Decoder prediction head (depth_net.py:87-92): Conv2D(1, 3, "same", linear) in fp32 arithmetic on bf16 features."""
+    from xpt_mde_2021_amd.hip import conv as xc
+    dev = gpu_device
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(3, C, H, W, generator=g).to(torch.bfloat16)
+    w = 0.1 * torch.randn(1, C, 3, 3, generator=g)
+    b = torch.tensor([0.3])
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, 1, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    (yr * gy).sum().backward()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    yd = xc.head_conv(xd, wd, bd)
+    assert yd.dtype == torch.float32 and yd.shape == yr.shape
+    (yd * gy.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert (yd.cpu() - yr).abs().max().item() < 1e-4 * max(yr.abs().max().item(), 1.0)          # fp32 both sides
+    assert (xd.grad.float().cpu() - xr.grad).abs().max().item() < 6e-3 * xr.grad.abs().max().item()   # bf16 dx
+    assert (wd.grad.cpu() - wr.grad).abs().max().item() < 1e-4 * wr.grad.abs().max().item()
+    assert abs(bd.grad.item() - br.grad.item()) < 1e-4 * max(abs(br.grad.item()), 1.0)

@@ -111,6 +111,15 @@ class ConvWeightPacker:
 packer = ConvWeightPacker()
 
 
+def _apply_env_tuning():
+    """XPT_WGRAD_TUNE="max partial MiB per layer,target workgroups" (benchmarking / diagnostics)."""
+    import os
+    spec = os.environ.get("XPT_WGRAD_TUNE")
+    if spec:
+        mib, blocks = (int(v) for v in spec.split(","))
+        _lib.load().xpt_conv2d_bwd_weight_tune(mib, blocks)
+
+
 # ------------------------------------------------------------------------------- activations as (pointer, pitch)
 def nhwc_view(t, channels=None):
     """NCHW-indexed bf16 tensor -> (tensor, pixel pitch in elements): dense channels_last tensors and channel slices of
@@ -130,12 +139,19 @@ def nhwc_view(t, channels=None):
     return t, sw
 
 
+_tuned = False
+
+
 class _Conv2dSame(torch.autograd.Function):
     """y = LeakyReLU_slope(conv2d_same(x [nearest-2x up-sampled], weight, stride) + bias)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, slope, upsample, valid):
         lib = _lib.load()
+        global _tuned
+        if not _tuned:
+            _apply_env_tuning()
+            _tuned = True
         x, xpitch = nhwc_view(x)
         B, Cx, PH, PW = x.shape
         need_dx = ctx.needs_input_grad[0]
@@ -255,3 +271,65 @@ def restack_bf16(image5d, channels_padded):
     _lib.check(lib.xpt_restack_bf16(image5d.data_ptr(), out.data_ptr(), B, S, H, W, channels_padded, _stream()),
                "xpt_restack_bf16")
     return out.permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------- decoder prediction heads (1 output channel)
+class _HeadConv(torch.autograd.Function):
+    """pre [B,1,H,W] fp32 = conv3x3_same(x bf16, weight [1,C,3,3]) + bias (csrc/xpt_headconv.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x, xpitch = nhwc_view(x)
+        B, C, H, W = x.shape
+        w = weight.detach()
+        if w.dtype != torch.float32 or tuple(w.shape) != (1, C, 3, 3):
+            raise _lib.XptHipError(f"head_conv: weight must be float32 [1, {C}, 3, 3], got {tuple(w.shape)} {w.dtype}")
+        if not (w.stride(1) == 1 and w.stride(3) == C and w.stride(2) == 3 * C):     # [kh][kw][C] in memory
+            w = w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        b_ = None if bias is None else bias.detach()
+        pre = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+        _lib.check(lib.xpt_headconv_fwd(x.data_ptr(), xpitch, w.data_ptr(), None if b_ is None else b_.data_ptr(),
+                                        pre.data_ptr(), B, H, W, C, _stream()), "xpt_headconv_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.geom = (B, C, H, W, xpitch)
+        ctx.sink = None
+        if _ops.grad_sink.wants(weight) and weight.flat_grad.numel() == 9 * C and (bias is None or _ops.grad_sink.wants(bias)):
+            ctx.sink = (weight.flat_grad, None if bias is None else bias.flat_grad)
+        ctx.has_bias = bias is not None
+        return pre
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        B, C, H, W, xpitch = ctx.geom
+        g = g.contiguous().float()
+        dx = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+        nblk = lib.xpt_headconv_bwd_blocks(B, H, W, C)
+        row = 9 * C + 1
+        if ctx.sink is not None:
+            ws = _ops.grad_sink.partials(ctx.sink[0], "head", nblk * row)
+        else:
+            ws = torch.empty(nblk * row, dtype=torch.float32, device=g.device)
+        _lib.check(lib.xpt_headconv_bwd(x.data_ptr(), xpitch, w.data_ptr(), g.data_ptr(), dx.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), B, H, W, C, _stream()), "xpt_headconv_bwd")
+        if ctx.sink is not None:
+            _ops.grad_sink.add(ctx.sink[0], ws, 0, 9 * C, nblk, row)
+            if ctx.sink[1] is not None:
+                _ops.grad_sink.add(ctx.sink[1], ws, 9 * C, 1, nblk, row)
+            return dx, None, None
+        tot = ws[:nblk * row].view(nblk, row).sum(0)
+        dw = tot[:9 * C].view(1, 3, 3, C).permute(0, 3, 1, 2)
+        return dx, dw, (tot[9 * C:].clone() if ctx.has_bias else None)
+
+
+def head_conv(x, weight, bias):
+    """Conv2D(1, 3, padding="same", linear) of get_scaled_depth (depth_net.py:87-92): x [B,C,H,W] bf16 (NHWC storage,
+    C in 16/32/64/128) -> [B,1,H,W] float32."""
+    return _HeadConv.apply(x, weight, bias)
+
+
+def head_usable(x, conv):
+    return x.is_cuda and x.dtype == torch.bfloat16 and conv.in_channels in (16, 32, 64, 128) and conv.out_channels == 1 \
+        and conv.kernel_size == (3, 3) and conv.weight.dtype == torch.float32 and conv.dilation == (1, 1) and conv.stride == (1, 1)

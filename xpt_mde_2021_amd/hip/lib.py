@@ -94,6 +94,9 @@ SIGNATURES = {
     "xpt_conv2d_bwd_weight_splits": (_i, [_i] * 8),
     "xpt_conv2d_bwd_weight_partials": (_i, [_p, _p, _p, _z, _i, _i, _i, _i, _i, ctypes.c_longlong, _i, ctypes.c_longlong,
                                             _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "xpt_headconv_bwd_blocks": (_i, [_i, _i, _i, _i]),
+    "xpt_headconv_fwd": (_i, [_p, ctypes.c_longlong, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "xpt_headconv_bwd": (_i, [_p, ctypes.c_longlong, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
     "xpt_restack_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "xpt_affine_act_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, ctypes.c_longlong, _i, _f, _i, _i, _p]),
     "xpt_affine_act_bwd_workspace_floats": (_z, [ctypes.c_longlong, _i]),

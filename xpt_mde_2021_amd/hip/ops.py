@@ -343,7 +343,7 @@ class GradSink:
         for jobs, blockmap, nblocks in self.table:
             _lib.check(lib.xpt_reduce_partials(_ptr(jobs), _ptr(blockmap), nblocks, _stream()), "xpt_reduce_partials")
 
-    MAX_SPLITS = 256       # per job and pass; more are folded by a first pass into groups of GROUP splits
+    MAX_SPLITS = int(__import__('os').environ.get('XPT_SINK_MAX_SPLITS', '256'))   # per job and pass; more are folded by a first pass into groups of GROUP splits
     GROUP = 64
 
     def _build(self, lib, pending):

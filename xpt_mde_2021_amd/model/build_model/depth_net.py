@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip import conv as _conv
 from ..model_util import layer_ops as lo
 from .pretrained_nets import PretrainedModel
 
@@ -52,7 +53,10 @@ class ScaledDepthHead(nn.Module):
 
     def forward(self, src, dst_height, dst_width):
         with torch.autocast(device_type=src.device.type, enabled=False):
-            conv = self.conv(src.float())
+            if _conv.head_usable(src, self.conv.conv) and self.conv.slope == 1.0:
+                conv = _conv.head_conv(src, self.conv.conv.weight, self.conv.conv.bias)     # bf16 features in, fp32 prediction out
+            else:
+                conv = self.conv(src.float())
             if hasattr(self.predict_depth, "with_disparity"):
                 depth, self.last_disp = self.predict_depth.with_disparity(conv)
             else:

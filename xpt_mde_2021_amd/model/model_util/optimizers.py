@@ -46,6 +46,10 @@ class FlatParameters:
                     # destination of the deferred gradient finishing (hip/ops.py GradSink): the gfx950 backward kernels
                     # of this parameter leave partial sums behind and ONE launch per step adds them into this view
                     p.flat_grad = gview
+                elif p.dim() == 4 and gview.is_contiguous(memory_format=torch.channels_last):
+                    # channels_last k x k kernels: memory order [cout][kh][kw][cin] -- exactly the layout of the dense
+                    # convolution's weight-gradient partials (hip/conv.py), so the destination is the flat chunk itself
+                    p.flat_grad = self.grad[off:off + p.numel()]
         if self.shadow is not None:
             self.shadow.copy_(self.data)
         self.offsets = offsets

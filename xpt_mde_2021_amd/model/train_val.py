@@ -208,6 +208,7 @@ class _StepGraph:
         self.static_in = None
         self.static_out = None
         self.signature = None
+        self.cache = {}                        # input signature -> (graph, static inputs, static outputs)
         self.eager_fallback = False            # set when no capture of the step survives the replay check
 
     @staticmethod
@@ -218,11 +219,17 @@ class _StepGraph:
         if self.eager_fallback:
             return self.fn(features)
         sig = self._sig(features)
-        if self.graph is None or sig != self.signature:
+        entry = self.cache.get(sig)
+        if entry is None:
+            # one captured graph per input signature (the mixed pretrain stream cycles through a handful of image sizes,
+            # config-example.py:25-30): captured on first sight, replayed ever after
             self._capture(features, sig)
             if self.eager_fallback:
                 return self.fn(features)
+            self.cache[sig] = (self.graph, self.static_in, self.static_out)
         else:
+            self.graph, self.static_in, self.static_out = entry
+            self.signature = sig
             for k, v in self.static_in.items():
                 v.copy_(features[k], non_blocking=True)
         self.graph.replay()
@@ -245,7 +252,8 @@ class _StepGraph:
         for t, s in zip(state, saved):
             t.copy_(s)
         self.signature = sig
-        report = self._replay_report(state, saved) if state else None
+        check = state and __import__("os").environ.get("XPT_REPLAY_CHECK", "1") != "0"      # 0: diagnostics only
+        report = self._replay_report(state, saved) if check else None
         if report is not None:
             # Some library convolution solvers return garbage from the second replay of a captured graph on this stack
             # (DESIGN.md section 6); which solver MIOpen's find picks can vary from process to process.  Fall back to
@@ -266,19 +274,24 @@ class _StepGraph:
                 opts.MIOPEN_FIND = False
                 self.graph = None
                 return self._capture(features, sig)
-            print(f"[StepGraph] captured step fails the replay check again ({report}): running the step EAGERLY "
-                  f"(about 3x slower) -- please report the shapes", file=sys.stderr, flush=True)
             self.graph = None
+            if not bool(int(__import__("os").environ.get("XPT_ALLOW_EAGER_FALLBACK", "0"))):
+                # a captured step that does not reproduce its own eager execution is a defect, not an operating mode:
+                # stop (tests and bench.py fail on this); XPT_ALLOW_EAGER_FALLBACK=1 trades that for a ~4x slower run
+                raise RuntimeError(f"[StepGraph] the captured training step fails the replay check: {report}")
+            print(f"[StepGraph] captured step fails the replay check again ({report}): XPT_ALLOW_EAGER_FALLBACK=1, running "
+                  f"the step EAGERLY (about 4x slower)", file=sys.stderr, flush=True)
             self.eager_fallback = True
 
     def _replay_report(self, state, saved, replays=3):
         """Replays the fresh graph a few times from the saved state and checks that
         (a) parameters, moments and gradients stay finite and bounded, (b) every later replay reproduces the first one
-        parameter by parameter in MAGNITUDE (the library failures this guards against are correct on the first replay and
-        yield garbage -- typically 1e25 ... inf, sometimes finite -- from the second on).  The comparison is deliberately
-        coarse (a gradient more than 8x its first-replay magnitude away): runs are not bit-repeatable (atomic
-        accumulation in library kernels), and for a rectified stereo pair ulp-level differences in the depth flip the
-        sampler's validity of whole border rows, which moves individual gradients by tens of percent.
+        parameter by parameter: the largest deviation inside a parameter must stay below half of that parameter's largest
+        gradient magnitude (the failures this guards against are correct on the first replay and yield garbage -- 1e25 ...
+        inf, sometimes finite tiles -- from the second on; honest run-to-run noise is orders of magnitude below the bar:
+        the hand-written kernels are bit-repeatable, rocBLAS split-K atomics move single elements by ~1e-3 relative, and
+        for a rectified stereo pair ulp-level depth differences flip the sampler's validity of border rows (DESIGN.md
+        section 8), worth a few percent of a parameter's largest gradient).
         Returns None when all is well, else a short description of what went wrong."""
         report, first, last, last_loss = None, None, None, None
         lengths = self.segments() if self.segments is not None else None
@@ -330,7 +343,7 @@ class _StepGraph:
             return float(out[1])
         return None
 
-    def _compare_replays(self, what, first, state, lengths, rtol=8.0):
+    def _compare_replays(self, what, first, state, lengths, rtol=0.5):
         for i, (a, b) in enumerate(zip(first, state)):
             # gradients and first moments only (indices 1, 2 of the optimizer state): Adam turns a rounding-noise
             # gradient into a +-lr step, so VALUES of parameters with a ~zero gradient legitimately differ between runs
