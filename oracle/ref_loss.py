@@ -175,6 +175,24 @@ def moa_loss_multi_scale(method, temp_synth_ms, stereo_synth_ms, original_target
     return merge_multi_scale_losses(losses, scale_weights)
 
 
+def md2comb_loss_multi_scale(method, synth_target_ms, warped_target_ms, original_target, scale_weights):
+    """MD2CombLossMultiScale.__call__, losses.py:324-374: static loss + 1000 where it exceeds twice the flow loss (finest
+    flow scale, both at the original size), min over sources, sum over the kept (< 1000) elements of each sample divided by
+    the kept-element count of the whole [B,H,W,3] tensor (tf.math.count_nonzero without axis, :369)."""
+    fn = PHOTOMETRIC[method]
+    ho, wo = original_target.shape[1:3]
+    flow_loss = fn(resize_bilinear_5d(warped_target_ms[0], (ho, wo)), original_target, False)
+    losses = []
+    for synt in synth_target_ms:
+        static_loss = fn(resize_bilinear_5d(synt, (ho, wo)), original_target, False)
+        mask = (static_loss > flow_loss * 2.0).to(static_loss.dtype)
+        static_loss = static_loss + mask * 1000.0
+        static_loss = torch.min(static_loss, dim=1).values
+        keep = (static_loss < 1000.0).to(static_loss.dtype)
+        losses.append(torch.sum(static_loss * keep, dim=[1, 2, 3]) / torch.count_nonzero(keep).to(static_loss.dtype))
+    return merge_multi_scale_losses(losses, scale_weights)
+
+
 def stereo_depth_loss(method, augm_data, scale_weights):
     """StereoDepthLoss.__call__, losses.py:447-478: left + right per scale, then scale merge."""
     fn = PHOTOMETRIC[method]

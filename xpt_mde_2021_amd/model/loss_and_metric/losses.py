@@ -239,6 +239,29 @@ class CombinedLossMultiScale(PhotometricLoss):
         return self.merge_multi_scale_losses(losses)
 
 
+class MD2CombLossMultiScale(PhotometricLoss):
+    """losses.py:324-374 (a class the reference defines but does not register in loss_factory.py): per-pixel static loss;
+    where it exceeds TWICE the optical-flow loss of the finest flow scale it is pushed out of the running by +1000; the
+    minimum over the source views is then averaged over the pixels that stayed below 1000 -- per sample sum, divided by
+    the number of kept elements of the WHOLE batch tensor (`tf.math.count_nonzero(mask)` without an axis, :369)."""
+
+    def __call__(self, features, predictions, augm_data):
+        synth_ms = augm_data["synth_target_ms" + self.key_suffix]
+        warped_ms = augm_data["warped_target_ms" + self.key_suffix]
+        original_target = augm_data["target" + self.key_suffix]
+        Ho, Wo = original_target.shape[1:3]
+        flow_loss = self.photometric_loss(resize_bilinear(warped_ms[0], (Ho, Wo)), original_target, False)
+        losses = []
+        for synt in synth_ms:
+            static_loss = self.photometric_loss(resize_bilinear(synt, (Ho, Wo)), original_target, False)
+            mask = (static_loss > flow_loss * 2.).to(static_loss.dtype)
+            static_loss = static_loss + mask * 1000.
+            static_loss = torch.min(static_loss, dim=1).values                # [B, H, W, 3]
+            keep = (static_loss < 1000.).to(static_loss.dtype)
+            losses.append(torch.sum(static_loss * keep, dim=[1, 2, 3]) / torch.count_nonzero(keep).to(static_loss.dtype))
+        return self.merge_multi_scale_losses(losses)
+
+
 class FlowWarpLossMultiScale(PhotometricLoss):
     """losses.py:497-519: photometric loss between the flow-warped sources and the target at every flow scale."""
 
