@@ -8,15 +8,18 @@ non-amsgrad update for step t = iterations + 1:
     m    = beta_1 m + (1 - beta_1) g
     v    = beta_2 v + (1 - beta_2) g^2
     var  = var - lr_t * m / (sqrt(v) + epsilon)          (epsilon on the UNcorrected sqrt(v): "epsilon hat")
-Restated in numpy float64.  Third-party arithmetic (not under the reference checkout): parity pinned only by this
-published update rule.
+Keras holds the hyper-parameters in the VARIABLE's dtype (float32: `_prepare_local` / `_get_hyper(name, var_dtype)`), so
+beta_2 is float32(0.999) = 0.99900001287..., and 1 - beta_2 = 9.9998713e-4 (not 1e-3): the restatement rounds lr, beta_1,
+beta_2 and epsilon to float32 first and then evaluates the update in float64.
+Third-party arithmetic (not under the reference checkout): parity pinned only by this published update rule.
 """
 import numpy as np
 
 
 class KerasAdamRef:
     def __init__(self, learning_rate, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
-        self.lr, self.b1, self.b2, self.eps = float(learning_rate), beta_1, beta_2, epsilon
+        f32 = lambda v: float(np.float32(v))                     # hyper-parameters live in float32 (the variable dtype)
+        self.lr, self.b1, self.b2, self.eps = f32(learning_rate), f32(beta_1), f32(beta_2), f32(epsilon)
         self.iterations = 0
         self.m = self.v = None
 

@@ -22,7 +22,7 @@ def test_keras_adam_first_step_closed_form():
     gval = np.array([2.0, -0.5, 1e-9, 0.0])
     out = ref.apply_gradients(np.zeros(4), gval)
     expect = -1e-3 * gval / (np.abs(gval) + 1e-7 / np.sqrt(1e-3))
-    assert np.allclose(out, expect, rtol=1e-12, atol=0)
+    assert np.allclose(out, expect, rtol=2e-5, atol=0)        # hyper-parameters are float32 values (1 - beta_2 = 9.99987e-4)
 
 
 def test_host_branch_matches_keras_adam():
@@ -61,11 +61,15 @@ def test_adam_kernel_matches_keras_adam(gpu_device, n, grad_scale):
                                      0.9, 0.999, 1e-7, grad_scale, 1, shadow.data_ptr(),
                                      torch.cuda.current_stream().cuda_stream), "xpt_adam_step")
         torch.cuda.synchronize()
+        m_prev = np.zeros(n) if ref.m is None else ref.m.copy()
         w = ref.apply_gradients(w, g.double().numpy())
         got = p.double().cpu().numpy()
         # fp32 arithmetic: the update lr_t * m / (sqrt(v) + eps) is <= ~lr * 3.2 per step and carries ~1e-6 relative error
         assert np.abs(got - w).max() < 2e-7 * np.abs(w).max() + 1e-9, np.abs(got - w).max()
-        assert np.allclose(m.double().cpu().numpy(), ref.m, rtol=2e-6, atol=1e-12)
+        # m = b1 m + (1 - b1) g in fp32: each of the two products and the sum round once (2^-24 each); with cancellation
+        # the error is relative to the operands, not to the result
+        bound = 3e-7 * (0.9 * np.abs(m_prev) + 0.1 * np.abs(g.double().numpy())) + 1e-30
+        assert (np.abs(m.double().cpu().numpy() - ref.m) <= bound).all()
         assert np.allclose(v.double().cpu().numpy(), ref.v, rtol=4e-6, atol=1e-30)
         assert float(gbuf.abs().max()) == 0.0                   # zero_grad happened in the same pass
         assert torch.equal(shadow, p.to(torch.bfloat16))        # bf16 shadow = round-to-nearest-even of the updated weight

@@ -578,6 +578,11 @@ __global__ void fused_bwd_reduce_kernel(const float* __restrict__ part, float* _
   if (t == 0 && bn < BN) dT[e] = sum;
 }
 
+__global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 inline FusedDims make_dims(int B, int N, int h, int w, float scale, int rows_per_chunk, int strip) {
   FusedDims d;
   d.B = B; d.N = N; d.h = h; d.w = w; d.scale = scale;
@@ -671,7 +676,10 @@ int xpt_photo_fused_bwd(const float* src, const float* depth, const float* T, co
     hipLaunchKernelGGL(fused_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, g_l1, g_ssim, ddepth,
                        workspace, d, inv_count);
   } else {
-    if (hipMemsetAsync(ddepth, 0, (size_t)B * h * w * sizeof(float), s) != hipSuccess) return XPT_ERR_LAUNCH;
+    // (a zero-fill KERNEL, not hipMemsetAsync: memset nodes of a captured hipGraph write garbage from the second replay
+    // on with this runtime -- tools/replay_probe_memset.py)
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(((long long)B * h * w + 255) / 256)), dim3(256), 0, s, ddepth,
+                       (long long)B * h * w);
     hipLaunchKernelGGL(fused_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, g_l1, g_ssim, ddepth,
                        workspace, d, inv_count);
   }

@@ -346,7 +346,13 @@ class _StepGraph:
             return float(out[1])
         return None
 
-    def _compare_replays(self, what, first, state, lengths, rtol=0.5):
+    def _compare_replays(self, what, first, state, lengths, rtol=None):
+        if rtol is None:
+            # bf16 steps run on this repo's kernels only (bit-repeatable: replays are expected to be IDENTICAL, the bar
+            # leaves room for a rocBLAS split-K atomic or two); fp32 steps go through MIOpen's atomically accumulating
+            # solvers, whose run-to-run noise the rectified-stereo border flips can turn into
+            # several-fold changes of single tiny gradients -- there only gross garbage is caught
+            rtol = 0.05 if opts.CONV_DTYPE == "bf16" else 8.0
         for i, (a, b) in enumerate(zip(first, state)):
             # gradients and first moments only (indices 1, 2 of the optimizer state): Adam turns a rounding-noise
             # gradient into a +-lr step, so VALUES of parameters with a ~zero gradient legitimately differ between runs
