@@ -54,6 +54,7 @@ def test_adam_kernel_matches_keras_adam(gpu_device, n, grad_scale):
     shadow = torch.zeros(n, dtype=torch.bfloat16, device=dev)
     step = torch.zeros(1, device=dev)
     ref, w = KerasAdamRef(1e-4), w0.double().numpy()
+    m_err = np.zeros(n)
     for g in grads:
         gbuf.copy_(g.to(dev) / grad_scale)                      # the kernel multiplies by grad_scale (1 / world size in DP)
         step += 1
@@ -68,8 +69,9 @@ def test_adam_kernel_matches_keras_adam(gpu_device, n, grad_scale):
         assert np.abs(got - w).max() < 2e-7 * np.abs(w).max() + 1e-9, np.abs(got - w).max()
         # m = b1 m + (1 - b1) g in fp32: each of the two products and the sum round once (2^-24 each); with cancellation
         # the error is relative to the operands, not to the result
-        bound = 3e-7 * (0.9 * np.abs(m_prev) + 0.1 * np.abs(g.double().numpy())) + 1e-30
-        assert (np.abs(m.double().cpu().numpy() - ref.m) <= bound).all()
+        # (and the fp32 state carries the error of the earlier steps, shrunk by b1 per step)
+        m_err = 0.9 * m_err + 2e-7 * (0.9 * np.abs(m_prev) + 0.1 * np.abs(g.double().numpy())) + 1e-30
+        assert (np.abs(m.double().cpu().numpy() - ref.m) <= m_err).all()
         assert np.allclose(v.double().cpu().numpy(), ref.v, rtol=4e-6, atol=1e-30)
         assert float(gbuf.abs().max()) == 0.0                   # zero_grad happened in the same pass
         assert torch.equal(shadow, p.to(torch.bfloat16))        # bf16 shadow = round-to-nearest-even of the updated weight

@@ -5,6 +5,7 @@ its input through UpSampling2D(2, "nearest") (model/build_model/depth_net.py:76-
 Nothing here goes through MIOpen: no library workspace, no find step, hipGraph-replay-safe by construction (every buffer
 a kernel touches is either a tensor of the step or a persistent partial-sum workspace of hip/ops.py GradSink).
 """
+import contextlib
 import ctypes
 import math
 import weakref
@@ -217,28 +218,58 @@ class _Conv2dSame(torch.autograd.Function):
         if N % 8 != 0:
             raise _lib.XptHipError(f"conv backward: {N} output channels are not a multiple of 8")
         dx = dw = None
+        if ctx.needs_input_grad[1]:
+            # the weight gradient is off the critical path (nothing downstream of it until the step's finishing launch):
+            # with a deferred destination it is forked onto a side stream BEFORE the data gradient is issued and runs next
+            # to the data-gradient chain -- inside a captured step that is a fork / join of the graph
+            side = _wgrad_side_stream(g.device) if (ctx.sink_w is not None and WGRAD_SIDE_STREAM) else None
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream())
+                g.record_stream(side)
+                x.record_stream(side)
+                _ops.grad_sink.join_streams.add(side)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                dw = _weight_grad(ctx, lib, g, gpitch, x)
         if ctx.needs_input_grad[0]:
             e = packer.get(weight, need_bwd=True)
             dx = torch.empty((B, Cp, PH, PW), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
             _lib.check(lib.xpt_conv2d_bwd_data(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"], gpitch,
                                                Cp, KH, KW, stride, pt, pl, PH, PW, Cp, ups, _stream()), "xpt_conv2d_bwd_data")
-        if ctx.needs_input_grad[1]:
-            nsplit = lib.xpt_conv2d_bwd_weight_splits(B, Cp, N, KH, KW, stride, OH, OW)
-            if nsplit < 1:
-                raise _lib.XptHipError(f"xpt_conv2d_bwd_weight_splits failed: {nsplit}")
-            n = N * KH * KW * C
-            if ctx.sink_w is not None:
-                ws = _ops.grad_sink.partials(ctx.sink_w, "convw", nsplit * n)
-            else:
-                ws = torch.empty(nsplit * n, dtype=torch.float32, device=g.device)
-            _lib.check(lib.xpt_conv2d_bwd_weight_partials(g.data_ptr(), x.data_ptr(), ws.data_ptr(), ws.numel(), B, PH, PW,
-                                                          Cp, C, xpitch, N, gpitch, KH, KW, stride, pt, pl, OH, OW, ups,
-                                                          _stream()), "xpt_conv2d_bwd_weight_partials")
-            if ctx.sink_w is not None:
-                _ops.grad_sink.add(ctx.sink_w, ws, 0, n, nsplit, n)
-            else:
-                dw = ws[:nsplit * n].view(nsplit, N, KH, KW, C).sum(0).permute(0, 3, 1, 2)
         return dx, dw, dbias, None, None, None, None
+
+
+WGRAD_SIDE_STREAM = __import__("os").environ.get("XPT_WGRAD_SIDE_STREAM", "1") == "1"
+_SIDE = {}
+
+
+def _wgrad_side_stream(device):
+    if device not in _SIDE:
+        _SIDE[device] = torch.cuda.Stream(device=device)
+    return _SIDE[device]
+
+
+def _weight_grad(ctx, lib, g, gpitch, x):
+    B, PH, PW, Cp, C, xpitch, N, KH, KW, stride, pt, pl, OH, OW, ups, slope = ctx.geom
+    nsplit = lib.xpt_conv2d_bwd_weight_splits(B, Cp, N, KH, KW, stride, OH, OW)
+    if nsplit < 1:
+        raise _lib.XptHipError(f"xpt_conv2d_bwd_weight_splits failed: {nsplit}")
+    n = N * KH * KW * C
+    if ctx.sink_w is not None:
+        ws = _ops.grad_sink.partials(ctx.sink_w, "convw", nsplit * n)
+    else:
+        ws = torch.empty(nsplit * n, dtype=torch.float32, device=g.device)
+    _lib.check(lib.xpt_conv2d_bwd_weight_partials(g.data_ptr(), x.data_ptr(), ws.data_ptr(), ws.numel(), B, PH, PW, Cp, C,
+                                                  xpitch, N, gpitch, KH, KW, stride, pt, pl, OH, OW, ups, _stream()),
+               "xpt_conv2d_bwd_weight_partials")
+    if ctx.sink_w is not None:
+        _ops.grad_sink.add(ctx.sink_w, ws, 0, n, nsplit, n)
+        return None
+    # no deferred destination (a weight outside FlatParameters, i.e. no optimizer bound: eager unit tests).  torch.sum must
+    # not end up inside a captured step -- its multi-block mode zeroes a semaphore with a memset node, which this runtime
+    # replays as garbage -- so a capture without a deferred destination is refused
+    if torch.cuda.is_current_stream_capturing():
+        raise _lib.XptHipError("conv weight gradient without a flat-gradient destination inside a graph capture")
+    return ws[:nsplit * n].view(nsplit, N, KH, KW, C).sum(0).permute(0, 3, 1, 2)
 
 
 def conv2d_same(x, weight, bias, stride=1, slope=1.0, upsample=False, valid=False):

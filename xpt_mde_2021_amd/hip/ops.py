@@ -308,6 +308,7 @@ class GradSink:
         self.signature = None
         self.table = None        # [(jobs tensor, blockmap tensor, nblocks)] per finishing launch
         self.scratch = None
+        self.join_streams = set()   # side streams that still produce partials of this step (hip/conv.py weight gradients)
 
     def wants(self, param):
         return self.enabled and param is not None and getattr(param, "flat_grad", None) is not None
@@ -331,6 +332,9 @@ class GradSink:
     def flush(self):
         pending, self.pending = self.pending, []
         self.uses.clear()
+        for side in self.join_streams:                 # partials produced off the main stream must have landed
+            torch.cuda.current_stream().wait_stream(side)
+        self.join_streams.clear()
         if not pending:
             return
         lib = _lib.load()
