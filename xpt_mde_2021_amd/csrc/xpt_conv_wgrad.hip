@@ -25,6 +25,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+constexpr int WGRAD_MAXCH = 12;     // 16-byte chunks a thread stages per pixel unit (48 KiB of LDS tiles at most)
+
 struct WgradArgs {
   const unsigned short* g;   // [B,OH,OW,N] bf16, pixel pitch gpitch
   const unsigned short* x;   // [B,PH,PW,C] bf16, pixel pitch xpitch (C = channels readable per pixel, multiple of 8)
@@ -44,6 +46,35 @@ __device__ inline bf16x8 tr_pair(const char* lds, unsigned off0, unsigned off1) 
   v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
   v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
   return __builtin_bit_cast(bf16x8, v);
+}
+
+// the 16-byte chunks of one unit's g tile and x halo tile, chunk ck = tid + 256 i, into registers
+template <int MAXCH>
+__device__ __forceinline__ void wgrad_fetch(const WgradArgs a, int u, int tid, int n0, int c0, int TNB, int TCB, int Wt,
+                                            int gchunks, int nchunks, uint4 (&stage)[MAXCH]) {
+  const int seg = u % a.nseg, rb = (u / a.nseg) % a.nrb, b = u / (a.nseg * a.nrb);
+  const int oh0 = rb * a.R, ow0 = seg * a.CB;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    // ONE unconditional load per chunk from a clamped address, zeroed by select (a guarded load would get its own
+    // branch and s_waitcnt: one memory round trip per chunk)
+    const int ck = tid + 256 * i;
+    const bool is_g = ck < gchunks;
+    const int gc8 = ck % (TNB / 8), gpix = ck / (TNB / 8);
+    const int oh = oh0 + gpix / a.CB, ow = ow0 + gpix % a.CB, n = n0 + 8 * gc8;
+    const bool gok = is_g && oh < a.OH && ow < a.OW && n < a.N;
+    const long long goff = (((long long)b * a.OH + oh) * a.OW + ow) * a.gpitch + n;
+    const int cx = is_g ? 0 : ck - gchunks;
+    const int xc8 = cx % (TCB / 8), xpix = cx / (TCB / 8);
+    const int th = oh0 * a.stride - a.pad_t + xpix / Wt, tw = ow0 * a.stride - a.pad_l + xpix % Wt, c = c0 + 8 * xc8;
+    const bool xok = !is_g && ck < nchunks && th >= 0 && th < a.Hlim && tw >= 0 && tw < a.Wlim && c < a.C;
+    const long long xoff = (((long long)b * a.PH + (th >> a.shift)) * a.PW + (tw >> a.shift)) * a.xpitch + c;
+    const unsigned short* src = is_g ? a.g + (gok ? goff : 0) : a.x + (xok ? xoff : 0);
+    uint4 ld = *(const uint4*)src;
+    const unsigned keep = (gok || xok) ? 0xffffffffu : 0u;     // (a uint4 select compiles to a scratch round trip)
+    ld.x &= keep; ld.y &= keep; ld.z &= keep; ld.w &= keep;
+    stage[i] = ld;
+  }
 }
 
 template <int TAPS>
@@ -84,31 +115,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+  // Staging is software-pipelined: the 16-byte chunks of unit u+1 are fetched into registers while unit u is being
+  // multiplied (the loads stay in flight across the MFMA loop), then written to LDS behind the barrier that retires
+  // unit u's reads.  MAXCH chunks per thread bound the tile (the plan keeps gchunks + xchunks <= 256 * MAXCH).
+  constexpr int MAXCH = WGRAD_MAXCH;
   const int gchunks = a.R * a.CB * (TNB / 8), xchunks = HR * Wt * (TCB / 8);
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
-  for (int u = blockIdx.y; u < a.units; u += a.nsplit) {
-    const int seg = u % a.nseg, rb = (u / a.nseg) % a.nrb, b = u / (a.nseg * a.nrb);
-    const int oh0 = rb * a.R, ow0 = seg * a.CB;
-    __syncthreads();                                           // the previous unit's reads are done
-    for (int ck = tid; ck < gchunks; ck += 256) {
-      const int c8 = ck % (TNB / 8), pix = ck / (TNB / 8);
-      const int cc = pix % a.CB, rr = pix / a.CB;
-      const int oh = oh0 + rr, ow = ow0 + cc, n = n0 + 8 * c8;
-      const bool ok = oh < a.OH && ow < a.OW && n < a.N;
-      const long long off = (((long long)b * a.OH + oh) * a.OW + ow) * a.gpitch + n;
-      const uint4 v = *(const uint4*)(a.g + (ok ? off : 0));
-      *(uint4*)(gs + (size_t)ck * 16) = ok ? v : zero4;
-    }
-    for (int ck = tid; ck < xchunks; ck += 256) {
-      const int c8 = ck % (TCB / 8), pix = ck / (TCB / 8);
-      const int wcx = pix % Wt, hr = pix / Wt;
-      const int th = oh0 * a.stride - a.pad_t + hr, tw = ow0 * a.stride - a.pad_l + wcx, c = c0 + 8 * c8;
-      const bool ok = th >= 0 && th < a.Hlim && tw >= 0 && tw < a.Wlim && c < a.C;
-      const long long off = (((long long)b * a.PH + (th >> a.shift)) * a.PW + (tw >> a.shift)) * a.xpitch + c;
-      const uint4 v = *(const uint4*)(a.x + (ok ? off : 0));
-      *(uint4*)(xs + (size_t)ck * 16) = ok ? v : zero4;
+  const int nchunks = gchunks + xchunks;
+  uint4 stage[MAXCH];
+  int u = blockIdx.y;
+  if (u < a.units) wgrad_fetch<MAXCH>(a, u, tid, n0, c0, TNB, TCB, Wt, gchunks, nchunks, stage);
+  for (; u < a.units; u += a.nsplit) {
+    __syncthreads();                                           // the previous unit's LDS reads are done
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      const int ck = tid + 256 * i;
+      if (ck < nchunks) *(uint4*)(smem + (size_t)ck * 16) = stage[i];     // gs and xs are contiguous: chunk order = LDS order
     }
     __syncthreads();
+    if (u + a.nsplit < a.units)                                // in flight during the products below
+      wgrad_fetch<MAXCH>(a, u + a.nsplit, tid, n0, c0, TNB, TCB, Wt, gchunks, nchunks, stage);
     if (active) {
       for (int rr = 0; rr < a.R; ++rr) {
         for (int c16 = 0; c16 < a.CB; c16 += 16) {
@@ -145,40 +170,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
 struct WgradPlan {
   int WN, WC, WT, TAPS, R, CB, nseg, nrb, units, nsplit;
+  long long blocks;
   size_t lds;
 };
 
-int g_wgrad_max_partial_mib = 24, g_wgrad_target_blocks = 768;
 
-bool make_plan(int B, int C, int N, int KH, int KW, int stride, int OH, int OW, WgradPlan& p) {
+int g_wgrad_max_partial_mib = 12, g_wgrad_target_blocks = 512;
+
+
+// one candidate decomposition: sub-tiles (WN x WC), taps split WT ways; pixel units bounded by the staging registers
+bool plan_for(int wn, int wc, int B, int C, int N, int KH, int KW, int stride, int OH, int OW, WgradPlan& p) {
   const int T = KH * KW;
-  // wave decomposition: sub-tiles first, taps with what is left of the 4 waves
-  p.WN = N > 32 ? 2 : 1;
-  p.WC = C > 32 ? 2 : 1;
-  if (p.WN * p.WC == 4 && T > 13) p.WC = 1;                   // 5x5 with 13+ taps per wave would not fit the registers
-  p.WT = 4 / (p.WN * p.WC);
-  int taps = (T + p.WT - 1) / p.WT;
-  const int allowed[] = {1, 3, 5, 7, 9, 13};
+  p.WN = wn; p.WC = wc;
+  p.WT = 4 / (wn * wc);
+  const int taps = (T + p.WT - 1) / p.WT;
+  const int allowed[] = {1, 3, 5, 7, 9};
   p.TAPS = 0;
   for (int v : allowed)
     if (v >= taps) { p.TAPS = v; break; }
   if (!p.TAPS) return false;
-  const int TNB = 32 * p.WN, TCB = 32 * p.WC;
-  // pixel units: CB columns (multiple of 16) x R rows; about 8+ k-steps per unit within 64 KiB of LDS
+  const int TNB = 32 * wn, TCB = 32 * wc;
+  const size_t max_lds = (size_t)WGRAD_MAXCH * 256 * 16;       // every thread stages at most WGRAD_MAXCH 16-byte chunks
   const int ow16 = (OW + 15) / 16 * 16;
   p.CB = ow16 < 64 ? ow16 : 64;
   p.nseg = (OW + p.CB - 1) / p.CB;
-  p.R = 128 / p.CB;
+  p.R = 256 / p.CB;
   if (p.R < 1) p.R = 1;
   if (p.R > OH) p.R = OH;
   for (;;) {
     const int HR = (p.R - 1) * stride + KH, Wt = (p.CB - 1) * stride + KW;
     p.lds = ((size_t)p.R * p.CB * TNB + (size_t)HR * Wt * TCB) * 2;
-    if (p.lds <= 64 * 1024 || (p.R == 1 && p.CB == 16)) break;
-    if (p.R > 1) p.R = (p.R + 1) / 2;
-    else { p.CB = (p.CB / 2 + 15) / 16 * 16; p.nseg = (OW + p.CB - 1) / p.CB; }
+    if (p.lds <= max_lds) break;
+    if (p.R > 1) p.R -= 1;
+    else if (p.CB > 16) { p.CB -= 16; p.nseg = (OW + p.CB - 1) / p.CB; }
+    else return false;
   }
-  if (p.lds > 160 * 1024) return false;
   p.nrb = (OH + p.R - 1) / p.R;
   p.units = B * p.nrb * p.nseg;
   const long long tiles = (long long)((N + TNB - 1) / TNB) * ((C + TCB - 1) / TCB);
@@ -189,7 +215,25 @@ bool make_plan(int B, int C, int N, int KH, int KW, int stride, int OH, int OW, 
   if (ns > p.units) ns = p.units;
   if (ns < 1) ns = 1;
   p.nsplit = (int)ns;
+  p.blocks = tiles * ns;
   return true;
+}
+
+// The kernels are latency-bound at these sizes, so the plan maximises the number of workgroups (up to the target) under
+// the cap on partial-sum bytes: large 64 x 64 blocks when they already fill the chip, else smaller blocks (more of them
+// for the same partial volume), the taps spread over the waves instead.
+bool make_plan(int B, int C, int N, int KH, int KW, int stride, int OH, int OW, WgradPlan& best) {
+  const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  bool have = false;
+  for (const auto& wc : cand) {
+    if ((wc[0] == 2 && N <= 32) || (wc[1] == 2 && C <= 32)) continue;
+    if (KH * KW > 9 && wc[0] * wc[1] > 1) continue;              // 5x5: 7 taps per wave at most
+    WgradPlan p;
+    if (!plan_for(wc[0], wc[1], B, C, N, KH, KW, stride, OH, OW, p)) continue;
+    if (!have || p.blocks > best.blocks) { best = p; have = true; }
+    if (best.blocks * 4 >= (long long)g_wgrad_target_blocks * 3) break;   // good enough: keep the larger block
+  }
+  return have;
 }
 
 }  // namespace
@@ -237,9 +281,6 @@ extern "C" int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, floa
   XPT_BEGIN_LAUNCH();
 #define XPT_WGRAD_CASE(TP)                                                                                         \
   case TP: {                                                                                                       \
-    if (p.lds > 64 * 1024)                                                                                         \
-      (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<TP>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                (int)p.lds);                                                                       \
     hipLaunchKernelGGL(conv_wgrad_kernel<TP>, grid, dim3(256), p.lds, s, a);                                       \
   } break;
   switch (p.TAPS) {
@@ -248,7 +289,6 @@ extern "C" int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, floa
     XPT_WGRAD_CASE(5)
     XPT_WGRAD_CASE(7)
     XPT_WGRAD_CASE(9)
-    XPT_WGRAD_CASE(13)
     default:
       return XPT_ERR_ARG;
   }

@@ -238,7 +238,8 @@ class _Conv2dSame(torch.autograd.Function):
         return dx, dw, dbias, None, None, None, None
 
 
-WGRAD_SIDE_STREAM = __import__("os").environ.get("XPT_WGRAD_SIDE_STREAM", "1") == "1"
+# measured: the fork / join edges cost more than the overlap returns inside the captured step (10.53 -> 11.9 ms), so off
+WGRAD_SIDE_STREAM = __import__("os").environ.get("XPT_WGRAD_SIDE_STREAM", "0") == "1"
 _SIDE = {}
 
 
