@@ -33,6 +33,7 @@ NETS_LABEL = {"rigid": "DepthNet(NASNetMobile)+PoseNetImproved", "flow": "PWCNet
               "joint": "DepthNet(NASNetMobile)+PoseNetImproved+PWCNet"}
 LOSS_LABEL = {"flow": "flowL2+flow_reg", "joint": "cmbL1+cmbSSIM+smoothness"}
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
 
 
 def parse():
@@ -240,6 +241,11 @@ def run(args):
     if rank == 0 and not args.no_roofline:
         result["roofline"] = roofline_leg(args, dataset)
         note("roofline leg done")
+        if args.nets == "rigid" and args.config != "c5":
+            from xpt_mde_2021_amd.hip import roofline as rf
+            result["roofline"]["mfma"] = rf.mfma_utilisation(args.height, args.width, args.batch, elapsed / args.steps,
+                                                             MFMA_PEAK_TFLOPS, args.stereo)
+            note("conv MAC count done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, args.cpu_baseline_seconds)
     return (result if rank == 0 else None), world

@@ -8,6 +8,7 @@ unit = one warped pixel = target pixel x source view x scale):
 The unfused kernels are priced too (warp_fwd P (4 + 24 N), photometric P (12 + 12 N)) for comparison.
 """
 import torch
+import torch.utils._python_dispatch
 
 
 def _time_kernel(fn, repeats, warmup=5, rounds=3):
@@ -125,3 +126,65 @@ def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
                                     "frac": round(gbs(lf_ms, lf_bytes) / hbm_peak_gbs, 4)},
                             "bwd": {"launch_us": round(lb_ms * 1e3, 2), "GBps": gbs(lb_ms, lb_bytes),
                                     "frac": round(gbs(lb_ms, lb_bytes) / hbm_peak_gbs, 4)}}}
+
+
+# ------------------------------------------------------------------------------- convolution arithmetic of one step
+class _MacCounter(torch.utils._python_dispatch.TorchDispatchMode):
+    """Counts multiply-accumulates of every aten convolution / matrix product executed under it, by kind:
+    dense (k x k, groups 1), pointwise (1x1 convolutions and matrix products), depthwise (groups > 1)."""
+
+    def __init__(self):
+        super().__init__()
+        self.macs = {"dense": 0, "pointwise": 0, "depthwise": 0}
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = func._overloadpacket.__name__
+        if name in ("convolution", "_convolution", "conv2d"):
+            w = args[1]
+            groups = args[8] if len(args) > 8 else 1
+            macs = out.numel() * w.shape[1] * w.shape[2] * w.shape[3]
+            kind = "depthwise" if groups > 1 else ("pointwise" if w.shape[2] * w.shape[3] == 1 else "dense")
+            self.macs[kind] += int(macs)
+        elif name in ("mm", "addmm", "bmm"):
+            a, b = (args[1], args[2]) if name == "addmm" else (args[0], args[1])
+            self.macs["pointwise"] += int(a.numel() * b.shape[-1])
+        return out
+
+
+def count_forward_macs(height, width, stereo=False):
+    """Multiply-accumulates of ONE snippet's forward through DepthNet + PoseNet, counted by a dispatch hook on the CPU
+    instance of the same modules (library ops there; the arithmetic is the same the gfx950 kernels perform)."""
+    from ..config import opts
+    from ..model.build_model.model_factory import ModelFactory
+    from ..utils import synthetic_data as sd
+    feats = sd.make_features(1, height, width, opts.SNIPPET_LEN, 1, stereo)
+    saved = opts.CONV_DTYPE
+    opts.CONV_DTYPE = "fp32"
+    try:
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ModelFactory(sd.tfr_config_for(feats), global_batch=1, net_names=opts.RIGID_NET).get_model()
+        with torch.no_grad(), _MacCounter() as counter:
+            model(feats)
+    finally:
+        opts.CONV_DTYPE = saved
+    return dict(counter.macs)
+
+
+def mfma_utilisation(height, width, batch, step_seconds, peak_tflops, stereo=False):
+    """bench.py's `mfma` object: matrix-core-eligible convolution FLOPs of a training step (dense + pointwise, forward +
+    data gradient + weight gradient = 3 x forward, 2 FLOP per MAC) over the measured step time, against the bf16 dense
+    peak.  Depthwise convolutions are VALU work and are reported separately."""
+    macs = count_forward_macs(height, width, stereo)
+    eligible = macs["dense"] + macs["pointwise"]
+    flops_step = 2.0 * 3.0 * eligible * batch
+    achieved = flops_step / step_seconds / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": peak_tflops, "unit": "TFLOP/s",
+            "frac": round(achieved / peak_tflops, 5),
+            "gmac_forward_per_snippet": {k: round(v / 1e9, 4) for k, v in macs.items()},
+            "flops_counted_per_step": flops_step,
+            "how": "dispatch-hook MAC count of DepthNet+PoseNet forward (CPU instance of the same modules) x 3 (forward, data "
+                   "gradient, weight gradient) x 2 FLOP x batch, divided by the timed step; the step is launch / latency "
+                   "bound at batch 8 (about 1,100 kernels of a few microseconds), which is what this fraction shows"}
