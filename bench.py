@@ -55,6 +55,9 @@ def parse():
                          "c5 = configs[4]: stereo + mono losses over the mixed dataset shapes cycled per step")
     ap.add_argument("--no-miopen-find", action="store_true", help="MIOpen immediate-mode heuristics instead of the fast find")
     ap.add_argument("--net-streams", type=int, default=None, help="1: PoseNet on a side stream next to DepthNet (fork/join in the graph)")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="only exercise the launcher path: every rank joins the process group (gloo without a GPU), one "
+                         "all-reduce, rank 0 prints the JSON line with the rank count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
@@ -165,6 +168,27 @@ def main():
         dist.destroy_process_group()
 
 
+def launcher_selftest(args, world, rank, local_rank):
+    """--selftest-launch: the distributed plumbing of this file without the training step (runs on CPU with gloo)."""
+    use_gpu = torch.cuda.device_count() >= max(world, 1)
+    if world > 1:
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl" if use_gpu else "gloo")
+    ones = torch.ones(4, device=f"cuda:{local_rank}" if use_gpu else "cpu")
+    if world > 1:
+        dist.all_reduce(ones)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert float(ones[0]) == float(max(world, 1))
+    if rank != 0:
+        return None
+    return {"metric": "launcher selftest (ranks joined, all-reduce of ones)", "value": float(ones[0]), "unit": "ranks",
+            "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": 0.0, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "launcher selftest", "ranks": dist.get_world_size() if world > 1 else 1,
+                       "backend": ("nccl" if use_gpu else "gloo") if world > 1 else "none"}}
+
+
 def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,6 +196,8 @@ def run(args):
     # every rank keeps its own MIOpen user database (eight ranks tuning into one file is an untested hazard)
     os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"xpt_miopen_db_rank{rank}"))
     os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
+    if args.selftest_launch:
+        return launcher_selftest(args, world, rank, local_rank), world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP ops have no CPU fallback)")
     torch.cuda.set_device(local_rank)

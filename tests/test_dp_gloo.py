@@ -101,3 +101,23 @@ def test_two_ranks_equal_one_process_full_batch():
     # each rank reports its shard's contribution to the global mean; the two contributions add up to the full loss
     for a, b, c in zip(l0, l1, ref_losses):
         assert abs((a + b) - c) < 1e-5 * max(1.0, abs(c)), (a, b, c)
+
+
+def test_bench_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` without a launcher around it must start the ranks itself (torch.distributed.run as a
+    child process, before this process touches any GPU) and relay rank 0's JSON line -- exercised here on the CPU with
+    the launcher self-test (gloo, 127.0.0.1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launch"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["value"] == 2.0 and out["config"]["backend"] == "gloo"

@@ -1,0 +1,93 @@
+"""Committed fixtures (tests/golden/*.npz, written by tools/make_golden.py from the fp64 oracle on seeded inputs):
+(CPU) the oracle still reproduces them -- drift of the restatement between rounds is caught; (GPU) the HIP kernels,
+called through the same ops the training step uses, reproduce them within the 1e-4 bar of BASELINE.json.
+The vectors are oracle outputs, not reference outputs (TensorFlow cannot run in this pipeline)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_loss, ref_pose, ref_synthesize as rs
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(glob.glob(os.path.join(GOLDEN, "synth_loss_*.npz")))
+
+
+def load(path):
+    with np.load(path) as z:
+        return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def test_fixtures_exist_and_are_small():
+    files = glob.glob(os.path.join(GOLDEN, "*.npz"))
+    assert len(files) >= 3
+    assert all(os.path.getsize(f) <= 100 * 1024 for f in files)
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c) for c in CASES])
+def test_oracle_reproduces_golden(path):
+    z = load(path)
+    d = z["depth"].double().requires_grad_(True)
+    p = z["pose"].double().requires_grad_(True)
+    synth = rs.synthesize_multi_scale(z["src"].double(), z["intrinsic"].double(), [d], p)[0]
+    assert torch.allclose(synth.float(), z["synth"], atol=1e-6)
+    l1 = ref_loss.photometric_loss_l1(synth, z["target"].double())
+    ss = ref_loss.photometric_loss_ssim(synth, z["target"].double())
+    assert torch.allclose(l1.float(), z["l1"], atol=1e-7) and torch.allclose(ss.float(), z["ssim"], atol=1e-7)
+    (l1.sum() + ss.sum()).backward()
+    assert torch.allclose(d.grad.float(), z["d_depth"], atol=1e-9, rtol=1e-5)
+    assert torch.allclose(p.grad.float(), z["d_pose"], atol=1e-8, rtol=1e-5)
+    smooth = ref_loss.smootheness_loss(ref_loss.safe_reciprocal_number(z["depth"].double()), z["target"].double())
+    assert torch.allclose(smooth.float(), z["smooth"], atol=1e-8)
+
+
+def test_pose_golden_cpu():
+    z = load(os.path.join(GOLDEN, "pose_6x4.npz"))
+    mat = ref_pose.pose_rvec2matr_batch(z["pose"].double())
+    assert torch.allclose(mat.float(), z["matrix"], atol=1e-6)
+    assert torch.allclose(ref_pose.pose_matr2rvec_batch(mat).float(), z["twist_back"], atol=1e-5)
+    assert torch.allclose(z["twist_back"], z["pose"], atol=1e-4)          # round trip (convert_pose.py:256-271)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(c) for c in CASES])
+def test_hip_kernels_reproduce_golden(gpu_device, path):
+    from xpt_mde_2021_amd.hip import ops
+    z = {k: v.to(gpu_device) for k, v in load(path).items()}
+    d = z["depth"].clone().requires_grad_(True)
+    p = z["pose"].clone().requires_grad_(True)
+    T = ops.pose_rvec2matr(p)
+    synth = ops.warp(z["src"], d, T, z["intrinsic"], 1)
+    bad = ((synth - z["synth"]).abs() > 1e-4).float().mean().item()
+    assert bad < 1e-3, bad                       # strict validity test: a rounding-level coordinate may flip single pixels
+    l1 = ops.photometric("L1", synth, z["target"])
+    ss = ops.photometric("SSIM", synth, z["target"])
+    assert torch.allclose(l1, z["l1"], atol=1e-4) and torch.allclose(ss, z["ssim"], atol=1e-4)
+    if "l1_map" in z:
+        m1 = ops.photometric("L1", synth, z["target"], reduce=False)
+        m2 = ops.photometric("SSIM", synth, z["target"], reduce=False)
+        assert ((m1 - z["l1_map"]).abs() > 1e-4).float().mean().item() < 2e-3
+        assert ((m2 - z["ssim_map"]).abs() > 1e-4).float().mean().item() < 5e-3
+    (l1.sum() + ss.sum()).backward()
+    scale_d, scale_p = z["d_depth"].abs().max().item(), z["d_pose"].abs().max().item()
+    assert ((d.grad - z["d_depth"]).abs() > 1e-3 * scale_d).float().mean().item() < 5e-3
+    assert (p.grad - z["d_pose"]).abs().max().item() < 2e-2 * scale_p
+    # the fused march kernels (the training path): same numbers without materialising the views
+    d2 = z["depth"].clone().requires_grad_(True)
+    p2 = z["pose"].clone().requires_grad_(True)
+    f1, f2 = ops.photo_fused(z["src"], d2, ops.pose_rvec2matr(p2), z["intrinsic"], z["target"], 1)
+    assert torch.allclose(f1, z["l1"], atol=1e-4) and torch.allclose(f2, z["ssim"], atol=1e-4)
+    (f1.sum() + f2.sum()).backward()
+    assert (p2.grad - z["d_pose"]).abs().max().item() < 2e-2 * scale_p
+    smooth = ops.smoothness(z["depth"], z["target"], 4.0, input_is_depth=True)
+    assert torch.allclose(smooth, z["smooth"], atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_pose_golden_gpu(gpu_device):
+    from xpt_mde_2021_amd.hip import ops
+    z = load(os.path.join(GOLDEN, "pose_6x4.npz"))
+    mat = ops.pose_rvec2matr(z["pose"].to(gpu_device))
+    assert torch.allclose(mat.cpu(), z["matrix"], atol=1e-5)

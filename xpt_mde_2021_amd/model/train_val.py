@@ -467,6 +467,9 @@ def merge_results(features, preds, loss, loss_by_type, stereo):
     0-dim tensors (cloned, so hipGraph replays do not overwrite them); fetch_results() moves a whole epoch to the
     host at once."""
     batch_result = {"loss": loss.detach().clone()}
+    if "pose" in preds:
+        trjabs, trjrel, roterr = get_pose_metric(preds, features)
+        batch_result["trjabs"], batch_result["trjrel"], batch_result["roterr"] = trjabs, trjrel, roterr
     if "depth_ms" in preds and "depth_gt" in features:
         batch_result["deprel"] = get_depth_metric(features, preds)
         gtdepth, prdepth = get_center_depths(features, preds)
@@ -509,6 +512,35 @@ def get_depth_metric(features, preds):
         err = torch.where(mask, torch.abs(gt - scaled) / torch.where(mask, gt, torch.ones_like(gt)), torch.zeros_like(gt))
         metrics.append(torch.where(cnt > 0, err.sum() / cnt.clamp(min=1), torch.zeros((), device=gt.device)))
     return torch.stack(metrics).mean()
+
+
+def get_pose_metric(preds, features):
+    """train_val.py:203-210 + evaluate/eval_utils.py:15-87 (PoseMetricNumpy) on the device: mean absolute-scale trajectory
+    error, mean scale-aligned trajectory error (metres) and mean rotational error (radians) of the snippet re-based on
+    its first frame.  Same arithmetic as evaluate/eval_utils.PoseMetricNumpy (the host version the reference's
+    known-answer tests pin); zeros when the dataset has no pose_gt (:209-210)."""
+    pose = preds["pose"].detach().float()
+    zero = torch.zeros((), device=pose.device)
+    if "pose_gt" not in features:
+        return zero, zero, zero
+    from ..utils import convert_pose as cp
+    pred = cp.pose_rvec2matr_batch_tf(pose)                # [B, N, 4, 4] (utils/convert_pose.py:32-71; the gfx950 kernel)
+    true = features["pose_gt"].float()
+
+    def from_first(poses):                       # [B, N, 4, 4] -> [B, N + 1, 4, 4], target (identity) in the middle
+        eye = torch.eye(4, device=poses.device).expand(poses.shape[0], 1, 4, 4)
+        mats = torch.cat([poses[:, :2], eye, poses[:, 2:]], dim=1)
+        return cp.rigid_inverse(mats[:, 0:1]) @ mats
+
+    pred, true = from_first(pred), from_first(true)
+    xyz_p, xyz_t = pred[:, :, :3, 3], true[:, :, :3, 3]
+    abs_err = (xyz_t - xyz_p).norm(dim=2)[:, 1:]
+    scale = (xyz_t * xyz_p).sum(dim=2) / (xyz_p ** 2).sum(dim=2)            # 0 / 0 only at the dropped origin frame
+    rel_err = (xyz_t - xyz_p * scale[..., None]).norm(dim=2)[:, 1:]
+    rel = pred[:, :, :3, :3].transpose(-1, -2) @ true[:, :, :3, :3]
+    cosine = ((rel.diagonal(dim1=-2, dim2=-1).sum(-1) - 1.0) / 2.0).clamp(-1.0, 1.0)
+    rot_err = torch.acos(cosine)[:, 1:]
+    return abs_err.mean(), rel_err.mean(), rot_err.mean()
 
 
 def get_center_depths(features, preds):
