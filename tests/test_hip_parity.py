@@ -220,19 +220,21 @@ def test_fused_warp_l1_ssim_fwd_bwd(ops, gpu_device, B, N, h, w, scale):
     frac_close(l1, l1_ref, 2e-5, rtol=1e-4, what="fused L1")
     frac_close(ss, ss_ref, 2e-5, rtol=1e-4, what="fused SSIM")
     l1b, ssb, synth = ops.photo_fused_with_synth(dev[0], d, T, dev[1], dev[2], scale)
-    assert torch.equal(l1b, l1) and torch.equal(ssb, ss)
+    # (separately compiled instantiations of the same expressions: the L1 sums are bit-identical, the SSIM sums agree to
+    # the compiler's FMA contraction, ~1e-7 relative)
+    assert torch.equal(l1b, l1) and torch.allclose(ssb, ss, rtol=2e-6, atol=0)
     frac_close(synth, synth_ref, 1e-4, max_bad_frac=2e-4, what="fused synth")
     # the compiler-scheduled and the hand-pipelined row loop are the same arithmetic in the same order
     from xpt_mde_2021_amd.hip import lib as hip_lib
     lib = hip_lib.load()
     try:
-        for variant in (0, 1):
+        for variant in (0, 1, 2):                   # 2 = neighbour texels staged in LDS per block of rows
             assert lib.xpt_photo_fused_variant(variant) == 0
             l1v, ssv = ops.photo_fused(dev[0], d.detach(), T.detach(), dev[1], dev[2], scale)
-            assert torch.equal(l1v, l1) and torch.equal(ssv, ss), f"forward variant {variant}"
+            assert torch.equal(l1v, l1) and torch.allclose(ssv, ss, rtol=2e-6, atol=0), f"forward variant {variant}"
     finally:
         lib.xpt_photo_fused_variant(1)
-    assert lib.xpt_photo_fused_variant(2) != 0
+    assert lib.xpt_photo_fused_variant(3) != 0
     gs = d_ref.grad.abs().max().item()
     frac_close(d.grad, d_ref.grad, 2e-4 * gs, rtol=2e-3, max_bad_frac=1e-3, what="fused ddepth")
     ts = T_ref.grad.abs().max().item()

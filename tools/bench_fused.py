@@ -4,7 +4,7 @@ from xpt_mde_2021_amd.hip import ops, roofline as rf, lib as _lib
 from xpt_mde_2021_amd.utils import synthetic_data as sd
 lib = _lib.load()
 feats = {k: v.cuda() for k, v in sd.make_features(8, 128, 416).items()}
-for fw, bw, mr, pipe in ((4096, 1536, 8, 0), (4096, 1536, 8, 1), (2048, 1536, 8, 1), (8192, 1536, 4, 1)):
+for fw, bw, mr, pipe in ((4096, 1536, 8, 0), (4096, 1536, 8, 1), (4096, 1536, 8, 2), (4096, 1536, 8, 10), (2048, 1024, 8, 1), (4096, 3072, 8, 1)):
     assert lib.xpt_photo_fused_tune(fw, bw, mr) == 0
     assert lib.xpt_photo_fused_variant(pipe) == 0
     out = []

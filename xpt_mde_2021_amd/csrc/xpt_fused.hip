@@ -49,6 +49,9 @@ __device__ inline float wave_sum_all(float v) {
 struct FusedDims {
   int B, N, h, w, S, CH, R;   // S strips per row, CH row chunks, R rows per chunk
   float scale;
+  int lds_ok;                 // source rows / images are 16-byte aligned: the LDS-staged variant may copy aligned lines
+  int dbg;                    // diagnostic of the compiler-scheduled march: 1 = no gathers at all (taps = target pixel),
+                              // i.e. what the kernel costs without its neighbour loads
 };
 
 // Which (batch, view, strip, chunk) a wave works on; all members are wave-uniform (SGPRs).
@@ -95,26 +98,56 @@ __device__ inline void load_taps(const float* __restrict__ simg, int w, const Ta
   }
 }
 
+// The forward needs sigma_x and sigma_y only as their sum, so ONE window sum Sq = S(x^2 + y^2) stands in for S(x^2) and
+// S(y^2): 12 window sums per pixel [x(3) y(3) x^2+y^2 (3) xy(3)], not 15.
+constexpr int NW = 12;
+
 // SSIM loss value of one channel from the 3x3 window sums (loss_util.py:80-93)
-__device__ inline float ssim_loss(float Sx, float Sy, float Sxx, float Syy, float Sxy, float ic) {
+__device__ inline float ssim_loss(float Sx, float Sy, float Sq, float Sxy, float ic) {
   const float mux = Sx * ic, muy = Sy * ic;
-  const float sx = Sxx * ic - mux * mux, sy = Syy * ic - muy * muy, sxy = Sxy * ic - mux * muy;
+  const float m2 = mux * mux + muy * muy;
+  const float sxy = Sxy * ic - mux * muy;
   const float n = (2.f * mux * muy + SSIM_C1) * (2.f * sxy + SSIM_C2);
-  const float dn = (mux * mux + muy * muy + SSIM_C1) * (sx + sy + SSIM_C2);
+  const float dn = (m2 + SSIM_C1) * ((Sq * ic - m2) + SSIM_C2);
   return clampf((1.f - n * rcpf(dn)) * 0.5f, 0.f, 1.f);
 }
 
 // two channels at once on packed-fp32 VALU ops (v_pk_add/mul/fma_f32: two results per issue slot)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ inline f32x2 ssim_loss2(f32x2 Sx, f32x2 Sy, f32x2 Sxx, f32x2 Syy, f32x2 Sxy, float ic) {
+__device__ inline f32x2 ssim_loss2(f32x2 Sx, f32x2 Sy, f32x2 Sq, f32x2 Sxy, float ic) {
   const f32x2 mux = Sx * ic, muy = Sy * ic;
-  const f32x2 sx = Sxx * ic - mux * mux, sy = Syy * ic - muy * muy, sxy = Sxy * ic - mux * muy;
+  const f32x2 m2 = mux * mux + muy * muy;
+  const f32x2 sxy = Sxy * ic - mux * muy;
   const f32x2 n = (2.f * mux * muy + SSIM_C1) * (2.f * sxy + SSIM_C2);
-  const f32x2 dn = (mux * mux + muy * muy + SSIM_C1) * (sx + sy + SSIM_C2);
+  const f32x2 dn = (m2 + SSIM_C1) * ((Sq * ic - m2) + SSIM_C2);
   f32x2 l;
   l.x = clampf((1.f - n.x * rcpf(dn.x)) * 0.5f, 0.f, 1.f);
   l.y = clampf((1.f - n.y * rcpf(dn.y)) * 0.5f, 0.f, 1.f);
   return l;
+}
+
+// horizontal 3-sums of the NW window terms of one row (x = target pixel, y = synthesized pixel of this lane)
+__device__ inline void window_terms(const float (&x)[3], const float (&y)[3], float (&cur)[NW]) {
+  const f32x2 x01{x[0], x[1]}, y01{y[0], y[1]};
+  const f32x2 q01 = x01 * x01 + y01 * y01, xy01 = x01 * y01;
+  const float p[NW] = {x[0], x[1], x[2], y[0], y[1], y[2], q01.x, q01.y, x[2] * x[2] + y[2] * y[2],
+                       xy01.x, xy01.y, x[2] * y[2]};
+#pragma unroll
+  for (int i = 0; i < NW; ++i) cur[i] = hsum3(p[i]);
+}
+
+// sum over the three channels of the SSIM loss of the window (m2, m1, cur) = rows (r-2, r-1, r), centre r-1
+__device__ inline float ssim_row(const float (&m2)[NW], const float (&m1)[NW], const float (&cur)[NW], float ic) {
+  // channels 0 and 1 ride together in packed registers, channel 2 stays scalar (same operation order per channel)
+  f32x2 W[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    W[q] = (f32x2{m2[3 * q], m2[3 * q + 1]} + f32x2{m1[3 * q], m1[3 * q + 1]}) + f32x2{cur[3 * q], cur[3 * q + 1]};
+  const f32x2 l01 = ssim_loss2(W[0], W[1], W[2], W[3], ic);
+  const f32x2 Wa = (f32x2{m2[2], m2[5]} + f32x2{m1[2], m1[5]}) + f32x2{cur[2], cur[5]};        // (x, y) of channel 2
+  const f32x2 Wb = (f32x2{m2[8], m2[11]} + f32x2{m1[8], m1[11]}) + f32x2{cur[8], cur[11]};     // (x^2 + y^2, xy)
+  const float l2 = ssim_loss(Wa.x, Wa.y, Wb.x, Wb.y, ic);
+  return (l01.x + l01.y) + l2;
 }
 
 __device__ inline float window_rcp(int r, int h, float cnt_c) {
@@ -175,13 +208,13 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
   const int row3 = 3 * d.w;
 
   float acc_l1 = 0.f, acc_ss = 0.f;
-  float hA[15], hB[15], hC[15];                    // horizontal window sums [x(3) y(3) xx(3) yy(3) xy(3)] of 3 rows
+  float hA[NW], hB[NW], hC[NW];                    // horizontal window sums [x(3) y(3) xx(3) yy(3) xy(3)] of 3 rows
 #pragma unroll
-  for (int i = 0; i < 15; ++i) { hA[i] = 0.f; hB[i] = 0.f; hC[i] = 0.f; }
+  for (int i = 0; i < NW; ++i) { hA[i] = 0.f; hB[i] = 0.f; hC[i] = 0.f; }
   bool black_prev = true;
 
   // body(r, cur, m1, m2): loads row r, fills cur, emits the SSIM of row r-1 from (m2, m1, cur)
-  auto body = [&](int r, float (&cur)[15], const float (&m1)[15], const float (&m2)[15]) {
+  auto body = [&](int r, float (&cur)[NW], const float (&m1)[NW], const float (&m2)[NW]) {
     float x[3] = {0.f, 0.f, 0.f}, y[3] = {0.f, 0.f, 0.f};
     if (r >= 0 && r < d.h && col_in) {             // r is wave-uniform
       const int p = r * d.w + col;
@@ -203,9 +236,17 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
       const float wff = wuf * wvf, wfc = wuf * wvc, wcf = wuc * wvf, wcc = wuc * wvc;
       const float* t0 = simg + off;
       const float* t1 = t0 + row3;
-      const f32x2 v01 = ((f32x2{t0[0], t0[1]} * wff + f32x2{t1[0], t1[1]} * wfc) + f32x2{t0[3], t0[4]} * wcf) +
-                        f32x2{t1[3], t1[4]} * wcc;
-      const float v2 = ((t0[2] * wff + t1[2] * wfc) + t0[5] * wcf) + t1[5] * wcc;
+      float ta[6], tb[6];
+      if (d.dbg == 1) {                            // wave-uniform: diagnostic without any gather
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { ta[e] = x[e % 3]; tb[e] = x[e % 3]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { ta[e] = t0[e]; tb[e] = t1[e]; }
+      }
+      const f32x2 v01 = ((f32x2{ta[0], ta[1]} * wff + f32x2{tb[0], tb[1]} * wfc) + f32x2{ta[3], ta[4]} * wcf) +
+                        f32x2{tb[3], tb[4]} * wcc;
+      const float v2 = ((ta[2] * wff + tb[2] * wfc) + ta[5] * wcf) + tb[5] * wcc;
       y[0] = ok ? v01.x : 0.f;
       y[1] = ok ? v01.y : 0.f;
       y[2] = ok ? v2 : 0.f;
@@ -216,27 +257,11 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
     const bool black = ((y[0] + y[1]) + y[2]) == 0.f;       // mean_c == 0  <=>  sum_c == 0
     if (out_lane && r >= r0 && r < r1 && !black)
       acc_l1 += (fabsf(y[0] - x[0]) + fabsf(y[1] - x[1])) + fabsf(y[2] - x[2]);
-    {
-      const f32x2 x01{x[0], x[1]}, y01{y[0], y[1]}, xy2{x[2], y[2]};
-      const f32x2 xx01 = x01 * x01, yy01 = y01 * y01, xy01 = x01 * y01, sq2 = xy2 * xy2;
-      const float p[15] = {x[0], x[1], x[2], y[0], y[1], y[2], xx01.x, xx01.y, sq2.x, yy01.x, yy01.y, sq2.y,
-                           xy01.x, xy01.y, x[2] * y[2]};
-#pragma unroll
-      for (int i = 0; i < 15; ++i) cur[i] = hsum3(p[i]);
-    }
+    window_terms(x, y, cur);
     const int rc = r - 1;                          // centre row of the window (m2, m1, cur)
     if (rc >= r0 && rc < r1) {
       const float ic = window_rcp(rc, d.h, cnt_c);
-      // channels 0 and 1 ride together in packed registers, channel 2 stays scalar (same operation order per channel)
-      f32x2 W[5];
-#pragma unroll
-      for (int q = 0; q < 5; ++q)
-        W[q] = (f32x2{m2[3 * q], m2[3 * q + 1]} + f32x2{m1[3 * q], m1[3 * q + 1]}) + f32x2{cur[3 * q], cur[3 * q + 1]};
-      const f32x2 l01 = ssim_loss2(W[0], W[1], W[2], W[3], W[4], ic);
-      const f32x2 Wa = (f32x2{m2[2], m2[5]} + f32x2{m1[2], m1[5]}) + f32x2{cur[2], cur[5]};        // (x, y) of channel 2
-      const f32x2 Wb = (f32x2{m2[8], m2[11]} + f32x2{m1[8], m1[11]}) + f32x2{cur[8], cur[11]};     // (xx, yy)
-      const float l2 = ssim_loss(Wa.x, Wa.y, Wb.x, Wb.y, m2[14] + m1[14] + cur[14], ic);
-      const float sum = (l01.x + l01.y) + l2;
+      const float sum = ssim_row(m2, m1, cur, ic);
       if (out_lane && !black_prev) acc_ss += sum;
     }
     black_prev = black;
@@ -267,7 +292,7 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
       asm volatile("global_load_dword %0, %1, off" : "=v"(nd) : "v"(pd) : "memory");
       asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(nx) : "v"(pt) : "memory");
     };
-    auto pbody = [&](int r, float (&cur)[15], const float (&m1)[15], const float (&m2)[15]) {
+    auto pbody = [&](int r, float (&cur)[NW], const float (&m1)[NW], const float (&m2)[NW]) {
       // the prefetched depth / target of this row have been waited for (end of the previous body or below)
       const bool valid = nvalid;
       const float dd = valid ? nd : 0.f;
@@ -300,26 +325,11 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
       const bool black = ((y[0] + y[1]) + y[2]) == 0.f;
       if (out_lane && r >= r0 && r < r1 && !black)
         acc_l1 += (fabsf(y[0] - x[0]) + fabsf(y[1] - x[1])) + fabsf(y[2] - x[2]);
-      {
-        const f32x2 x01{x[0], x[1]}, y01{y[0], y[1]}, xy2{x[2], y[2]};
-        const f32x2 xx01 = x01 * x01, yy01 = y01 * y01, xy01 = x01 * y01, sq2 = xy2 * xy2;
-        const float p[15] = {x[0], x[1], x[2], y[0], y[1], y[2], xx01.x, xx01.y, sq2.x, yy01.x, yy01.y, sq2.y,
-                             xy01.x, xy01.y, x[2] * y[2]};
-#pragma unroll
-        for (int i = 0; i < 15; ++i) cur[i] = hsum3(p[i]);
-      }
+      window_terms(x, y, cur);
       const int rc = r - 1;
       if (rc >= r0 && rc < r1) {
         const float ic = window_rcp(rc, d.h, cnt_c);
-        f32x2 W[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q)
-          W[q] = (f32x2{m2[3 * q], m2[3 * q + 1]} + f32x2{m1[3 * q], m1[3 * q + 1]}) + f32x2{cur[3 * q], cur[3 * q + 1]};
-        const f32x2 l01 = ssim_loss2(W[0], W[1], W[2], W[3], W[4], ic);
-        const f32x2 Wa = (f32x2{m2[2], m2[5]} + f32x2{m1[2], m1[5]}) + f32x2{cur[2], cur[5]};
-        const f32x2 Wb = (f32x2{m2[8], m2[11]} + f32x2{m1[8], m1[11]}) + f32x2{cur[8], cur[11]};
-        const float l2 = ssim_loss(Wa.x, Wa.y, Wb.x, Wb.y, m2[14] + m1[14] + cur[14], ic);
-        const float sum = (l01.x + l01.y) + l2;
+        const float sum = ssim_row(m2, m1, cur, ic);
         if (out_lane && !black_prev) acc_ss += sum;
       }
       black_prev = black;
@@ -343,6 +353,204 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
     const long long gw = ((long long)(job.b * d.S + job.s) * d.CH + job.ck) * d.N + job.n;
     part[16 * gw] = acc_l1;
     part[16 * gw + 1] = acc_ss;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, LDS-staged taps
+// Variant 2.  The gather of the four bilinear neighbours is what bounds the march above: every source texel is
+// requested by two lanes and by two consecutive row steps, as unaligned 16 + 8 byte loads per lane and tap row -- the
+// address path (TA / L1) is ~50 % busy at 25 % of the HBM rate (profiles/r01_d_pmc_fused.md).  Here a wave works in blocks of
+// FB = 6 target rows:
+//   pass 1  streams the block's depth / target rows (12 coalesced loads in flight together) and projects all pixels;
+//   a wave reduction gives the bounding box [umin, umax] x [vmin, vmax] of the neighbours the block touches;
+//   if it fits (<= FT rows, one 1 KiB line of floats per row), the box is copied ROW BY ROW into the wave's LDS tile
+//   with ONE aligned 16-byte load per lane and row (all in flight together) -- each texel leaves L2 once per block;
+//   pass 2  takes the 12 neighbour values of every pixel from LDS (4-byte reads, texel stride 3 dwords: conflict-free)
+//   and runs the same L1 / SSIM arithmetic as the other variants.
+// A block whose box does not fit (strong zoom / rotation, depth discontinuities spanning the strip) gathers from global
+// memory exactly like variant 0; the decision is wave-uniform.  The same texels enter the same expressions as in the
+// other variants (L1 sums are bit-identical; the SSIM sums agree to ~1e-7 relative: FMA contraction of a separately
+// compiled body).
+constexpr int FB = 6;            // target rows per block (a multiple of 3: the register rotation of the row history)
+constexpr int FT = 10;           // source rows the LDS tile holds
+constexpr int FROW = 256;        // floats per tile row = 64 lanes x 16 bytes
+
+__device__ inline int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ inline int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(256) void fused_fwd_lds_kernel(const float* __restrict__ src, const float* __restrict__ depth,
+                                                            const float* __restrict__ T, const float* __restrict__ K,
+                                                            const float* __restrict__ target, float* __restrict__ part,
+                                                            FusedDims d) {
+  __shared__ __attribute__((aligned(16))) float tiles[4][FT * FROW];
+  const WaveJob job = wave_job(d);
+  if (!job.valid) return;                          // no block-level synchronisation in this kernel
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* tile = tiles[wid];
+  const int P = d.h * d.w;
+  const int col = job.s * STRIP - 1 + lane;
+  const bool col_in = (col >= 0) && (col < d.w);
+  const bool out_lane = (lane >= 1) && (lane <= STRIP) && col_in;
+  const int col_c = min(max(col, 0), d.w - 1);
+  const int r0 = job.ck * d.R, r1 = min(r0 + d.R, d.h);
+  const Cam cam = load_cam(K + 9 * job.b, d.scale);
+  const Pose pose = load_pose(T + 16 * (job.b * d.N + job.n));
+  const float* simg = src + (long long)(job.b * d.N + job.n) * P * 3;
+  const float* dimg = depth + (long long)job.b * P;
+  const float* timg = target + (long long)job.b * P * 3;
+  const float cnt_c = (float)((col > 0 ? 1 : 0) + 1 + (col < d.w - 1 ? 1 : 0));
+  float M[9], kt[3], m_c[3];
+  {
+    float KR[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        KR[3 * i + j] = cam.k[3 * i] * pose.r[j] + cam.k[3 * i + 1] * pose.r[3 + j] + cam.k[3 * i + 2] * pose.r[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        M[3 * i + j] = KR[3 * i] * cam.ki[j] + KR[3 * i + 1] * cam.ki[3 + j] + KR[3 * i + 2] * cam.ki[6 + j];
+      kt[i] = cam.k[3 * i] * pose.t[0] + cam.k[3 * i + 1] * pose.t[1] + cam.k[3 * i + 2] * pose.t[2];
+      m_c[i] = M[3 * i] * (float)col + M[3 * i + 2];
+    }
+  }
+  const float fu_max = (float)(d.w - 2), fv_max = (float)(d.h - 2);
+  const int row3 = 3 * d.w;
+
+  float acc_l1 = 0.f, acc_ss = 0.f;
+  float hA[NW], hB[NW], hC[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { hA[i] = 0.f; hB[i] = 0.f; hC[i] = 0.f; }
+  bool black_prev = true;
+
+  // one row of the march once x (target) and y (synthesized) are known: L1, horizontal window sums, SSIM of row r-1
+  auto emit = [&](int r, const float (&x)[3], const float (&y)[3], float (&cur)[NW], const float (&m1)[NW],
+                  const float (&m2)[NW]) {
+    const bool black = ((y[0] + y[1]) + y[2]) == 0.f;
+    if (out_lane && r >= r0 && r < r1 && !black)
+      acc_l1 += (fabsf(y[0] - x[0]) + fabsf(y[1] - x[1])) + fabsf(y[2] - x[2]);
+    window_terms(x, y, cur);
+    const int rc = r - 1;
+    if (rc >= r0 && rc < r1) {
+      const float ic = window_rcp(rc, d.h, cnt_c);
+      const float sum = ssim_row(m2, m1, cur, ic);
+      if (out_lane && !black_prev) acc_ss += sum;
+    }
+    black_prev = black;
+  };
+
+  const int rend = r1;                             // inclusive: one halo row below the chunk
+  int n_blocks = 0, n_staged = 0;                  // diagnostics (workspace slots 2, 3 of the wave)
+  for (int rb = r0 - 1; rb <= rend; rb += FB) {
+    // ---- pass 1: stream depth / target of the block's rows, project, find the box of touched source texels
+    float dd[FB];
+    f32x3 xx[FB];
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {                 // unconditional loads from clamped rows (zeroed below)
+      const int p = min(max(rb + i, 0), d.h - 1) * d.w + col_c;
+      dd[i] = dimg[p];
+      xx[i] = *(const f32x3*)(timg + 3 * p);
+    }
+    float up[FB], vp[FB];
+    int offs[FB];                                  // (fv * w + fu) * 3 of valid pixels, -1 otherwise
+    int umin = 0x7fffffff, umax = -1, vmin = 0x7fffffff, vmax = -1;
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int r = rb + i;
+      const bool rvalid = r >= 0 && r < d.h && r <= rend && col_in;
+      if (!rvalid) { dd[i] = 0.f; xx[i] = f32x3{0.f, 0.f, 0.f}; }
+      const float fr = (float)r;
+      const float q0 = (M[1] * fr + m_c[0]) * dd[i] + kt[0];
+      const float q1 = (M[4] * fr + m_c[1]) * dd[i] + kt[1];
+      const float q2 = (M[7] * fr + m_c[2]) * dd[i] + kt[2];
+      const float zinv = rcpf(q2 + 1e-10f);
+      up[i] = q0 * zinv;
+      vp[i] = q1 * zinv;
+      const float fu = floorf(up[i]), fv = floorf(vp[i]);
+      const bool ok = rvalid && (fu >= 0.f) && (fu <= fu_max) && (fv >= 0.f) && (fv <= fv_max) && (dd[i] != 0.f);
+      const int iu = ok ? (int)fu : 0, iv = ok ? (int)fv : 0;
+      offs[i] = ok ? (iv * d.w + iu) * 3 : -1;
+      if (ok) {
+        umin = min(umin, iu); umax = max(umax, iu + 1);
+        vmin = min(vmin, iv); vmax = max(vmax, iv + 1);
+      }
+    }
+    umin = wave_min_i(umin); umax = wave_max_i(umax);
+    vmin = wave_min_i(vmin); vmax = wave_max_i(vmax);
+    const bool any_ok = vmax >= 0;                                   // wave-uniform from here on
+    // tile geometry: row segment [a0, a0 + len) of source row vmin (float indices inside the image), a0 16-byte aligned
+    const int f0 = (vmin * d.w + umin) * 3;
+    const int a0 = f0 & ~3;
+    const int cu0 = a0 - vmin * row3;                                // float offset of tile column 0 inside a source row
+    const int len = umax * 3 + 3 - cu0;                              // floats needed per row
+    const bool staged = any_ok && d.lds_ok && (vmax - vmin + 1 <= FT) && (len <= FROW);
+    n_blocks += any_ok ? 1 : 0;
+    n_staged += staged ? 1 : 0;
+    if (staged) {
+      const int nrows = vmax - vmin + 1;
+      f32x4 seg[FT];
+#pragma unroll
+      for (int t = 0; t < FT; ++t) {                                 // every needed row's line in flight together
+        const bool need = t < nrows && 4 * lane < len;
+        const float* g = simg + a0 + (need ? t * row3 + 4 * lane : 0);
+        const f32x4 v = *(const f32x4*)g;
+        seg[t] = need ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int t = 0; t < FT; ++t)
+        if (t < nrows) *(f32x4*)(tile + t * FROW + 4 * lane) = seg[t];
+    }
+    // ---- pass 2: neighbours from the tile (or from global memory), loss arithmetic
+#pragma unroll
+    for (int i = 0; i < FB; ++i) {
+      const int r = rb + i;
+      if (r > rend) break;                                           // wave-uniform; nothing after the last row
+      const bool ok = offs[i] >= 0;
+      const float fu = floorf(up[i]), fv = floorf(vp[i]);
+      const float wuf = (fu + 1.f) - up[i], wuc = up[i] - fu, wvf = (fv + 1.f) - vp[i], wvc = vp[i] - fv;
+      const float wff = wuf * wvf, wfc = wuf * wvc, wcf = wuc * wvf, wcc = wuc * wvc;
+      float a[6], b[6];
+      if (staged) {
+        const int o = ok ? offs[i] - vmin * row3 : cu0;              // (fv * w + fu) * 3 relative to source row vmin
+        const int trow = ok ? (o / row3) : 0;                        // fv - vmin   (0 <= o - trow*row3 < row3)
+        const float* t0 = tile + trow * FROW + (o - trow * row3) - cu0;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { a[e] = t0[e]; b[e] = t0[FROW + e]; }
+      } else {
+        const float* t0 = simg + (ok ? offs[i] : 0);
+        const float* t1 = t0 + row3;
+#pragma unroll
+        for (int e = 0; e < 6; ++e) { a[e] = t0[e]; b[e] = t1[e]; }
+      }
+      const f32x2 v01 = ((f32x2{a[0], a[1]} * wff + f32x2{b[0], b[1]} * wfc) + f32x2{a[3], a[4]} * wcf) +
+                        f32x2{b[3], b[4]} * wcc;
+      const float v2 = ((a[2] * wff + b[2] * wfc) + a[5] * wcf) + b[5] * wcc;
+      const float y[3] = {ok ? v01.x : 0.f, ok ? v01.y : 0.f, ok ? v2 : 0.f};
+      const float x[3] = {xx[i].x, xx[i].y, xx[i].z};
+      if (i % 3 == 0) emit(r, x, y, hA, hC, hB);
+      else if (i % 3 == 1) emit(r, x, y, hB, hA, hC);
+      else emit(r, x, y, hC, hB, hA);
+    }
+  }
+  acc_l1 = wave_sum_all(acc_l1);
+  acc_ss = wave_sum_all(acc_ss);
+  if (lane == 0) {
+    const long long gw = ((long long)(job.b * d.S + job.s) * d.CH + job.ck) * d.N + job.n;
+    part[16 * gw] = acc_l1;
+    part[16 * gw + 1] = acc_ss;
+    part[16 * gw + 2] = (float)n_staged;
+    part[16 * gw + 3] = (float)n_blocks;
   }
 }
 
@@ -371,12 +579,13 @@ struct RowState {
   bool black;
 };
 
-__device__ inline void ssim_coeffs(float Sx, float Sy, float Sxx, float Syy, float Sxy, float ic, float g, float& A,
-                                   float& Bq, float& Cq) {
+__device__ inline void ssim_coeffs(float Sx, float Sy, float Sq, float Sxy, float ic, float g, float& A, float& Bq,
+                                   float& Cq) {
   const float mux = Sx * ic, muy = Sy * ic;
-  const float sx = Sxx * ic - mux * mux, sy = Syy * ic - muy * muy, sxy = Sxy * ic - mux * muy;
+  const float m2 = mux * mux + muy * muy;
+  const float sxy = Sxy * ic - mux * muy;
   const float n1 = 2.f * mux * muy + SSIM_C1, n2 = 2.f * sxy + SSIM_C2;
-  const float d1 = mux * mux + muy * muy + SSIM_C1, d2 = sx + sy + SSIM_C2;
+  const float d1 = m2 + SSIM_C1, d2 = (Sq * ic - m2) + SSIM_C2;            // sigma_x + sigma_y from S(x^2 + y^2)
   const float i1 = rcpf(d1), i2 = rcpf(d2);
   const float inv12 = i1 * i2;
   const float ssim = n1 * n2 * inv12;
@@ -421,10 +630,10 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
   float dRt[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) dRt[i] = 0.f;
-  float hA[15], hB[15], hC[15], cA[9], cB[9], cC[9];
+  float hA[NW], hB[NW], hC[NW], cA[9], cB[9], cC[9];
   RowState sA, sB, sC;
 #pragma unroll
-  for (int i = 0; i < 15; ++i) { hA[i] = 0.f; hB[i] = 0.f; hC[i] = 0.f; }
+  for (int i = 0; i < NW; ++i) { hA[i] = 0.f; hB[i] = 0.f; hC[i] = 0.f; }
 #pragma unroll
   for (int i = 0; i < 9; ++i) { cA[i] = 0.f; cB[i] = 0.f; cC[i] = 0.f; }
   auto clear_state = [](RowState& st) {
@@ -435,8 +644,8 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
   };
   clear_state(sA); clear_state(sB); clear_state(sC);
 
-  auto body = [&](int r, RowState& scur, const RowState& sm1, const RowState& sm2, float (&hcur)[15],
-                  const float (&hm1)[15], const float (&hm2)[15], float (&ccur)[9], const float (&cm1)[9],
+  auto body = [&](int r, RowState& scur, const RowState& sm1, const RowState& sm2, float (&hcur)[NW],
+                  const float (&hm1)[NW], const float (&hm2)[NW], float (&ccur)[9], const float (&cm1)[9],
                   const float (&cm2)[9]) {
     // ---- stage A: synthesize row r; keep y and its derivatives w.r.t. the sampling position
     clear_state(scur);
@@ -467,9 +676,8 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
     for (int c = 0; c < 3; ++c) {
       hcur[c] = hsum3(scur.x[c]);
       hcur[3 + c] = hsum3(scur.y[c]);
-      hcur[6 + c] = hsum3(scur.x[c] * scur.x[c]);
-      hcur[9 + c] = hsum3(scur.y[c] * scur.y[c]);
-      hcur[12 + c] = hsum3(scur.x[c] * scur.y[c]);
+      hcur[6 + c] = hsum3(scur.x[c] * scur.x[c] + scur.y[c] * scur.y[c]);
+      hcur[9 + c] = hsum3(scur.x[c] * scur.y[c]);
     }
     // ---- stage B: SSIM coefficients of centre row p = r-1 (state sm1), then their horizontal sums
     {
@@ -483,8 +691,8 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int c = 0; c < 3; ++c)
           ssim_coeffs(hm2[c] + hm1[c] + hcur[c], hm2[3 + c] + hm1[3 + c] + hcur[3 + c],
-                      hm2[6 + c] + hm1[6 + c] + hcur[6 + c], hm2[9 + c] + hm1[9 + c] + hcur[9 + c],
-                      hm2[12 + c] + hm1[12 + c] + hcur[12 + c], ic, g, co[c], co[3 + c], co[6 + c]);
+                      hm2[6 + c] + hm1[6 + c] + hcur[6 + c], hm2[9 + c] + hm1[9 + c] + hcur[9 + c], ic, g, co[c],
+                      co[3 + c], co[6 + c]);
       }
 #pragma unroll
       for (int i = 0; i < 9; ++i) ccur[i] = hsum3(co[i]);
@@ -586,13 +794,15 @@ __global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
 inline FusedDims make_dims(int B, int N, int h, int w, float scale, int rows_per_chunk, int strip) {
   FusedDims d;
   d.B = B; d.N = N; d.h = h; d.w = w; d.scale = scale;
+  d.lds_ok = 0;
+  d.dbg = 0;
   d.S = (w + strip - 1) / strip;
   d.R = rows_per_chunk < h ? rows_per_chunk : h;
   d.CH = (h + d.R - 1) / d.R;
   return d;
 }
 
-int g_fwd_min_waves = 4096, g_bwd_min_waves = 1536, g_min_rows = 8, g_fwd_pipe = 1;
+int g_fwd_min_waves = 4096, g_bwd_min_waves = 1536, g_min_rows = 8, g_fwd_pipe = 1, g_fwd_dbg = 0;
 
 // Rows per chunk: enough waves to cover 256 CUs x 4 SIMDs a few times over, as few halo rows as possible.
 inline int pick_rows(int B, int N, int h, int w, long long min_waves) {
@@ -615,9 +825,16 @@ int xpt_photo_fused_tune(int fwd_min_waves, int bwd_min_waves, int min_rows) {
   return XPT_OK;
 }
 
-/* 1: the hand-pipelined forward (asm loads, explicit s_waitcnt); 0: the compiler-scheduled one */
+/* 2: blocks of rows with the neighbour texels staged in LDS; 1: the hand-pipelined march (asm loads, explicit
+ * s_waitcnt); 0: the compiler-scheduled march.  Same results. */
 int xpt_photo_fused_variant(int pipelined) {
-  if (pipelined != 0 && pipelined != 1) return XPT_ERR_ARG;
+  if (pipelined == 10) {                           // diagnostic: the compiler-scheduled march without its neighbour loads
+    g_fwd_pipe = 0;
+    g_fwd_dbg = 1;
+    return XPT_OK;
+  }
+  if (pipelined < 0 || pipelined > 2) return XPT_ERR_ARG;
+  g_fwd_dbg = 0;
   g_fwd_pipe = pipelined;
   return XPT_OK;
 }
@@ -636,12 +853,16 @@ int xpt_photo_fused_fwd(const float* src, const float* depth, const float* T, co
   if ((loss_l1 == nullptr) != (loss_ssim == nullptr)) return XPT_ERR_NULL;     // both, or neither (partials only)
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || !(scale > 0.f) || (long long)h * w * 3 >= (1LL << 31)) return XPT_ERR_SHAPE;
   if (workspace_floats < xpt_photo_fused_workspace_floats(B, N, h, w)) return XPT_ERR_WORKSPACE;
-  const FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w, g_fwd_min_waves), STRIP);
+  FusedDims d = make_dims(B, N, h, w, scale, pick_rows(B, N, h, w, g_fwd_min_waves), STRIP);
+  d.lds_ok = (w % 4 == 0) && (((uintptr_t)src) % 16 == 0);        // rows of 3 w floats and images of 3 h w floats stay aligned
+  d.dbg = g_fwd_dbg;
   const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
   const unsigned blocks = (unsigned)((nwaves + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
-  if (synth)
+  if (!synth && g_fwd_pipe == 2)
+    hipLaunchKernelGGL(fused_fwd_lds_kernel, dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, workspace, d);
+  else if (synth)
     hipLaunchKernelGGL((fused_fwd_kernel<true, false>), dim3(blocks), dim3(256), 0, s, src, depth, T, K, target, synth,
                        workspace, d);
   else if (g_fwd_pipe)

@@ -41,6 +41,7 @@ class ConvWeightPacker:
         self.entries = {}          # id(weight) -> dict(ref, fwd, bwd, geometry)
         self.signature = None
         self.table = None
+        self.retired = []
         self.nblocks = 0
 
     def get(self, weight, need_bwd=True):
@@ -102,6 +103,8 @@ class ConvWeightPacker:
                 job.N, job.T, job.KW, job.C, job.Cp, job.Np = e["N"], e["T"], e["KW"], e["C"], e["Cp"], e["Np"]
                 job.first_block = first
                 first += (e["N"] * e["T"] * e["Cp"] + e["Cp"] * e["T"] * e["Np"] + 255) // 256
+            if self.table is not None:
+                self.retired.append(self.table)     # a captured step may still launch with the old table
             self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(live[0][0].device)
             self.nblocks = first
             self.signature = sig

@@ -308,6 +308,11 @@ class GradSink:
         self.signature = None
         self.table = None        # [(jobs tensor, blockmap tensor, nblocks)] per finishing launch
         self.scratch = None
+        # Captured hipGraphs keep raw pointers to the job tables, the scratch matrix and the partial-sum workspaces.  A
+        # trainer holds one captured step per input signature (mixed image sizes), so nothing a capture may have seen is
+        # ever freed: tables are cached per job signature, outgrown workspaces are retired, not released.
+        self.tables = {}         # job signature -> (table, scratch)
+        self.retired = []
         self.join_streams = set()   # side streams that still produce partials of this step (hip/conv.py weight gradients)
 
     def wants(self, param):
@@ -321,6 +326,8 @@ class GradSink:
         if buf is None or buf.numel() < nfloats:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.XptHipError("GradSink: new workspace requested during graph capture (run an eager step first)")
+            if buf is not None:
+                self.retired.append(buf)           # an earlier capture may still write here
             buf = self.buffers[key] = torch.empty(nfloats, dtype=torch.float32, device=dst.device)
         return buf
 
@@ -340,9 +347,13 @@ class GradSink:
         lib = _lib.load()
         sig = tuple((d.data_ptr(), s.data_ptr() + 4 * off, n, ns, st) for d, s, off, n, ns, st in pending)
         if sig != self.signature:
-            if torch.cuda.is_current_stream_capturing():
-                raise _lib.XptHipError("GradSink: the set of deferred gradients changed during graph capture")
-            self.table = self._build(lib, pending)
+            cached = self.tables.get(sig)
+            if cached is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise _lib.XptHipError("GradSink: the set of deferred gradients changed during graph capture")
+                self.scratch = None
+                cached = self.tables[sig] = (self._build(lib, pending), self.scratch)
+            self.table, self.scratch = cached
             self.signature = sig
         for jobs, blockmap, nblocks in self.table:
             _lib.check(lib.xpt_reduce_partials(_ptr(jobs), _ptr(blockmap), nblocks, _stream()), "xpt_reduce_partials")
