@@ -264,6 +264,25 @@ def run(args):
                        "final_loss": round(loss, 6)},
         }
     note(f"timed region done: {elapsed:.3f} s")
+    if rank == 0 and world == 1 and args.config != "c5" and not args.no_roofline:
+        # the real loop (train_val.py:43-64 run_an_epoch): the same steps PLUS merge_results per step (abs-rel with two
+        # sorts per sample, centre depths, pose errors, eager, outside the captured graph) and the per-epoch fetch
+        import contextlib
+        import io
+        dataset.steps = args.steps
+        trainer.steps_per_epoch = args.steps
+        with contextlib.redirect_stdout(io.StringIO()):
+            trainer.run_an_epoch(dataset)              # untimed: captures the per-step metrics graph
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            trainer.run_an_epoch(dataset)
+        torch.cuda.synchronize()
+        loop = time.perf_counter() - t1
+        result["epoch_loop"] = {"value": round(global_batch * args.steps / loop, 3), "unit": "images/sec",
+                                "ms_per_step": round(1000.0 * loop / args.steps, 4),
+                                "what": "run_an_epoch over the same batches: training step + per-step metrics (merge_results)"}
+        note(f"epoch loop done: {loop:.3f} s")
     if rank == 0 and not args.no_roofline:
         result["roofline"] = roofline_leg(args, dataset)
         note("roofline leg done")

@@ -54,3 +54,33 @@ def test_pose_metric_matches_eval_utils(gpu_device):
                            torch.zeros((), device=gpu_device), {}, False)
     assert {"trjabs", "trjrel", "roterr"} <= set(out)
     assert tv.get_pose_metric({"pose": pose.to(gpu_device)}, {})[0].item() == 0.0
+
+
+def test_metrics_graph_matches_eager(gpu_device):
+    """run_an_epoch's per-step record comes from a captured graph (train_val._MetricsGraph) that reads the training
+    graph's static buffers: every replay must equal the eager merge_results on the same tensors."""
+    from xpt_mde_2021_amd.config import opts
+    from xpt_mde_2021_amd.model import model_main as mm, train_val as tv
+    saved = (opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE, dict(opts.IMAGE_SIZES))
+    opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 2
+    opts.CONV_DTYPE = "bf16"
+    opts.IMAGE_SIZES["kitti_raw"] = (64, 192)
+    try:
+        dataset, cfg, _ = mm.get_dataset("synthetic", "train", True)
+        model, _, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, opts.LOSS_RIGID_T1, opts.SCALE_WEIGHT_T1,
+                                                                   opts.RIGID_NET, ckpt_name="__test__")
+        trainer, _ = tv.train_val_factory("graph", model, loss_object, 0, False, None, optimizer)
+        for step in range(4):
+            feats = dataset.batches[step % len(dataset.batches)]
+            preds, loss, by_type = trainer.run_a_batch(feats)
+            got = trainer.step_metrics(feats, preds, loss, by_type)
+            ref = tv.merge_results(trainer._graph.static_in, preds, loss, by_type, False)
+            assert set(got) == set(ref) and {"loss", "deprel", "trjabs", "trjrel", "roterr", "L1", "SSIM", "smoothe"} <= set(got)
+            for k in ref:
+                assert torch.allclose(got[k].float(), ref[k].float(), rtol=1e-6, atol=1e-7), (step, k, got[k], ref[k])
+        frame, hours = trainer.run_an_epoch(dataset)
+        assert len(frame) == dataset.steps and frame["loss"].notna().all()
+    finally:
+        opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
+        opts.IMAGE_SIZES.clear()
+        opts.IMAGE_SIZES.update(saved[3])
