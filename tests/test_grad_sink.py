@@ -13,10 +13,11 @@ def test_reduce_partials_jobs(gpu_device):
     from xpt_mde_2021_amd.hip import ops
     sink = ops.GradSink()
     g = torch.Generator().manual_seed(0)
-    cases = [(5, 3), (300, 8), (1100, 9), (77, 32), (1000, 33), (40, 128), (13, 257), (257, 500), (70, 3328), (4096, 1)]
+    cases = [(5, 3), (300, 8), (1100, 9), (77, 32), (1000, 33), (40, 128), (13, 257), (257, 500), (70, 3328), (4096, 1),
+             (4608, 768), (1936, 100), (256, 3), (864, 300), (18432, 5)]          # the last five: 16-byte aligned rows (wide mode)
     expect, dsts = [], []
     for n, nsplit in cases:
-        stride = n + 7
+        stride = n if n in (4608, 1936, 256, 864, 18432) else n + 7
         src = torch.randn(nsplit * stride, generator=g).to(gpu_device)
         dst = torch.full((n,), float("nan"), device=gpu_device)
         sink.add(dst, src, 3 if nsplit * stride - 3 >= (nsplit - 1) * stride + n else 0, n, nsplit, stride)

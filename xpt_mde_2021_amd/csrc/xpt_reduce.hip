@@ -16,11 +16,53 @@
 
 namespace {
 
+// Wide mode (jobs whose rows are 16-byte aligned, n >= 256): a workgroup owns 256 consecutive outputs; every wave reads
+// WHOLE 1 KiB rows of the partial matrix (one float4 per lane: 4x the bytes in flight of the scalar modes and DRAM bursts
+// of 1 KiB instead of 256 B), the 4 waves take the splits round-robin and are combined through LDS in wave order.
+__device__ inline void reduce_wide(const xpt_reduce_job& job, int first) {
+  __shared__ float4 redw[3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long i = (long long)first + 4 * lane;
+  const bool live = i + 3 < job.n;                                     // n % 4 == 0 in this mode
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int g = 0; g < job.nseg; ++g) {
+    const float* src = job.src[g] + (live ? i : 0);
+    const long long stride = job.stride[g];
+    const int ns = job.nsplit[g];
+    for (int s0 = wave; s0 < ns; s0 += 32) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + 4 * u;
+        const float4 x = *(const float4*)(src + (long long)min(s, ns - 1) * stride);
+        const float keep = s < ns ? 1.f : 0.f;
+        v[u] = make_float4(x.x * keep, x.y * keep, x.z * keep, x.w * keep);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+    }
+  }
+  if (wave > 0) redw[wave - 1][lane] = sum;
+  __syncthreads();
+  if (wave == 0 && live) {
+    float4 o;
+    o.x = ((sum.x + redw[0][lane].x) + redw[1][lane].x) + redw[2][lane].x;
+    o.y = ((sum.y + redw[0][lane].y) + redw[1][lane].y) + redw[2][lane].y;
+    o.z = ((sum.z + redw[0][lane].z) + redw[1][lane].z) + redw[2][lane].z;
+    o.w = ((sum.w + redw[0][lane].w) + redw[1][lane].w) + redw[2][lane].w;
+    *(float4*)(job.dst + i) = o;
+  }
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const xpt_reduce_job* __restrict__ jobs,
                                                                const int2* __restrict__ blockmap) {
   __shared__ float red[3][64];
   const int2 bm = blockmap[blockIdx.x];
   const xpt_reduce_job job = jobs[bm.x];
+  if (job.split_waves == 16) {                 // wide mode: 256 outputs per workgroup, 16-byte loads (below)
+    reduce_wide(job, bm.y);
+    return;
+  }
   const int SW = job.split_waves;              // 1 or 4 waves share one 64-output group
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long i = (long long)bm.y + (SW == 1 ? threadIdx.x : lane);

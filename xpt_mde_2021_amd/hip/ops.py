@@ -404,11 +404,16 @@ class GradSink:
         blockmap = []
         for j, (dst, n, segs) in enumerate(entries):
             waves = 1 if max(ns for _, ns, _ in segs) <= 8 else 4
+            # wide mode (csrc/xpt_reduce.hip reduce_wide): whole 1 KiB rows per wave when every row is 16-byte aligned
+            wide = n >= 256 and n % 4 == 0 and dst % 16 == 0 and max(ns for _, ns, _ in segs) > 1 and \
+                all(ptr % 16 == 0 and st % 4 == 0 for ptr, _, st in segs)
+            if wide:
+                waves = 16
             job = jobs[j]
             job.dst, job.n, job.nseg, job.split_waves = dst, n, len(segs), waves
             for g, (ptr, ns, st) in enumerate(segs):
                 job.src[g], job.nsplit[g], job.stride[g] = ptr, ns, st
-            blockmap.extend((j, first) for first in range(0, n, 256 if waves == 1 else 64))
+            blockmap.extend((j, first) for first in range(0, n, 64 if waves == 4 else 256))
         jobs_t = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         map_t = torch.from_numpy(np.asarray(blockmap, dtype=np.int32).reshape(-1, 2)).to(dev)
         return jobs_t, map_t, len(blockmap)
