@@ -357,16 +357,21 @@ int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
     rm = g_conv_plan / 100;
     rn = (g_conv_plan / 10) % 10;
     nkw = 1 << (g_conv_plan % 10);
-  } else if (waves11 >= 8192) {
-    rm = a.N > 32 ? 2 : 1;
-    rn = 2;
-  } else if (waves11 >= 3072) {
-    rn = 2;
-  } else if (waves11 >= 1024) {
-  } else if (waves11 >= 384) {
-    nkw = 4;
   } else {
-    nkw = 8;
+    // measured per layer (tools/bench_conv.py, batch 8): 64 x 64 wave tiles pay when the output has at least two
+    // 32-channel tiles AND the launch still fills the chip (4 MFMAs per 4 fragment loads); everything else runs best on
+    // 32 x 32 tiles at 91 VGPRs (4-5 waves per SIMD), the K loop split over the waves of a workgroup when even those
+    // are too few.  (The 32 x 64 instantiation lost everywhere: 155 VGPRs for 2 MFMAs per 3 loads.)
+    const long long waves22 = ((a.N + 63) / 64) * ((Mmax + 63) / 64) * classes;
+    if (ntile >= 2 && waves22 >= 768) {
+      rm = 2;
+      rn = 2;
+    } else if (waves11 >= 1024) {
+    } else if (waves11 >= 384) {
+      nkw = 4;
+    } else {
+      nkw = 8;
+    }
   }
   if (rm == 2 && rn == 2 && nkw == 1) return launch_igemm<2, 2, 1>(a, Mmax, classes, s);
   if (rm == 1 && rn == 2 && nkw == 1) return launch_igemm<1, 2, 1>(a, Mmax, classes, s);
