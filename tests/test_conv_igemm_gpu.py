@@ -43,11 +43,24 @@ SHAPES = [
 ]
 
 
+@pytest.fixture
+def conv_plan():
+    """Forces one kernel instantiation for forward + data gradient (xpt_conv2d_tune), restores the automatic choice."""
+    from xpt_mde_2021_amd.hip import lib as _lib
+    lib = _lib.load()
+    yield lambda plan: _lib.check(lib.xpt_conv2d_tune(plan), "tune")
+    lib.xpt_conv2d_tune(0)
+
+
+# 0: automatic choice; 901 / 902: the LDS-staged kernel (32 / 64 output channels per workgroup) forced on EVERY layer
+# shape (ragged tiles, residue classes, quad fold, 8-channel inputs); 110: the direct 32 x 32 kernel forced likewise
 @pytest.mark.parametrize("cin,cout,k,stride,H,W,ups", SHAPES)
+@pytest.mark.parametrize("plan", [0, 901, 902, 110])
 @pytest.mark.parametrize("batch", [2])
-def test_conv_fwd_bwd_matches_fp32_reference(gpu_device, cin, cout, k, stride, H, W, ups, batch):
+def test_conv_fwd_bwd_matches_fp32_reference(gpu_device, conv_plan, cin, cout, k, stride, H, W, ups, batch, plan):
     from xpt_mde_2021_amd.hip import conv as xc
     dev = gpu_device
+    conv_plan(plan)
     g = torch.Generator().manual_seed(cin * 131 + cout * 7 + k)
     cp = xc.round_up(cin, 8)
     x = torch.randn(batch, cin, H, W, generator=g).to(torch.bfloat16)

@@ -67,7 +67,8 @@ for name, cin, cout, k, s, H, W, ups in LAYERS:
     flops = 2.0 * B * OH * OW * cout * k * k * cin
     row = []
     for plan in plans:
-        lib.xpt_conv2d_tune(plan)
+        lib.xpt_conv2d_tune(-1000 if plan == -1 else -1512)      # plan -1: automatic WITHOUT the LDS-staged kernel
+        lib.xpt_conv2d_tune(max(plan, 0))
         t_f = timeit(lambda: _lib.check(lib.xpt_conv2d_fwd(x.data_ptr(), e["fwd"].data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W,
                                                            cp, cp, cout, k, k, s, pt, pl, OH, OW, cout, int(ups), 0.1,
                                                            torch.cuda.current_stream().cuda_stream), "fwd"))
@@ -76,6 +77,7 @@ for name, cin, cout, k, s, H, W, ups in LAYERS:
                                                                 torch.cuda.current_stream().cuda_stream), "dgrad"))
         row.append((t_f, t_d))
         tot[plan] = tot.get(plan, 0.0) + t_f + t_d
+    lib.xpt_conv2d_tune(-1512)
     lib.xpt_conv2d_tune(0)
     t_w = timeit(lambda: _lib.check(lib.xpt_conv2d_bwd_weight_partials(g.data_ptr(), x.data_ptr(), part.data_ptr(), part.numel(), B, H, W,
                                                                        cp, cin, cp, cout, cout, k, k, s, pt, pl, OH, OW, int(ups),

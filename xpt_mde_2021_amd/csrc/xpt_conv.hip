@@ -264,6 +264,204 @@ __global__ __launch_bounds__(NKW > 1 ? 64 * NKW : 256) void conv_igemm_kernel(Co
   }
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-staged variant
+// The direct kernel above issues one 16-byte load per lane per fragment; the 64 lanes of such a load touch 32 different
+// cache lines (32 rows x 32 bytes), so on the large maps it runs at the L1's line rate, not at its byte rate (measured:
+// ~2x slower than the library on the 64x208 ... 128x416 layers).  This variant is the classic tiling for those layers:
+// a workgroup owns TN = 32 RM output channels x 128 pixels, the K axis is enumerated in 16-byte "pieces" (8 channels of
+// one tap; K = taps x C/8 pieces, dense even when C is 16) and consumed in chunks of 8 pieces (64 elements).  All 256
+// threads stage a chunk with COALESCED loads (8 consecutive lanes read 128 contiguous bytes of one pixel / one weight
+// row) into LDS rows of 64 elements padded to 144 bytes (ds_read_b128 of 16 consecutive rows is conflict free), the next
+// chunk is fetched into registers while the MFMAs of the current one run.  Pixel decoding, residue classes, the quad fold
+// and the epilogue are those of the direct kernel, so every mode it serves is served here.
+template <int RM>
+__global__ __launch_bounds__(256) void conv_lds_kernel(ConvArgs a) {
+  constexpr int TN = 32 * RM, TP = 128, PITCH = 64 * 2 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(TN + TP) * PITCH];
+  unsigned char* const lA = lds;
+  unsigned char* const lB = lds + TN * PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int cls = blockIdx.z, ch = cls / a.xs, cw = cls % a.xs;
+  const int rows_c = (a.OH - ch + a.xs - 1) / a.xs, cols_c = (a.OW - cw + a.xs - 1) / a.xs;
+  const long long Mc = (long long)a.B * rows_c * cols_c;
+  int kh0 = 0, kw0 = 0, kstep = 1;
+  if (a.xs > 1) {
+    kh0 = (ch + a.off_h) % a.xs;
+    kw0 = (cw + a.off_w) % a.xs;
+    kstep = a.xs;
+  }
+  const int nkh = kh0 < a.KH ? (a.KH - kh0 + kstep - 1) / kstep : 0;
+  const int nkw = kw0 < a.KW ? (a.KW - kw0 + kstep - 1) / kstep : 0;
+  const int cp8 = a.C >> 3;
+  const int npieces = nkh * nkw * cp8;
+  const int nchunks = (npieces + 7) >> 3;
+  const float inv_cp8 = 1.f / (float)cp8, inv_nkw = nkw > 0 ? 1.f / (float)nkw : 0.f;
+
+  const long long m0 = (long long)blockIdx.y * TP;
+  const int n0 = blockIdx.x * TN;
+  if (m0 >= Mc) return;                                              // uniform per workgroup
+
+  // (32-bit index arithmetic: the launcher refuses pixel grids of 2^31 or more; a 64-bit division costs ~10x a 32-bit one
+  //  and a thread decodes five pixels)
+  const unsigned Mc32 = (unsigned)Mc;
+  auto decode = [&](long long m64, int& b, int& oh, int& ow) -> bool {
+    const bool ok = m64 < Mc;
+    const unsigned m = ok ? (unsigned)m64 : Mc32 - 1u;
+    if (a.quad) {
+      const unsigned child = m & 3u;
+      unsigned p = m >> 2;
+      const unsigned pw_ = (unsigned)a.OW >> 1, ph_ = (unsigned)a.OH >> 1;
+      const unsigned q1 = p / pw_, c = p - q1 * pw_;
+      const unsigned q2 = q1 / ph_, rr = q1 - q2 * ph_;
+      b = (int)q2;
+      oh = (int)(2u * rr + (child >> 1));
+      ow = (int)(2u * c + (child & 1u));
+    } else {
+      const unsigned q1 = m / (unsigned)cols_c, c = m - q1 * (unsigned)cols_c;
+      const unsigned q2 = q1 / (unsigned)rows_c, rr = q1 - q2 * (unsigned)rows_c;
+      b = (int)q2;
+      oh = (int)rr * a.xs + ch;
+      ow = (int)c * a.xs + cw;
+    }
+    return ok;
+  };
+
+  // ---- staging role of this thread: piece slot sp of the rows srow + 32 i
+  const int sp = tid & 7, srow = tid >> 3;
+  int sb[4], base_h[4], base_w[4];
+  bool sok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int b, oh, ow;
+    sok[i] = decode(m0 + srow + 32 * i, b, oh, ow);
+    sb[i] = b;
+    base_h[i] = oh * a.so + a.off_h;
+    base_w[i] = ow * a.so + a.off_w;
+  }
+  const int T = a.KH * a.KW;
+  const unsigned short* wrow[RM];
+  bool nok[RM];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    const int n = n0 + srow + 32 * i;
+    nok[i] = n < a.N;
+    wrow[i] = a.w + (long long)(nok[i] ? n : a.N - 1) * T * a.C;
+  }
+
+  f32x16 acc[RM];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+  uint4 ra[RM], rb[4];
+  auto fetch = [&](int ck) {
+    const int p = ck * 8 + sp;
+    const bool live = p < npieces;
+    const int it = live ? (int)(((float)p + 0.5f) * inv_cp8) : 0;     // tap index of the piece (exact: operands are small)
+    const int c0 = live ? (p - it * cp8) * 8 : 0;
+    const int khi = (int)(((float)it + 0.5f) * inv_nkw);
+    const int kwi = it - khi * nkw;
+    const int kh = kh0 + khi * kstep, kw = kw0 + kwi * kstep;
+    const long long woff = (long long)(kh * a.KW + kw) * a.C + c0;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+      const uint4 v = *(const uint4*)(wrow[i] + (live ? woff : 0));
+      const unsigned keep = (live && nok[i]) ? 0xffffffffu : 0u;      // and-mask, not a 16-byte select (that went to scratch)
+      ra[i] = make_uint4(v.x & keep, v.y & keep, v.z & keep, v.w & keep);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int th = base_h[i] + a.sgn * kh, tw = base_w[i] + a.sgn * kw;
+      const bool ok = live && sok[i] && th >= 0 && th < a.Hlim && tw >= 0 && tw < a.Wlim;
+      const int row = ok ? (th >> a.shift) : 0, col = ok ? (tw >> a.shift) : 0;
+      const long long xoff = (((long long)sb[i] * a.PH + row) * a.PW + col) * a.xpitch + c0;
+      const uint4 v = *(const uint4*)(a.x + (ok ? xoff : 0));
+      const unsigned keep = ok ? 0xffffffffu : 0u;
+      rb[i] = make_uint4(v.x & keep, v.y & keep, v.z & keep, v.w & keep);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int i = 0; i < RM; ++i) *(uint4*)(lA + (srow + 32 * i) * PITCH + sp * 16) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(uint4*)(lB + (srow + 32 * i) * PITCH + sp * 16) = rb[i];
+  };
+
+  if (nchunks > 0) {
+    fetch(0);
+    stash();
+    __syncthreads();
+  }
+  const unsigned char* const fB = lB + (wave * 32 + r) * PITCH + h * 16;
+  const unsigned char* const fA = lA + r * PITCH + h * 16;
+  for (int ck = 0; ck < nchunks; ++ck) {
+    const bool more = ck + 1 < nchunks;
+    if (more) fetch(ck + 1);
+    const int left = npieces - ck * 8;                                // pieces of this chunk that hold data (uniform)
+#pragma unroll
+    for (int k16 = 0; k16 < 4; ++k16) {
+      if (2 * k16 < left) {
+        const uint4 fb = *(const uint4*)(fB + k16 * 32);
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+          const uint4 fa = *(const uint4*)(fA + 32 * i * PITCH + k16 * 32);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
+                                                           acc[i], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      __syncthreads();
+      stash();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (as in the direct kernel; this wave's pixels are m0 + 32 wave + r)
+  int pb, poh, pow_;
+  const long long m = m0 + 32 * wave + r;
+  const bool store = decode(m, pb, poh, pow_);
+  const long long opix = a.quad ? (m >> 2) : ((long long)pb * a.OH + poh) * a.OW + pow_;
+  const bool vec_ok = (a.N % 4 == 0) && (a.ypitch % 4 == 0) && (((uintptr_t)a.y) % 8 == 0);
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+#pragma unroll
+    for (int qg = 0; qg < 4; ++qg) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * qg + e];
+      if (a.quad) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += __shfl_xor(v[e], 1, 64);
+          v[e] += __shfl_xor(v[e], 2, 64);
+        }
+      }
+      const int n = n0 + 32 * i + 8 * qg + 4 * h;
+      if (!store || (a.quad && (r & 3) != 0) || n >= a.N) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (a.bias != nullptr && n + e < a.N) v[e] += a.bias[n + e];
+        v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+      }
+      unsigned short* dst = a.y + opix * a.ypitch + n;
+      if (vec_ok) {
+        uint2 pk;
+        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *(uint2*)dst = pk;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < a.N) dst[e] = f2bf(v[e]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight packer
 // One launch per step converts every dense convolution weight from its fp32 master copy (any strides; the flat parameter
 // buffer keeps them in channels_last order [N][KH][KW][C]) into the two bf16 operand layouts of the kernels above:
@@ -344,7 +542,18 @@ int launch_igemm(const ConvArgs& a, long long Mmax, int classes, hipStream_t s) 
   return xpt_launch_status();
 }
 
-int g_conv_plan = 0;   // 0 = automatic; otherwise RM*100 + RN*10 + log2(NKW) (benchmarking)
+template <int RM>
+int launch_lds(const ConvArgs& a, long long Mmax, int classes, hipStream_t s) {
+  const long long gy = (Mmax + 127) / 128;
+  if (gy > 65535 || Mmax >= 0x7fffffffLL) return XPT_ERR_SHAPE;
+  const dim3 grid((a.N + 32 * RM - 1) / (32 * RM), (unsigned)gy, classes);
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL((conv_lds_kernel<RM>), grid, dim3(256), 0, s, a);
+  return xpt_launch_status();
+}
+
+int g_conv_plan = 0;   // 0 = automatic; otherwise RM*100 + RN*10 + log2(NKW), or 900 + RM for the LDS-staged kernel
+int g_conv_lds_min_blocks = 512;
 
 int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
   const int classes = a.xs * a.xs;
@@ -353,6 +562,14 @@ int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
   const long long ntile = (a.N + 31) / 32, mtile = (Mmax + 31) / 32;
   const long long waves11 = ntile * mtile * classes;
   int rm = 1, rn = 1, nkw = 1;
+  if (g_conv_plan == 901) return launch_lds<1>(a, Mmax, classes, s);
+  if (g_conv_plan == 902) return launch_lds<2>(a, Mmax, classes, s);
+  if (!g_conv_plan && g_conv_lds_min_blocks > 0) {
+    // large maps: the LDS-staged kernel (coalesced staging instead of 32 cache lines per fragment load)
+    const int lrm = a.N > 32 ? 2 : 1;
+    const long long blocks = ((a.N + 32 * lrm - 1) / (32 * lrm)) * ((Mmax + 127) / 128) * classes;
+    if (blocks >= g_conv_lds_min_blocks) return lrm == 2 ? launch_lds<2>(a, Mmax, classes, s) : launch_lds<1>(a, Mmax, classes, s);
+  }
   if (g_conv_plan) {
     rm = g_conv_plan / 100;
     rn = (g_conv_plan / 10) % 10;
@@ -385,6 +602,10 @@ int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" int xpt_conv2d_tune(int plan) {
+  if (plan <= -1000) {          // -1000 - n: minimum workgroups for the LDS-staged kernel (n = 0 disables it)
+    g_conv_lds_min_blocks = -plan - 1000;
+    return XPT_OK;
+  }
   g_conv_plan = plan;
   return XPT_OK;
 }
