@@ -205,7 +205,13 @@ def run(args):
         dist.init_process_group(backend="nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
+    # seeded weights and augmentation draws (per rank): "final_loss" is then the same number in every run of one build
+    import random
+    random.seed(20211119)
+    torch.manual_seed(20211119)
     trainer, dataset, mode, _ = build_step(args, world)
+    random.seed(20211119 + rank)
+    torch.manual_seed(20211119 + rank)
     batches = dataset.batches
 
     def sync():

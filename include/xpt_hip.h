@@ -324,6 +324,23 @@ int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* const* w, c
 int xpt_sum_rows(const void* const* inputs, const long long* pitches, int n, void* out, long long rows, int C, int dtype,
                  void* stream);
 
+/* ------------------------------------------------------------------ a2: the elementwise tail of a NASNet-A cell
+ * Replaces the keras layers that end _normal_a_cell / _reduction_a_cell of tensorflow.keras.applications.nasnet (built by
+ * the reference at model/build_model/pretrained_nets.py:11-44) together with the Activation('relu') every consumer of a
+ * cell output starts with:  out[:, s F:(s+1) F] = relu(sum_k scale * (pooled ? AveragePooling2D(3,1,'same')(in) : in)).
+ * src / pitch / pooled / scale hold two slots per slice (index s*2 + k, k < nterms[s] <= 2); all tensors are NHWC rows
+ * [B H W][channels]; dtype 0 float32 / 1 bfloat16. */
+int xpt_cell_tail_fwd(int nslices, const int* nterms, const void* const* src, const long long* pitch, const int* pooled,
+                      const float* scale, void* out, long long out_pitch, int B, int H, int W, int F, int dtype,
+                      void* stream);
+
+/* its backward in one launch: gm [M, nslices F] = [out > 0] * (sum of the ngrads <= 4 consumer gradients); dense input
+ * gradient j < ndense <= 4: dense_out[j] [M, F] = sum of bterms[j] <= 3 terms (slice / pooled / scale at index j*3 + k) of
+ * the masked gradient (pooled: through the adjoint of the average pooling). */
+int xpt_cell_tail_bwd(int ngrads, const void* const* grads, const long long* gpitch, const void* out, long long out_pitch,
+                      void* gm, int nslices, int ndense, void* const* dense_out, const int* bterms, const int* slice,
+                      const int* pooled, const float* scale, int B, int H, int W, int F, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ deferred parameter gradients (one finishing launch per step)
  * The *_partials entry points compute the same parameter gradients as xpt_affine_act_bwd / xpt_dwconv_bwd_weight /
  * xpt_conv1x1_bwd_weight (tape.gradient of the layer variables, model/train_val.py:85-86) but stop at the

@@ -1,0 +1,81 @@
+"""The fused NASNet cell tail (csrc/xpt_celltail.hip: pools + adds + concat + the consumers' relu in one launch, and the
+gradient fan-in + relu mask + pool adjoints + concat split in one backward launch) against the same function composed
+from PyTorch ops in fp32 -- the keras layers it replaces: AveragePooling2D(3, 1, 'same') (divisor without the padding),
+add, concatenate, Activation('relu') of tensorflow.keras.applications.nasnet's _normal_a_cell / _reduction_a_cell
+(the backbone the reference instantiates at model/build_model/pretrained_nets.py:11-44)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+NORMAL = (((0, 0, 1.0),), ((1, 0, 1.0),), ((2, 0, 1.0),), ((3, 1, 1.0), (0, 0, 1.0)), ((0, 1, 2.0),), ((4, 0, 1.0),))
+REDUCTION = (((0, 0, 1.0),), ((1, 0, 1.0),), ((0, 0, 1.0), (2, 1, 1.0)), ((3, 0, 1.0),))
+
+
+def reference(spec, inputs):
+    slices = []
+    for terms in spec:
+        acc = 0
+        for i, pooled, scale in terms:
+            t = inputs[i]
+            if pooled:
+                t = F.avg_pool2d(t, 3, 1, 1, count_include_pad=False)
+            acc = acc + scale * t
+        slices.append(acc)
+    return torch.relu(torch.cat(slices, dim=1))
+
+
+@pytest.mark.parametrize("spec,n_in", [(NORMAL, 5), (REDUCTION, 4)])
+@pytest.mark.parametrize("dtype,F_,H,W", [(torch.float32, 12, 5, 7), (torch.bfloat16, 44, 16, 52), (torch.bfloat16, 88, 8, 26),
+                                          (torch.bfloat16, 22, 9, 13), (torch.bfloat16, 11, 6, 5), (torch.float32, 6, 1, 3)])
+def test_cell_tail_matches_composed_ops(gpu_device, spec, n_in, dtype, F_, H, W):
+    from xpt_mde_2021_amd.hip import ops
+    dev = gpu_device
+    g = torch.Generator().manual_seed(F_ * 100 + H)
+    B = 2
+    host = [torch.randn(B, F_, H, W, generator=g).to(dtype) for _ in range(n_in)]
+    # input 1 is a channel slice of a wider tensor (what torch.cat's backward / a multi-layer launch hands out)
+    wide = torch.randn(B, 2 * F_, H, W, generator=g).to(dtype)
+    host[1] = wide[:, F_:]
+    ref_in = [t.float().clone().requires_grad_(True) for t in host]
+    ref = reference(spec, ref_in)
+    # three consumers with different gradients, one of them unused (None gradient)
+    w0 = torch.randn(ref.shape, generator=g).to(dtype)
+    w1 = torch.randn(ref.shape, generator=g).to(dtype)
+    (ref * w0.float() + ref * w1.float()).sum().backward()
+
+    wide_d = wide.to(dev).contiguous(memory_format=torch.channels_last)
+    dev_in = [t.to(dev).contiguous(memory_format=torch.channels_last) for t in host]
+    dev_in[1] = wide_d[:, F_:]
+    dev_in = [t.detach().requires_grad_(True) for t in dev_in]
+    outs = ops.cell_tail(spec, dev_in, 3)
+    assert len(outs) == 3 and all(o.data_ptr() == outs[0].data_ptr() for o in outs)
+    ((outs[0].float() * w0.to(dev).float()).sum() + (outs[2].float() * w1.to(dev).float()).sum()).backward()
+    torch.cuda.synchronize()
+
+    tol = 1e-5 if dtype == torch.float32 else 1.2e-2          # bf16: one rounding of the result (2^-8) and of each gradient
+    scale = ref.abs().max().item() + 1e-12
+    assert (outs[0].float().cpu() - ref.detach()).abs().max().item() <= tol * scale
+    # the relu mask must agree wherever the reference is not within rounding of zero
+    for i in range(n_in):
+        gr = ref_in[i].grad
+        gd = dev_in[i].grad.float().cpu()
+        gs = gr.abs().max().item() + 1e-12
+        # elements whose pre-activation is within rounding of 0 may flip their mask in bf16: compare away from them
+        err = (gd - gr).abs()
+        if dtype == torch.float32:
+            assert err.max().item() <= 1e-5 * gs, f"input {i}"
+        else:
+            assert (err > 3e-2 * gs).float().mean().item() < 2e-3, f"input {i}: too many gradient elements off"
+            assert err.median().item() <= 1e-2 * gs
+
+
+def test_cell_tail_without_grad_and_single_alias(gpu_device):
+    from xpt_mde_2021_amd.hip import ops
+    dev = gpu_device
+    x = [torch.randn(1, 8, 4, 4, device=dev) for _ in range(4)]
+    with torch.no_grad():
+        out, = ops.cell_tail(REDUCTION, x, 1)
+    assert torch.allclose(out, reference(REDUCTION, x), atol=1e-6)
+    assert out.is_contiguous(memory_format=torch.channels_last)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Loss sequence of K full training steps (forward, backward, fused Adam) from the seeded initial weights: two processes
+must print the same numbers.   python tools/determinism_train.py [eager|graph] [aug|noaug] [K]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from xpt_mde_2021_amd.config import opts  # noqa: E402
+from xpt_mde_2021_amd.model import model_main as mm, train_val as tv  # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
+use_aug = (sys.argv[2] if len(sys.argv) > 2 else "aug") == "aug"
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+opts.CONV_DTYPE = "bf16"
+opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 8
+opts.TRAIN_MODE = mode
+torch.manual_seed(0)
+dataset, cfg, _ = mm.get_dataset("synthetic", "train", True)
+model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, opts.LOSS_RIGID_T1, opts.SCALE_WEIGHT_T1,
+                                                              opts.RIGID_NET, ckpt_name="__det__")
+trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, False, aug if use_aug else None, optimizer)
+losses = []
+for i in range(K):
+    out = trainer.run_a_batch(dataset.batches[i % len(dataset.batches)])
+    losses.append(float(out[1]))
+torch.cuda.synchronize()
+flat = optimizer.flat
+print("LOSSES", mode, "aug" if use_aug else "noaug", " ".join(f"{v:.9f}" for v in losses))
+print("PARAMSUM", f"{float(flat.data.double().abs().sum()):.9f}" if hasattr(flat, "data") else "")

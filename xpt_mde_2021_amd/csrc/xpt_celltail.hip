@@ -1,0 +1,347 @@
+// xpt_celltail.hip -- the elementwise "tail" of a NASNet-A cell in ONE launch forward and ONE launch backward (gfx950).
+//
+// keras builds the end of every cell from small layers (tensorflow.keras.applications.nasnet as instantiated by the
+// reference's PretrainedModel, model/build_model/pretrained_nets.py:11-44):
+//   _normal_a_cell:     x3 = add([AveragePooling2D(3,1,'same')(h), p]);  x4 = add([avgpool(p), avgpool(p)]);
+//                       x  = concatenate([p, x1, x2, x3, x4, x5])
+//   _reduction_a_cell:  x4 = add([x2, avgpool(x1)]);  x = concatenate([x2, x3, x4, x5])
+// and the ONLY consumers of a cell output are Activation('relu') layers (the next cell's 1x1 "squeeze" convolution, the
+// adjust block of the cell after, the final activation / the decoder taps).  So the tail is one function
+//   out[:, s F:(s+1) F] = relu( sum_k scale_k * (pooled_k ? avgpool3same(in_k) : in_k) )         s = 0 .. nslices-1
+// of a handful of F-channel NHWC tensors: 5 launches (2 pools, add, concat, relu) become 1, and in the backward the
+// gradient accumulation over the consumers, the ReLU mask, the two pool adjoints and the concat split become 1.
+//
+// Layout: activations are NHWC rows [M = B H W][channels] (bf16 or fp32), inputs may be channel slices (row pitch).
+// grid.y = slice (forward) / job (backward), so the term table of a workgroup is wave-uniform (SGPR loads).
+#include <hip/hip_bf16.h>
+
+#include "xpt_common.h"
+
+namespace {
+
+template <typename T> __device__ inline float ldf(const T* p);
+template <> __device__ inline float ldf<float>(const float* p) { return *p; }
+template <> __device__ inline float ldf<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <typename T> __device__ inline void stf(T* p, float v);
+template <> __device__ inline void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ inline void stf<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+
+template <typename T, int V> struct RowVec;
+template <> struct RowVec<float, 4> { typedef float4 type; };
+template <> struct RowVec<float, 2> { typedef float2 type; };
+template <> struct RowVec<float, 1> { typedef float type; };
+template <> struct RowVec<__hip_bfloat16, 8> { typedef uint4 type; };
+template <> struct RowVec<__hip_bfloat16, 4> { typedef uint2 type; };
+template <> struct RowVec<__hip_bfloat16, 2> { typedef unsigned type; };
+template <> struct RowVec<__hip_bfloat16, 1> { typedef unsigned short type; };
+
+template <typename T, int V>
+__device__ inline void load_row(const T* p, float (&out)[V]) {
+  typename RowVec<T, V>::type raw = *(const typename RowVec<T, V>::type*)p;
+  const T* e = (const T*)&raw;
+#pragma unroll
+  for (int i = 0; i < V; ++i) out[i] = ldf<T>(e + i);
+}
+
+template <typename T, int V>
+__device__ inline void store_row(T* p, const float (&v)[V]) {
+  typename RowVec<T, V>::type raw;
+  T* e = (T*)&raw;
+#pragma unroll
+  for (int i = 0; i < V; ++i) stf<T>(e + i, v[i]);
+  *(typename RowVec<T, V>::type*)p = raw;
+}
+
+constexpr int MAX_SLICES = 8, MAX_TERMS = 2, MAX_GRADS = 4, MAX_DENSE = 4, MAX_BTERMS = 3;
+
+struct FwdTerm {
+  const void* src;
+  long long pitch;
+  int pooled;
+  float scale;
+};
+struct TailFwd {
+  FwdTerm t[MAX_SLICES][MAX_TERMS];
+  int nterms[MAX_SLICES];
+};
+
+__device__ inline int window_count(int y, int x, int H, int W) {
+  return ((y > 0) + 1 + (y < H - 1)) * ((x > 0) + 1 + (x < W - 1));
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void cell_tail_fwd_kernel(TailFwd a, T* __restrict__ out, long long out_pitch, int B, int H,
+                                                            int W, int F) {
+  const int s = blockIdx.y;
+  const int groups = F / V;
+  const long long total = (long long)B * H * W * groups;
+  const int nt = a.nterms[s];
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % groups) * V;
+    long long p = idx / groups;
+    const long long pix = p;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAX_TERMS; ++k) {
+      if (k >= nt) break;                                              // uniform per workgroup
+      const FwdTerm t = a.t[s][k];
+      const T* src = (const T*)t.src;
+      if (!t.pooled) {
+        float v[V];
+        load_row<T, V>(src + pix * t.pitch + c0, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += v[j] * t.scale;
+      } else {
+        float sum[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) sum[j] = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int ny = y + dy, nx = x + dx;
+            const bool ok = ny >= 0 && ny < H && nx >= 0 && nx < W;
+            const int cy = min(max(ny, 0), H - 1), cx = min(max(nx, 0), W - 1);
+            float v[V];
+            load_row<T, V>(src + (((long long)b * H + cy) * W + cx) * t.pitch + c0, v);
+            const float wgt = ok ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < V; ++j) sum[j] += v[j] * wgt;
+          }
+        }
+        const float norm = t.scale / (float)window_count(y, x, H, W);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += sum[j] * norm;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    store_row<T, V>(out + pix * out_pitch + (long long)s * F + c0, acc);
+  }
+}
+
+// Backward.  gm = [out > 0] * (sum of the consumers' gradients), written for every slice (the inputs that enter the tail
+// through ONE identity term take their gradient as a channel-slice view of gm, times nothing: such terms have scale 1);
+// the inputs with a pooled term or several terms get a dense gradient of their own:
+//   d_in[m] = sum_terms scale * (pooled ? sum_{n in window(m)} gm_slice[n] / cnt(n) : gm_slice[m])
+// evaluated from the consumers' gradients directly (gm of the neighbours is recomputed, not read back: one launch).
+struct BwdTerm {
+  int slice, pooled;
+  float scale;
+};
+struct BwdDense {
+  void* out;                   // [M, F] dense
+  int nterms;
+  BwdTerm t[MAX_BTERMS];
+};
+struct TailBwd {
+  const void* g[MAX_GRADS];    // consumers' gradients [M, nslices F] (row pitch each)
+  long long gpitch[MAX_GRADS];
+  int ngrads;
+  const void* out;             // the forward output (its sign is the ReLU mask)
+  long long out_pitch;
+  void* gm;                    // [M, nslices F] dense
+  int nslices, ndense;
+  BwdDense d[MAX_DENSE];
+};
+
+template <typename T, int V>
+__device__ inline void masked_grad(const TailBwd& a, long long pix, long long ch, float (&gmv)[V]) {
+  float o[V];
+  load_row<T, V>((const T*)a.out + pix * a.out_pitch + ch, o);
+#pragma unroll
+  for (int j = 0; j < V; ++j) gmv[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAX_GRADS; ++k) {
+    if (k >= a.ngrads) break;
+    float v[V];
+    load_row<T, V>((const T*)a.g[k] + pix * a.gpitch[k] + ch, v);
+#pragma unroll
+    for (int j = 0; j < V; ++j) gmv[j] += v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) gmv[j] = o[j] > 0.f ? gmv[j] : 0.f;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void cell_tail_bwd_kernel(TailBwd a, int B, int H, int W, int F) {
+  const int job = blockIdx.y;
+  const int groups = F / V;
+  const long long total = (long long)B * H * W * groups;
+  const long long gm_pitch = (long long)a.nslices * F;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % groups) * V;
+    long long p = idx / groups;
+    const long long pix = p;
+    if (job < a.nslices) {                                             // uniform per workgroup
+      float gmv[V];
+      const long long ch = (long long)job * F + c0;
+      masked_grad<T, V>(a, pix, ch, gmv);
+      store_row<T, V>((T*)a.gm + pix * gm_pitch + ch, gmv);
+      continue;
+    }
+    const BwdDense& d = a.d[job - a.nslices];
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAX_BTERMS; ++k) {
+      if (k >= d.nterms) break;
+      const BwdTerm t = d.t[k];
+      const long long ch = (long long)t.slice * F + c0;
+      if (!t.pooled) {
+        float v[V];
+        masked_grad<T, V>(a, pix, ch, v);
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] += v[j] * t.scale;
+      } else {
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int ny = y + dy, nx = x + dx;
+            const bool ok = ny >= 0 && ny < H && nx >= 0 && nx < W;
+            const int cy = min(max(ny, 0), H - 1), cx = min(max(nx, 0), W - 1);
+            float v[V];
+            masked_grad<T, V>(a, ((long long)b * H + cy) * W + cx, ch, v);
+            const float wgt = ok ? t.scale / (float)window_count(cy, cx, H, W) : 0.f;
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += v[j] * wgt;
+          }
+        }
+      }
+    }
+    store_row<T, V>((T*)d.out + pix * F + c0, acc);
+  }
+}
+
+inline bool aligned_for(const void* p, long long pitch, int v, int esz) {
+  return ((uintptr_t)p) % (size_t)(v * esz) == 0 && pitch % v == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* out [M, nslices F] (row pitch out_pitch) = relu(sum of <= 2 terms per slice); term k of slice s: src[s*2+k] ([M, F] rows
+ * with pitch[s*2+k]), pooled[s*2+k] (3x3 SAME average, divisor without the padding), scale[s*2+k].  dtype 0 fp32, 1 bf16. */
+int xpt_cell_tail_fwd(int nslices, const int* nterms, const void* const* src, const long long* pitch, const int* pooled,
+                      const float* scale, void* out, long long out_pitch, int B, int H, int W, int F, int dtype,
+                      void* stream) {
+  XPT_CHECK_PTR(nterms); XPT_CHECK_PTR(src); XPT_CHECK_PTR(pitch); XPT_CHECK_PTR(pooled); XPT_CHECK_PTR(scale);
+  XPT_CHECK_PTR(out);
+  if (nslices < 1 || nslices > MAX_SLICES || (dtype != 0 && dtype != 1)) return XPT_ERR_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || F <= 0 || out_pitch < (long long)nslices * F) return XPT_ERR_SHAPE;
+  const int esz = dtype == 0 ? 4 : 2;
+  int v = dtype == 0 ? 4 : 8;
+  TailFwd a;
+  for (;;) {
+    bool all = F % v == 0 && aligned_for(out, out_pitch, v, esz);
+    for (int s = 0; s < nslices && all; ++s)
+      for (int k = 0; k < nterms[s] && k < MAX_TERMS && all; ++k) all = aligned_for(src[s * 2 + k], pitch[s * 2 + k], v, esz);
+    if (all || v == 1) break;
+    v >>= 1;
+  }
+  for (int s = 0; s < nslices; ++s) {
+    if (nterms[s] < 1 || nterms[s] > MAX_TERMS) return XPT_ERR_ARG;
+    a.nterms[s] = nterms[s];
+    for (int k = 0; k < nterms[s]; ++k) {
+      if (src[s * 2 + k] == nullptr) return XPT_ERR_NULL;
+      if (pitch[s * 2 + k] < F) return XPT_ERR_SHAPE;
+      a.t[s][k] = FwdTerm{src[s * 2 + k], pitch[s * 2 + k], pooled[s * 2 + k], scale[s * 2 + k]};
+    }
+  }
+  const long long total = (long long)B * H * W * (F / v);
+  long long gx = (total + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  const dim3 grid((unsigned)gx, nslices);
+  hipStream_t st = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+#define XPT_TAIL(T, V) \
+  hipLaunchKernelGGL((cell_tail_fwd_kernel<T, V>), grid, dim3(256), 0, st, a, (T*)out, out_pitch, B, H, W, F)
+  if (dtype == 0) {
+    if (v == 4) XPT_TAIL(float, 4);
+    else if (v == 2) XPT_TAIL(float, 2);
+    else XPT_TAIL(float, 1);
+  } else {
+    if (v == 8) XPT_TAIL(__hip_bfloat16, 8);
+    else if (v == 4) XPT_TAIL(__hip_bfloat16, 4);
+    else if (v == 2) XPT_TAIL(__hip_bfloat16, 2);
+    else XPT_TAIL(__hip_bfloat16, 1);
+  }
+#undef XPT_TAIL
+  return xpt_launch_status();
+}
+
+/* Backward of xpt_cell_tail_fwd.  grads[ngrads] ([M, nslices F] rows, pitch gpitch[]) are the consumers' gradients of out;
+ * gm [M, nslices F] (dense) receives [out > 0] * their sum.  Dense input gradient j (0 .. ndense-1): dense_out[j] [M, F] =
+ * sum over its bterms[j] terms (slice, pooled, scale at index j*3 + k) of the (pooled-adjoint of the) masked gradient. */
+int xpt_cell_tail_bwd(int ngrads, const void* const* grads, const long long* gpitch, const void* out, long long out_pitch,
+                      void* gm, int nslices, int ndense, void* const* dense_out, const int* bterms, const int* slice,
+                      const int* pooled, const float* scale, int B, int H, int W, int F, int dtype, void* stream) {
+  XPT_CHECK_PTR(grads); XPT_CHECK_PTR(gpitch); XPT_CHECK_PTR(out); XPT_CHECK_PTR(gm);
+  if (ngrads < 1 || ngrads > MAX_GRADS || nslices < 1 || nslices > MAX_SLICES || ndense < 0 || ndense > MAX_DENSE ||
+      (dtype != 0 && dtype != 1))
+    return XPT_ERR_ARG;
+  if (B <= 0 || H <= 0 || W <= 0 || F <= 0 || out_pitch < (long long)nslices * F) return XPT_ERR_SHAPE;
+  if (ndense > 0 && (dense_out == nullptr || bterms == nullptr || slice == nullptr || pooled == nullptr || scale == nullptr))
+    return XPT_ERR_NULL;
+  const int esz = dtype == 0 ? 4 : 2;
+  int v = dtype == 0 ? 4 : 8;
+  TailBwd a;
+  a.ngrads = ngrads; a.out = out; a.out_pitch = out_pitch; a.gm = gm; a.nslices = nslices; a.ndense = ndense;
+  for (int k = 0; k < ngrads; ++k) {
+    if (grads[k] == nullptr) return XPT_ERR_NULL;
+    if (gpitch[k] < (long long)nslices * F) return XPT_ERR_SHAPE;
+    a.g[k] = grads[k];
+    a.gpitch[k] = gpitch[k];
+  }
+  for (int j = 0; j < ndense; ++j) {
+    if (dense_out[j] == nullptr) return XPT_ERR_NULL;
+    if (bterms[j] < 1 || bterms[j] > MAX_BTERMS) return XPT_ERR_ARG;
+    a.d[j].out = dense_out[j];
+    a.d[j].nterms = bterms[j];
+    for (int k = 0; k < bterms[j]; ++k) {
+      if (slice[j * 3 + k] < 0 || slice[j * 3 + k] >= nslices) return XPT_ERR_ARG;
+      a.d[j].t[k] = BwdTerm{slice[j * 3 + k], pooled[j * 3 + k], scale[j * 3 + k]};
+    }
+  }
+  for (;;) {
+    bool all = F % v == 0 && aligned_for(out, out_pitch, v, esz) && aligned_for(gm, (long long)nslices * F, v, esz);
+    for (int k = 0; k < ngrads && all; ++k) all = aligned_for(grads[k], gpitch[k], v, esz);
+    for (int j = 0; j < ndense && all; ++j) all = aligned_for(dense_out[j], F, v, esz);
+    if (all || v == 1) break;
+    v >>= 1;
+  }
+  const long long total = (long long)B * H * W * (F / v);
+  long long gx = (total + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  const dim3 grid((unsigned)gx, nslices + ndense);
+  hipStream_t st = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+#define XPT_TAIL(T, V) hipLaunchKernelGGL((cell_tail_bwd_kernel<T, V>), grid, dim3(256), 0, st, a, B, H, W, F)
+  if (dtype == 0) {
+    if (v == 4) XPT_TAIL(float, 4);
+    else if (v == 2) XPT_TAIL(float, 2);
+    else XPT_TAIL(float, 1);
+  } else {
+    if (v == 8) XPT_TAIL(__hip_bfloat16, 8);
+    else if (v == 4) XPT_TAIL(__hip_bfloat16, 4);
+    else if (v == 2) XPT_TAIL(__hip_bfloat16, 2);
+    else XPT_TAIL(__hip_bfloat16, 1);
+  }
+#undef XPT_TAIL
+  return xpt_launch_status();
+}
+
+}  // extern "C"

@@ -82,6 +82,8 @@ SIGNATURES = {
     "xpt_depth_head_fwd": (_i, [_p, _p, _p, ctypes.c_longlong, _p]),
     "xpt_depth_head_bwd": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p]),
     "xpt_sum_rows": (_i, [_p, _p, _i, _p, ctypes.c_longlong, _i, _i, _p]),
+    "xpt_cell_tail_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _i, _i, _i, _i, _i, _p]),
+    "xpt_cell_tail_bwd": (_i, [_i, _p, _p, _p, ctypes.c_longlong, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "xpt_crc32c": (ctypes.c_uint32, [_p, _z]),
     "xpt_conv_pack_job_bytes": (_i, []),
     "xpt_conv_pack_weights": (_i, [_p, _i, ctypes.c_longlong, _p]),

@@ -754,6 +754,99 @@ def avg_pool3_same(x, scale=1.0):
     return _AvgPool3Same.apply(x, scale)
 
 
+# ------------------------------------------------------------------------------- the elementwise tail of a NASNet cell
+class _CellTail(torch.autograd.Function):
+    """relu(concat_s(sum_k scale * [avgpool3same](in))) in one launch; n_alias aliases of the result, one per consumer,
+    so that the backward sees the consumers' gradients SEPARATELY and sums, masks, un-pools and splits them in one
+    launch of its own (csrc/xpt_celltail.hip).  spec = tuple over slices of tuples of (input index, pooled, scale)."""
+
+    @staticmethod
+    def forward(ctx, spec, n_alias, *inputs):
+        import ctypes
+        lib = _lib.load()
+        first = inputs[0]
+        B, F, H, W = first.shape
+        dtype = first.dtype
+        if any(t.shape != first.shape for t in inputs):
+            raise _lib.XptHipError("cell_tail: the inputs must share one shape")
+        prepared = [_rows_with_pitch(_nhwc_any(t if t.dtype == dtype else t.to(dtype))) for t in inputs]
+        ns = len(spec)
+        out = torch.empty((B, ns * F, H, W), dtype=dtype, device=first.device, memory_format=torch.channels_last)
+        nterms = (ctypes.c_int * ns)(*[len(s) for s in spec])
+        src = (ctypes.c_void_p * (2 * ns))()
+        pitch = (ctypes.c_longlong * (2 * ns))()
+        pooled = (ctypes.c_int * (2 * ns))()
+        scale = (ctypes.c_float * (2 * ns))()
+        for s, terms in enumerate(spec):
+            for k, (i, pl, sc) in enumerate(terms):
+                t, p = prepared[i]
+                src[2 * s + k], pitch[2 * s + k], pooled[2 * s + k], scale[2 * s + k] = t.data_ptr(), p, int(pl), float(sc)
+        dt = 0 if dtype == torch.float32 else 1
+        _lib.check(lib.xpt_cell_tail_fwd(ns, nterms, src, pitch, pooled, scale, out.data_ptr(), ns * F, B, H, W, F, dt,
+                                         _stream()), "xpt_cell_tail_fwd")
+        ctx.save_for_backward(out)
+        ctx.cfg = (spec, len(inputs), F, dt)
+        ctx.set_materialize_grads(False)
+        return (out,) + tuple(out.view_as(out) for _ in range(n_alias - 1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        lib = _lib.load()
+        out, = ctx.saved_tensors
+        spec, n_in, F, dt = ctx.cfg
+        live = [g for g in grads if g is not None]
+        if not live:
+            return (None, None) + (None,) * n_in
+        while len(live) > 4:                                   # more consumers than the kernel sums: fold the rest first
+            live = live[:3] + [sum_rows(live[3:])]
+        B, C, H, W = out.shape
+        ns = len(spec)
+        prepared = [_rows_with_pitch(g if g.dtype == out.dtype else g.to(out.dtype)) for g in live]
+        gm = torch.empty((B, C, H, W), dtype=out.dtype, device=out.device, memory_format=torch.channels_last)
+        # terms per input; an input with one un-pooled, unscaled term takes its gradient as a channel slice of gm
+        uses = [[] for _ in range(n_in)]
+        for s, terms in enumerate(spec):
+            for i, pl, sc in terms:
+                uses[i].append((s, int(pl), float(sc)))
+        need = ctx.needs_input_grad[2:]
+        dense = [i for i in range(n_in) if need[i] and uses[i] and not (len(uses[i]) == 1 and not uses[i][0][1]
+                                                                         and uses[i][0][2] == 1.0)]
+        if len(dense) > 4 or any(len(uses[i]) > 3 for i in dense):
+            raise _lib.XptHipError("cell_tail: at most 4 dense input gradients of at most 3 terms each")
+        nd = len(dense)
+        douts = [torch.empty((B, F, H, W), dtype=out.dtype, device=out.device, memory_format=torch.channels_last)
+                 for _ in dense]
+        n3 = max(3 * nd, 1)
+        bterms = (ctypes.c_int * max(nd, 1))(*[len(uses[i]) for i in dense])
+        slice_ = (ctypes.c_int * n3)()
+        pooled = (ctypes.c_int * n3)()
+        scale = (ctypes.c_float * n3)()
+        for j, i in enumerate(dense):
+            for k, (s, pl, sc) in enumerate(uses[i]):
+                slice_[3 * j + k], pooled[3 * j + k], scale[3 * j + k] = s, pl, sc
+        P = ctypes.c_void_p
+        _lib.check(lib.xpt_cell_tail_bwd(len(prepared), (P * len(prepared))(*[t.data_ptr() for t, _ in prepared]),
+                                         (ctypes.c_longlong * len(prepared))(*[p for _, p in prepared]), out.data_ptr(),
+                                         C, gm.data_ptr(), ns, nd, (P * max(nd, 1))(*[d.data_ptr() for d in douts]),
+                                         bterms, slice_, pooled, scale, B, H, W, F, dt, _stream()), "xpt_cell_tail_bwd")
+        result = [None] * n_in
+        for j, i in enumerate(dense):
+            result[i] = douts[j]
+        for i in range(n_in):
+            if need[i] and result[i] is None and uses[i]:
+                s = uses[i][0][0]
+                result[i] = gm[:, s * F:(s + 1) * F]
+        return (None, None, *result)
+
+
+def cell_tail(spec, inputs, n_alias=3):
+    """-> list of n_alias aliases of relu(concat(slices)), marked as already rectified (pretrained_nets.shared_relu hands
+    them to the consumers one by one)."""
+    outs = _CellTail.apply(tuple(tuple(t) for t in spec), n_alias, *inputs)
+    return list(outs)
+
+
 # ------------------------------------------------------------------------------- gradient fan-in
 def sum_rows(tensors):
     """Sum of 2..8 NCHW-indexed tensors of one shape / dtype in ONE launch (dense channels_last result); operands may

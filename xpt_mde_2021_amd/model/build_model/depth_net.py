@@ -26,6 +26,11 @@ class UpconvWithSkip(nn.Module):
         else:
             up = self.conv1(F.interpolate(bef_layer, scale_factor=2, mode="bilinear", align_corners=False))
         parts = [up] + [s.to(up.dtype) for s in skips]
+        if up.is_cuda:
+            # a one-channel map is "contiguous" in both layouts; give it channels_last strides explicitly, or torch.cat
+            # sees mixed layouts, answers in NCHW and the convolution below pays a full re-layout copy of the concatenation
+            parts = [p.as_strided(p.shape, (p.shape[2] * p.shape[3], 1, p.shape[3], 1))
+                     if p.shape[1] == 1 and p.is_contiguous() else p for p in parts]
         total = sum(p.shape[1] for p in parts)
         if up.is_cuda and up.dtype == torch.bfloat16 and total % 8:
             # the matrix-core convolution reads 8-channel groups: the concatenation is built with its zero pad channels

@@ -53,6 +53,9 @@ class FrozenBatchNorm(nn.Module):
 def shared_relu(x):
     """relu(x), computed once per tensor: a cell output is the `ip` of the next cell and the `p` of the one after,
     and both start with Activation('relu') on it."""
+    pool = getattr(x, "_xpt_relu_aliases", None)
+    if pool is not None:               # a cell output produced already rectified (cell_tail): one alias per consumer
+        return pool.pop() if len(pool) > 1 else pool[0]
     cached = getattr(x, "_xpt_relu", None)
     if cached is None:
         cached = F.relu(x)
@@ -301,6 +304,17 @@ def multi_conv1x1_bn(xs, weights, bns, residuals=None):
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
 _WIDE_CELL = __import__("os").environ.get("XPT_DEBUG_NARROW_CELL", "0") != "1"          # A/B: per-branch depthwise launches
+_CELL_TAIL = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CELL_TAIL", "0") != "1"     # A/B: pools / add / concat / relu as separate launches
+
+
+def _rectified_concat(spec, inputs):
+    """relu(concat(...)) of a cell in one launch (csrc/xpt_celltail.hip).  Every consumer of a cell output starts with
+    Activation('relu') (shared_relu), so the cell hands out the rectified tensor; its aliases carry one gradient edge per
+    consumer (next cell's squeeze convolution, the adjust block after it, a decoder tap)."""
+    outs = _ops.cell_tail(spec, inputs, 3)
+    head = outs[0]
+    head._xpt_relu_aliases = outs
+    return head
 _PWCONV_MAX_CIN = 320
 _LIBRARY_PWCONV = __import__("os").environ.get("XPT_DEBUG_LIBRARY_PWCONV", "0") == "1"    # A/B: rocBLAS GEMM + epilogue launch
 
@@ -465,8 +479,9 @@ class NormalCell(nn.Module):
             # The five separable-conv branches are mutually independent and of one shape: their depthwise halves run as
             # ONE launch per stage (and one backward launch each, which also sums the gradients of h and p over the
             # branches); the pointwise + BatchNorm halves follow per branch, the branch adds in their epilogues.
+            fused_tail = _CELL_TAIL and h.dtype == p.dtype and h.shape == p.shape
             hs = _ops.fan_out(h, 3)
-            ps = _ops.fan_out(p, 4)
+            ps = _ops.fan_out(p, 2 if fused_tail else 4)
             y1 = _ops.multi_depthwise([hs[0], hs[0], ps[0], ps[0], ps[0]], [b.conv1.depthwise.weight for b in blocks])
             z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
             y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
@@ -477,6 +492,11 @@ class NormalCell(nn.Module):
                                           [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight,
                                            self.left5.conv2.pointwise.weight],
                                           [self.left1.bn2, self.left2.bn2, self.left5.bn2], [r1, r2, hs[2]])
+            if fused_tail:
+                # concat([p, x1, x2, avg(h) + p, avg(p) + avg(p), x5]) and the consumers' relu: inputs (p, x1, x2, h, x5)
+                spec = (((0, 0, 1.0),), ((1, 0, 1.0),), ((2, 0, 1.0),), ((3, 1, 1.0), (0, 0, 1.0)), ((0, 1, 2.0),),
+                        ((4, 0, 1.0),))
+                return _rectified_concat(spec, [ps[1], x1, x2, hs[1], x5]), ip
             x3 = avg_pool_same(hs[1]) + ps[1]
             x4 = avg_pool_same(ps[2], 2.0)                   # add([avg(p), avg(p)]): x + x == 2 x exactly
             return torch.cat([ps[3], x1, x2, x3, x4, x5], dim=1), ip
@@ -547,6 +567,11 @@ class ReductionCell(nn.Module):
             x3 = outs[2] if wide3 else self.right3(p, taps, residual=ap)
             x1 = conv1x1_bn(y2[0], self.left1.conv2.pointwise.weight, self.left1.bn2, residual=r1)
             x1a, x1b = _ops.fan_out(x1, 2)
+            if _CELL_TAIL and x1.dtype == x2.dtype == x3.dtype:
+                # concat([x2, x3, x2 + avg(x1), x5]) and the consumers' relu: inputs (x2, x3, x1, x5)
+                x5 = self.left4(x1b, taps, residual=mp2)
+                spec = (((0, 0, 1.0),), ((1, 0, 1.0),), ((0, 0, 1.0), (2, 1, 1.0)), ((3, 0, 1.0),))
+                return _rectified_concat(spec, [x2, x3, x1a, x5]), ip
             x2a, x2b = _ops.fan_out(x2, 2)
             x4 = x2a + avg_pool_same(x1a)
             x5 = self.left4(x1b, taps, residual=mp2)
@@ -647,7 +672,7 @@ class NASNetMobileEncoder(nn.Module):
         p = None
         for cell in self.cells:
             x, p = cell(x, x if p is None else p, taps)
-        x = F.relu(x)
+        x = shared_relu(x)
         taps.offer(self.final_act_id, x)
         return [taps.found[k] for k in self.TAP_ACTIVATIONS]
 
