@@ -341,6 +341,22 @@ int xpt_cell_tail_bwd(int ngrads, const void* const* grads, const long long* gpi
                       void* gm, int nslices, int ndense, void* const* dense_out, const int* bterms, const int* slice,
                       const int* pooled, const float* scale, int B, int H, int W, int F, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ a2: "spatial" adjust block and reduction-cell pools
+ * keras nasnet._adjust_block when p has twice the cell's resolution: p1 = AveragePooling2D((1,1), strides 2)(p) = p[2i,2j],
+ * p2 = the same after ZeroPadding2D(((0,1),(0,1))) + Cropping2D(((1,0),(1,0))) = p[2i+1,2j+1] (0 outside).  One gather
+ * builds out [B, ceil(H/2), ceil(W/2), 2C] = [p1 | p2]; one scatter is its backward (d1 / d2 may be NULL). */
+int xpt_adjust_gather(const void* in, long long in_pitch, void* out, int B, int H, int W, int C, int dtype, void* stream);
+int xpt_adjust_scatter(const void* d1, long long pitch1, const void* d2, long long pitch2, void* out, int B, int H, int W,
+                       int C, int dtype, void* stream);
+
+/* keras nasnet._reduction_a_cell: ZeroPadding2D(correct_pad(h, 3)) -> MaxPooling2D(3, strides 2, 'valid') and
+ * AveragePooling2D(3, strides 2, 'valid') of the same h, in one launch (arg: uint8 arg-max tap per output element) and
+ * one backward launch (gmp / gap may be NULL).  pad_t / pad_l: the leading zero padding (0 or 1). */
+int xpt_pool_pair_fwd(const void* in, long long in_pitch, void* mp, void* ap, void* arg, int B, int H, int W, int C, int OH,
+                      int OW, int pad_t, int pad_l, int dtype, void* stream);
+int xpt_pool_pair_bwd(const void* gmp, long long pitch_m, const void* gap, long long pitch_a, const void* arg, void* dh, int B,
+                      int H, int W, int C, int OH, int OW, int pad_t, int pad_l, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ deferred parameter gradients (one finishing launch per step)
  * The *_partials entry points compute the same parameter gradients as xpt_affine_act_bwd / xpt_dwconv_bwd_weight /
  * xpt_conv1x1_bwd_weight (tape.gradient of the layer variables, model/train_val.py:85-86) but stop at the

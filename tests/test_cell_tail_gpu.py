@@ -79,3 +79,55 @@ def test_cell_tail_without_grad_and_single_alias(gpu_device):
         out, = ops.cell_tail(REDUCTION, x, 1)
     assert torch.allclose(out, reference(REDUCTION, x), atol=1e-6)
     assert out.is_contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("dtype,C,H,W", [(torch.float32, 6, 6, 10), (torch.float32, 5, 7, 9), (torch.bfloat16, 32, 16, 52),
+                                         (torch.bfloat16, 44, 9, 14), (torch.bfloat16, 11, 4, 6)])
+def test_adjust_gather_matches_pad_crop_stride(gpu_device, dtype, C, H, W):
+    """keras _adjust_block, spatial mode: p[::2, ::2] and ZeroPadding2D(((0,1),(0,1))) -> Cropping2D(((1,0),(1,0))) -> [::2, ::2]."""
+    from xpt_mde_2021_amd.hip import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(2, C, H, W, generator=g).to(dtype)
+    xr = x.float().requires_grad_(True)
+    r1 = xr[:, :, ::2, ::2]
+    r2 = F.pad(xr, (0, 1, 0, 1))[:, :, 1:, 1:][:, :, ::2, ::2]
+    w1, w2 = torch.randn(r1.shape, generator=g).to(dtype), torch.randn(r2.shape, generator=g).to(dtype)
+    ((r1 * w1.float()).sum() + (r2 * w2.float()).sum()).backward()
+    xd = x.to(gpu_device).contiguous(memory_format=torch.channels_last).detach().requires_grad_(True)
+    d1, d2 = ops.adjust_gather(xd)
+    assert d1.shape == r1.shape and d2.shape == r2.shape
+    assert torch.equal(d1.float().cpu(), r1.detach()) and torch.equal(d2.float().cpu(), r2.detach())
+    ((d1.float() * w1.to(gpu_device).float()).sum() + (d2.float() * w2.to(gpu_device).float()).sum()).backward()
+    assert torch.equal(xd.grad.float().cpu(), xr.grad.to(dtype).float())
+    # one half unused: its gradient is None
+    xd2 = x.to(gpu_device).contiguous(memory_format=torch.channels_last).detach().requires_grad_(True)
+    e1, _ = ops.adjust_gather(xd2)
+    (e1.float() * w1.to(gpu_device).float()).sum().backward()
+    only1 = torch.zeros_like(xr.grad)
+    only1[:, :, ::2, ::2] = w1.float()
+    assert torch.equal(xd2.grad.float().cpu(), only1)
+
+
+@pytest.mark.parametrize("dtype,C,H,W", [(torch.float32, 6, 8, 12), (torch.float32, 5, 7, 9), (torch.bfloat16, 32, 16, 52),
+                                         (torch.bfloat16, 22, 9, 13), (torch.bfloat16, 88, 8, 26)])
+def test_pool_pair_matches_padded_library_pools(gpu_device, dtype, C, H, W):
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model.pretrained_nets import correct_pad
+    g = torch.Generator().manual_seed(C * 3 + W)
+    x = torch.randn(2, C, H, W, generator=g).to(dtype)
+    pads = correct_pad(H, W, 3)
+    (pt, pb), (pl, pr) = pads
+    xr = x.float().requires_grad_(True)
+    xp = F.pad(xr, (pl, pr, pt, pb))
+    mr, ar = F.max_pool2d(xp, 3, 2), F.avg_pool2d(xp, 3, 2)
+    wm, wa = torch.randn(mr.shape, generator=g).to(dtype), torch.randn(ar.shape, generator=g).to(dtype)
+    ((mr * wm.float()).sum() + (ar * wa.float()).sum()).backward()
+    xd = x.to(gpu_device).contiguous(memory_format=torch.channels_last).detach().requires_grad_(True)
+    md, ad = ops.pool_pair(xd, pads)
+    assert md.shape == mr.shape and ad.shape == ar.shape
+    assert torch.equal(md.float().cpu(), mr.detach())                          # a maximum is one of the inputs: exact
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert (ad.float().cpu() - ar.detach()).abs().max().item() <= tol * (ar.abs().max().item() + 1e-12)
+    ((md.float() * wm.to(gpu_device).float()).sum() + (ad.float() * wa.to(gpu_device).float()).sum()).backward()
+    scale = xr.grad.abs().max().item()
+    assert (xd.grad.float().cpu() - xr.grad).abs().max().item() <= (1e-5 if dtype == torch.float32 else 1e-2) * scale

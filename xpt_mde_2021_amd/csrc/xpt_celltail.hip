@@ -225,6 +225,156 @@ __global__ __launch_bounds__(256) void cell_tail_bwd_kernel(TailBwd a, int B, in
   }
 }
 
+// ------------------------------------------------------------------------------------------------ adjust block gather
+// _adjust_block of keras NASNet when p has twice the resolution of the cell ("spatial" mode):
+//   p1 = AveragePooling2D((1,1), strides 2)(relu p)            = p[2i, 2j]
+//   p2 = the same of Cropping2D(((1,0),(1,0)))(ZeroPadding2D(((0,1),(0,1)))(relu p))     = p[2i+1, 2j+1] (0 outside)
+// followed by one 1x1 convolution each.  Forward: ONE gather into out [M/4][2C] (the two halves feed the two GEMMs as
+// channel slices); backward: ONE scatter of the two data gradients into a dense d_p (the other positions are zero).
+// PyTorch's formulation costs pad (2 launches) + two strided copies forward and four slice_backward (zeros + copy) pairs,
+// a pad backward and an accumulation in the backward.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void adjust_gather_kernel(const T* __restrict__ in, long long in_pitch, T* __restrict__ out,
+                                                            int B, int H, int W, int C, int H2, int W2) {
+  const int groups = C / V;
+  const long long total = (long long)B * H2 * W2 * 2 * groups;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % groups) * V;
+    long long p = idx / groups;
+    const int half = (int)(p & 1); p >>= 1;
+    const long long opix = p;
+    const int j = (int)(p % W2); p /= W2;
+    const int i = (int)(p % H2);
+    const int b = (int)(p / H2);
+    const int y = 2 * i + half, x = 2 * j + half;
+    float v[V];
+    const bool ok = y < H && x < W;
+    load_row<T, V>(in + (((long long)b * H + (ok ? y : 0)) * W + (ok ? x : 0)) * in_pitch + c0, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = ok ? v[e] : 0.f;
+    store_row<T, V>(out + opix * (2LL * C) + (long long)half * C + c0, v);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void adjust_scatter_kernel(const T* __restrict__ d1, long long pitch1,
+                                                             const T* __restrict__ d2, long long pitch2, T* __restrict__ out,
+                                                             int B, int H, int W, int C, int H2, int W2) {
+  const int groups = C / V;
+  const long long total = (long long)B * H * W * groups;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % groups) * V;
+    long long p = idx / groups;
+    const long long pix = p;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    float v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = 0.f;
+    const long long src = ((long long)b * H2 + (y >> 1)) * W2 + (x >> 1);
+    if (((y | x) & 1) == 0) {
+      if (d1 != nullptr) load_row<T, V>(d1 + src * pitch1 + c0, v);
+    } else if ((y & x & 1) == 1) {
+      if (d2 != nullptr) load_row<T, V>(d2 + src * pitch2 + c0, v);
+    }
+    store_row<T, V>(out + pix * C + c0, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ reduction-cell pools
+// _reduction_a_cell pools h twice with one geometry: ZeroPadding2D(correct_pad(h, 3)) -> MaxPooling2D(3, strides 2,
+// 'valid') and -> AveragePooling2D(3, strides 2, 'valid') (padding zeros take part in the max and in the divisor 9).
+// Forward: one launch for both (+ the arg-max tap for the backward); backward: one gather per input pixel over the <= 4
+// windows that contain it (deterministic, no atomics).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool_pair_fwd_kernel(const T* __restrict__ in, long long in_pitch, T* __restrict__ mp,
+                                                            T* __restrict__ ap, unsigned char* __restrict__ arg, int B, int H,
+                                                            int W, int C, int OH, int OW, int pad_t, int pad_l) {
+  const int groups = C / V;
+  const long long total = (long long)B * OH * OW * groups;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % groups) * V;
+    long long p = idx / groups;
+    const long long opix = p;
+    const int j = (int)(p % OW); p /= OW;
+    const int i = (int)(p % OH);
+    const int b = (int)(p / OH);
+    float best[V], sum[V];
+    int at[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { best[e] = -INFINITY; sum[e] = 0.f; at[e] = 0; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int y = 2 * i - pad_t + t / 3, x = 2 * j - pad_l + t % 3;
+      const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+      float v[V];
+      load_row<T, V>(in + (((long long)b * H + (ok ? y : 0)) * W + (ok ? x : 0)) * in_pitch + c0, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float u = ok ? v[e] : 0.f;
+        sum[e] += u;
+        if (u > best[e]) { best[e] = u; at[e] = t; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) sum[e] *= (1.f / 9.f);
+    store_row<T, V>(mp + opix * C + c0, best);
+    store_row<T, V>(ap + opix * C + c0, sum);
+#pragma unroll
+    for (int e = 0; e < V; ++e) arg[opix * C + c0 + e] = (unsigned char)at[e];
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void pool_pair_bwd_kernel(const T* __restrict__ gmp, long long pitch_m,
+                                                            const T* __restrict__ gap, long long pitch_a,
+                                                            const unsigned char* __restrict__ arg, T* __restrict__ dh, int B,
+                                                            int H, int W, int C, int OH, int OW, int pad_t, int pad_l) {
+  const int groups = C / V;
+  const long long total = (long long)B * H * W * groups;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)(idx % groups) * V;
+    long long p = idx / groups;
+    const long long pix = p;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    // windows (i, j) with 2 i - pad_t <= y <= 2 i - pad_t + 2
+    const int yy = y + pad_t, xx = x + pad_l;
+#pragma unroll
+    for (int di = 0; di < 2; ++di) {
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const int i = (yy >> 1) - di, j = (xx >> 1) - dj;
+        const int ty = yy - 2 * i, tx = xx - 2 * j;                   // tap of this pixel inside window (i, j)
+        const bool ok = i >= 0 && i < OH && j >= 0 && j < OW && ty <= 2 && tx <= 2;
+        const long long o = ((long long)b * OH + (ok ? i : 0)) * OW + (ok ? j : 0);
+        float gm[V], ga[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { gm[e] = 0.f; ga[e] = 0.f; }
+        if (gmp != nullptr) load_row<T, V>(gmp + o * pitch_m + c0, gm);
+        if (gap != nullptr) load_row<T, V>(gap + o * pitch_a + c0, ga);
+        const int tap = ty * 3 + tx;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const bool mine = arg[o * C + c0 + e] == (unsigned char)tap;
+          const float g = (mine ? gm[e] : 0.f) + ga[e] * (1.f / 9.f);
+          acc[e] += ok ? g : 0.f;
+        }
+      }
+    }
+    store_row<T, V>(dh + pix * C + c0, acc);
+  }
+}
+
 inline bool aligned_for(const void* p, long long pitch, int v, int esz) {
   return ((uintptr_t)p) % (size_t)(v * esz) == 0 && pitch % v == 0;
 }
@@ -341,6 +491,106 @@ int xpt_cell_tail_bwd(int ngrads, const void* const* grads, const long long* gpi
     else XPT_TAIL(__hip_bfloat16, 1);
   }
 #undef XPT_TAIL
+  return xpt_launch_status();
+}
+
+/* "spatial" adjust block: out [B, H2, W2, 2C] (dense) = [p[2i, 2j] | p[2i+1, 2j+1] or 0], H2 = ceil(H/2), W2 = ceil(W/2) */
+int xpt_adjust_gather(const void* in, long long in_pitch, void* out, int B, int H, int W, int C, int dtype, void* stream) {
+  XPT_CHECK_PTR(in); XPT_CHECK_PTR(out);
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || in_pitch < C) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, esz = dtype == 0 ? 4 : 2;
+  int v = dtype == 0 ? 4 : 8;
+  while (v > 1 && !(C % v == 0 && aligned_for(in, in_pitch, v, esz) && aligned_for(out, C, v, esz))) v >>= 1;
+  const long long total = (long long)B * H2 * W2 * 2 * (C / v);
+  long long gx = (total + 255) / 256;
+  if (gx > 8192) gx = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+#define XPT_K(T, V) \
+  hipLaunchKernelGGL((adjust_gather_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)in, in_pitch, (T*)out, B, H, W, C, H2, W2)
+  if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
+  else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
+#undef XPT_K
+  return xpt_launch_status();
+}
+
+/* its backward: dp [B, H, W, C] (dense) <- d1 [B, H2, W2, C] at the (even, even) pixels, d2 at the (odd, odd) ones, 0
+ * elsewhere; d1 / d2 may be NULL (no gradient through that half) and may have a row pitch */
+int xpt_adjust_scatter(const void* d1, long long pitch1, const void* d2, long long pitch2, void* out, int B, int H, int W,
+                       int C, int dtype, void* stream) {
+  XPT_CHECK_PTR(out);
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (d1 && pitch1 < C) || (d2 && pitch2 < C)) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, esz = dtype == 0 ? 4 : 2;
+  int v = dtype == 0 ? 4 : 8;
+  while (v > 1 && !(C % v == 0 && aligned_for(out, C, v, esz) && (!d1 || aligned_for(d1, pitch1, v, esz)) &&
+                    (!d2 || aligned_for(d2, pitch2, v, esz))))
+    v >>= 1;
+  const long long total = (long long)B * H * W * (C / v);
+  long long gx = (total + 255) / 256;
+  if (gx > 8192) gx = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+#define XPT_K(T, V)                                                                                                  \
+  hipLaunchKernelGGL((adjust_scatter_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)d1, pitch1, (const T*)d2, \
+                     pitch2, (T*)out, B, H, W, C, H2, W2)
+  if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
+  else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
+#undef XPT_K
+  return xpt_launch_status();
+}
+
+/* max and average 3x3 / stride-2 pooling of the zero-padded h in one launch: mp, ap [B, OH, OW, C] dense, arg (uint8,
+ * same shape) = the tap (0..8, row-major) holding the maximum (first one on ties, zero padding included) */
+int xpt_pool_pair_fwd(const void* in, long long in_pitch, void* mp, void* ap, void* arg, int B, int H, int W, int C, int OH,
+                      int OW, int pad_t, int pad_l, int dtype, void* stream) {
+  XPT_CHECK_PTR(in); XPT_CHECK_PTR(mp); XPT_CHECK_PTR(ap); XPT_CHECK_PTR(arg);
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || in_pitch < C) return XPT_ERR_SHAPE;
+  if ((dtype != 0 && dtype != 1) || pad_t < 0 || pad_l < 0 || pad_t > 2 || pad_l > 2) return XPT_ERR_ARG;
+  if (2 * (OH - 1) - pad_t >= H || 2 * (OW - 1) - pad_l >= W) return XPT_ERR_SHAPE;      // last window starts inside
+  const int esz = dtype == 0 ? 4 : 2;
+  int v = dtype == 0 ? 4 : 8;
+  while (v > 1 && !(C % v == 0 && aligned_for(in, in_pitch, v, esz) && aligned_for(mp, C, v, esz) && aligned_for(ap, C, v, esz)))
+    v >>= 1;
+  const long long total = (long long)B * OH * OW * (C / v);
+  long long gx = (total + 255) / 256;
+  if (gx > 8192) gx = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+#define XPT_K(T, V)                                                                                                 \
+  hipLaunchKernelGGL((pool_pair_fwd_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)in, in_pitch, (T*)mp, \
+                     (T*)ap, (unsigned char*)arg, B, H, W, C, OH, OW, pad_t, pad_l)
+  if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
+  else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
+#undef XPT_K
+  return xpt_launch_status();
+}
+
+/* backward: dh [B, H, W, C] dense = max-pool gradient routed to the arg-max taps + average-pool gradient / 9; gmp / gap may
+ * be NULL and may have a row pitch */
+int xpt_pool_pair_bwd(const void* gmp, long long pitch_m, const void* gap, long long pitch_a, const void* arg, void* dh, int B,
+                      int H, int W, int C, int OH, int OW, int pad_t, int pad_l, int dtype, void* stream) {
+  XPT_CHECK_PTR(arg); XPT_CHECK_PTR(dh);
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || (gmp && pitch_m < C) || (gap && pitch_a < C))
+    return XPT_ERR_SHAPE;
+  if ((dtype != 0 && dtype != 1) || pad_t < 0 || pad_l < 0 || pad_t > 2 || pad_l > 2) return XPT_ERR_ARG;
+  const int esz = dtype == 0 ? 4 : 2;
+  int v = dtype == 0 ? 4 : 8;
+  while (v > 1 && !(C % v == 0 && aligned_for(dh, C, v, esz) && (!gmp || aligned_for(gmp, pitch_m, v, esz)) &&
+                    (!gap || aligned_for(gap, pitch_a, v, esz))))
+    v >>= 1;
+  const long long total = (long long)B * H * W * (C / v);
+  long long gx = (total + 255) / 256;
+  if (gx > 8192) gx = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+#define XPT_K(T, V)                                                                                                    \
+  hipLaunchKernelGGL((pool_pair_bwd_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)gmp, pitch_m, (const T*)gap, \
+                     pitch_a, (const unsigned char*)arg, (T*)dh, B, H, W, C, OH, OW, pad_t, pad_l)
+  if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
+  else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
+#undef XPT_K
   return xpt_launch_status();
 }
 

@@ -847,6 +847,83 @@ def cell_tail(spec, inputs, n_alias=3):
     return list(outs)
 
 
+class _AdjustGather(torch.autograd.Function):
+    """p [B,C,H,W] -> (p[:, :, ::2, ::2], p shifted by (1, 1) then [::2, ::2] with zeros past the border) as the two channel
+    halves of ONE [B, 2C, H/2, W/2] buffer: one gather launch, and one scatter launch for the gradient of p."""
+
+    @staticmethod
+    def forward(ctx, p):
+        lib = _lib.load()
+        pr, pitch = _rows_with_pitch(_nhwc_any(p))
+        B, C, H, W = p.shape
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        out = torch.empty((B, 2 * C, H2, W2), dtype=p.dtype, device=p.device, memory_format=torch.channels_last)
+        dt = 0 if p.dtype == torch.float32 else 1
+        _lib.check(lib.xpt_adjust_gather(_ptr(pr), pitch, _ptr(out), B, H, W, C, dt, _stream()), "xpt_adjust_gather")
+        ctx.cfg = (B, C, H, W, dt, p.dtype)
+        ctx.set_materialize_grads(False)
+        return out[:, :C], out[:, C:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None and g2 is None:
+            return None
+        lib = _lib.load()
+        B, C, H, W, dt, dtype = ctx.cfg
+        (r1, p1) = _rows_with_pitch(g1.to(dtype)) if g1 is not None else (None, 0)
+        (r2, p2) = _rows_with_pitch(g2.to(dtype)) if g2 is not None else (None, 0)
+        like = g1 if g1 is not None else g2
+        dp = torch.empty((B, C, H, W), dtype=dtype, device=like.device, memory_format=torch.channels_last)
+        _lib.check(lib.xpt_adjust_scatter(_ptr(r1), p1, _ptr(r2), p2, _ptr(dp), B, H, W, C, dt, _stream()),
+                   "xpt_adjust_scatter")
+        return dp
+
+
+def adjust_gather(p):
+    return _AdjustGather.apply(p)
+
+
+class _PoolPair(torch.autograd.Function):
+    """(max_pool2d, avg_pool2d)(zero_pad(h), 3, stride 2) in one launch; the backward routes both gradients in one."""
+
+    @staticmethod
+    def forward(ctx, h, pad_t, pad_b, pad_l, pad_r):
+        lib = _lib.load()
+        hr, pitch = _rows_with_pitch(_nhwc_any(h))
+        B, C, H, W = h.shape
+        OH, OW = (H + pad_t + pad_b - 3) // 2 + 1, (W + pad_l + pad_r - 3) // 2 + 1
+        mp = torch.empty((B, C, OH, OW), dtype=h.dtype, device=h.device, memory_format=torch.channels_last)
+        ap = torch.empty_like(mp)
+        arg = torch.empty((B, OH, OW, C), dtype=torch.uint8, device=h.device)
+        dt = 0 if h.dtype == torch.float32 else 1
+        _lib.check(lib.xpt_pool_pair_fwd(_ptr(hr), pitch, _ptr(mp), _ptr(ap), _ptr(arg), B, H, W, C, OH, OW, pad_t, pad_l, dt,
+                                         _stream()), "xpt_pool_pair_fwd")
+        ctx.save_for_backward(arg)
+        ctx.cfg = (B, C, H, W, OH, OW, pad_t, pad_l, dt, h.dtype)
+        ctx.set_materialize_grads(False)
+        return mp, ap
+
+    @staticmethod
+    def backward(ctx, gm, ga):
+        if gm is None and ga is None:
+            return None, None, None, None, None
+        lib = _lib.load()
+        arg, = ctx.saved_tensors
+        B, C, H, W, OH, OW, pad_t, pad_l, dt, dtype = ctx.cfg
+        (rm, pm) = _rows_with_pitch(gm.to(dtype)) if gm is not None else (None, 0)
+        (ra, pa) = _rows_with_pitch(ga.to(dtype)) if ga is not None else (None, 0)
+        dh = torch.empty((B, C, H, W), dtype=dtype, device=arg.device, memory_format=torch.channels_last)
+        _lib.check(lib.xpt_pool_pair_bwd(_ptr(rm), pm, _ptr(ra), pa, _ptr(arg), _ptr(dh), B, H, W, C, OH, OW, pad_t, pad_l, dt,
+                                         _stream()), "xpt_pool_pair_bwd")
+        return dh, None, None, None, None
+
+
+def pool_pair(h, pads):
+    """pads = ((top, bottom), (left, right)) of the zero padding -> (max pooled, average pooled), 3x3 windows, stride 2."""
+    (pt, pb), (pl, pr) = pads
+    return _PoolPair.apply(h, pt, pb, pl, pr)
+
+
 # ------------------------------------------------------------------------------- gradient fan-in
 def sum_rows(tensors):
     """Sum of 2..8 NCHW-indexed tensors of one shape / dtype in ONE launch (dense channels_last result); operands may

@@ -10,6 +10,19 @@ from ..model_util import layer_ops as lo
 from .pretrained_nets import PretrainedModel
 
 
+class _ChannelsLastOne(torch.autograd.Function):
+    """[B,1,H,W] contiguous -> the same memory with channels_last strides (a view); the gradient passes through as it
+    comes (as_strided's own backward would materialise it with a zero fill and a copy)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.as_strided(x.shape, (x.shape[2] * x.shape[3], 1, x.shape[3], 1))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class UpconvWithSkip(nn.Module):
     """upconv_with_skip_connection of DepthNetNoResize (depth_net.py:101-109):
     nearest 2x -> conv3x3 -> concat([., skip][, up-sampled previous prediction]) -> conv3x3."""
@@ -29,8 +42,7 @@ class UpconvWithSkip(nn.Module):
         if up.is_cuda:
             # a one-channel map is "contiguous" in both layouts; give it channels_last strides explicitly, or torch.cat
             # sees mixed layouts, answers in NCHW and the convolution below pays a full re-layout copy of the concatenation
-            parts = [p.as_strided(p.shape, (p.shape[2] * p.shape[3], 1, p.shape[3], 1))
-                     if p.shape[1] == 1 and p.is_contiguous() else p for p in parts]
+            parts = [_ChannelsLastOne.apply(p) if p.shape[1] == 1 and p.is_contiguous() else p for p in parts]
         total = sum(p.shape[1] for p in parts)
         if up.is_cuda and up.dtype == torch.bfloat16 and total % 8:
             # the matrix-core convolution reads 8-channel groups: the concatenation is built with its zero pad channels

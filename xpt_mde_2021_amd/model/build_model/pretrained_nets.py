@@ -425,6 +425,9 @@ class AdjustBlock(nn.Module):
     def forward(self, p, taps):
         if self.mode == "spatial":
             p = shared_relu(p)
+            if p.is_cuda and _CELL_TAIL and p.dtype in (torch.float32, torch.bfloat16):
+                p1, p2 = _ops.adjust_gather(p)                  # both sub-sampled copies in one launch (one scatter backward)
+                return self.bn(torch.cat([conv1x1(p1, self.conv1.weight), conv1x1(p2, self.conv2.weight)], dim=1))
             p1 = conv1x1(p[:, :, ::2, ::2], self.conv1.weight)                       # AveragePooling2D((1,1), strides 2)
             p2 = F.pad(p, (0, 1, 0, 1))[:, :, 1:, 1:]                # ZeroPadding2D(((0,1),(0,1))) + Cropping2D(((1,0),(1,0)))
             p2 = conv1x1(p2[:, :, ::2, ::2], self.conv2.weight)
@@ -539,8 +542,13 @@ class ReductionCell(nn.Module):
         h = shared_relu(ip)
         taps.offer(self.act_id, h)
         h = conv1x1_bn(h, self.conv.weight, self.bn)
-        h3 = zero_pad(h, correct_pad(h.shape[2], h.shape[3], 3))
-        mp = F.max_pool2d(h3, 3, 2)                      # MaxPooling2D of h feeds x2 and x5: pooled once
+        if h.is_cuda and _CELL_TAIL and h.dtype in (torch.float32, torch.bfloat16):
+            # both poolings of the zero-padded h in one launch (and one backward launch)
+            mp, ap_h = _ops.pool_pair(h, correct_pad(h.shape[2], h.shape[3], 3))
+        else:
+            h3 = zero_pad(h, correct_pad(h.shape[2], h.shape[3], 3))
+            mp = F.max_pool2d(h3, 3, 2)                      # MaxPooling2D of h feeds x2 and x5: pooled once
+            ap_h = None
         mp1, mp2 = _ops.fan_out(mp, 2)
         def tapped(b):
             return taps.wants(b.act_id1) or taps.wants(b.act_id2)
@@ -560,7 +568,7 @@ class ReductionCell(nn.Module):
                                       stride=2, pads=pads)
             z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
             y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
-            ap = F.avg_pool2d(h3, 3, 2)
+            ap = ap_h if ap_h is not None else F.avg_pool2d(h3, 3, 2)
             outs = multi_conv1x1_bn(y2[1:], [b.conv2.pointwise.weight for b in blocks[1:]], [b.bn2 for b in blocks[1:]],
                                     [None, mp1] + ([ap] if wide3 else []))
             r1, x2 = outs[0], outs[1]
@@ -581,7 +589,7 @@ class ReductionCell(nn.Module):
         x1a, x1b = _ops.fan_out(x1, 2)
         x2 = self.right2(p2, taps, residual=mp1)
         x2a, x2b = _ops.fan_out(x2, 2)
-        x3 = self.right3(p3, taps, residual=F.avg_pool2d(h3, 3, 2))
+        x3 = self.right3(p3, taps, residual=ap_h if ap_h is not None else F.avg_pool2d(h3, 3, 2))
         x4 = x2a + avg_pool_same(x1a)
         x5 = self.left4(x1b, taps, residual=mp2)
         x2 = x2b
