@@ -127,6 +127,22 @@ int xpt_photo_fused_bwd(const float* src, const float* depth, const float* T, co
                         const float* g_l1, const float* g_ssim, float* ddepth, float* dT, float* workspace,
                         size_t workspace_floats, int B, int N, int h, int w, float scale, void* stream);
 
+/* All scales of the loss pyramid in ONE march launch (+ one finishing launch) -- SynthesizeMultiScale.__call__
+ * (model/synthesize/synthesize_base.py:13-20) followed by PhotometricLossMultiScale (model/loss_and_metric/losses.py:179-195)
+ * over every scale.  Arrays hold nscales <= 4 entries (scale 0 first): src[s] [B,N,h_s,w_s,3], depth[s] [B,h_s,w_s],
+ * target[s] [B,h_s,w_s,3], scale[s] = the divisor of the full-resolution intrinsic.  losses [2 nscales][B]: row s = the
+ * photometric L1 of scale s, row nscales + s = its SSIM loss.  workspace >= sum of the per-scale
+ * xpt_photo_fused_workspace_floats.  Per scale the arithmetic is that of xpt_photo_fused_fwd / _bwd. */
+int xpt_photo_fused_ms_fwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
+                           const float* const* target, float* losses, float* workspace, size_t workspace_floats,
+                           int B, int N, const int* h, const int* w, const float* scale, void* stream);
+
+/* g_l1[s] / g_ssim[s] [B] -> ddepth[s] [B,h_s,w_s]; dT [B,N,4,4] = the sum over the scales.  N must be 4 or 1. */
+int xpt_photo_fused_ms_bwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
+                           const float* const* target, const float* const* g_l1, const float* const* g_ssim,
+                           float* const* ddepth, float* dT, float* workspace, size_t workspace_floats, int B, int N,
+                           const int* h, const int* w, const float* scale, void* stream);
+
 /* ------------------------------------------------------------------ K6 (+a4): edge-aware smoothness
  * replaces SmoothenessLossMultiScale.smootheness_loss (losses.py:409-440) for one scale
  * (the caller divides by the scale, losses.py:401-402).

@@ -251,6 +251,46 @@ def test_fused_warp_l1_ssim_fwd_bwd(ops, gpu_device, B, N, h, w, scale):
     frac_close(T.grad, T2.grad, 1e-4 * ts, rtol=1e-3, what="fused vs unfused dT")
 
 
+@pytest.mark.parametrize("B,N,H,W,nscales", [(2, 4, 64, 208, 4), (3, 1, 32, 104, 3), (1, 4, 24, 70, 2)])
+def test_fused_multi_scale_launch_equals_per_scale_calls(ops, gpu_device, B, N, H, W, nscales):
+    """xpt_photo_fused_ms_{fwd,bwd}: every scale of the pyramid in one march launch runs the SAME device function per
+    scale as the per-scale entry points -> losses and depth gradients bit-identical, pose gradient = the sum of the
+    per-scale pose gradients (added in scale order by the finishing kernel: compared to rounding)."""
+    g = gen(77 + H)
+    srcs, depths, tgts, scales = [], [], [], []
+    pose = None
+    for k in range(nscales):
+        sc = 2 ** k
+        h, w = H // sc, W // sc
+        src, depth, K, p = warp_inputs(B, N, h, w, 900 + k, sc)
+        pose = p if pose is None else pose
+        srcs.append(src.to(gpu_device))
+        depths.append(depth.to(gpu_device))
+        tgts.append((src[:, 0] * 0.6 + 0.4 * sd.smooth_noise((B, h, w, 3), g)).clamp(-1, 1).contiguous().to(gpu_device))
+        scales.append(sc)
+    Kd = K.to(gpu_device)
+    weights = [(torch.rand(B, generator=g) + 0.5).to(gpu_device) for _ in range(2 * nscales)]
+
+    def run(multi):
+        ds = [d.clone().requires_grad_(True) for d in depths]
+        T = ref_pose.pose_rvec2matr_batch(pose).to(gpu_device).requires_grad_(True)
+        if multi:
+            pairs = ops.photo_fused_multi_scale(srcs, ds, T, Kd, tgts, scales)
+        else:
+            pairs = [ops.photo_fused(srcs[k], ds[k], T, Kd, tgts[k], scales[k]) for k in range(nscales)]
+        total = sum((l1 * weights[2 * k]).sum() + (ss * weights[2 * k + 1]).sum() for k, (l1, ss) in enumerate(pairs))
+        total.backward()
+        return pairs, ds, T
+
+    pm, dm, Tm = run(True)
+    ps, dsingle, Ts = run(False)
+    for k in range(nscales):
+        assert torch.equal(pm[k][0], ps[k][0]) and torch.equal(pm[k][1], ps[k][1]), f"losses of scale {k}"
+        assert torch.equal(dm[k].grad, dsingle[k].grad), f"depth gradient of scale {k}"
+    scale_t = Ts.grad.abs().max().item()
+    assert (Tm.grad - Ts.grad).abs().max().item() <= 2e-6 * scale_t
+
+
 # ------------------------------------------------------------------------------------------------ K6
 @pytest.mark.parametrize("B,h,w", [(4, 128, 416), (2, 16, 52), (1, 2, 2)])
 @pytest.mark.parametrize("is_depth", [False, True])

@@ -60,9 +60,9 @@ struct WaveJob {
   bool valid;
 };
 
-__device__ inline WaveJob wave_job(const FusedDims& d) {
+__device__ inline WaveJob wave_job(const FusedDims& d, unsigned block) {
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const long long gw = (long long)blockIdx.x * 4 + wid;
+  const long long gw = (long long)block * 4 + wid;
   const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
   WaveJob j;
   j.valid = gw < nwaves;
@@ -164,12 +164,14 @@ typedef float f32x3 __attribute__((ext_vector_type(3)));
 // s_waitcnt, so that the streaming loads of row r+1 (depth, target) are in flight BEHIND the gathers of row r and are
 // only waited for when row r's arithmetic is done -- the compiler's own waitcnt insertion cannot express that (vector
 // memory returns in order and loop-carried load destinations are waited for conservatively).
+// (the march itself is a device function of the workgroup index: the per-scale kernel passes blockIdx.x, the multi-scale
+//  kernel below the index inside its scale's range of workgroups)
 template <bool EMIT_SYNTH, bool PIPE>
-__global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
-                                                        const float* __restrict__ T, const float* __restrict__ K,
-                                                        const float* __restrict__ target, float* __restrict__ synth,
-                                                        float* __restrict__ part, FusedDims d) {
-  const WaveJob job = wave_job(d);
+__device__ __forceinline__ void fused_fwd_body(const float* __restrict__ src, const float* __restrict__ depth,
+                                               const float* __restrict__ T, const float* __restrict__ K,
+                                               const float* __restrict__ target, float* __restrict__ synth,
+                                               float* __restrict__ part, const FusedDims& d, unsigned block) {
+  const WaveJob job = wave_job(d, block);
   if (!job.valid) return;                          // no block-level synchronisation in this kernel
   const int lane = threadIdx.x & 63;
   const int P = d.h * d.w;
@@ -356,6 +358,42 @@ __global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict_
   }
 }
 
+template <bool EMIT_SYNTH, bool PIPE>
+__global__ __launch_bounds__(256) void fused_fwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
+                                                        const float* __restrict__ T, const float* __restrict__ K,
+                                                        const float* __restrict__ target, float* __restrict__ synth,
+                                                        float* __restrict__ part, FusedDims d) {
+  fused_fwd_body<EMIT_SYNTH, PIPE>(src, depth, T, K, target, synth, part, d, blockIdx.x);
+}
+
+// All scales of the loss pyramid in ONE launch: the workgroups of scale 0 come first, then scale 1, ... (the small scales
+// are latency chains of ~10 dependent row steps on a handful of waves: alone each costs a 10 us launch, here they run
+// under the shadow of scale 0).  The scale of a workgroup is wave-uniform; its arguments are scalar loads.
+struct MsArgs {
+  const float* src[4];
+  const float* depth[4];
+  const float* target[4];
+  const float* g_l1[4];
+  const float* g_ss[4];
+  float* ddepth[4];
+  long long part_off[4];       // offset (floats) of the scale's per-wave partials in the workspace
+  FusedDims d[4];
+  float inv_count[4];
+  unsigned block_off[5];       // first workgroup of every scale; unused scales = the total
+  int waves_per_b[4];
+};
+
+__device__ inline int ms_scale_of(const MsArgs& m, unsigned b) {
+  return (int)(b >= m.block_off[1]) + (int)(b >= m.block_off[2]) + (int)(b >= m.block_off[3]);
+}
+
+__global__ __launch_bounds__(256) void fused_fwd_ms_kernel(MsArgs m, const float* __restrict__ T, const float* __restrict__ K,
+                                                           float* __restrict__ part) {
+  const int s = ms_scale_of(m, blockIdx.x);
+  fused_fwd_body<false, true>(m.src[s], m.depth[s], T, K, m.target[s], nullptr, part + m.part_off[s], m.d[s],
+                              blockIdx.x - m.block_off[s]);
+}
+
 // ------------------------------------------------------------------------------------------------ forward, LDS-staged taps
 // Variant 2.  The gather of the four bilinear neighbours is what bounds the march above: every source texel is
 // requested by two lanes and by two consecutive row steps, as unaligned 16 + 8 byte loads per lane and tap row -- the
@@ -391,7 +429,7 @@ __global__ __launch_bounds__(256) void fused_fwd_lds_kernel(const float* __restr
                                                             const float* __restrict__ target, float* __restrict__ part,
                                                             FusedDims d) {
   __shared__ __attribute__((aligned(16))) float tiles[4][FT * FROW];
-  const WaveJob job = wave_job(d);
+  const WaveJob job = wave_job(d, blockIdx.x);
   if (!job.valid) return;                          // no block-level synchronisation in this kernel
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -599,14 +637,13 @@ __device__ inline void ssim_coeffs(float Sx, float Sy, float Sq, float Sxy, floa
 // MODE 0: N == 4, the 4 waves of a workgroup hold the 4 views of one strip -> d_depth summed through LDS;
 // MODE 1: N == 1 -> direct store;  MODE 2: any other N -> atomicAdd into a zeroed d_depth.
 template <int MODE>
-__global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
-                                                        const float* __restrict__ T, const float* __restrict__ K,
-                                                        const float* __restrict__ target,
-                                                        const float* __restrict__ g_l1, const float* __restrict__ g_ssim,
-                                                        float* __restrict__ ddepth, float* __restrict__ part,
-                                                        FusedDims d, float inv_count) {
+__device__ __forceinline__ void fused_bwd_body(const float* __restrict__ src, const float* __restrict__ depth,
+                                               const float* __restrict__ T, const float* __restrict__ K,
+                                               const float* __restrict__ target, const float* __restrict__ g_l1,
+                                               const float* __restrict__ g_ssim, float* __restrict__ ddepth,
+                                               float* __restrict__ part, const FusedDims& d, float inv_count, unsigned block) {
   __shared__ float lds_dd[4][64];
-  const WaveJob job = wave_job(d);
+  const WaveJob job = wave_job(d, block);
   if (!job.valid) return;                   // MODE 0: nwaves % 4 == 0, whole workgroups leave together
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -769,6 +806,60 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict_
   }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void fused_bwd_kernel(const float* __restrict__ src, const float* __restrict__ depth,
+                                                        const float* __restrict__ T, const float* __restrict__ K,
+                                                        const float* __restrict__ target,
+                                                        const float* __restrict__ g_l1, const float* __restrict__ g_ssim,
+                                                        float* __restrict__ ddepth, float* __restrict__ part,
+                                                        FusedDims d, float inv_count) {
+  fused_bwd_body<MODE>(src, depth, T, K, target, g_l1, g_ssim, ddepth, part, d, inv_count, blockIdx.x);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void fused_bwd_ms_kernel(MsArgs m, const float* __restrict__ T, const float* __restrict__ K,
+                                                           float* __restrict__ part) {
+  const int s = ms_scale_of(m, blockIdx.x);
+  fused_bwd_body<MODE>(m.src[s], m.depth[s], T, K, m.target[s], m.g_l1[s], m.g_ss[s], m.ddepth[s], part + m.part_off[s],
+                       m.d[s], m.inv_count[s], blockIdx.x - m.block_off[s]);
+}
+
+// multi-scale finishers: grid.y = scale (forward); the pose gradient adds the scales in order
+__global__ void fused_reduce_ms_kernel(MsArgs m, const float* __restrict__ part, float* __restrict__ losses) {
+  const int b = blockIdx.x, s = blockIdx.y, t = threadIdx.x, B = gridDim.x, nscales = gridDim.y;
+  const int waves_per_b = m.waves_per_b[s];
+  const float* q = part + m.part_off[s] + (long long)b * waves_per_b * 16;
+  float s0 = 0.f, s1 = 0.f;
+  for (int k = t; k < waves_per_b; k += 64) { s0 += q[16 * k]; s1 += q[16 * k + 1]; }
+  s0 = wave_sum_all(s0);
+  s1 = wave_sum_all(s1);
+  if (t == 0) {
+    losses[s * B + b] = s0 * m.inv_count[s];
+    losses[(nscales + s) * B + b] = s1 * m.inv_count[s];
+  }
+}
+
+__global__ void fused_bwd_reduce_ms_kernel(MsArgs m, int nscales, const float* __restrict__ part, float* __restrict__ dT, int BN,
+                                           int N) {
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4);      // entry in [0, BN*16)
+  const int t = threadIdx.x & 15;
+  const int bn = e / 16, i = e % 16;
+  float total = 0.f;
+  for (int s = 0; s < nscales; ++s) {
+    float sum = 0.f;
+    if (bn < BN && i < 12) {
+      const int b = bn / N, n = bn % N;
+      const int waves_per_b = m.waves_per_b[s], per_view = waves_per_b / N;
+      const float* ps = part + m.part_off[s];
+      for (int k = t; k < per_view; k += 16) sum += ps[16 * ((long long)b * waves_per_b + (long long)k * N + n) + i];
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) sum += __shfl_down(sum, off, 16);
+    total += sum;
+  }
+  if (t == 0 && bn < BN) dT[e] = total;
+}
+
 // dT[b,n] (4x4, last row 0) = sum over the (strip, chunk) waves of view (b,n), fixed order; 16 threads per entry.
 __global__ void fused_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dT, int BN, int N,
                                         int waves_per_b) {
@@ -906,6 +997,81 @@ int xpt_photo_fused_bwd(const float* src, const float* depth, const float* T, co
   }
   hipLaunchKernelGGL(fused_bwd_reduce_kernel, dim3((B * N * 16 + 15) / 16), dim3(256), 0, s, workspace, dT, B * N, N,
                      d.S * d.CH * d.N);
+  return xpt_launch_status();
+}
+
+/* ---- all scales of the pyramid in one launch (same arithmetic per scale as the calls above).
+ * Arrays of nscales (<= 4) entries: src[s] [B,N,h_s,w_s,3], depth[s] [B,h_s,w_s], target[s] [B,h_s,w_s,3], scale[s]
+ * (intrinsic divisor).  losses [2 nscales][B]: row s = photometric L1 of scale s, row nscales + s = its SSIM loss.
+ * Workspace: the sum of the per-scale xpt_photo_fused_workspace_floats. */
+int xpt_photo_fused_ms_fwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
+                           const float* const* target, float* losses, float* workspace, size_t workspace_floats,
+                           int B, int N, const int* h, const int* w, const float* scale, void* stream) {
+  XPT_CHECK_PTR(src); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(T); XPT_CHECK_PTR(K); XPT_CHECK_PTR(target);
+  XPT_CHECK_PTR(losses); XPT_CHECK_PTR(workspace); XPT_CHECK_PTR(h); XPT_CHECK_PTR(w); XPT_CHECK_PTR(scale);
+  if (nscales < 1 || nscales > 4 || B <= 0 || N <= 0) return XPT_ERR_ARG;
+  MsArgs m{};
+  size_t need = 0;
+  unsigned blocks = 0;
+  for (int s = 0; s < nscales; ++s) {
+    if (!src[s] || !depth[s] || !target[s]) return XPT_ERR_NULL;
+    if (h[s] <= 0 || w[s] <= 0 || !(scale[s] > 0.f) || (long long)h[s] * w[s] * 3 >= (1LL << 31)) return XPT_ERR_SHAPE;
+    FusedDims d = make_dims(B, N, h[s], w[s], scale[s], pick_rows(B, N, h[s], w[s], g_fwd_min_waves), STRIP);
+    const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
+    m.src[s] = src[s]; m.depth[s] = depth[s]; m.target[s] = target[s];
+    m.d[s] = d;
+    m.part_off[s] = (long long)need;
+    m.inv_count[s] = 1.0f / ((float)N * (float)h[s] * (float)w[s] * 3.0f);
+    m.waves_per_b[s] = d.S * d.CH * d.N;
+    m.block_off[s] = blocks;
+    blocks += (unsigned)((nwaves + 3) / 4);
+    need += xpt_photo_fused_workspace_floats(B, N, h[s], w[s]);
+  }
+  for (int s = nscales; s <= 4; ++s) m.block_off[s] = blocks;
+  if (workspace_floats < need) return XPT_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(fused_fwd_ms_kernel, dim3(blocks), dim3(256), 0, st, m, T, K, workspace);
+  hipLaunchKernelGGL(fused_reduce_ms_kernel, dim3(B, nscales), dim3(64), 0, st, m, workspace, losses);
+  return xpt_launch_status();
+}
+
+/* backward of the above: g_l1[s] / g_ssim[s] [B] -> ddepth[s] [B,h_s,w_s] and dT [B,N,4,4] = the sum over the scales
+ * (added in scale order).  N must be 4 or 1 (the modes that write d_depth without atomics). */
+int xpt_photo_fused_ms_bwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
+                           const float* const* target, const float* const* g_l1, const float* const* g_ssim,
+                           float* const* ddepth, float* dT, float* workspace, size_t workspace_floats, int B, int N,
+                           const int* h, const int* w, const float* scale, void* stream) {
+  XPT_CHECK_PTR(src); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(T); XPT_CHECK_PTR(K); XPT_CHECK_PTR(target); XPT_CHECK_PTR(g_l1);
+  XPT_CHECK_PTR(g_ssim); XPT_CHECK_PTR(ddepth); XPT_CHECK_PTR(dT); XPT_CHECK_PTR(workspace); XPT_CHECK_PTR(h);
+  XPT_CHECK_PTR(w); XPT_CHECK_PTR(scale);
+  if (nscales < 1 || nscales > 4 || B <= 0 || (N != 4 && N != 1)) return XPT_ERR_ARG;
+  MsArgs m{};
+  size_t need = 0;
+  unsigned blocks = 0;
+  for (int s = 0; s < nscales; ++s) {
+    if (!src[s] || !depth[s] || !target[s] || !g_l1[s] || !g_ssim[s] || !ddepth[s]) return XPT_ERR_NULL;
+    if (h[s] <= 0 || w[s] <= 0 || !(scale[s] > 0.f) || (long long)h[s] * w[s] * 3 >= (1LL << 31)) return XPT_ERR_SHAPE;
+    FusedDims d = make_dims(B, N, h[s], w[s], scale[s], pick_rows(B, N, h[s], w[s], g_bwd_min_waves), STRIP_B);
+    const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
+    m.src[s] = src[s]; m.depth[s] = depth[s]; m.target[s] = target[s];
+    m.g_l1[s] = g_l1[s]; m.g_ss[s] = g_ssim[s]; m.ddepth[s] = ddepth[s];
+    m.d[s] = d;
+    m.part_off[s] = (long long)need;
+    m.inv_count[s] = 1.0f / ((float)N * (float)h[s] * (float)w[s] * 3.0f);
+    m.waves_per_b[s] = d.S * d.CH * d.N;
+    m.block_off[s] = blocks;
+    blocks += (unsigned)((nwaves + 3) / 4);
+    need += xpt_photo_fused_workspace_floats(B, N, h[s], w[s]);
+  }
+  for (int s = nscales; s <= 4; ++s) m.block_off[s] = blocks;
+  if (workspace_floats < need) return XPT_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  XPT_BEGIN_LAUNCH();
+  if (N == 4) hipLaunchKernelGGL(fused_bwd_ms_kernel<0>, dim3(blocks), dim3(256), 0, st, m, T, K, workspace);
+  else hipLaunchKernelGGL(fused_bwd_ms_kernel<1>, dim3(blocks), dim3(256), 0, st, m, T, K, workspace);
+  hipLaunchKernelGGL(fused_bwd_reduce_ms_kernel, dim3((B * N * 16 + 15) / 16), dim3(256), 0, st, m, nscales, workspace, dT,
+                     B * N, N);
   return xpt_launch_status();
 }
 

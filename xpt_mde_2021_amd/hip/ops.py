@@ -235,6 +235,78 @@ def photo_fused(src, depth, T, K, target, scale):
     return _PhotoFused.apply(src, depth, T, K, target, scale)
 
 
+class _PhotoFusedMS(torch.autograd.Function):
+    """photo_fused for every scale of the pyramid in ONE march launch (+ one finishing launch) forward and backward;
+    the pose gradient comes back already summed over the scales.  args = (T, K, scales, src_0.., depth_0.., target_0..)."""
+
+    @staticmethod
+    def forward(ctx, T, K, scales, *tensors):
+        import ctypes
+        lib = _lib.load()
+        n = len(scales)
+        srcs = [_dev(t, "src") for t in tensors[:n]]
+        depths = [_dev(t, "depth") for t in tensors[n:2 * n]]
+        targets = [_dev(t, "target") for t in tensors[2 * n:3 * n]]
+        T, K = _dev(T, "T"), _dev(K, "K")
+        B, N = srcs[0].shape[:2]
+        hs, ws_ = [s.shape[2] for s in srcs], [s.shape[3] for s in srcs]
+        for s, d, t in zip(srcs, depths, targets):
+            if s.shape[:2] != (B, N) or s.shape[4] != 3 or d.numel() != B * s.shape[2] * s.shape[3] \
+                    or tuple(t.shape) != (B, s.shape[2], s.shape[3], 3):
+                raise _lib.XptHipError(f"photo_fused_ms: inconsistent shapes src{tuple(s.shape)} depth{tuple(d.shape)} "
+                                       f"target{tuple(t.shape)}")
+        if T.numel() != B * N * 16 or K.numel() != B * 9:
+            raise _lib.XptHipError(f"photo_fused_ms: T{tuple(T.shape)} K{tuple(K.shape)}")
+        losses = torch.empty((2 * n, B), dtype=torch.float32, device=T.device)
+        nws = sum(lib.xpt_photo_fused_workspace_floats(B, N, h, w) for h, w in zip(hs, ws_))
+        ws = torch.empty(nws, dtype=torch.float32, device=T.device)
+        P = ctypes.c_void_p * n
+        ptrs = lambda ts: P(*[t.data_ptr() for t in ts])       # noqa: E731
+        _lib.check(lib.xpt_photo_fused_ms_fwd(n, ptrs(srcs), ptrs(depths), _ptr(T), _ptr(K), ptrs(targets), _ptr(losses),
+                                              _ptr(ws), nws, B, N, (ctypes.c_int * n)(*hs), (ctypes.c_int * n)(*ws_),
+                                              (ctypes.c_float * n)(*[float(s) for s in scales]), _stream()),
+                   "xpt_photo_fused_ms_fwd")
+        ctx.save_for_backward(T, K, *srcs, *depths, *targets)
+        ctx.cfg = (n, tuple(float(s) for s in scales), hs, ws_, nws)
+        ctx.set_materialize_grads(False)
+        return tuple(losses[i] for i in range(2 * n))          # l1 of every scale, then ssim of every scale
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        lib = _lib.load()
+        n, scales, hs, ws_, nws = ctx.cfg
+        saved = ctx.saved_tensors
+        T, K = saved[0], saved[1]
+        srcs, depths, targets = saved[2:2 + n], saved[2 + n:2 + 2 * n], saved[2 + 2 * n:2 + 3 * n]
+        B, N = srcs[0].shape[:2]
+        zero = None
+        gs = []
+        for g in grads:
+            if g is None:
+                if zero is None:
+                    zero = torch.zeros(B, dtype=torch.float32, device=T.device)
+                g = zero
+            gs.append(_dev(g, "grad"))
+        ddepths = [torch.empty_like(d) for d in depths]
+        dT = torch.empty_like(T)
+        ws = torch.empty(nws, dtype=torch.float32, device=T.device)
+        P = ctypes.c_void_p * n
+        ptrs = lambda ts: P(*[t.data_ptr() for t in ts])       # noqa: E731
+        _lib.check(lib.xpt_photo_fused_ms_bwd(n, ptrs(srcs), ptrs(depths), _ptr(T), _ptr(K), ptrs(targets), ptrs(gs[:n]),
+                                              ptrs(gs[n:]), ptrs(ddepths), _ptr(dT), _ptr(ws), nws, B, N,
+                                              (ctypes.c_int * n)(*hs), (ctypes.c_int * n)(*ws_),
+                                              (ctypes.c_float * n)(*scales), _stream()), "xpt_photo_fused_ms_bwd")
+        return (dT, None, None, *([None] * n), *ddepths, *([None] * n))
+
+
+def photo_fused_multi_scale(srcs, depths, T, K, targets, scales):
+    """[(l1 [B], ssim [B]) per scale] of photo_fused, all scales in one launch (N must be 4 or 1, at most 4 scales)."""
+    n = len(scales)
+    out = _PhotoFusedMS.apply(T, K, tuple(scales), *srcs, *depths, *targets)
+    return [(out[i], out[n + i]) for i in range(n)]
+
+
 def photo_fused_with_synth(src, depth, T, K, target, scale):
     """Forward only (no autograd): also returns the synthesized views [B,N,h,w,3] (for image logging / tests)."""
     lib = _lib.load()
@@ -787,7 +859,9 @@ class _CellTail(torch.autograd.Function):
         ctx.save_for_backward(out)
         ctx.cfg = (spec, len(inputs), F, dt)
         ctx.set_materialize_grads(False)
-        return (out,) + tuple(out.view_as(out) for _ in range(n_alias - 1))
+        # every alias is a view of the (never returned) buffer: were the first alias the base of the others, the list of
+        # aliases the caller hangs on it would close a reference cycle (alias._base -> head -> list -> alias)
+        return tuple(out.view_as(out) for _ in range(n_alias))
 
     @staticmethod
     def backward(ctx, *grads):

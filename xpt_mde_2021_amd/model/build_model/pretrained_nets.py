@@ -55,7 +55,7 @@ def shared_relu(x):
     and both start with Activation('relu') on it."""
     pool = getattr(x, "_xpt_relu_aliases", None)
     if pool is not None:               # a cell output produced already rectified (cell_tail): one alias per consumer
-        return pool.pop() if len(pool) > 1 else pool[0]
+        return pool.pop() if pool else x
     cached = getattr(x, "_xpt_relu", None)
     if cached is None:
         cached = F.relu(x)
@@ -313,7 +313,7 @@ def _rectified_concat(spec, inputs):
     consumer (next cell's squeeze convolution, the adjust block after it, a decoder tap)."""
     outs = _ops.cell_tail(spec, inputs, 3)
     head = outs[0]
-    head._xpt_relu_aliases = outs
+    head._xpt_relu_aliases = outs[1:]        # (not the head itself: a tensor -> list -> tensor cycle would outlive the step)
     return head
 _PWCONV_MAX_CIN = 320
 _LIBRARY_PWCONV = __import__("os").environ.get("XPT_DEBUG_LIBRARY_PWCONV", "0") == "1"    # A/B: rocBLAS GEMM + epilogue launch

@@ -71,11 +71,9 @@ class TotalLoss:
                 coef.append(w * w_type / self.batch_size)           # tf.nn.compute_average_loss, then the type weight
                 terms.append(tensor.reshape(-1))
             rows.append(row)
-        stacked = torch.stack(terms)                                  # [terms, batch]
-        c_vec, a_mat = self._merge_constants(coef, rows, stacked.device)
-        row_sums = stacked.sum(dim=1)
-        total_loss = torch.dot(c_vec, row_sums)
-        by_type = torch.mv(a_mat, row_sums.detach())
+        c_vec, a_mat = self._merge_constants(coef, rows, terms[0].device)
+        total_loss, row_sums = _WeightedTotal.apply(c_vec, *terms)
+        by_type = torch.mv(a_mat, row_sums)
         loss_by_type = {name: by_type[i] for i, name in enumerate(outputs)}
         return total_loss, loss_by_type
 
@@ -147,6 +145,28 @@ class _DeferredTerms:
 
     def __init__(self, index):
         self.index = index
+
+
+class _WeightedTotal(torch.autograd.Function):
+    """total = c . rowsum(stack(terms)) with a backward that hands every term ONE row of a dense [terms, batch] matrix
+    (one multiply + one copy): autograd's own chain (dot, sum, stack) gives each term an expanded stride-0 gradient that
+    the loss kernels then copy one by one (12 launches per step)."""
+
+    @staticmethod
+    def forward(ctx, c_vec, *terms):
+        stacked = torch.stack(terms)                                  # [terms, batch]
+        row_sums = stacked.sum(dim=1)
+        ctx.save_for_backward(c_vec)
+        ctx.shape = tuple(stacked.shape)
+        ctx.mark_non_differentiable(row_sums)
+        return torch.dot(c_vec, row_sums), row_sums
+
+    @staticmethod
+    def backward(ctx, g_total, _):
+        c_vec, = ctx.saved_tensors
+        n, batch = ctx.shape
+        grads = (c_vec * g_total).unsqueeze(1).expand(n, batch).contiguous()
+        return (None, *grads.unbind(0))
 
 
 class LossBase:

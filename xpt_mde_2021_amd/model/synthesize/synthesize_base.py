@@ -5,6 +5,9 @@ from ...hip import ops as _ops
 from ...utils.convert_pose import pose_rvec2matr_batch_tf
 
 
+_FUSED_MULTI_SCALE = __import__("os").environ.get("XPT_DEBUG_PER_SCALE_LOSS", "0") != "1"     # A/B: one launch per scale
+
+
 class SynthesizeMultiScale:
     def __call__(self, source_image, intrinsic, pred_depth_ms, pred_pose):
         """
@@ -21,6 +24,15 @@ class SynthesizeMultiScale:
         """Fused fast path: per scale (photometric L1 [batch], photometric SSIM [batch]) of the synthesized views
         against target_ms, computed by the warp+L1+SSIM march kernel without materialising the views."""
         poses_matr = pose_rvec2matr_batch_tf(pred_pose)
+        if source_image.shape[1] in (1, 4) and len(pred_depth_ms) <= 4 and _FUSED_MULTI_SCALE:
+            # every scale in one march launch (csrc/xpt_fused.hip: fused_fwd_ms_kernel / fused_bwd_ms_kernel)
+            singles = [SynthesizeSingleScale() for _ in pred_depth_ms]
+            sources = []
+            for single, depth_sc in zip(singles, pred_depth_ms):
+                single.read_shape(source_image, depth_sc)
+                sources.append(single.resize_source_images(source_image))
+            return _ops.photo_fused_multi_scale(sources, list(pred_depth_ms), poses_matr, intrinsic, list(target_ms),
+                                                [s.scale for s in singles])
         return [SynthesizeSingleScale().photometric_losses(source_image, intrinsic, depth_sc, poses_matr, target_sc)
                 for depth_sc, target_sc in zip(pred_depth_ms, target_ms)]
 
