@@ -131,7 +131,7 @@ int xpt_photo_fused_bwd(const float* src, const float* depth, const float* T, co
  * (model/synthesize/synthesize_base.py:13-20) followed by PhotometricLossMultiScale (model/loss_and_metric/losses.py:179-195)
  * over every scale.  Arrays hold nscales <= 4 entries (scale 0 first): src[s] [B,N,h_s,w_s,3], depth[s] [B,h_s,w_s],
  * target[s] [B,h_s,w_s,3], scale[s] = the divisor of the full-resolution intrinsic.  losses [2 nscales][B]: row s = the
- * photometric L1 of scale s, row nscales + s = its SSIM loss.  workspace >= sum of the per-scale
+ * photometric L1 of scale s, row nscales + s = its SSIM loss (NULL: per-wave partials only, no finishing launch).  workspace >= sum of the per-scale
  * xpt_photo_fused_workspace_floats.  Per scale the arithmetic is that of xpt_photo_fused_fwd / _bwd. */
 int xpt_photo_fused_ms_fwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
                            const float* const* target, float* losses, float* workspace, size_t workspace_floats,
@@ -224,6 +224,8 @@ int xpt_affine_act_bwd(const void* x, const void* y, const void* dy, long long d
  * xpt_conv1x1_bwd_weight_tune: launch-plan knobs (waves per workgroup 4|16, row pairs per wave, workgroups per launch,
  * KiB of partial tiles per output tile); process-wide, for benchmarking -- the defaults are the measured optimum. */
 int xpt_conv1x1_bwd_weight_tune(int waves, int pairs_per_wave, int max_blocks, int max_partial_kib);
+/* deferred mode: MiB of split partials one layer may leave for xpt_reduce_partials (default 8; benchmarking) */
+int xpt_conv1x1_bwd_weight_defer_cap(int mib);
 size_t xpt_conv1x1_bwd_weight_workspace_floats(long long M, int cout, int cin);
 int xpt_conv1x1_bwd_weight_counters(long long M, int cout, int cin);
 int xpt_conv1x1_bwd_weight(const void* dy, const void* x, float* dw, float* workspace, size_t workspace_floats,

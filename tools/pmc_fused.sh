@@ -17,7 +17,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
     if "fused_fwd" in k or "fused_bwd_kernel" in k or "affine_act_fwd_kernel<float>" in k:
         import re
-        m = re.search(r"(fused_fwd_kernel<[\w, ]+>|fused_bwd_kernel<\d>|affine_act_fwd_kernel<float>)", k)
+        m = re.search(r"(fused_fwd_ms_kernel|fused_bwd_ms_kernel<\d>|fused_fwd_kernel<[\w, ]+>|fused_bwd_kernel<\d>|affine_act_fwd_kernel<float>)", k)
         key = (m.group(1) if m else k[:40], r["Grid_Size"])
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for key, cs in sorted(agg.items()):

@@ -16,6 +16,11 @@ for batch in (8, 128):
     print(f"B={batch}: fwd {f * 1e3:.1f} us ({fb / f / 1e6:.0f} GB/s algorithmic, {fb} B)  "
           f"bwd {b * 1e3:.1f} us ({bb / b / 1e6:.0f} GB/s algorithmic, {bb} B)")
 
+for batch in (8, 128):
+    f, b, fb, bb, shape = rf.measure_fused_ms(ops, feats, 10, batch=batch)
+    print(f"B={batch} 4 scales in one launch: fwd {f * 1e3:.1f} us ({fb / f / 1e6:.0f} GB/s algorithmic, {fb} B)  "
+          f"bwd {b * 1e3:.1f} us ({bb / b / 1e6:.0f} GB/s algorithmic, {bb} B)")
+
 # calibration launches for the PMC passes: known byte counts with this kernel family's access widths
 #   affine_act_fwd_kernel<float>: 4 B / lane loads and stores, reads 4n + writes 4n bytes
 #   torch float4 copy (vectorized_elementwise / copyBuffer): 16 B / lane

@@ -1008,7 +1008,7 @@ int xpt_photo_fused_ms_fwd(int nscales, const float* const* src, const float* co
                            const float* const* target, float* losses, float* workspace, size_t workspace_floats,
                            int B, int N, const int* h, const int* w, const float* scale, void* stream) {
   XPT_CHECK_PTR(src); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(T); XPT_CHECK_PTR(K); XPT_CHECK_PTR(target);
-  XPT_CHECK_PTR(losses); XPT_CHECK_PTR(workspace); XPT_CHECK_PTR(h); XPT_CHECK_PTR(w); XPT_CHECK_PTR(scale);
+  XPT_CHECK_PTR(workspace); XPT_CHECK_PTR(h); XPT_CHECK_PTR(w); XPT_CHECK_PTR(scale);     // losses == NULL: partials only
   if (nscales < 1 || nscales > 4 || B <= 0 || N <= 0) return XPT_ERR_ARG;
   MsArgs m{};
   size_t need = 0;
@@ -1032,7 +1032,7 @@ int xpt_photo_fused_ms_fwd(int nscales, const float* const* src, const float* co
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(fused_fwd_ms_kernel, dim3(blocks), dim3(256), 0, st, m, T, K, workspace);
-  hipLaunchKernelGGL(fused_reduce_ms_kernel, dim3(B, nscales), dim3(64), 0, st, m, workspace, losses);
+  if (losses) hipLaunchKernelGGL(fused_reduce_ms_kernel, dim3(B, nscales), dim3(64), 0, st, m, workspace, losses);
   return xpt_launch_status();
 }
 

@@ -33,6 +33,7 @@ int g_waves = 16;             // waves per workgroup
 int g_pairs_per_wave = 16;    // row pairs (MFMAs) each wave should at least get
 int g_max_blocks = 1024;      // workgroups per launch
 int g_max_partial_kib = 512;  // partial tiles the finishing workgroup adds, per output tile
+int g_defer_cap_mib = 8;      // deferred mode: bytes of split partials one layer may leave for xpt_reduce_partials
 
 inline WgradPlan wgrad_plan(long long M, int cout, int cin, bool defer = false) {
   WgradPlan p;
@@ -46,7 +47,7 @@ inline WgradPlan wgrad_plan(long long M, int cout, int cin, bool defer = false) 
   const int kslices = p.waves / quadrants;
   long long rows = 2LL * g_pairs_per_wave * kslices;
   // splits: bounded by what the finishing workgroup can add (in-kernel finish) or by 8 MiB of partials (deferred)
-  long long smax = defer ? (8LL << 20) / ((long long)cout * cin * 4)
+  long long smax = defer ? ((long long)g_defer_cap_mib << 20) / ((long long)cout * cin * 4)
                          : ((long long)g_max_partial_kib * 1024) / ((long long)p.tco * p.tci * 4);
   const long long by_blocks = g_max_blocks / ntiles;
   if (smax > by_blocks) smax = by_blocks;
@@ -398,6 +399,12 @@ extern "C" int xpt_conv1x1_bwd_weight_tune(int waves, int pairs_per_wave, int ma
   g_pairs_per_wave = pairs_per_wave;
   g_max_blocks = max_blocks;
   g_max_partial_kib = max_partial_kib;
+  return XPT_OK;
+}
+
+extern "C" int xpt_conv1x1_bwd_weight_defer_cap(int mib) {
+  if (mib < 1 || mib > 64) return XPT_ERR_ARG;
+  g_defer_cap_mib = mib;
   return XPT_OK;
 }
 

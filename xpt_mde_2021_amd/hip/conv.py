@@ -122,6 +122,9 @@ def _apply_env_tuning():
     if spec:
         mib, blocks = (int(v) for v in spec.split(","))
         _lib.load().xpt_conv2d_bwd_weight_tune(mib, blocks)
+    cap = os.environ.get("XPT_PW_DEFER_CAP_MIB")           # pointwise weight gradient: MiB of split partials per layer
+    if cap:
+        _lib.load().xpt_conv1x1_bwd_weight_defer_cap(int(cap))
 
 
 # ------------------------------------------------------------------------------- activations as (pointer, pitch)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "xpt_dwconv_bwd_both": (_i, [_p, _p, _p, _p, _p, _z] + [_i] * 12 + [_p]),
     "xpt_dwconv_multi_fwd": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
     "xpt_dwconv_multi_bwd": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
+    "xpt_conv1x1_bwd_weight_defer_cap": (_i, [_i]),
     "xpt_conv1x1_bwd_weight_splits": (_i, [ctypes.c_longlong, _i, _i]),
     "xpt_conv1x1_bn_bwd_partials": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _z, _p, _z, ctypes.c_longlong, _i, _i,
                                          ctypes.c_longlong, ctypes.c_longlong, _p]),

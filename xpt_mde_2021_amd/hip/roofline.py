@@ -78,6 +78,48 @@ def measure_fused(ops, feats, repeats, batch=None):
             {"B": B, "N": N, "h": H, "w": W})
 
 
+def measure_fused_ms(ops, feats, repeats, batch=None, nscales=4):
+    """(fwd ms, bwd ms, algorithmic fwd bytes, algorithmic bwd bytes, shape) of the MULTI-SCALE march launches (what the
+    training step runs: all pyramid scales in one launch, csrc/xpt_fused.hip fused_fwd_ms_kernel / fused_bwd_ms_kernel)."""
+    import ctypes
+    from . import lib as _lib
+    x = _inputs(feats, batch)
+    lib = _lib.load()
+    B, N, H, W = x["B"], x["N"], x["H"], x["W"]
+    T = ops.pose_rvec2matr(x["pose"])
+    srcs, depths, tgts, hs, ws_, scales = [], [], [], [], [], []
+    for k in range(nscales):
+        sc = 2 ** k
+        h, w = H // sc, W // sc
+        srcs.append(x["src"] if sc == 1 else ops.resize_down(x["src"].reshape(B * N, H, W, 3), sc).reshape(B, N, h, w, 3))
+        tgts.append(x["tgt"] if sc == 1 else ops.resize_down(x["tgt"], sc))
+        depths.append(x["depth"] if sc == 1 else x["depth"].reshape(B, H, W)[:, ::sc, ::sc].contiguous())
+        hs.append(h), ws_.append(w), scales.append(float(sc))
+    nws = sum(lib.xpt_photo_fused_workspace_floats(B, N, h, w) for h, w in zip(hs, ws_))
+    ws = torch.empty(nws, device=T.device)
+    g1 = torch.ones(B, device=T.device)
+    ddepths = [torch.empty_like(d) for d in depths]
+    dT = torch.empty_like(T)
+    st = torch.cuda.current_stream().cuda_stream
+    P = ctypes.c_void_p * nscales
+    ptrs = lambda ts: P(*[t.data_ptr() for t in ts])  # noqa: E731
+    ci, cf = (ctypes.c_int * nscales), (ctypes.c_float * nscales)
+    a_src, a_dep, a_tgt, a_g, a_dd = ptrs(srcs), ptrs(depths), ptrs(tgts), ptrs([g1] * nscales), ptrs(ddepths)
+    a_h, a_w, a_s = ci(*hs), ci(*ws_), cf(*scales)
+
+    def fwd():     # losses NULL: the march launch alone
+        _lib.check(lib.xpt_photo_fused_ms_fwd(nscales, a_src, a_dep, T.data_ptr(), x["K"].data_ptr(), a_tgt, None,
+                                              ws.data_ptr(), nws, B, N, a_h, a_w, a_s, st), "fused ms fwd")
+
+    def bwd():     # march + the pose-gradient finisher (one small launch)
+        _lib.check(lib.xpt_photo_fused_ms_bwd(nscales, a_src, a_dep, T.data_ptr(), x["K"].data_ptr(), a_tgt, a_g, a_g, a_dd,
+                                              dT.data_ptr(), ws.data_ptr(), nws, B, N, a_h, a_w, a_s, st), "fused ms bwd")
+
+    pixels = sum(h * w for h, w in zip(hs, ws_))
+    return (_time_kernel(fwd, repeats), _time_kernel(bwd, repeats), B * pixels * (16 + 12 * N), B * pixels * (20 + 12 * N),
+            {"B": B, "N": N, "h": H, "w": W, "scales": nscales})
+
+
 def _pmc_traffic(kernel, shape):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: separate
     FETCH_SIZE / WRITE_SIZE runs with the gfx950 x2 FETCH_SIZE correction); None when no pass exists for this shape."""
@@ -107,19 +149,22 @@ def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
     extra["unfused warp_fwd_kernel"] = (ms, B * P * (4 + 24 * N))
     ms = _time_kernel(lambda: ops.photometric("SSIM", synth, x["tgt"], True), repeats)
     extra["unfused photo_fwd_kernel<SSIM>"] = (ms, B * P * (12 + 12 * N))
-    f_ms, b_ms, f_bytes, b_bytes, shape = measure_fused(ops, feats, repeats)
-    extra["fused_bwd_kernel"] = (b_ms, b_bytes)
-    lf_ms, lb_ms, lf_bytes, lb_bytes, lshape = measure_fused(ops, feats, max(repeats // 5, 5), batch=large_batch)
+    s_ms, sb_ms, s_bytes, sb_bytes, _ = measure_fused(ops, feats, repeats)
+    extra["fused_fwd_kernel<false, true> (scale 1 alone)"] = (s_ms, s_bytes)
+    extra["fused_bwd_kernel<0> (scale 1 alone, + its finisher)"] = (sb_ms, sb_bytes)
+    f_ms, b_ms, f_bytes, b_bytes, shape = measure_fused_ms(ops, feats, repeats)
+    extra["fused_bwd_ms_kernel<0> (4 scales, + its finisher)"] = (b_ms, b_bytes)
+    lf_ms, lb_ms, lf_bytes, lb_bytes, lshape = measure_fused_ms(ops, feats, max(repeats // 5, 5), batch=large_batch)
     achieved = f_bytes / (f_ms * 1e-3) / 1e9
-    traffic = _pmc_traffic("fused_fwd_kernel<false, true>", shape)
+    traffic = _pmc_traffic("fused_fwd_ms_kernel", shape)
 
     def gbs(ms_, nbytes):
         return round(nbytes / (ms_ * 1e-3) / 1e9, 2)
 
-    return {"bound": "hbm", "kernel": "fused_fwd_kernel<false, true> (warp + L1 + SSIM, scale 1; hand-pipelined row loop)",
+    return {"bound": "hbm", "kernel": "fused_fwd_ms_kernel (warp + L1 + SSIM, the 4 pyramid scales in one launch; hand-pipelined row loop)",
             "achieved": round(achieved, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(achieved / hbm_peak_gbs, 4),
             "traffic": traffic, "launch_us": round(f_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(f_bytes),
-            "bytes_per_warped_pixel": round(f_bytes / (B * N * P), 3), "shape": shape,
+            "bytes_per_warped_pixel": round((16 + 12 * N) / N, 3), "shape": shape,
             "all": {k: {"launch_us": round(v[0] * 1e3, 3), "GBps": gbs(*v)} for k, v in extra.items()},
             "large_batch": {"shape": lshape,
                             "fwd": {"launch_us": round(lf_ms * 1e3, 2), "GBps": gbs(lf_ms, lf_bytes),

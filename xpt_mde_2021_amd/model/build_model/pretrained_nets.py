@@ -315,7 +315,7 @@ def _rectified_concat(spec, inputs):
     head = outs[0]
     head._xpt_relu_aliases = outs[1:]        # (not the head itself: a tensor -> list -> tensor cycle would outlive the step)
     return head
-_PWCONV_MAX_CIN = 320
+_PWCONV_MAX_CIN = int(__import__("os").environ.get("XPT_PWCONV_MAX_CIN", "320"))     # deeper reductions: library GEMM + epilogue launch
 _LIBRARY_PWCONV = __import__("os").environ.get("XPT_DEBUG_LIBRARY_PWCONV", "0") == "1"    # A/B: rocBLAS GEMM + epilogue launch
 
 

@@ -66,7 +66,10 @@ class _ConvFp32WeightGrad(torch.autograd.Function):
         dx = dw = None
         small = dy.shape[2] * dy.shape[3] <= SMALL_MAP_AREA
         with torch.autocast(device_type=dy.device.type, enabled=False):
-            if ctx.needs_input_grad[0] and small and safe_dgrad:
+            # small maps: ALWAYS the forward-convolution form (the library's data-gradient solvers for these shapes came
+            # back with garbage from the second replay of a captured step on, intermittently -- which solver MIOpen's
+            # find picks varies from run to run; first seen on PWC-Net, then on PoseNet's 2x7 level in fp32 mode)
+            if ctx.needs_input_grad[0] and small:
                 dx = flipped_conv_data_grad(dy.to(compute_dtype), _low_precision_weight(weight, compute_dtype),
                                             xc.shape, stride, padding, dilation)
             elif ctx.needs_input_grad[0]:
