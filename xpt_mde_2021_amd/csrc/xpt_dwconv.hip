@@ -222,6 +222,90 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x
   }
 }
 
+// ---------------------------------------------------------------- vectorised multi-layer kernels (stride 1)
+// The scalar multi-layer kernels below issue one 2-byte load per lane and tap: measured, their time is the texture
+// addresser's instruction rate (dw_multi_bwd: 11 us at 0.27 M threads ... 57 us at 1.5 M, linear in the thread count).
+// Here a thread owns V consecutive channels of OXT = 2 neighbouring outputs; the taps of the workgroup's job(s) sit in
+// LDS as sW[tap][c] (read as one vector per tap), activations move as 4 / 8 / 16-byte vectors.
+template <typename T, int K, int V, int OXT>
+__device__ __forceinline__ void dw_vec_accumulate(const T* __restrict__ src, const float* __restrict__ sW, int C, int SH,
+                                                  int SW, int pad_t, int pad_l, int b, int oy, int ox0, int c0, bool relu,
+                                                  float (&acc)[OXT][V]) {
+  constexpr int IN = OXT - 1 + K;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int sy = oy + ky - pad_t;
+    const bool row_ok = sy >= 0 && sy < SH;
+    const T* row = src + (((long long)b * SH + min(max(sy, 0), SH - 1)) * SW) * C + c0;
+    float in[IN][V];
+#pragma unroll
+    for (int i = 0; i < IN; ++i) {                   // unconditional loads on clamped columns, zeroed by a select
+      const int sx = ox0 - pad_l + i;
+      load_chan<T, V>(row + (long long)min(max(sx, 0), SW - 1) * C, in[i]);
+      const bool ok = row_ok && sx >= 0 && sx < SW;
+#pragma unroll
+      for (int v = 0; v < V; ++v) in[i][v] = ok ? (relu ? fmaxf(in[i][v], 0.f) : in[i][v]) : 0.f;
+    }
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      float wv[V];
+      const float* wp = sW + (ky * K + kx) * C + c0;
+#pragma unroll
+      for (int v = 0; v < V; ++v) wv[v] = wp[v];
+#pragma unroll
+      for (int i = 0; i < OXT; ++i)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[i][v] += in[i + kx][v] * wv[v];
+    }
+  }
+}
+
+template <typename T, int V>
+__device__ __forceinline__ void dw_vec_accumulate_k(int k, const T* __restrict__ src, const float* __restrict__ sW, int C,
+                                                    int SH, int SW, int pad_t, int pad_l, int b, int oy, int ox0, int c0,
+                                                    bool relu, float (&acc)[2][V]) {
+  if (k == 3) dw_vec_accumulate<T, 3, V, 2>(src, sW, C, SH, SW, pad_t, pad_l, b, oy, ox0, c0, relu, acc);
+  else if (k == 5) dw_vec_accumulate<T, 5, V, 2>(src, sW, C, SH, SW, pad_t, pad_l, b, oy, ox0, c0, relu, acc);
+  else dw_vec_accumulate<T, 7, V, 2>(src, sW, C, SH, SW, pad_t, pad_l, b, oy, ox0, c0, relu, acc);
+}
+
+// sW[(flip ? kk - 1 - tap : tap) * C + c] = w[c][tap]
+__device__ inline void dw_stage_taps(float* sW, const float* __restrict__ w, int C, int kk, bool flip) {
+  for (int i = threadIdx.x; i < C * kk; i += 256) {
+    const int c = i / kk, tap = i - c * kk;
+    sW[(flip ? kk - 1 - tap : tap) * C + c] = w[i];
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dw_multi_fwd_vec_kernel(DwMultiFwd m, DwDims d, int relu_in, int blocks_per_job) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];
+  const int job = blockIdx.x / blocks_per_job, blk = blockIdx.x - job * blocks_per_job;
+  const int k = m.k[job];
+  dw_stage_taps(sW, m.w[job], d.C, k * k, false);
+  __syncthreads();
+  const T* x = (const T*)m.x[job];
+  T* y = (T*)m.y[job];
+  const int CG = d.C / V, OXG = (d.OW + 1) / 2;
+  const long long total = (long long)d.B * d.OH * OXG * CG;
+  for (long long idx = blk * 256LL + threadIdx.x; idx < total; idx += 256LL * blocks_per_job) {
+    const int c0 = (int)(idx % CG) * V;
+    long long r = idx / CG;
+    const int ox0 = (int)(r % OXG) * 2; r /= OXG;
+    const int oy = (int)(r % d.OH);
+    const int b = (int)(r / d.OH);
+    float acc[2][V];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[i][v] = 0.f;
+    dw_vec_accumulate_k<T, V>(k, x, sW, d.C, d.H, d.W, m.pad_t[job], m.pad_l[job], b, oy, ox0, c0, relu_in != 0, acc);
+    const long long o = (((long long)b * d.OH + oy) * d.OW + ox0) * d.C + c0;
+    store_chan<T, V>(y + o, acc[0]);
+    if (ox0 + 1 < d.OW) store_chan<T, V>(y + o + d.C, acc[1]);
+  }
+}
+
 // ---------------------------------------------------------------- data gradient
 // dx[b,iy,ix,c] = [x>0 if relu] * sum_{ky,kx : (iy+pad_t-ky) % S == 0, ...} dy[b,(iy+pad_t-ky)/S,(ix+pad_l-kx)/S,c] * w[c,ky,kx]
 // sum over the taps of one input element: dy[b, (iy+pad_t-ky)/S, (ix+pad_l-kx)/S, c] * w[c, ky, kx]
@@ -298,13 +382,16 @@ inline int wrw_groups(long long ngrp, int C) {
   while (grp < 32 && ((ngrp + grp - 1) / grp) * cchunks > 2048) grp <<= 1;
   return grp;
 }
-template <typename T, int K, int S>
+// (EXT: the cross-wave fold uses caller-provided LDS -- 3 * 64 * K * K floats -- instead of a static array, for kernels
+//  that already carry dynamic LDS)
+template <typename T, int K, int S, bool EXT = false>
 __device__ inline void dw_bwd_weight_body(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
                                           const DwDims& d, int relu_in, int RG, int GRP, int block_c,
-                                          long long block_g) {
+                                          long long block_g, float* red_ext = nullptr) {
   constexpr int OXT = (S == 1) ? 4 : 2;
   constexpr int IN = (OXT - 1) * S + K;
-  __shared__ float red[3][64 * K * K];
+  __shared__ float red_static[EXT ? 1 : 3 * 64 * K * K];
+  float (*red)[64 * K * K] = (float (*)[64 * K * K])(EXT ? red_ext : red_static);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rg = (RG > 1) ? lane / d.C : 0;
   const int cl = (RG > 1) ? lane - rg * d.C : lane;
@@ -460,6 +547,76 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims 
     dw_bwd_weight_body<T, 7, S>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
 }
 
+// The same launch with the data-gradient part vectorised (stride 1): dx_u = [x_u > 0] * sum over the jobs j reading input u
+// of conv(dy_j, w_j rotated by 180 degrees, pad' = k_j - 1 - pad_j); the rotated taps of those jobs sit in LDS.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwDims d, int relu_in, int RG, int GRP,
+                                                               int data_blocks, int cchunks, int wblocks_per_job) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];
+  const int ndata = m.n_inputs * data_blocks;
+  if ((int)blockIdx.x < ndata) {
+    const int u = blockIdx.x / data_blocks, blk = blockIdx.x - u * data_blocks;
+    int off = 0;
+    for (int j = 0; j < m.n; ++j) {
+      if (m.input_of[j] != u) continue;
+      dw_stage_taps(sW + off, m.w[j], d.C, m.k[j] * m.k[j], true);
+      off += m.k[j] * m.k[j] * d.C;
+    }
+    __syncthreads();
+    const T* x = (const T*)m.xin[u];
+    T* dx = (T*)m.dxin[u];
+    const int CG = d.C / V, IXG = (d.W + 1) / 2;
+    const long long total = (long long)d.B * d.H * IXG * CG;
+    for (long long idx = blk * 256LL + threadIdx.x; idx < total; idx += 256LL * data_blocks) {
+      const int c0 = (int)(idx % CG) * V;
+      long long r = idx / CG;
+      const int ix0 = (int)(r % IXG) * 2; r /= IXG;
+      const int iy = (int)(r % d.H);
+      const int b = (int)(r / d.H);
+      float acc[2][V];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int v = 0; v < V; ++v) acc[i][v] = 0.f;
+      int o2 = 0;
+      for (int j = 0; j < m.n; ++j) {
+        if (m.input_of[j] != u) continue;
+        const int k = m.k[j];
+        dw_vec_accumulate_k<T, V>(k, (const T*)m.dy[j], sW + o2, d.C, d.OH, d.OW, k - 1 - m.pad_t[j], k - 1 - m.pad_l[j], b,
+                                  iy, ix0, c0, false, acc);
+        o2 += k * k * d.C;
+      }
+      const long long o = (((long long)b * d.H + iy) * d.W + ix0) * d.C + c0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (ix0 + i >= d.W) break;
+        if (relu_in) {
+          float mk[V];
+          load_chan<T, V>(x + o + (long long)i * d.C, mk);
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            if (!(mk[v] > 0.f)) acc[i][v] = 0.f;
+        }
+        store_chan<T, V>(dx + o + (long long)i * d.C, acc[i]);
+      }
+    }
+    return;
+  }
+  const int t = (int)blockIdx.x - ndata;
+  const int job = t / wblocks_per_job, tt = t - job * wblocks_per_job;
+  DwDims dj = d;
+  dj.pad_t = m.pad_t[job];
+  dj.pad_l = m.pad_l[job];
+  const T* x = (const T*)m.xin[m.input_of[job]];
+  const T* dy = (const T*)m.dy[job];
+  if (m.k[job] == 3)
+    dw_bwd_weight_body<T, 3, 1, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, sW);
+  else if (m.k[job] == 5)
+    dw_bwd_weight_body<T, 5, 1, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, sW);
+  else
+    dw_bwd_weight_body<T, 7, 1, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, sW);
+}
+
 // dw[i] = sum_k part[k][i]: 64 threads per output (few dependent round trips), fixed tree -> deterministic.
 __global__ void dw_wrw_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int nchunk) {
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -477,6 +634,15 @@ inline unsigned grid_for(long long total) {
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
+}
+
+int g_dw_multi_vec = 1;     // 0: the scalar multi-layer kernels (A/B, xpt_dwconv_tune(-1) / (-2))
+
+// channel vector width of the vectorised multi-layer kernels: 8 / 4 / 2 bf16 or 4 / 2 floats dividing C; 1 = none
+inline int multi_vec_width(int dtype, int C, std::initializer_list<const void*>) {
+  int v = dtype == 0 ? 4 : 8;
+  while (v > 1 && C % v != 0) v >>= 1;
+  return v;
 }
 
 // widest channel vector (elements) the tensors allow; 1 = use the scalar kernels
@@ -652,6 +818,10 @@ int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* works
 /* launch-plan knob (process-wide, for benchmarking): groups of 4 (stride 1) / 2 (stride 2) outputs per workgroup of the
  * weight-gradient kernel; 4, 8, 16 or 32, 0 = automatic */
 int xpt_dwconv_tune(int wrw_groups) {
+  if (wrw_groups == -1 || wrw_groups == -2) {        // -1: scalar multi-layer kernels, -2: vectorised (default)
+    g_dw_multi_vec = wrw_groups == -2;
+    return XPT_OK;
+  }
   if (wrw_groups != 0 && wrw_groups != 4 && wrw_groups != 8 && wrw_groups != 16 && wrw_groups != 32) return XPT_ERR_ARG;
   g_dw_wrw_grp = wrw_groups;
   return XPT_OK;
@@ -706,9 +876,30 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
     m.x[j] = x[j]; m.w[j] = w[j]; m.y[j] = y[j]; m.k[j] = k[j]; m.pad_t[j] = pad_t[j]; m.pad_l[j] = pad_l[j];
   }
   const DwDims d{B, H, W, C, OH, OW, 0, 0};
+  hipStream_t s = (hipStream_t)stream;
+  if (stride == 1 && g_dw_multi_vec) {      // vectorised path: V channels per thread, taps in LDS
+    int kmax = 0;
+    std::initializer_list<const void*> none{};
+    int v = multi_vec_width(dtype, C, none);
+    for (int j = 0; j < n && v > 1; ++j) {
+      kmax = k[j] > kmax ? k[j] : kmax;
+      const size_t a = (size_t)v * (dtype == 0 ? 4 : 2);
+      if (((uintptr_t)x[j]) % a || ((uintptr_t)y[j]) % a) v = 1;
+    }
+    const size_t lds = (size_t)kmax * kmax * C * sizeof(float);
+    if (v > 1 && lds <= 64 * 1024) {
+      const int bpjv = (int)grid_for((long long)B * OH * ((OW + 1) / 2) * (C / v));
+      XPT_BEGIN_LAUNCH();
+#define XPT_MV(T, V) \
+  hipLaunchKernelGGL((dw_multi_fwd_vec_kernel<T, V>), dim3(bpjv * n), dim3(256), lds, s, m, d, relu_in, bpjv)
+      if (dtype == 0) { if (v == 4) XPT_MV(float, 4); else XPT_MV(float, 2); }
+      else { if (v == 8) XPT_MV(__hip_bfloat16, 8); else if (v == 4) XPT_MV(__hip_bfloat16, 4); else XPT_MV(__hip_bfloat16, 2); }
+#undef XPT_MV
+      return xpt_launch_status();
+    }
+  }
   const int oxt = stride == 1 ? 4 : 2;
   const int bpj = (int)grid_for((long long)B * OH * ((OW + oxt - 1) / oxt) * C);
-  hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
 #define XPT_MULTI(T, S) hipLaunchKernelGGL((dw_multi_fwd_kernel<T, S>), dim3(bpj * n), dim3(256), 0, s, m, d, relu_in, bpj)
   if (dtype == 0) {
@@ -751,10 +942,40 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
   const int nchunk = (int)((ngrp + GRP - 1) / GRP);
   const int RG = (C <= 32) ? (64 / C > GRP / 4 ? (GRP / 4 > 0 ? GRP / 4 : 1) : 64 / C) : 1;
   const int cchunks = (C + 63) / 64;
-  const int data_blocks = (int)grid_for((long long)B * H * W * C);
   const int wbpj = cchunks * nchunk;
-  const dim3 grid(n_inputs * data_blocks + n * wbpj);
   hipStream_t s = (hipStream_t)stream;
+  if (stride == 1 && g_dw_multi_vec) {
+    std::initializer_list<const void*> none{};
+    int v = multi_vec_width(dtype, C, none);
+    const size_t a = (size_t)v * (dtype == 0 ? 4 : 2);
+    for (int u = 0; u < n_inputs && v > 1; ++u)
+      if (((uintptr_t)xin[u]) % a || ((uintptr_t)dxin[u]) % a) v = 1;
+    size_t lds = 0;
+    for (int u = 0; u < n_inputs; ++u) {
+      size_t l = 0;
+      for (int j = 0; j < n; ++j)
+        if (input_of[j] == u) l += (size_t)k[j] * k[j] * C * sizeof(float);
+      lds = l > lds ? l : lds;
+    }
+    for (int j = 0; j < n; ++j) {
+      if (((uintptr_t)dy[j]) % a) v = 1;
+      const size_t fold = (size_t)3 * 64 * k[j] * k[j] * sizeof(float);      // the weight-gradient workgroups' fold buffer
+      lds = fold > lds ? fold : lds;
+    }
+    if (v > 1 && lds <= 64 * 1024) {
+      const int dbv = (int)grid_for((long long)B * H * ((W + 1) / 2) * (C / v));
+      const dim3 gridv(n_inputs * dbv + n * wbpj);
+      XPT_BEGIN_LAUNCH();
+#define XPT_MV(T, V) \
+  hipLaunchKernelGGL((dw_multi_bwd_vec_kernel<T, V>), gridv, dim3(256), lds, s, m, d, relu_in, RG, GRP, dbv, cchunks, wbpj)
+      if (dtype == 0) { if (v == 4) XPT_MV(float, 4); else XPT_MV(float, 2); }
+      else { if (v == 8) XPT_MV(__hip_bfloat16, 8); else if (v == 4) XPT_MV(__hip_bfloat16, 4); else XPT_MV(__hip_bfloat16, 2); }
+#undef XPT_MV
+      return xpt_launch_status();
+    }
+  }
+  const int data_blocks = (int)grid_for((long long)B * H * W * C);
+  const dim3 grid(n_inputs * data_blocks + n * wbpj);
   XPT_BEGIN_LAUNCH();
 #define XPT_MULTI(T, S) \
   hipLaunchKernelGGL((dw_multi_bwd_kernel<T, S>), grid, dim3(256), 0, s, m, d, relu_in, RG, GRP, data_blocks, cchunks, wbpj)
