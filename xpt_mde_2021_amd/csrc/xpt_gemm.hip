@@ -30,7 +30,7 @@ struct WgradPlan {
 
 // tuning knobs (xpt_conv1x1_bwd_weight_tune; defaults measured on MI355X)
 int g_waves = 16;             // waves per workgroup
-int g_pairs_per_wave = 16;    // row pairs (MFMAs) each wave should at least get
+int g_pairs_per_wave = 8;     // row pairs (MFMAs) each wave should at least get (in-step sweep: 16 -> 8.70 ms, 8 -> 8.59 ms, 4 -> 8.74 ms)
 int g_max_blocks = 1024;      // workgroups per launch
 int g_max_partial_kib = 512;  // partial tiles the finishing workgroup adds, per output tile
 int g_defer_cap_mib = 8;      // deferred mode: bytes of split partials one layer may leave for xpt_reduce_partials

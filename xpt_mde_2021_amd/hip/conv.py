@@ -122,6 +122,9 @@ def _apply_env_tuning():
     if spec:
         mib, blocks = (int(v) for v in spec.split(","))
         _lib.load().xpt_conv2d_bwd_weight_tune(mib, blocks)
+    spec = os.environ.get("XPT_PW_WGRAD_TUNE")             # pointwise weight gradient: waves, row pairs per wave, max workgroups, KiB
+    if spec:
+        _lib.load().xpt_conv1x1_bwd_weight_tune(*[int(v) for v in spec.split(",")])
     cap = os.environ.get("XPT_PW_DEFER_CAP_MIB")           # pointwise weight gradient: MiB of split partials per layer
     if cap:
         _lib.load().xpt_conv1x1_bwd_weight_defer_cap(int(cap))
