@@ -210,14 +210,6 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
   const bool ci_ok = ci < cin;
   const bool bn_tile = BN && blockIdx.x == 0;               // this workgroup also emits g and the BN partial sums
   const bool bn_sums = bn_tile && qb == 0;                  // ... summed by the waves of the first column quadrant
-  if (BN) {
-    if (threadIdx.x < TCO) {
-      const int c = co0 + threadIdx.x;
-      sS[threadIdx.x] = c < cout ? bn.gamma[c] * rsqrtf(bn.var[c] + bn.eps) : 0.f;
-    }
-    __syncthreads();
-  }
-  const float a_scale = BN ? sS[qa * 32 + r] : 1.f;
   float sum_dy = 0.f, sum_dyy = 0.f;
 
   f32x16 acc;
@@ -236,6 +228,15 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
   if constexpr (BN) {
     if (bn_tile) stage_load<VA, TCO, RC, NT>(gy, bn.ypre, cout, k_begin, k_end, co0, cout);
   }
+  // the BatchNorm scales: fetched BEHIND the first chunk's loads (their round trip used to head every workgroup)
+  if (BN) {
+    if (threadIdx.x < TCO) {
+      const int c = co0 + threadIdx.x;
+      sS[threadIdx.x] = c < cout ? bn.gamma[c] * rsqrtf(bn.var[c] + bn.eps) : 0.f;
+    }
+    __syncthreads();
+  }
+  const float a_scale = BN ? sS[qa * 32 + r] : 1.f;
   const unsigned short* myA = sA + h * TCO + qa * 32 + r;
   const unsigned short* myB = sB + h * TCI + qb * 32 + r;
   const unsigned short* myY = sY + h * TCO + qa * 32 + r;
