@@ -251,6 +251,36 @@ def test_fused_warp_l1_ssim_fwd_bwd(ops, gpu_device, B, N, h, w, scale):
     frac_close(T.grad, T2.grad, 1e-4 * ts, rtol=1e-3, what="fused vs unfused dT")
 
 
+def test_fused_planar_image_gradients_tight(ops, gpu_device):
+    """The fused march on a source image that is affine in (u, v), against a target offset far enough that no L1 sign
+    flips: the sampler's coordinate gradient is then the same in every cell (floor() flips cannot change it), so the
+    depth / pose gradients of L1 + SSIM must match the fp64 oracle tightly -- the fused counterpart of
+    test_warp_bwd_planar_image_tight."""
+    B, N, h, w = 2, 4, 64, 208
+    _, depth, K, pose = warp_inputs(B, N, h, w, 78, 2)
+    vv, uu = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    plane = torch.stack([0.003 * uu - 0.002 * vv, 0.001 * uu + 0.004 * vv - 0.3, -0.002 * uu + 0.1], dim=-1)
+    src = plane.reshape(1, 1, h, w, 3).repeat(B, N, 1, 1, 1).contiguous()
+    g = gen(18)
+    tgt = (plane.reshape(1, h, w, 3).repeat(B, 1, 1, 1) + 0.35 + 0.02 * sd.smooth_noise((B, h, w, 3), g)).contiguous()
+    gl1, gss = torch.rand(B, generator=g) + 0.5, torch.rand(B, generator=g) + 0.5
+    d_ref = depth.clone().double().requires_grad_(True)
+    T_ref = ref_pose.pose_rvec2matr_batch(pose.double()).requires_grad_(True)
+    coords = rs.warp_pixel_coords(d_ref, T_ref, rs.scale_intrinsic(K.double(), 2), h, w)
+    synth_ref = rs.bilinear_interpolation(src.double(), coords, d_ref)
+    l1_ref = ref_loss.photometric_loss_l1(synth_ref, tgt.double())
+    ss_ref = ref_loss.photometric_loss_ssim(synth_ref, tgt.double())
+    ((l1_ref * gl1.double()).sum() + (ss_ref * gss.double()).sum()).backward()
+    d = depth.to(gpu_device).requires_grad_(True)
+    T = ref_pose.pose_rvec2matr_batch(pose).to(gpu_device).requires_grad_(True)
+    l1, ss = ops.photo_fused(src.to(gpu_device), d, T, K.to(gpu_device), tgt.to(gpu_device), 2)
+    ((l1 * gl1.to(gpu_device)).sum() + (ss * gss.to(gpu_device)).sum()).backward()
+    frac_close(l1, l1_ref, 1e-5, rtol=1e-4, what="fused L1 planar")
+    frac_close(ss, ss_ref, 1e-5, rtol=1e-4, what="fused SSIM planar")
+    frac_close(d.grad, d_ref.grad, 1e-4 * d_ref.grad.abs().max().item(), rtol=1e-3, max_bad_frac=2e-4, what="fused ddepth planar")
+    frac_close(T.grad, T_ref.grad, 2e-4 * T_ref.grad.abs().max().item(), rtol=1e-3, what="fused dT planar")
+
+
 @pytest.mark.parametrize("B,N,H,W,nscales", [(2, 4, 64, 208, 4), (3, 1, 32, 104, 3), (1, 4, 24, 70, 2)])
 def test_fused_multi_scale_launch_equals_per_scale_calls(ops, gpu_device, B, N, H, W, nscales):
     """xpt_photo_fused_ms_{fwd,bwd}: every scale of the pyramid in one march launch runs the SAME device function per

@@ -155,6 +155,10 @@ def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
     f_ms, b_ms, f_bytes, b_bytes, shape = measure_fused_ms(ops, feats, repeats)
     extra["fused_bwd_ms_kernel<0> (4 scales, + its finisher)"] = (b_ms, b_bytes)
     lf_ms, lb_ms, lf_bytes, lb_bytes, lshape = measure_fused_ms(ops, feats, max(repeats // 5, 5), batch=large_batch)
+    # configs[3]'s shape: 256 x 832, batch 4 (twice the pixels per launch at half the batch)
+    from ..utils import synthetic_data as sd
+    hfeats = {k: v.to(x["src"].device) for k, v in sd.make_features(4, 2 * H, 2 * W, feats["image5d"].shape[1], 7).items()}
+    hf_ms, hb_ms, hf_bytes, hb_bytes, hshape = measure_fused_ms(ops, hfeats, repeats)
     achieved = f_bytes / (f_ms * 1e-3) / 1e9
     traffic = _pmc_traffic("fused_fwd_ms_kernel", shape)
 
@@ -166,6 +170,11 @@ def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
             "traffic": traffic, "launch_us": round(f_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(f_bytes),
             "bytes_per_warped_pixel": round((16 + 12 * N) / N, 3), "shape": shape,
             "all": {k: {"launch_us": round(v[0] * 1e3, 3), "GBps": gbs(*v)} for k, v in extra.items()},
+            "hires": {"shape": hshape,
+                      "fwd": {"launch_us": round(hf_ms * 1e3, 2), "GBps": gbs(hf_ms, hf_bytes),
+                              "frac": round(gbs(hf_ms, hf_bytes) / hbm_peak_gbs, 4)},
+                      "bwd": {"launch_us": round(hb_ms * 1e3, 2), "GBps": gbs(hb_ms, hb_bytes),
+                              "frac": round(gbs(hb_ms, hb_bytes) / hbm_peak_gbs, 4)}},
             "large_batch": {"shape": lshape,
                             "fwd": {"launch_us": round(lf_ms * 1e3, 2), "GBps": gbs(lf_ms, lf_bytes),
                                     "frac": round(gbs(lf_ms, lf_bytes) / hbm_peak_gbs, 4)},
