@@ -125,6 +125,9 @@ def _apply_env_tuning():
     spec = os.environ.get("XPT_PW_WGRAD_TUNE")             # pointwise weight gradient: waves, row pairs per wave, max workgroups, KiB
     if spec:
         _lib.load().xpt_conv1x1_bwd_weight_tune(*[int(v) for v in spec.split(",")])
+    for code in os.environ.get("XPT_DW_TUNE", "").split(","):     # depthwise knobs (xpt_dwconv_tune codes, see xpt_hip.h)
+        if code:
+            _lib.load().xpt_dwconv_tune(int(code))
     cap = os.environ.get("XPT_PW_DEFER_CAP_MIB")           # pointwise weight gradient: MiB of split partials per layer
     if cap:
         _lib.load().xpt_conv1x1_bwd_weight_defer_cap(int(cap))
