@@ -375,6 +375,15 @@ int xpt_pool_pair_fwd(const void* in, long long in_pitch, void* mp, void* ap, vo
 int xpt_pool_pair_bwd(const void* gmp, long long pitch_m, const void* gap, long long pitch_a, const void* arg, void* dh, int B,
                       int H, int W, int C, int OH, int OW, int pad_t, int pad_l, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ f-3: the per-step depth metric of the training loop
+ * get_depth_metric (model/train_val.py:180-200) = valid_depth_filter + median scaling + abs-rel
+ * (evaluate/eval_utils.py:109-131) for every sample of the batch in one launch (radix selection instead of two sorts):
+ * per_sample[b] = mean over mask of |gt - clip(pred * median(gt)/median(pred), min, max)| / gt,
+ * mask = (gt > min_depth) & (gt < max_depth) & rows [r0, r1) & columns [c0, c1) (the Garg crop); 0 for an empty mask.
+ * pred, gt [B, h, w] float32 contiguous. */
+int xpt_depth_metric(const float* pred, const float* gt, float* per_sample, int B, int h, int w, int r0, int r1, int c0,
+                     int c1, float min_depth, float max_depth, void* stream);
+
 /* ------------------------------------------------------------------ deferred parameter gradients (one finishing launch per step)
  * The *_partials entry points compute the same parameter gradients as xpt_affine_act_bwd / xpt_dwconv_bwd_weight /
  * xpt_conv1x1_bwd_weight (tape.gradient of the layer variables, model/train_val.py:85-86) but stop at the

@@ -536,12 +536,30 @@ def fetch_results(results):
 
 def get_depth_metric(features, preds):
     """train_val.py:180-200 + evaluate/eval_utils.py:109-131 (valid_depth_filter: 1e-3 < gt < 80, Garg crop,
-    median scaling, clip) -> mean abs-rel over the batch, computed on the device for the whole batch at once (two
-    batched sorts instead of the reference's per-sample numpy loop; ~20 launches, no host synchronisation)."""
+    median scaling, clip) -> mean abs-rel over the batch.  On the GPU ONE launch for the whole batch
+    (csrc/xpt_metric.hip: exact medians by radix selection; the library formulation below needs two full sorts, ~110
+    launches and 0.5 ms per step); host tensors take the batched torch formulation."""
     depth_pred = preds["depth_ms"][0].detach()[..., 0].float()
     depth_true = features["depth_gt"][..., 0]
     B, h, w = depth_true.shape
     crop = (np.array([0.40810811 * h, 0.99189189 * h, 0.03594771 * w, 0.96405229 * w])).astype(np.int32)
+    if depth_true.is_cuda:
+        from ..hip import lib as _hip_lib
+        from ..hip import ops as _hip_ops
+        lib = _hip_lib.load()
+        pred_c, true_c = depth_pred.contiguous(), depth_true.float().contiguous()
+        per_sample = torch.empty(B, dtype=torch.float32, device=depth_true.device)
+        _hip_lib.check(lib.xpt_depth_metric(pred_c.data_ptr(), true_c.data_ptr(), per_sample.data_ptr(), B, h, w,
+                                            int(crop[0]), int(crop[1]), int(crop[2]), int(crop[3]), float(opts.MIN_DEPTH),
+                                            float(opts.MAX_DEPTH), _hip_ops._stream()), "xpt_depth_metric")
+        return per_sample.mean()
+    return depth_metric_batched(depth_pred, depth_true, crop)
+
+
+def depth_metric_batched(depth_pred, depth_true, crop):
+    """The same metric with torch ops on the whole batch (two batched sorts): host tensors, and the cross-check of the
+    kernel in tests/test_inloop_metrics_gpu.py."""
+    B, h, w = depth_true.shape
     crop_mask = torch.zeros((h, w), dtype=torch.bool, device=depth_true.device)
     crop_mask[crop[0]:crop[1], crop[2]:crop[3]] = True
     gt, pr = depth_true.reshape(B, -1), depth_pred.reshape(B, -1)
