@@ -254,7 +254,7 @@ class _MultiConv1x1Bn(torch.autograd.Function):
             sink.add(b_dst, bparts[j], 0, cout, nsplit, 2 * cout)
             sink.add(g_dst, bparts[j], cout, cout, nsplit, 2 * cout)
         need = [ctx.needs_input_grad[2 + j] for j in range(n)]
-        if n >= 3 and all(need):
+        if n >= 2 and all(need) and (n >= 3 or _is_stacked(shadows)):
             # data gradients of all layers as ONE strided-batched GEMM: the g_j are already one [n, M, cout] buffer and the
             # weights sit equally spaced in the flat shadow buffer (FlatParameters groups them: stack_groups()), so the
             # [n, cout, cin] operand is a strided view; one stack launch otherwise
@@ -264,6 +264,16 @@ class _MultiConv1x1Bn(torch.autograd.Function):
             dxs = [torch.mm(g_all[j], shadows[j]).view(B, H, W, cin).permute(0, 3, 1, 2) if need[j] else None
                    for j in range(n)]
         return (None, None, *dxs, *none, *none, *none, *none, *none, *dres)
+
+
+def _is_stacked(mats):
+    """True when the matrices sit equally spaced in one storage (no copy needed for the batched GEMM operand)."""
+    first = mats[0]
+    step = mats[1].data_ptr() - first.data_ptr()
+    return (step > 0 and step % first.element_size() == 0
+            and all(m.is_contiguous() and m.shape == first.shape for m in mats)
+            and all(m.data_ptr() - first.data_ptr() == j * step for j, m in enumerate(mats))
+            and all(m.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() for m in mats))
 
 
 def _stacked_view(mats):
@@ -469,7 +479,8 @@ class NormalCell(nn.Module):
         """Pointwise weights the wide cell consumes as one strided batch (order = the multi_conv1x1_bn calls below)."""
         blocks = (self.left1, self.left5, self.right1, self.left2, self.right2)
         return [[b.conv1.pointwise.weight for b in blocks],
-                [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight, self.left5.conv2.pointwise.weight]]
+                [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight, self.left5.conv2.pointwise.weight],
+                [self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight]]
 
     def forward(self, ip, p, taps):
         p = self.adjust(p, taps)
