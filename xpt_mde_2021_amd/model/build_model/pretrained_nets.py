@@ -546,7 +546,8 @@ class ReductionCell(nn.Module):
         self.out_channels = 4 * filters
 
     def stack_groups(self):
-        return [[b.conv1.pointwise.weight for b in (self.left1, self.right1, self.right2)]]
+        return [[b.conv1.pointwise.weight for b in (self.left1, self.right1, self.right2)],
+                [self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight]]
 
     def forward(self, ip, p, taps):
         p = self.adjust(p, taps)
