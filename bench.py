@@ -246,7 +246,9 @@ def run(args):
 
     result = None
     step_graph = getattr(trainer, "_graph", None)
-    if step_graph is not None and getattr(step_graph, "eager_fallback", False):
+    if step_graph is not None and getattr(step_graph, "library_path", False):
+        mode += " (library convolutions on the path: executed eagerly by design, DESIGN.md section 6)"
+    elif step_graph is not None and getattr(step_graph, "eager_fallback", False):
         mode += " (eager fallback: no captured step passed the replay check)"
     if getattr(trainer, "trains_flow_net", False):
         mode += " (PWC-Net is trained eagerly: see DESIGN.md section 6)"

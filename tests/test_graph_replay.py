@@ -29,6 +29,9 @@ def test_graph_replays_match_eager(gpu_device, nets, dtype):
                      if "[diff]" in l or "StepGraph" in l or "Error" in l)
     assert run.returncode == 0, f"replayed gradients differ from eager:\n{tail}"
     assert "eager fallback: False" in run.stdout and "repairs: 0" in run.stdout, tail
+    # bf16 = own kernels only: the step IS captured.  fp32 goes through MIOpen: by design such a step is executed
+    # eagerly (memset nodes of captured graphs are defective on this runtime), which the same comparison then covers
+    assert f"library path (executed eagerly by design): {dtype == 'fp32'}" in run.stdout, run.stdout[-1500:]
 
 
 def _loss_sequence(mode, aug, steps):

@@ -60,6 +60,7 @@ class _UpConvFp32(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        lo.note_library_conv(x)
         return F.conv_transpose2d(x, weight, None, 2, 1)
 
     @staticmethod

@@ -37,6 +37,17 @@ def make_activation(name, param=None):
 SMALL_MAP_AREA = int(__import__("os").environ.get("XPT_DEBUG_SMALL_MAP_AREA", "64"))     # A/B: 0 = library solvers everywhere
 
 
+# Convolutions that went through the library (MIOpen) on the GPU since process start.  A training step that contains any is
+# not captured into a hipGraph (train_val._StepGraph): MIOpen solvers that zero a workspace with a memset node return garbage
+# from the second replay on with this runtime; the bf16 rigid step has none.
+LIBRARY_CONV_CALLS = [0]
+
+
+def note_library_conv(tensor):
+    if tensor.is_cuda:
+        LIBRARY_CONV_CALLS[0] += 1
+
+
 class _ConvFp32WeightGrad(torch.autograd.Function):
     """Library convolution (MIOpen) whose WEIGHT gradient is always evaluated in fp32.
 
@@ -53,6 +64,7 @@ class _ConvFp32WeightGrad(torch.autograd.Function):
         w = _low_precision_weight(weight, compute_dtype)
         xc = x.to(compute_dtype)
         with torch.autocast(device_type=x.device.type, enabled=False):
+            note_library_conv(xc)
             y = F.conv2d(xc, w, None, stride, padding, dilation)
         ctx.save_for_backward(xc, weight)
         ctx.cfg = (stride, padding, compute_dtype, dilation, safe_dgrad)
@@ -194,6 +206,7 @@ class Conv2DSame(nn.Module):
         if fused and self.conv.groups == 1:
             y = conv2d_library(x, self.conv.weight, self.s, (ph[0], pw[0]), self.d, self.replay_safe_dgrad)
         else:
+            note_library_conv(x)
             y = F.conv2d(x, self.conv.weight, bias, self.s, (ph[0], pw[0]), self.d, self.conv.groups)
         if fused:
             return _ops.bias_act(y, self.conv.bias, self.slope)

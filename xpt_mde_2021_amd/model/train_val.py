@@ -214,6 +214,7 @@ class _StepGraph:
         self.signature = None
         self.cache = {}                        # input signature -> (graph, static inputs, static outputs)
         self.eager_fallback = False            # set when no capture of the step survives the replay check
+        self.library_path = False              # the step contains library (MIOpen) convolutions: executed eagerly by design
 
     @staticmethod
     def _sig(features):
@@ -243,6 +244,8 @@ class _StepGraph:
         self.static_in = {k: v.clone() for k, v in features.items() if torch.is_tensor(v)}
         state = self.state() if self.state is not None else []
         saved = [t.clone() for t in state]     # warm-up executes real steps: roll the weights / moments back after it
+        from .model_util import layer_ops as _lo
+        library_before = _lo.LIBRARY_CONV_CALLS[0]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -250,6 +253,21 @@ class _StepGraph:
                 self.fn(self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if _lo.LIBRARY_CONV_CALLS[0] > library_before and not getattr(opts, "CAPTURE_LIBRARY_STEPS", False):
+            # The step went through MIOpen (fp32 mode, PWC-Net's dilated / transposed convolutions): such steps are NOT
+            # captured.  Solvers that zero a workspace do it with a memset node, and memset nodes of a captured graph
+            # write garbage from the second replay on with this runtime -- which solver the library
+            # picks varies from run to run, the failure can appear after the replay check, and it can be silent (a net
+            # whose gradient is all zeros).  Eager execution of the same step is correct; opts.CAPTURE_LIBRARY_STEPS = True
+            # restores the capture (with the replay check) for those who accept that.
+            import sys
+            for t, s in zip(state, saved):
+                t.copy_(s)
+            print("[StepGraph] the step contains library (MIOpen) convolutions: it is executed eagerly, not captured",
+                  file=sys.stderr, flush=True)
+            self.library_path = self.eager_fallback = True
+            self.graph = None
+            return
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_out = self.fn(self.static_in)
