@@ -252,8 +252,8 @@ int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const fl
  *
  * xpt_conv_pack_weights: ONE launch converts the fp32 master weights into the kernels' bf16 operand layouts,
  *   fwd [N][KH*KW][Cp] (Cp = C rounded up to 8, zero filled) and bwd [Cp][KH*KW][Np] (Np = N rounded up to 8).
- *   jobs = device array of xpt_conv_pack_job (first_block = running sum of ceil((N*T*Cp + Cp*T*Np) / 256) over the
- *   preceding jobs; nblocks = the total).
+ *   jobs = device array of xpt_conv_pack_job (first_block = running sum of T * ceil(max(N, Np) / 64) * ceil(Cp / 64)
+ *   over the preceding jobs: one workgroup per tap and 64 x 64 channel tile; nblocks = the total).
  * xpt_conv2d_fwd: y[b,oh,ow,n] = act(bias[n] + sum_{kh,kw,c} x[b, oh*stride + kh - pad_t, ow*stride + kw - pad_l, c] w[n,kh,kw,c]),
  *   zero outside the input (TF SAME: asymmetric pads are given explicitly), act = LeakyReLU(slope) (1 = linear);
  *   x has PH x PW physical pixels of C channels (C % 8 == 0, pad channels must be finite); upsample = 1: the taps index

@@ -480,6 +480,7 @@ struct PackJob {
 __global__ __launch_bounds__(256) void conv_pack_kernel(const PackJob* __restrict__ jobs, int njobs) {
   // find the job of this workgroup (jobs are few: linear scan by one thread, broadcast through LDS)
   __shared__ int sj;
+  __shared__ float tile[64][65];            // [n][c] of one tap; 65: conflict-free transposed reads
   if (threadIdx.x == 0) {
     int j = 0;
     while (j + 1 < njobs && jobs[j + 1].first_block <= (long long)blockIdx.x) ++j;
@@ -487,24 +488,37 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const PackJob* __restric
   }
   __syncthreads();
   const PackJob jb = jobs[sj];
-  const long long local = ((long long)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
-  const long long nf = (long long)jb.N * jb.T * jb.Cp;
-  const long long nb = (long long)jb.Cp * jb.T * jb.Np;
-  if (local < nf) {                                            // forward layout: element (n, t, c)
-    const int c = (int)(local % jb.Cp);
-    const long long nt = local / jb.Cp;
-    const int t = (int)(nt % jb.T);
-    const long long n = nt / jb.T;
-    const float v = c < jb.C ? jb.src[n * jb.sn + (t / jb.KW) * jb.sh + (t % jb.KW) * jb.sw + c * jb.sc] : 0.f;
-    jb.fwd[local] = f2bf(v);
-  } else if (local < nf + nb && jb.bwd != nullptr) {           // backward layout: element (c, t, n)
-    const long long l2 = local - nf;
-    const int n = (int)(l2 % jb.Np);
-    const long long ct = l2 / jb.Np;
-    const int t = (int)(ct % jb.T);
-    const int c = (int)(ct / jb.T);
-    const float v = (n < jb.N && c < jb.C) ? jb.src[n * jb.sn + (t / jb.KW) * jb.sh + (t % jb.KW) * jb.sw + c * jb.sc] : 0.f;
-    jb.bwd[l2] = f2bf(v);
+  // a workgroup owns one tap and a 64 (output channels) x 64 (input channels) tile: the fp32 master is read along its
+  // contiguous axis, the forward layout [n][t][c] is written along c and the backward layout [c][t][n] along n (through
+  // the LDS transpose) -- one thread per element with a strided read made this launch 64 us per step
+  const int tiles_c = (jb.Cp + 63) / 64;
+  const int nmax = jb.Np > jb.N ? jb.Np : jb.N;
+  const int tiles_n = (nmax + 63) / 64;
+  int blk = (int)((long long)blockIdx.x - jb.first_block);
+  if (blk >= jb.T * tiles_n * tiles_c) return;
+  const int tc = blk % tiles_c; blk /= tiles_c;
+  const int tn = blk % tiles_n;
+  const int t = blk / tiles_n;
+  const int n0 = tn * 64, c0 = tc * 64;
+  const int kh = t / jb.KW, kw = t - kh * jb.KW;
+  const bool c_fast = jb.sc <= jb.sn;        // which axis of the master copy is the contiguous one
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int i = c_fast ? e >> 6 : e & 63, j = c_fast ? e & 63 : e >> 6;      // i: n offset, j: c offset
+    const int n = n0 + i, c = c0 + j;
+    tile[i][j] = (n < jb.N && c < jb.C) ? jb.src[n * jb.sn + kh * jb.sh + kw * jb.sw + c * jb.sc] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {           // forward layout: c fastest
+    const int i = e >> 6, j = e & 63;
+    const int n = n0 + i, c = c0 + j;
+    if (n < jb.N && c < jb.Cp) jb.fwd[((long long)n * jb.T + t) * jb.Cp + c] = f2bf(tile[i][j]);
+  }
+  if (jb.bwd != nullptr) {
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {         // backward layout: n fastest
+      const int j = e >> 6, i = e & 63;
+      const int n = n0 + i, c = c0 + j;
+      if (c < jb.Cp && n < jb.Np) jb.bwd[((long long)c * jb.T + t) * jb.Np + n] = f2bf(tile[i][j]);
+    }
   }
 }
 

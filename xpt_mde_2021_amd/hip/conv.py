@@ -102,7 +102,8 @@ class ConvWeightPacker:
                 job.sn, job.sc, job.sh, job.sw = sn, sc, sh, sw
                 job.N, job.T, job.KW, job.C, job.Cp, job.Np = e["N"], e["T"], e["KW"], e["C"], e["Cp"], e["Np"]
                 job.first_block = first
-                first += (e["N"] * e["T"] * e["Cp"] + e["Cp"] * e["T"] * e["Np"] + 255) // 256
+                # one workgroup per (tap, 64 output channels, 64 input channels) tile (csrc/xpt_conv.hip conv_pack_kernel)
+                first += e["T"] * ((max(e["N"], e["Np"]) + 63) // 64) * ((e["Cp"] + 63) // 64)
             if self.table is not None:
                 self.retired.append(self.table)     # a captured step may still launch with the old table
             self.table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(live[0][0].device)
