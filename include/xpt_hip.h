@@ -384,6 +384,11 @@ int xpt_pool_pair_bwd(const void* gmp, long long pitch_m, const void* gap, long 
 int xpt_depth_metric(const float* pred, const float* gt, float* per_sample, int B, int h, int w, int r0, int r1, int c0,
                      int c1, float min_depth, float max_depth, void* stream);
 
+/* get_pose_metric (model/train_val.py:203-210) = PoseMetricNumpy (evaluate/eval_utils.py:15-87) for the batch in one launch:
+ * out[0..2] = mean absolute-scale trajectory error, mean scale-aligned trajectory error, mean rotation error (radians) of
+ * pred [B, N, 4, 4] (pose matrices, e.g. from xpt_pose_rvec2matr_fwd) against truth [B, N, 4, 4]. */
+int xpt_pose_metric(const float* pred, const float* truth, float* out, int B, int N, void* stream);
+
 /* ------------------------------------------------------------------ deferred parameter gradients (one finishing launch per step)
  * The *_partials entry points compute the same parameter gradients as xpt_affine_act_bwd / xpt_dwconv_bwd_weight /
  * xpt_conv1x1_bwd_weight (tape.gradient of the layer variables, model/train_val.py:85-86) but stop at the

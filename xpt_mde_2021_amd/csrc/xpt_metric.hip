@@ -158,6 +158,78 @@ __global__ __launch_bounds__(NT) void depth_metric_kernel(const float* __restric
   if (threadIdx.x == 0) out[b] = err / (float)cnt;
 }
 
+// ------------------------------------------------------------------------------------------------ pose metrics
+// get_pose_metric (model/train_val.py:203-210) = PoseMetricNumpy (evaluate/eval_utils.py:15-87) for the whole batch in one
+// launch: the snippet [P0, P1, I (target), P2, ...] re-based on its first frame (inv(M0) M_j in closed form for rigid
+// transforms), then per frame j >= 1 the absolute-scale trajectory error |t_true - t_pred|, the scale-aligned one
+// |t_true - t_pred (t_true . t_pred) / (t_pred . t_pred)| and the rotation angle acos((tr(R_pred^T R_true) - 1) / 2);
+// out = their means over batch x frames.  ~60 tiny launches of matrix slicing / bmm / norm before.
+struct Rigid {
+  float R[9], t[3];
+};
+
+__device__ inline Rigid load_frame(const float* __restrict__ mats, int b, int N, int f) {
+  // frame f of [poses[:2], identity, poses[2:]]
+  Rigid m;
+  const int split = N < 2 ? N : 2;
+  if (f == split) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m.R[i] = (i % 4 == 0) ? 1.f : 0.f;
+    m.t[0] = m.t[1] = m.t[2] = 0.f;
+    return m;
+  }
+  const float* p = mats + ((long long)b * N + (f < split ? f : f - 1)) * 16;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) m.R[3 * i + j] = p[4 * i + j];
+    m.t[i] = p[4 * i + 3];
+  }
+  return m;
+}
+
+// inv(a) * c for rigid transforms: R = Ra^T Rc, t = Ra^T (tc - ta)
+__device__ inline Rigid relative_to(const Rigid& a, const Rigid& c) {
+  Rigid o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o.R[3 * i + j] = a.R[i] * c.R[j] + a.R[3 + i] * c.R[3 + j] + a.R[6 + i] * c.R[6 + j];
+    o.t[i] = a.R[i] * (c.t[0] - a.t[0]) + a.R[3 + i] * (c.t[1] - a.t[1]) + a.R[6 + i] * (c.t[2] - a.t[2]);
+  }
+  return o;
+}
+
+__global__ __launch_bounds__(256) void pose_metric_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
+                                                          float* __restrict__ out, int B, int N) {
+  __shared__ float red[3][256];
+  float s_abs = 0.f, s_rel = 0.f, s_rot = 0.f;
+  const int items = B * N;                                  // frames 1 .. N of every snippet
+  for (int it = threadIdx.x; it < items; it += 256) {
+    const int b = it / N, f = it % N + 1;
+    const Rigid p = relative_to(load_frame(pred, b, N, 0), load_frame(pred, b, N, f));
+    const Rigid q = relative_to(load_frame(truth, b, N, 0), load_frame(truth, b, N, f));
+    const float d0 = q.t[0] - p.t[0], d1 = q.t[1] - p.t[1], d2 = q.t[2] - p.t[2];
+    s_abs += sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+    const float sc = (q.t[0] * p.t[0] + q.t[1] * p.t[1] + q.t[2] * p.t[2]) / (p.t[0] * p.t[0] + p.t[1] * p.t[1] + p.t[2] * p.t[2]);
+    const float e0 = q.t[0] - p.t[0] * sc, e1 = q.t[1] - p.t[1] * sc, e2 = q.t[2] - p.t[2] * sc;
+    s_rel += sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+    float tr = 0.f;                                         // trace(Rp^T Rq) = sum_ij Rp[i][j] Rq[i][j]
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tr += p.R[i] * q.R[i];
+    s_rot += acosf(fminf(fmaxf((tr - 1.f) * 0.5f, -1.f), 1.f));
+  }
+  red[0][threadIdx.x] = s_abs;
+  red[1][threadIdx.x] = s_rel;
+  red[2][threadIdx.x] = s_rot;
+  __syncthreads();
+  if (threadIdx.x < 3) {                                    // fixed order: deterministic
+    float t = 0.f;
+    for (int i = 0; i < 256; ++i) t += red[threadIdx.x][i];
+    out[threadIdx.x] = t / (float)items;
+  }
+}
+
 }  // namespace
 
 /* per_sample[b] = abs-rel of pred[b] against gt[b] after valid_depth_filter + median scaling (see the file header);
@@ -170,5 +242,16 @@ extern "C" int xpt_depth_metric(const float* pred, const float* gt, float* per_s
   const MetricDims d{B, h, w, r0, r1, c0, c1, min_depth, max_depth};
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(depth_metric_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, pred, gt, per_sample, d);
+  return xpt_launch_status();
+}
+
+/* out[0..2] = mean absolute-scale trajectory error, mean scale-aligned trajectory error, mean rotation error (radians) of
+ * the predicted pose matrices pred [B, N, 4, 4] against truth [B, N, 4, 4] (both target -> source transforms; the snippet is
+ * re-based on its first frame with the identity target pose inserted after the second source). */
+extern "C" int xpt_pose_metric(const float* pred, const float* truth, float* out, int B, int N, void* stream) {
+  XPT_CHECK_PTR(pred); XPT_CHECK_PTR(truth); XPT_CHECK_PTR(out);
+  if (B <= 0 || N <= 0) return XPT_ERR_SHAPE;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(pose_metric_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, truth, out, B, N);
   return xpt_launch_status();
 }

@@ -608,6 +608,14 @@ def get_pose_metric(preds, features):
     from ..utils import convert_pose as cp
     pred = cp.pose_rvec2matr_batch_tf(pose)                # [B, N, 4, 4] (utils/convert_pose.py:32-71; the gfx950 kernel)
     true = features["pose_gt"].float()
+    if pred.is_cuda:                                       # one launch for the three means (csrc/xpt_metric.hip)
+        from ..hip import lib as _hip_lib
+        from ..hip import ops as _hip_ops
+        out = torch.empty(3, dtype=torch.float32, device=pred.device)
+        pred_c, true_c = pred.contiguous(), true.contiguous()
+        _hip_lib.check(_hip_lib.load().xpt_pose_metric(pred_c.data_ptr(), true_c.data_ptr(), out.data_ptr(), pred.shape[0],
+                                                       pred.shape[1], _hip_ops._stream()), "xpt_pose_metric")
+        return out[0], out[1], out[2]
 
     def from_first(poses):                       # [B, N, 4, 4] -> [B, N + 1, 4, 4], target (identity) in the middle
         eye = torch.eye(4, device=poses.device).expand(poses.shape[0], 1, 4, 4)
