@@ -200,9 +200,11 @@ def run(args):
         return launcher_selftest(args, world, rank, local_rank), world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP ops have no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # (XPT_DIST_BACKEND=gloo + several ranks on one card: the rehearsal of the data-parallel GPU path on a one-GPU box,
+    #  tests/test_dp_gpu_rehearsal.py; the real thing is nccl = RCCL with one card per rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     if world > 1:
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend=os.environ.get("XPT_DIST_BACKEND", "nccl"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     # seeded weights and augmentation draws (per rank): "final_loss" is then the same number in every run of one build

@@ -32,9 +32,9 @@ class DistributionStrategy:
             if not dist.is_initialized():
                 if "RANK" not in os.environ:
                     return None                                # single process: no strategy, like non-distributed modes
-                backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-                if backend == "nccl":
-                    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+                backend = backend or os.environ.get("XPT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+                if torch.cuda.is_available():
+                    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
                 dist.init_process_group(backend=backend)
             cls.strategy = cls(dist.get_backend())
             opts.BATCH_SIZE = cls.strategy.num_replicas_in_sync * opts.PER_REPLICA_BATCH      # distributer.py:12

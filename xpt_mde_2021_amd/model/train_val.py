@@ -469,7 +469,10 @@ class ModelTrainerDistrib(ModelTrainer):
         self.set_name("Train (distributed)")
         self.strategy = DistributionStrategy.get_strategy()
         if self.strategy is not None:
-            self.strategy.broadcast_parameters(self.optimizer.flat.data)
+            flat = self.optimizer.flat
+            self.strategy.broadcast_parameters(flat.data)
+            if flat.shadow is not None:          # the bf16 copies the kernels read follow the broadcast weights at once
+                flat.shadow.copy_(flat.data)     # (otherwise only the first Adam step would refresh them)
         weights = getattr(loss_object, "loss_weights", None) or {}           # see ModelTrainerGraph
         self.trains_flow_net = "flownet" in getattr(model, "models", {}) and any(k.startswith("flow") for k in weights)
         self._graph = _StepGraph(self.forward_backward, state=self.optimizer_state, describe=self.describe_state,
