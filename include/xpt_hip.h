@@ -375,6 +375,21 @@ int xpt_pool_pair_fwd(const void* in, long long in_pitch, void* mp, void* ap, vo
 int xpt_pool_pair_bwd(const void* gmp, long long pitch_m, const void* gap, long long pitch_a, const void* arg, void* dh, int B,
                       int H, int W, int C, int OH, int OW, int pad_t, int pad_l, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ f-2: the in-step augmentation
+ * TotalAugment over [CropAndResize(p_crop), HorizontalFlip(p_flip), ColorJitter(p_jit)] (model/model_util/augmentation.py:
+ * 22-219; called inside the training step, model/train_val.py:79-81) in ONE launch: crop box from four uniforms (:94-109),
+ * tf.image.crop_and_resize sampling (bilinear, corner aligned, zeros outside; nearest for the ground-truth depth), image
+ * flip, saturation + gamma jitter, and the matching rewrites of intrinsics (:111-129, :169-173), ground-truth poses and the
+ * stereo extrinsic (:175-186).  u [8] device uniforms in [0,1): crop y1, x1, y2, x2; flip; jitter; gamma; saturation;
+ * params [8] out: the box, flip (0/1), jitter (0/1), gamma, saturation.  img / img_out [n_img, H, W, 3] float32 (second
+ * pair: the right camera, or NULL); depth [n_depth, H, W] or NULL; K [B, 3, 3]; pose [n_pose, 4, 4] or NULL; stereo
+ * [B, 4, 4] or NULL.  Outputs must not alias inputs. */
+int xpt_augment(const float* u, float* params, const float* img0, float* img0_out, const float* img1, float* img1_out,
+                int n_img, const float* depth, float* depth_out, int n_depth, const float* K0, float* K0_out, const float* K1,
+                float* K1_out, int B, const float* pose0, float* pose0_out, const float* pose1, float* pose1_out, int n_pose,
+                const float* stereo, float* stereo_out, int H, int W, float p_crop, float p_flip, float p_jit,
+                float half_crop, void* stream);
+
 /* ------------------------------------------------------------------ f-3: the per-step depth metric of the training loop
  * get_depth_metric (model/train_val.py:180-200) = valid_depth_filter + median scaling + abs-rel
  * (evaluate/eval_utils.py:109-131) for every sample of the batch in one launch (radix selection instead of two sorts):

@@ -46,3 +46,88 @@ def test_flip_and_identity_crop_images_on_device(gpu_device):
     same = cropper(dict(feats))
     assert torch.allclose(same["image5d"], feats["image5d"], atol=1e-5)
     assert torch.allclose(same["intrinsic"], feats["intrinsic"], atol=1e-4)
+
+
+def _sequential(feats, params, p_crop):
+    """The augmenter chain composed from the per-class methods with the parameters the fused kernel reports."""
+    box, flip, jit, gamma, sat = params[0:4], bool(params[4] > 0.5), bool(params[5] > 0.5), params[6], params[7]
+    f = dict(feats)
+    cropper = aug.CropAndResize(aug_prob=p_crop)
+    cropper.random_crop_boxes = lambda n, device=None: box.unsqueeze(0).repeat(n, 1)
+    f = cropper(f)
+    if flip:
+        f = aug.HorizontalFlip(aug_prob=1.1)(f)
+    if jit:
+        for key in ("image5d", "image5d_R"):
+            if key in f:
+                f[key] = aug.ColorJitter().jitter_color(f[key], gamma, sat)
+    return f
+
+
+@pytest.mark.parametrize("u", [
+    [0.1, 0.2, 0.3, 0.4, 0.9, 0.9, 0.5, 0.5],          # identity box (all four draws clamp), no flip, no jitter
+    [0.95, 0.99, 0.03, 0.01, 0.05, 0.9, 0.5, 0.5],     # all four sides cropped, flip
+    [0.9, 0.1, 0.5, 0.02, 0.9, 0.1, 0.9, 0.1],         # two sides cropped, jitter (gamma 1.4, saturation 0.6)
+    [0.97, 0.93, 0.06, 0.04, 0.1, 0.1, 0.05, 0.95],    # everything at once
+])
+@pytest.mark.parametrize("stereo", [False, True])
+def test_fused_augmentation_equals_the_chain(gpu_device, u, stereo):
+    """xpt_augment (one launch) == CropAndResize -> HorizontalFlip -> ColorJitter composed from the per-class methods, for
+    images, ground-truth depth, intrinsics, ground-truth poses and the stereo extrinsic."""
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    B, S, H, W = 2, 5, 20, 36
+    feats = {"image5d": (torch.rand(B, S, H, W, 3, generator=g) * 2 - 1).to(dev),
+             "intrinsic": torch.tensor([[[18., 0, 17.5], [0, 16., 9.5], [0, 0, 1]]]).repeat(B, 1, 1).to(dev),
+             "depth_gt": (torch.rand(B, H, W, 1, generator=g) * 10).to(dev),
+             "pose_gt": ref_pose.pose_rvec2matr_batch(torch.rand(B, 4, 6, generator=g) - 0.5).to(dev)}
+    if stereo:
+        feats["image5d_R"] = (torch.rand(B, S, H, W, 3, generator=g) * 2 - 1).to(dev)
+        feats["intrinsic_R"] = feats["intrinsic"] * 1.01
+        feats["pose_gt_R"] = ref_pose.pose_rvec2matr_batch(torch.rand(B, 4, 6, generator=g) - 0.5).to(dev)
+        feats["stereo_T_LR"] = ref_pose.pose_rvec2matr_batch(torch.rand(B, 1, 6, generator=g) - 0.5)[:, 0].to(dev)
+    probs = {"CropAndResize": 0.2, "HorizontalFlip": 0.2, "ColorJitter": 0.2}
+    total = aug.augmentation_factory(probs)
+    assert total._fusable(feats)
+    got = total._fused(feats, torch.tensor(u, device=dev))
+    params = total.params
+    assert bool(params[4] > 0.5) == (u[4] < 0.2) and bool(params[5] > 0.5) == (u[5] < 0.2)
+    assert torch.allclose(params[6:8].cpu(), torch.tensor([u[6] + 0.5, u[7] + 0.5]))
+    want = _sequential(feats, params, 0.2)
+    assert set(got) == set(want) == set(feats)
+    for key in want:
+        a, b = got[key], want[key]
+        assert a.shape == b.shape, key
+        if key == "depth_gt":      # nearest neighbour: a sample within rounding of x.5 may pick the other texel
+            assert (a != b).float().mean().item() < 2e-3, key
+        elif key.startswith("image5d") and bool(params[5] > 0.5):
+            # x ** gamma with gamma < 1 has an unbounded slope at 0: rounding-level differences of the bilinear sample
+            # (1e-7) grow to 1e-4 on near-black pixels -- in any two implementations
+            # -> compared before the gamma curve (x = ((y + 1) / 2) ** (1 / gamma)) at the usual bar, after it loosely
+            inv = 1.0 / float(params[6])
+            ua, ub = ((a + 1) / 2).clamp_min(0) ** inv, ((b + 1) / 2).clamp_min(0) ** inv
+            assert torch.allclose(ua, ub, atol=3e-5, rtol=1e-5), (key, (ua - ub).abs().max().item())
+            assert (a - b).abs().max().item() < 3e-3, (key, (a - b).abs().max().item())
+        else:
+            assert torch.allclose(a, b, atol=3e-5, rtol=1e-5), (key, (a - b).abs().max().item())
+    # the inputs are untouched
+    assert torch.equal(feats["intrinsic"][0], torch.tensor([[18., 0, 17.5], [0, 16., 9.5], [0, 0, 1]], device=dev))
+
+
+def test_fused_augmentation_draws_like_the_chain(gpu_device):
+    """The crop box the kernel derives from its uniforms has the distribution of CropAndResize.random_crop_boxes: each side
+    is cropped with probability aug_prob, by at most 10 %; flip / jitter fire with their probabilities."""
+    dev = gpu_device
+    torch.manual_seed(11)
+    feats = {"image5d": torch.zeros(1, 5, 8, 12, 3, device=dev), "intrinsic": torch.eye(3, device=dev).unsqueeze(0)}
+    total = aug.augmentation_factory({"CropAndResize": 0.3, "HorizontalFlip": 0.25, "ColorJitter": 0.4})
+    rows = []
+    for _ in range(400):
+        total(feats)
+        rows.append(total.params.clone())
+    p = torch.stack(rows).cpu()
+    assert (p[:, 0:2] >= 0).all() and (p[:, 0:2] <= 0.1 + 1e-6).all() and (p[:, 2:4] >= 0.9 - 1e-6).all() and (p[:, 2:4] <= 1).all()
+    cropped = torch.cat([(p[:, 0:2] > 0).float(), (p[:, 2:4] < 1).float()], dim=1).mean().item()
+    assert abs(cropped - 0.3) < 0.05, cropped
+    assert abs(p[:, 4].mean().item() - 0.25) < 0.07 and abs(p[:, 5].mean().item() - 0.4) < 0.08
+    assert (p[:, 6:8] >= 0.5).all() and (p[:, 6:8] < 1.5).all()

@@ -27,6 +27,8 @@ class TotalAugment:
         self.augment_objects = augment_objects or []
 
     def __call__(self, features):
+        if self._fusable(features):
+            return self._fused(features)
         feat_aug = dict(features)                      # never mutate the caller's dict (augmentation.py:33-38)
         for augmenter in self.augment_objects:
             feat_aug = augmenter(feat_aug)
@@ -34,6 +36,65 @@ class TotalAugment:
             if "image5d" + sfx in feat_aug:
                 feat_aug["image5d" + sfx] = feat_aug["image5d" + sfx].contiguous()
         return feat_aug
+
+
+    # ---- gfx950 fast path: the default chain [CropAndResize, HorizontalFlip, ColorJitter] on device tensors in ONE launch
+    #      (csrc/xpt_augment.hip) instead of ~60 (0.49 ms of an 8.5 ms step)
+    def _fusable(self, features):
+        img = features.get("image5d")
+        objs = self.augment_objects
+        return (torch.is_tensor(img) and img.is_cuda and img.dtype == torch.float32 and img.dim() == 5 and img.shape[-1] == 3
+                and "intrinsic" in features and [type(a) for a in objs] == [CropAndResize, HorizontalFlip, ColorJitter]
+                and all(a.aug_prob > 0 for a in objs))
+
+    def _fused(self, features, u=None):
+        from ...hip import lib as _lib
+        from ...hip import ops as _ops
+        crop, flip, jit = self.augment_objects
+        lib = _lib.load()
+        img = features["image5d"].contiguous()
+        b, s, h, w, _ = img.shape
+        dev = img.device
+        if u is None:
+            u = torch.rand(8, device=dev)             # device generator: new draws on every replay of a captured step
+        params = torch.empty(8, device=dev)
+        out = dict(features)
+
+        def pair(key, shape_tail):
+            x = features.get(key)
+            if x is None:
+                return None, None
+            x = x.contiguous().float()
+            if tuple(x.shape[-len(shape_tail):]) != shape_tail:
+                raise WrongInputException(f"augmentation: {key} has shape {tuple(x.shape)}")
+            y = torch.empty_like(x)
+            out[key] = y
+            return x, y
+
+        img0_out = torch.empty_like(img)
+        out["image5d"] = img0_out
+        img1, img1_out = pair("image5d_R", (h, w, 3))
+        depth, depth_out = pair("depth_gt", (h, w, 1))
+        k0, k0_out = pair("intrinsic", (3, 3))
+        k1, k1_out = pair("intrinsic_R", (3, 3))
+        p0, p0_out = pair("pose_gt", (4, 4))
+        p1, p1_out = pair("pose_gt_R", (4, 4))
+        st, st_out = pair("stereo_T_LR", (4, 4))
+        if img1 is not None and img1.shape != img.shape:
+            raise WrongInputException("augmentation: image5d_R must have the shape of image5d")
+        n_pose = 0 if p0 is None else p0.numel() // 16
+        if p1 is not None and p1.numel() // 16 != n_pose:
+            raise WrongInputException("augmentation: pose_gt_R must have the shape of pose_gt")
+        ptr = _ops._ptr
+        _lib.check(lib.xpt_augment(ptr(u), ptr(params), ptr(img), ptr(img0_out), ptr(img1), ptr(img1_out), b * s, ptr(depth),
+                                   ptr(depth_out), 0 if depth is None else depth.shape[0], ptr(k0), ptr(k0_out), ptr(k1),
+                                   ptr(k1_out), b, ptr(p0), ptr(p0_out), ptr(p1), ptr(p1_out), n_pose, ptr(st), ptr(st_out),
+                                   h, w, float(crop.aug_prob), float(flip.aug_prob), float(jit.aug_prob),
+                                   float(crop.half_crop_ratio), _ops._stream()), "xpt_augment")
+        crop.param = params[0:4]
+        jit.param = params[6:8] * params[5]
+        self.params = params
+        return out
 
 
 class AugmentBase:
