@@ -390,6 +390,11 @@ int xpt_augment(const float* u, float* params, const float* img0, float* img0_ou
                 const float* stereo, float* stereo_out, int H, int W, float p_crop, float p_flip, float p_jit,
                 float half_crop, void* stream);
 
+/* Encoder input as PretrainedModel prepares it (model/build_model/pretrained_nets.py:36-43): image / 127.5 - 1, bilinear resize
+ * (TF2 half-pixel centres) to (H+2, W+2), written as the NHWC bf16 tensor [B, H+2, W+2, 8] (channels 3..7 zero) the stem
+ * convolution reads.  image: B frames [H, W, 3] float32, frame b at image + b * batch_stride elements. */
+int xpt_stem_input(const float* image, long long batch_stride, void* out, int B, int H, int W, void* stream);
+
 /* ------------------------------------------------------------------ f-3: the per-step depth metric of the training loop
  * get_depth_metric (model/train_val.py:180-200) = valid_depth_filter + median scaling + abs-rel
  * (evaluate/eval_utils.py:109-131) for every sample of the batch in one launch (radix selection instead of two sorts):

@@ -156,3 +156,26 @@ def test_head_conv_fwd_bwd(gpu_device, C, H, W):
     assert (xd.grad.float().cpu() - xr.grad).abs().max().item() < 6e-3 * xr.grad.abs().max().item()   # bf16 dx
     assert (wd.grad.cpu() - wr.grad).abs().max().item() < 1e-4 * wr.grad.abs().max().item()
     assert abs(bd.grad.item() - br.grad.item()) < 1e-4 * max(abs(br.grad.item()), 1.0)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 128, 416), (1, 37, 53), (3, 64, 192)])
+def test_stem_input_matches_the_reference_preprocessing(gpu_device, B, H, W):
+    """xpt_stem_input == PretrainedModel's preprocessing (pretrained_nets.py:36-43: image / 127.5 - 1, TF2 bilinear resize
+    to (H+2, W+2)) followed by the bf16 cast and the 3 -> 8 channel padding the stem convolution reads; the frame is read in
+    place out of a [B, S, H, W, 3] snippet tensor."""
+    from xpt_mde_2021_amd.hip import conv as xc
+    g = torch.Generator().manual_seed(H)
+    image5d = (torch.rand(B, 5, H, W, 3, generator=g) * 255.0).to(gpu_device)
+    image = image5d[:, -1].permute(0, 3, 1, 2)                      # [B,3,H,W] view of the NHWC target frame
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert xc.stem_input_usable(image)
+        got = xc.stem_input(image)
+    assert not xc.stem_input_usable(image)                          # outside bf16 autocast: the tensor-op path
+    x = image / 127.5 - 1.0
+    want = F.interpolate(x, size=(H + 2, W + 2), mode="bilinear", align_corners=False, antialias=False).to(torch.bfloat16)
+    assert got.shape == (B, 8, H + 2, W + 2) and got.dtype == torch.bfloat16
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert float(got[:, 3:].abs().max()) == 0.0
+    diff = (got[:, :3].float() - want.float()).abs()
+    # same fp32 expression, then one bf16 rounding: a last-bit difference of the fp32 value can flip that rounding
+    assert (diff > 0).float().mean().item() < 1e-3 and diff.max().item() <= 2 ** -7

@@ -166,7 +166,62 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ encoder input
+// PretrainedModel's preprocessing (model/build_model/pretrained_nets.py:36-43): x = image / 127.5 - 1, bilinear resize to
+// (H + 2, W + 2) (TF2 half-pixel centres, no antialias) so that the "valid" stem convolution returns H/2 x W/2 -- written
+// straight in the layout that convolution reads: NHWC bf16 with the 3 channels padded to 8 (one 16-byte store per pixel).
+// As tensor ops: div, sub, resize, cast, zero fill + copy of the channel pad = 6 launches.
+__global__ __launch_bounds__(256) void stem_input_kernel(const float* __restrict__ img, long long batch_stride,
+                                                         unsigned short* __restrict__ out, int B, int H, int W) {
+  const int OH = H + 2, OW = W + 2;
+  const long long total = (long long)B * OH * OW;
+  const float ry = (float)H / (float)OH, rx = (float)W / (float)OW;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
+    const int x = (int)(p % OW);
+    const long long r = p / OW;
+    const int y = (int)(r % OH);
+    const long long b = r / OH;
+    const float fy = fmaxf(ry * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(rx * ((float)x + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const float* base = img + b * batch_stride;
+    const float* q00 = base + ((long long)y0 * W + x0) * 3;
+    const float* q01 = base + ((long long)y0 * W + x1) * 3;
+    const float* q10 = base + ((long long)y1 * W + x0) * 3;
+    const float* q11 = base + ((long long)y1 * W + x1) * 3;
+    unsigned short v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float a00 = q00[c] / 127.5f - 1.f, a01 = q01[c] / 127.5f - 1.f, a10 = q10[c] / 127.5f - 1.f,
+                  a11 = q11[c] / 127.5f - 1.f;
+      // at::upsample_bilinear2d: (1 - wy) * ((1 - wx) a00 + wx a01) + wy * ((1 - wx) a10 + wx a11)
+      const float t = (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
+      v[c] = __builtin_bit_cast(unsigned short, (__bf16)t);
+    }
+    uint4 pk;
+    pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2]; pk.z = 0u; pk.w = 0u;
+    *(uint4*)(out + p * 8) = pk;
+  }
+}
+
 }  // namespace
+
+/* Encoder input of NASNetMobile as the reference prepares it (pretrained_nets.py:36-43): out [B, H+2, W+2, 8] bf16 NHWC
+ * (channels 3..7 zero) = resize_bilinear(image / 127.5 - 1, (H+2, W+2)); image: B frames of [H, W, 3] float32, frame b at
+ * image + b * batch_stride (elements) -- the target frame of a snippet tensor is read in place. */
+extern "C" int xpt_stem_input(const float* image, long long batch_stride, void* out, int B, int H, int W, void* stream) {
+  XPT_CHECK_PTR(image); XPT_CHECK_PTR(out);
+  if (B <= 0 || H <= 0 || W <= 0 || batch_stride < (long long)H * W * 3) return XPT_ERR_SHAPE;
+  if (((uintptr_t)out) % 16 != 0) return XPT_ERR_ARG;
+  const long long total = (long long)B * (H + 2) * (W + 2);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(stem_input_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, image, batch_stride,
+                     (unsigned short*)out, B, H, W);
+  return xpt_launch_status();
+}
 
 /* One launch for TotalAugment([CropAndResize(p_crop), HorizontalFlip(p_flip), ColorJitter(p_jit)]):
  * u [8] uniforms in [0, 1) (device), params [8] out (box y1 x1 y2 x2, flip, jitter, gamma, saturation);

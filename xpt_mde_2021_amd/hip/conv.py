@@ -303,6 +303,25 @@ def usable(x, conv, slope):
         and conv.weight.dtype == torch.float32
 
 
+def stem_input_usable(image):
+    """[B,3,H,W] float32 view of NHWC frames (channel stride 1, pixel stride 3) on the GPU under bf16 autocast."""
+    if not (torch.is_tensor(image) and image.is_cuda and image.dtype == torch.float32 and image.dim() == 4
+            and image.shape[1] == 3 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        return False
+    sb, sc, sh, sw = image.stride()
+    return sc == 1 and sw == 3 and sh == 3 * image.shape[3] and sb >= 3 * image.shape[2] * image.shape[3]
+
+
+def stem_input(image):
+    """PretrainedModel's preprocessing + the stem convolution's input layout in one launch (csrc/xpt_augment.hip
+    stem_input_kernel): [B,3,H,W] float32 (NHWC view) -> [B,8,H+2,W+2] bf16 channels_last, channels 3..7 zero."""
+    lib = _lib.load()
+    B, _, H, W = image.shape
+    out = torch.empty((B, 8, H + 2, W + 2), dtype=torch.bfloat16, device=image.device, memory_format=torch.channels_last)
+    _lib.check(lib.xpt_stem_input(image.data_ptr(), image.stride(0), out.data_ptr(), B, H, W, _stream()), "xpt_stem_input")
+    return out
+
+
 def restack_bf16(image5d, channels_padded):
     """restack_on_channels (pose_net.py:44-50) + cast: [B,S,H,W,3] float32 -> [B,Cp,H,W] bf16 (NHWC storage)."""
     lib = _lib.load()

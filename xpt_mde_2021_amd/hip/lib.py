@@ -87,6 +87,7 @@ SIGNATURES = {
     "xpt_photo_fused_ms_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),
     "xpt_augment": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i,
                          _f, _f, _f, _f, _p]),
+    "xpt_stem_input": (_i, [_p, ctypes.c_longlong, _p, _i, _i, _i, _p]),
     "xpt_pose_metric": (_i, [_p, _p, _p, _i, _i, _p]),
     "xpt_depth_metric": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p]),
     "xpt_adjust_gather": (_i, [_p, ctypes.c_longlong, _p, _i, _i, _i, _i, _i, _p]),

@@ -682,13 +682,19 @@ class NASNetMobileEncoder(nn.Module):
 
     def forward(self, image):
         taps = _Taps(self.TAP_ACTIVATIONS)
+        if _conv.stem_input_usable(image) and self.stem_conv.weight.dtype == torch.float32:
+            # preprocessing, resize, cast and channel padding in one launch, then the matrix-core stem convolution
+            x = _conv.conv2d_same(_conv.stem_input(image), self.stem_conv.weight, None, 2, 1.0, valid=True)
+            return self._cells(self.stem_bn(x), taps)
         x = self.preprocess(image)
         if _conv.usable(x, self.stem_conv, 1.0):          # keras Conv2D(32, 3, strides 2, padding="valid") on the matrix cores
             x = F.pad(x.to(torch.bfloat16), (0, 0, 0, 0, 0, 5))                   # 3 -> 8 channels (16-byte pixel rows)
             x = _conv.conv2d_same(x, self.stem_conv.weight, None, 2, 1.0, valid=True)
         else:
             x = conv2d_library(x, self.stem_conv.weight, 2, (0, 0))
-        x = self.stem_bn(x)
+        return self._cells(self.stem_bn(x), taps)
+
+    def _cells(self, x, taps):
         p = None
         for cell in self.cells:
             x, p = cell(x, x if p is None else p, taps)

@@ -159,6 +159,7 @@ class _WeightedTotal(torch.autograd.Function):
         ctx.save_for_backward(c_vec)
         ctx.shape = tuple(stacked.shape)
         ctx.mark_non_differentiable(row_sums)
+        ctx.set_materialize_grads(False)         # no zero-filled gradient for the non-differentiable second output
         return torch.dot(c_vec, row_sums), row_sums
 
     @staticmethod

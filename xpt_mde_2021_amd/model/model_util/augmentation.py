@@ -92,7 +92,7 @@ class TotalAugment:
                                    h, w, float(crop.aug_prob), float(flip.aug_prob), float(jit.aug_prob),
                                    float(crop.half_crop_ratio), _ops._stream()), "xpt_augment")
         crop.param = params[0:4]
-        jit.param = params[6:8] * params[5]
+        jit.param = params[5:8]                   # (applied 0/1, gamma, saturation) -- views, no extra launch
         self.params = params
         return out
 
