@@ -474,6 +474,14 @@ int xpt_conv1x1_bn_bwd_partials(const void* dy, const void* ypre, const void* x,
                                 const float* mean, float eps, void* g_out, float* w_partials, size_t w_partial_floats,
                                 float* bn_partials, size_t bn_partial_floats, long long M, int cout, int cin,
                                 long long pitch_dy, long long pitch_x, void* stream);
+/* the same with the output gradient arriving in up to three pieces (the layer's output feeds several branches of a cell:
+ * dy + dy2 + dy3 summed on load in fp32 and rounded to bf16 once, i.e. the result of a separate xpt_sum_rows launch);
+ * dy2 / dy3 may be NULL */
+int xpt_conv1x1_bn_bwd_partials_sum(const void* dy, const void* dy2, const void* dy3, const void* ypre, const void* x,
+                                    const float* gamma, const float* var, const float* mean, float eps, void* g_out,
+                                    float* w_partials, size_t w_partial_floats, float* bn_partials,
+                                    size_t bn_partial_floats, long long M, int cout, int cin, long long pitch_dy,
+                                    long long pitch_dy2, long long pitch_dy3, long long pitch_x, void* stream);
 int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, float* partials, size_t partial_floats, long long M,
                                     int cout, int cin, long long pitch_dy, long long pitch_x, void* stream);
 

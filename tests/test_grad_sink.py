@@ -172,6 +172,48 @@ def test_fused_conv1x1_bn_backward(gpu_device, shape, with_residual, library_for
         close(rg.grad, rr.grad, 1e-6, "dres")
 
 
+@pytest.mark.parametrize("shape,n_alias,live", [((2, 264, 44, 16, 52), 3, (0, 1, 2)), ((1, 528, 88, 8, 26), 3, (0, 2)),
+                                                ((2, 36, 33, 3, 5), 2, (0, 1)), ((1, 44, 44, 9, 13), 4, (0, 1, 2, 3))])
+def test_conv1x1_bn_fan_in_inside_the_backward_launch(gpu_device, shape, n_alias, live, monkeypatch):
+    """conv1x1_bn(..., fan_out=n): the gradients of the n consumers are added inside the weight-gradient launch
+    (xpt_conv1x1_bn_bwd_partials_sum) -- bit for bit what the separate gradient fan-in launch (xpt_sum_rows) produced:
+    fp32 accumulation in the same order, one bf16 rounding.  One piece is a channel slice of a wider tensor."""
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
+    B, cin, cout, H, W = shape
+    dev = gpu_device
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).bfloat16()
+    wide = torch.randn(B, 2 * cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    gys = [wide[:, cout:]] + [torch.randn(B, cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+                              for _ in range(n_alias - 1)]
+
+    def run(fused):
+        monkeypatch.setattr(pn, "_FUSE_FAN_IN", fused)
+        weight = torch.nn.Parameter(w.float().to(dev))
+        weight.shadow_bf16 = w.to(dev)
+        weight.flat_grad = torch.zeros(cout, cin, 1, 1, device=dev)
+        bn = pn.FrozenBatchNorm(cout).to(dev)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.weight.copy_(torch.linspace(0.5, 1.5, cout)); bn.bias.fill_(0.1)
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.2, cout)); bn.running_var.copy_(torch.linspace(0.4, 1.3, cout))
+        bn.weight.flat_grad = torch.zeros(cout, device=dev)
+        bn.bias.flat_grad = torch.zeros(cout, device=dev)
+        xg = x.clone().requires_grad_(True)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            ys = pn.conv1x1_bn(xg, weight, bn, fan_out=n_alias)
+        assert isinstance(ys, tuple) and len(ys) == n_alias
+        torch.autograd.backward([ys[i] for i in live], [gys[i] for i in live])
+        ops.grad_sink.flush()
+        torch.cuda.synchronize()
+        return ys[0].detach(), xg.grad, weight.flat_grad, bn.weight.flat_grad, bn.bias.flat_grad
+
+    a, b = run(True), run(False)
+    for u, v, what in zip(a, b, ("y", "dx", "dW", "dgamma", "dbeta")):
+        assert torch.equal(u, v), what
+
+
 @pytest.mark.parametrize("k,stride,C", [(3, 1, 44), (5, 1, 88), (7, 2, 22), (5, 2, 11), (3, 1, 176)])
 @pytest.mark.parametrize("relu_in", [False, True])
 def test_depthwise_backward_in_one_launch(gpu_device, k, stride, C, relu_in):

@@ -116,12 +116,49 @@ struct BnFuse {
   const unsigned short* ypre;   // [M, cout] bf16, dense
   unsigned short* g_out;        // [M, cout] bf16, dense
   float* partial;               // [nsplit][2][cout]
+  // gradient fan-in: dy is the SUM of up to three tensors (the layer's output feeds several branches of a cell); the
+  // extras are added on load (fp32, rounded to bf16 once: what the separate sum_rows launch produced)
+  const unsigned short* dy_extra[2];
+  long long pitch_extra[2];
+  int n_extra;
 };
 
 __device__ inline unsigned short f32_to_bf16_bits(float f) {   // round to nearest even
   unsigned u = __float_as_uint(f);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
+}
+
+// reg += the same elements of up to two more tensors (fp32 accumulation in source order, one bf16 rounding)
+template <int V, int TW, int RC, int NT>
+__device__ inline void stage_accumulate(typename StageVec<V>::type (&reg)[(RC * TW / V + NT - 1) / NT],
+                                        const unsigned short* const (&src)[2], const long long (&pitch)[2], int nsrc,
+                                        long long k0, long long k_end, int c0, int C) {
+  typedef typename StageVec<V>::type vec_t;
+  constexpr int VPR = TW / V, NV = RC * VPR, PER = (NV + NT - 1) / NT;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int v = threadIdx.x + i * NT;
+    const int row = v / VPR, c = c0 + (v % VPR) * V;
+    const bool ok = v < NV && k0 + row < k_end && c < C;
+    const long long rr = k0 + row < k_end ? k0 + row : k_end - 1;
+    vec_t extra[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)                      // unconditional loads (clamped), see stage_load
+      extra[q] = *(const vec_t*)(src[q < nsrc ? q : 0] + rr * pitch[q < nsrc ? q : 0] + (c < C ? c : C - V));
+    vec_t cur = reg[i], out;
+    const unsigned short* e = (const unsigned short*)&cur;
+    unsigned short* o = (unsigned short*)&out;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float f = bf16_bits_to_f32(e[j]);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        f += q < nsrc ? bf16_bits_to_f32(((const unsigned short*)&extra[q])[j]) : 0.f;
+      o[j] = f32_to_bf16_bits(f);
+    }
+    reg[i] = ok ? out : vec_t();
+  }
 }
 
 // g = dy * s for this thread's staged vectors of dy, written to g_out (rows / channels outside the tensor skipped)
@@ -224,6 +261,8 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
   typename StageVec<VB>::type gb[(RC * TCI / VB + NT - 1) / NT];
   typename StageVec<VA>::type gy[BN ? (RC * TCO / VA + NT - 1) / NT : 1];
   stage_load<VA, TCO, RC, NT>(ga, dy, pitch_dy, k_begin, k_end, co0, cout);
+  if (BN && bn.n_extra > 0)                          // uniform: the layer's output gradient arrives in pieces
+    stage_accumulate<VA, TCO, RC, NT>(ga, bn.dy_extra, bn.pitch_extra, bn.n_extra, k_begin, k_end, co0, cout);
   stage_load<VB, TCI, RC, NT>(gb, x, pitch_x, k_begin, k_end, ci0, cin);
   if constexpr (BN) {
     if (bn_tile) stage_load<VA, TCO, RC, NT>(gy, bn.ypre, cout, k_begin, k_end, co0, cout);
@@ -253,6 +292,8 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
     __syncthreads();
     if (k0 + RC < k_end) {
       stage_load<VA, TCO, RC, NT>(ga, dy, pitch_dy, k0 + RC, k_end, co0, cout);
+      if (BN && bn.n_extra > 0)
+        stage_accumulate<VA, TCO, RC, NT>(ga, bn.dy_extra, bn.pitch_extra, bn.n_extra, k0 + RC, k_end, co0, cout);
       stage_load<VB, TCI, RC, NT>(gb, x, pitch_x, k0 + RC, k_end, ci0, cin);
       if constexpr (BN) {
         if (bn_tile) stage_load<VA, TCO, RC, NT>(gy, bn.ypre, cout, k0 + RC, k_end, co0, cout);
@@ -443,6 +484,10 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
     const int vy = width(bn->ypre, cout, cout), vg = width(bn->g_out, cout, cout);
     if (vy < v) v = vy;
     if (vg < v) v = vg;
+    for (int q = 0; q < bn->n_extra; ++q) {
+      const int ve = width(bn->dy_extra[q], bn->pitch_extra[q], cout);
+      if (ve < v) v = ve;
+    }
   }
   WgradMulti mj{};
   if (multi) {
@@ -530,20 +575,34 @@ extern "C" int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, fl
  *   w_partials [splits][cout][cin]                            filter-gradient partials, D = g^T x
  *   bn_partials [splits][2][cout]                             row 0: dbeta partials, row 1: dgamma partials
  * splits = xpt_conv1x1_bwd_weight_splits(M, cout, cin); all partials are finished by xpt_reduce_partials. */
+extern "C" int xpt_conv1x1_bn_bwd_partials_sum(const void* dy, const void* dy2, const void* dy3, const void* ypre,
+                                               const void* x, const float* gamma, const float* var, const float* mean,
+                                               float eps, void* g_out, float* w_partials, size_t w_partial_floats,
+                                               float* bn_partials, size_t bn_partial_floats, long long M, int cout,
+                                               int cin, long long pitch_dy, long long pitch_dy2, long long pitch_dy3,
+                                               long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(x); XPT_CHECK_PTR(gamma); XPT_CHECK_PTR(var);
+  XPT_CHECK_PTR(mean); XPT_CHECK_PTR(g_out); XPT_CHECK_PTR(w_partials); XPT_CHECK_PTR(bn_partials);
+  if (M <= 0 || cout <= 0 || cin <= 0 || pitch_dy < cout || pitch_x < cin) return XPT_ERR_SHAPE;
+  if (dy3 != nullptr && dy2 == nullptr) return XPT_ERR_NULL;
+  if ((dy2 && pitch_dy2 < cout) || (dy3 && pitch_dy3 < cout)) return XPT_ERR_SHAPE;
+  const WgradPlan p = wgrad_plan(M, cout, cin, true);
+  if (w_partial_floats < (size_t)p.nsplit * cout * cin) return XPT_ERR_WORKSPACE;
+  if (bn_partial_floats < (size_t)p.nsplit * 2 * cout) return XPT_ERR_WORKSPACE;
+  if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
+  BnFuse bn{gamma, var, mean, eps, (const unsigned short*)ypre, (unsigned short*)g_out, bn_partials,
+            {(const unsigned short*)dy2, (const unsigned short*)dy3}, {pitch_dy2, pitch_dy3}, dy3 ? 2 : (dy2 ? 1 : 0)};
+  return wgrad_launch(dy, x, nullptr, w_partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream, &bn);
+}
+
 extern "C" int xpt_conv1x1_bn_bwd_partials(const void* dy, const void* ypre, const void* x, const float* gamma,
                                            const float* var, const float* mean, float eps, void* g_out,
                                            float* w_partials, size_t w_partial_floats, float* bn_partials,
                                            size_t bn_partial_floats, long long M, int cout, int cin,
                                            long long pitch_dy, long long pitch_x, void* stream) {
-  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(x); XPT_CHECK_PTR(gamma); XPT_CHECK_PTR(var);
-  XPT_CHECK_PTR(mean); XPT_CHECK_PTR(g_out); XPT_CHECK_PTR(w_partials); XPT_CHECK_PTR(bn_partials);
-  if (M <= 0 || cout <= 0 || cin <= 0 || pitch_dy < cout || pitch_x < cin) return XPT_ERR_SHAPE;
-  const WgradPlan p = wgrad_plan(M, cout, cin, true);
-  if (w_partial_floats < (size_t)p.nsplit * cout * cin) return XPT_ERR_WORKSPACE;
-  if (bn_partial_floats < (size_t)p.nsplit * 2 * cout) return XPT_ERR_WORKSPACE;
-  if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
-  const BnFuse bn{gamma, var, mean, eps, (const unsigned short*)ypre, (unsigned short*)g_out, bn_partials};
-  return wgrad_launch(dy, x, nullptr, w_partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream, &bn);
+  return xpt_conv1x1_bn_bwd_partials_sum(dy, nullptr, nullptr, ypre, x, gamma, var, mean, eps, g_out, w_partials,
+                                         w_partial_floats, bn_partials, bn_partial_floats, M, cout, cin, pitch_dy, 0, 0,
+                                         pitch_x, stream);
 }
 
 /* The same for n (<= 6) layers of one shape (M, cout, cin, pitch_x) in one launch; arrays of n pointers, pitch_dy per

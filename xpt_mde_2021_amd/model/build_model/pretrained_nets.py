@@ -120,7 +120,9 @@ class _Conv1x1BnBf16(torch.autograd.Function):
     kernel + GEMM.  Only used when all three parameters are deferred-gradient views (training on flat buffers)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, mean, var, eps, residual):
+    def forward(ctx, x, weight, gamma, beta, mean, var, eps, residual, n_alias=1):
+        """n_alias > 1 (no residual): n aliases of y, one per consumer -- the backward then sees the consumers' gradients
+        separately and the weight-gradient kernel adds them on load (no gradient fan-in launch)."""
         lib = _ops._lib.load()
         B, cin, H, W = x.shape
         cout = weight.shape[0]
@@ -150,22 +152,35 @@ class _Conv1x1BnBf16(torch.autograd.Function):
         ctx.save_for_backward(x2, ws, ypre, g_, mean, var)
         ctx.dims = (B, cin, H, W, cout, float(eps))
         ctx.dst = (weight.flat_grad, gamma.flat_grad, beta.flat_grad)
+        if n_alias > 1:
+            if residual is not None:
+                raise WrongInputException("conv1x1_bn: aliases and a residual cannot be combined")
+            ctx.set_materialize_grads(False)
+            return tuple(y.view_as(y) for _ in range(n_alias))
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *dys):
         x2, ws, ypre, gamma, mean, var = ctx.saved_tensors
-        dx = _conv_bn_backward(x2, ws, ypre, gamma, mean, var, ctx.dims, ctx.dst, dy, ctx.needs_input_grad[0])
-        dres = dy if ctx.needs_input_grad[7] else None
-        return dx, None, None, None, None, None, None, dres
+        live = [d for d in dys if d is not None]
+        if not live:
+            return (None,) * 9
+        if len(live) > 3:                                     # the kernel adds up to three pieces: more go through
+            live = [_ops.sum_rows(live)]                      # the fan-in kernel (same single rounding)
+        dx = _conv_bn_backward(x2, ws, ypre, gamma, mean, var, ctx.dims, ctx.dst, live[0], ctx.needs_input_grad[0],
+                               extra=live[1:])
+        dres = live[0] if ctx.needs_input_grad[7] else None
+        return dx, None, None, None, None, None, None, dres, None
 
 
-def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx):
-    """One gfx950 launch (g = dy * s, split-K partials of dW / dgamma / dbeta -> GradSink) + one rocBLAS GEMM (dx)."""
+def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx, extra=()):
+    """One gfx950 launch (g = dy * s, split-K partials of dW / dgamma / dbeta -> GradSink) + one rocBLAS GEMM (dx).
+    extra: up to two more pieces of the output gradient (added to dy on load by the kernel)."""
     lib = _ops._lib.load()
     B, cin, H, W, cout, eps = dims
     w_dst, g_dst, b_dst = dst
     dy2 = _ops.as_rows(dy.to(torch.bfloat16))
+    more = [_ops.as_rows(e.to(torch.bfloat16)) for e in extra]
     M = dy2.shape[0]
     g = torch.empty((M, cout), dtype=torch.bfloat16, device=dy.device)
     nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
@@ -174,11 +189,15 @@ def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx):
     bpart = sink.partials(b_dst, "bnfuse", nsplit * 2 * cout)
     pitch_dy = dy2.stride(0) if M > 1 else cout
     pitch_x = x2.stride(0) if M > 1 else cin
-    _ops._lib.check(lib.xpt_conv1x1_bn_bwd_partials(dy2.data_ptr(), ypre.data_ptr(), x2.data_ptr(), gamma.data_ptr(),
-                                                    var.data_ptr(), mean.data_ptr(), eps, g.data_ptr(),
-                                                    wpart.data_ptr(), wpart.numel(), bpart.data_ptr(), bpart.numel(),
-                                                    M, cout, cin, pitch_dy, pitch_x, _ops._stream()),
-                    "xpt_conv1x1_bn_bwd_partials")
+    pitch_of = lambda t: t.stride(0) if M > 1 else cout           # noqa: E731
+    e1 = more[0] if len(more) > 0 else None
+    e2 = more[1] if len(more) > 1 else None
+    _ops._lib.check(lib.xpt_conv1x1_bn_bwd_partials_sum(dy2.data_ptr(), _ops._ptr(e1), _ops._ptr(e2), ypre.data_ptr(),
+                                                        x2.data_ptr(), gamma.data_ptr(), var.data_ptr(), mean.data_ptr(),
+                                                        eps, g.data_ptr(), wpart.data_ptr(), wpart.numel(),
+                                                        bpart.data_ptr(), bpart.numel(), M, cout, cin, pitch_dy,
+                                                        0 if e1 is None else pitch_of(e1), 0 if e2 is None else pitch_of(e2),
+                                                        pitch_x, _ops._stream()), "xpt_conv1x1_bn_bwd_partials_sum")
     sink.add(w_dst, wpart, 0, cout * cin, nsplit, cout * cin)
     sink.add(b_dst, bpart, 0, cout, nsplit, 2 * cout)
     sink.add(g_dst, bpart, cout, cout, nsplit, 2 * cout)
@@ -314,6 +333,7 @@ def multi_conv1x1_bn(xs, weights, bns, residuals=None):
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
 _WIDE_CELL = __import__("os").environ.get("XPT_DEBUG_NARROW_CELL", "0") != "1"          # A/B: per-branch depthwise launches
+_FUSE_FAN_IN = __import__("os").environ.get("XPT_DEBUG_SEPARATE_FAN_IN", "0") != "1"     # A/B: gradient fan-in as its own launch
 _CELL_TAIL = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CELL_TAIL", "0") != "1"     # A/B: pools / add / concat / relu as separate launches
 
 
@@ -329,15 +349,20 @@ _PWCONV_MAX_CIN = int(__import__("os").environ.get("XPT_PWCONV_MAX_CIN", "320"))
 _LIBRARY_PWCONV = __import__("os").environ.get("XPT_DEBUG_LIBRARY_PWCONV", "0") == "1"    # A/B: rocBLAS GEMM + epilogue launch
 
 
-def conv1x1_bn(x, weight, bn, residual=None):
+def conv1x1_bn(x, weight, bn, residual=None, fan_out=1):
     """bn(conv1x1(x, weight)) [+ residual]: the fused-backward path when training on flat (deferred-gradient)
-    parameters in bf16, the two separate ops otherwise."""
+    parameters in bf16, the two separate ops otherwise.  fan_out = n > 1 (no residual): a tuple of n aliases of the
+    result, one per consumer; on the fused path their gradients are added inside the weight-gradient launch."""
     sink = _ops.grad_sink
     if (_FUSE_CONV_BN and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_autocast_enabled()
             and torch.is_grad_enabled() and hasattr(weight, "shadow_bf16") and not _LIBRARY_WGRAD
             and sink.wants(weight) and sink.wants(bn.weight) and sink.wants(bn.bias)):
-        return _Conv1x1BnBf16.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS, residual)
-    return bn(conv1x1(x, weight), residual)
+        if fan_out > 1 and residual is None and _FUSE_FAN_IN:
+            return _Conv1x1BnBf16.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS, None, fan_out)
+        y = _Conv1x1BnBf16.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS, residual)
+    else:
+        y = bn(conv1x1(x, weight), residual)
+    return y if fan_out == 1 else _ops.fan_out(y, fan_out)
 
 
 def correct_pad(h, w, k):
@@ -432,21 +457,24 @@ class AdjustBlock(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity="relu")
 
-    def forward(self, p, taps):
+    def forward(self, p, taps, fan_out=1):
+        """fan_out = n > 1: a tuple of n aliases of the result, one per consumer (conv1x1_bn adds their gradients inside
+        its weight-gradient launch; the other modes go through the fan-in kernel)."""
+        if self.mode == "project":
+            p = shared_relu(p)
+            taps.offer(self.act_id, p)
+            return conv1x1_bn(p, self.conv.weight, self.bn, fan_out=fan_out)
         if self.mode == "spatial":
             p = shared_relu(p)
             if p.is_cuda and _CELL_TAIL and p.dtype in (torch.float32, torch.bfloat16):
                 p1, p2 = _ops.adjust_gather(p)                  # both sub-sampled copies in one launch (one scatter backward)
-                return self.bn(torch.cat([conv1x1(p1, self.conv1.weight), conv1x1(p2, self.conv2.weight)], dim=1))
-            p1 = conv1x1(p[:, :, ::2, ::2], self.conv1.weight)                       # AveragePooling2D((1,1), strides 2)
-            p2 = F.pad(p, (0, 1, 0, 1))[:, :, 1:, 1:]                # ZeroPadding2D(((0,1),(0,1))) + Cropping2D(((1,0),(1,0)))
-            p2 = conv1x1(p2[:, :, ::2, ::2], self.conv2.weight)
-            return self.bn(torch.cat([p1, p2], dim=1))
-        if self.mode == "project":
-            p = shared_relu(p)
-            taps.offer(self.act_id, p)
-            return conv1x1_bn(p, self.conv.weight, self.bn)
-        return p
+                p = self.bn(torch.cat([conv1x1(p1, self.conv1.weight), conv1x1(p2, self.conv2.weight)], dim=1))
+            else:
+                p1 = conv1x1(p[:, :, ::2, ::2], self.conv1.weight)                   # AveragePooling2D((1,1), strides 2)
+                p2 = F.pad(p, (0, 1, 0, 1))[:, :, 1:, 1:]            # ZeroPadding2D(((0,1),(0,1))) + Cropping2D(((1,0),(1,0)))
+                p2 = conv1x1(p2[:, :, ::2, ::2], self.conv2.weight)
+                p = self.bn(torch.cat([p1, p2], dim=1))
+        return p if fan_out == 1 else _ops.fan_out(p, fan_out)
 
 
 def avg_pool_same(x, scale=1.0):
@@ -483,19 +511,23 @@ class NormalCell(nn.Module):
                 [self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight]]
 
     def forward(self, ip, p, taps):
-        p = self.adjust(p, taps)
+        blocks = (self.left1, self.left5, self.right1, self.left2, self.right2)
+        wide = ip.is_cuda and not _DISABLE_HIP_DWCONV and _WIDE_CELL and not any(
+            taps.wants(b.act_id1) or taps.wants(b.act_id2) for b in blocks)
+        # h and p feed several branches each: one alias per consumer; where they come out of a fused pointwise + BatchNorm
+        # layer their gradients are added inside that layer's weight-gradient launch, elsewhere by one fan-in kernel
+        n_h, n_p = (3, 2 if _CELL_TAIL else 4) if wide else (4, 6)
+        ps = self.adjust(p, taps, fan_out=n_p)
         h = shared_relu(ip)
         taps.offer(self.act_id, h)
-        h = conv1x1_bn(h, self.conv.weight, self.bn)
-        blocks = (self.left1, self.left5, self.right1, self.left2, self.right2)
-        if h.is_cuda and not _DISABLE_HIP_DWCONV and _WIDE_CELL and not any(
-                taps.wants(b.act_id1) or taps.wants(b.act_id2) for b in blocks):
+        hs = conv1x1_bn(h, self.conv.weight, self.bn, fan_out=n_h)
+        if wide:
             # The five separable-conv branches are mutually independent and of one shape: their depthwise halves run as
             # ONE launch per stage (and one backward launch each, which also sums the gradients of h and p over the
             # branches); the pointwise + BatchNorm halves follow per branch, the branch adds in their epilogues.
-            fused_tail = _CELL_TAIL and h.dtype == p.dtype and h.shape == p.shape
-            hs = _ops.fan_out(h, 3)
-            ps = _ops.fan_out(p, 2 if fused_tail else 4)
+            fused_tail = _CELL_TAIL and hs[0].dtype == ps[0].dtype and hs[0].shape == ps[0].shape
+            if not fused_tail and len(ps) < 4:
+                ps = (ps[0],) + tuple(_ops.fan_out(ps[1], 3))
             y1 = _ops.multi_depthwise([hs[0], hs[0], ps[0], ps[0], ps[0]], [b.conv1.depthwise.weight for b in blocks])
             z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
             y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
@@ -516,8 +548,8 @@ class NormalCell(nn.Module):
             return torch.cat([ps[3], x1, x2, x3, x4, x5], dim=1), ip
         # every `add` whose operand ends in a BatchNorm rides in that BatchNorm's epilogue kernel; h and p feed several
         # branches each: their gradients are summed by one fan-in kernel instead of a chain of pairwise adds
-        h1, h2, h3, h4 = _ops.fan_out(h, 4)
-        p1, p2, p3, p4, p5, p6 = _ops.fan_out(p, 6)
+        h1, h2, h3, h4 = hs
+        p1, p2, p3, p4, p5, p6 = ps
         x1 = self.left1(h1, taps, residual=self.right1(p1, taps))
         x2 = self.left2(p2, taps, residual=self.right2(p3, taps))
         x3 = avg_pool_same(h2) + p4
