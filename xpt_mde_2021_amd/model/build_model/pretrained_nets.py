@@ -582,15 +582,17 @@ class ReductionCell(nn.Module):
                 [self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight]]
 
     def forward(self, ip, p, taps):
-        p = self.adjust(p, taps)
+        # h feeds the pooling pair and the left branch, p the stride-2 branches and the tapped right3 block: two aliases
+        # each (their gradients are added inside the producing layer's weight-gradient launch where that layer is fused)
+        p, p_tap = self.adjust(p, taps, fan_out=2)
         h = shared_relu(ip)
         taps.offer(self.act_id, h)
-        h = conv1x1_bn(h, self.conv.weight, self.bn)
+        h, h_pool = conv1x1_bn(h, self.conv.weight, self.bn, fan_out=2)
         if h.is_cuda and _CELL_TAIL and h.dtype in (torch.float32, torch.bfloat16):
             # both poolings of the zero-padded h in one launch (and one backward launch)
-            mp, ap_h = _ops.pool_pair(h, correct_pad(h.shape[2], h.shape[3], 3))
+            mp, ap_h = _ops.pool_pair(h_pool, correct_pad(h.shape[2], h.shape[3], 3))
         else:
-            h3 = zero_pad(h, correct_pad(h.shape[2], h.shape[3], 3))
+            h3 = zero_pad(h_pool, correct_pad(h.shape[2], h.shape[3], 3))
             mp = F.max_pool2d(h3, 3, 2)                      # MaxPooling2D of h feeds x2 and x5: pooled once
             ap_h = None
         mp1, mp2 = _ops.fan_out(mp, 2)
@@ -616,7 +618,7 @@ class ReductionCell(nn.Module):
             outs = multi_conv1x1_bn(y2[1:], [b.conv2.pointwise.weight for b in blocks[1:]], [b.bn2 for b in blocks[1:]],
                                     [None, mp1] + ([ap] if wide3 else []))
             r1, x2 = outs[0], outs[1]
-            x3 = outs[2] if wide3 else self.right3(p, taps, residual=ap)
+            x3 = outs[2] if wide3 else self.right3(p_tap, taps, residual=ap)
             x1 = conv1x1_bn(y2[0], self.left1.conv2.pointwise.weight, self.left1.bn2, residual=r1)
             x1a, x1b = _ops.fan_out(x1, 2)
             if _CELL_TAIL and x1.dtype == x2.dtype == x3.dtype:
@@ -628,7 +630,8 @@ class ReductionCell(nn.Module):
             x4 = x2a + avg_pool_same(x1a)
             x5 = self.left4(x1b, taps, residual=mp2)
             return torch.cat([x2b, x3, x4, x5], dim=1), ip
-        p1, p2, p3 = _ops.fan_out(p, 3)
+        p1, p2 = _ops.fan_out(p, 2)
+        p3 = p_tap
         x1 = self.left1(h, taps, residual=self.right1(p1, taps))
         x1a, x1b = _ops.fan_out(x1, 2)
         x2 = self.right2(p2, taps, residual=mp1)
