@@ -56,6 +56,13 @@ int xpt_pose_rvec2matr_bwd(const float* pose, const float* dT, float* dpose, int
  * down-scale factor (synthesize_base.py:74-85 resize_source_images, util_funcs.py:163-175
  * multi_scale_like_depth).  img [M,H,W,C] -> out [M,H/scale,W/scale,C]; scale in {1,2,4,8,..}. */
 int xpt_resize_down_fwd(const float* img, float* out, int M, int H, int W, int C, int scale, void* stream);
+/* Every image the loss stage reads from a snippet batch image5d [B,S,H,W,3] (TotalLoss.append_data, losses.py:57-104:
+ * sources = frames 0..S-2, target = frame S-1, each resized to every depth scale, synthesize_base.py:74-85 and
+ * util_funcs.py:163-175) in one launch: job j = frames first_frame[j] .. +nframes[j]-1 of every snippet resized by the
+ * exact factor scale[j] (1 = dense copy, else even) -> out[j] [B*nframes[j], H/scale[j], W/scale[j], 3]; at most 10 jobs.
+ * Same values as xpt_resize_down_fwd on the dense frames. */
+int xpt_image_pyramids(const float* image5d, int B, int S, int H, int W, int njobs, const int* first_frame,
+                       const int* nframes, const int* scale, float* const* out, void* stream);
 
 /* ------------------------------------------------------------------ K2+K3: view synthesis
  * replaces SynthesizeSingleScale.synthesize_batch_view (synthesize_base.py:88-178:
@@ -155,6 +162,15 @@ int xpt_smooth_fwd(const float* disp, const float* image, float* loss, float* wo
                    int B, int h, int w, float grad_factor, int input_is_depth, void* stream);
 int xpt_smooth_bwd(const float* disp, const float* image, const float* gloss, float* dinput,
                    int B, int h, int w, float grad_factor, int input_is_depth, void* stream);
+/* Every scale of SmoothenessLossMultiScale.__call__ (losses.py:391-407) in one forward pair / one backward launch:
+ * nscales (1..4) arrays disp[s] [B,h_s,w_s], image[s] [B,h_s,w_s,3] -> losses [nscales][B] (one buffer); same values as
+ * xpt_smooth_fwd / xpt_smooth_bwd per scale.  workspace_floats >= the sum of xpt_smooth_workspace_floats(B,h_s,w_s). */
+int xpt_smooth_ms_fwd(int nscales, const float* const* disp, const float* const* image, float* losses,
+                      float* workspace, size_t workspace_floats, int B, const int* h, const int* w, float grad_factor,
+                      int input_is_depth, void* stream);
+int xpt_smooth_ms_bwd(int nscales, const float* const* disp, const float* const* image, const float* const* gloss,
+                      float* const* dinput, int B, const int* h, const int* w, float grad_factor, int input_is_depth,
+                      void* stream);
 
 /* ------------------------------------------------------------------ a14: fused Adam (Keras semantics)
  * replaces tf.optimizers.Adam(lr).apply_gradients (model/model_util/optimizers.py:7-13,
@@ -308,6 +324,12 @@ int xpt_headconv_bwd(const void* x, long long xpitch, const float* w, const floa
  * bwd: gx = d depth/dx (g_depth + d disp/d depth g_disp); g_depth or g_disp may be NULL (not both). */
 int xpt_depth_head_fwd(const float* x, float* depth, float* disp, long long n, void* stream);
 int xpt_depth_head_bwd(const float* x, const float* g_depth, const float* g_disp, float* gx, long long n, void* stream);
+/* The decoder's four prediction scales (depth_net.py:137-167) in one launch each way: nscales (1..4) arrays of n[s]
+ * elements.  bwd: g_depth[s] / g_disp[s] may be NULL; a scale with both NULL gets gx[s] = 0. */
+int xpt_depth_head_ms_fwd(int nscales, const float* const* x, float* const* depth, float* const* disp, const long long* n,
+                          void* stream);
+int xpt_depth_head_ms_bwd(int nscales, const float* const* x, const float* const* g_depth, const float* const* g_disp,
+                          float* const* gx, const long long* n, void* stream);
 
 /* ------------------------------------------------------------------ f-4: PWC-Net correlation cost volume
  * tfa.layers.CorrelationCost(kernel_size=1, max_displacement=md, stride_1=1, stride_2=s2, pad=md, channels_last)
@@ -417,14 +439,16 @@ int xpt_pose_metric(const float* pred, const float* truth, float* out, int B, in
  *   dwconv:   partials[chunks][C][k][k]  chunks = xpt_dwconv_bwd_weight_chunks()
  *   conv1x1:  partials[splits][cout][cin] splits = xpt_conv1x1_bwd_weight_splits()
  * xpt_reduce_partials then finishes all layers at once: block b of the launch serves job blockmap[b].x and the outputs
- * starting at blockmap[b].y (256 outputs per block when split_waves == 1, 64 when it is 4);
+ * starting at blockmap[b].y (256 outputs per block when split_waves is 1 or 16, 64 when it is 4, 2048 when it is 32);
  *   dst[i] = sum over segments g < nseg, splits s < nsplit[g] of src[g][s * stride[g] + i],  i < n   (fixed order).
  * jobs and blockmap are device arrays built once by the host (the layer list of a model is static). */
 typedef struct xpt_reduce_job {
   float* dst;
   long long n;
   int nseg;          /* 1..4 segments (a layer applied several times per step contributes one segment per use) */
-  int split_waves;   /* 1: one output per thread (nsplit <= 8); 4: the 4 waves of a block share 64 outputs */
+  int split_waves;   /* 1: one output per thread (nsplit <= 8); 4: the 4 waves of a block share 64 outputs;
+                      * 16 ("wide") and 32 ("flat", for few splits): float4 loads, needing n % 4 == 0, n >= 256 and
+                      * dst, src[], stride[] 16-byte aligned */
   const float* src[4];
   long long stride[4];
   int nsplit[4];

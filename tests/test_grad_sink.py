@@ -14,10 +14,11 @@ def test_reduce_partials_jobs(gpu_device):
     sink = ops.GradSink()
     g = torch.Generator().manual_seed(0)
     cases = [(5, 3), (300, 8), (1100, 9), (77, 32), (1000, 33), (40, 128), (13, 257), (257, 500), (70, 3328), (4096, 1),
-             (4608, 768), (1936, 100), (256, 3), (864, 300), (18432, 5)]          # the last five: 16-byte aligned rows (wide mode)
+             (4608, 768), (1936, 100), (256, 3), (864, 300), (18432, 5), (2500, 8), (5000, 2), (2048, 7), (6144, 1)]
+    # the last nine: 16-byte aligned rows (wide mode; "flat" mode of 2048 outputs per workgroup when <= 8 splits)
     expect, dsts = [], []
     for n, nsplit in cases:
-        stride = n if n in (4608, 1936, 256, 864, 18432) else n + 7
+        stride = n if n in (4608, 1936, 256, 864, 18432, 2500, 5000, 2048, 6144) else n + 7
         src = torch.randn(nsplit * stride, generator=g).to(gpu_device)
         dst = torch.full((n,), float("nan"), device=gpu_device)
         sink.add(dst, src, 3 if nsplit * stride - 3 >= (nsplit - 1) * stride + n else 0, n, nsplit, stride)
@@ -30,6 +31,12 @@ def test_reduce_partials_jobs(gpu_device):
     dst2 = torch.zeros(n2, device=gpu_device)
     sink.add(dst2, a, 0, n2, 4, n2)
     sink.add(dst2, b, 0, n2, 40, n2)
+    # ... and one whose two uses both have few splits (flat mode with two segments, ragged against 2048)
+    n3 = 3000
+    a3, b3 = torch.randn(5 * n3, generator=g).to(gpu_device), torch.randn(8 * n3, generator=g).to(gpu_device)
+    dst3 = torch.zeros(n3, device=gpu_device)
+    sink.add(dst3, a3, 0, n3, 5, n3)
+    sink.add(dst3, b3, 0, n3, 8, n3)
     jobs_again = list(sink.pending)
     sink.flush()
     torch.cuda.synchronize()
@@ -37,6 +44,8 @@ def test_reduce_partials_jobs(gpu_device):
         assert torch.allclose(d.double(), e, atol=1e-5 * max(1, nsplit) ** 0.5), (n, nsplit)
     e2 = a.double().view(4, n2).sum(0) + b.double().view(40, n2).sum(0)
     assert torch.allclose(dst2.double(), e2, atol=1e-4)
+    e3 = a3.double().view(5, n3).sum(0) + b3.double().view(8, n3).sum(0)
+    assert torch.allclose(dst3.double(), e3, atol=1e-4)
     # the cached table is reused when the same jobs come back
     table = sink.table
     for (n, nsplit), d in zip(cases, dsts):

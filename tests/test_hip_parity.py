@@ -65,6 +65,25 @@ def test_resize_down(ops, gpu_device, scale):
     frac_close(out, ref, 1e-6, what=f"resize/{scale}")
 
 
+@pytest.mark.parametrize("shape,scales", [((2, 5, 32, 48, 3), [1, 2, 4, 8]), ((3, 3, 16, 24, 3), [2, 4]),
+                                          ((1, 2, 6, 10, 3), [1, 2])])
+def test_image_pyramids_equal_resize_down_of_the_dense_slices(ops, gpu_device, shape, scales):
+    """xpt_image_pyramids (sources + target, every scale, one launch) == resize_down of image5d[:, :-1] / [:, -1],
+    bit for bit; scale 1 (the dense copies) is always part of the answer."""
+    g = gen(13)
+    img = (torch.rand(shape, generator=g) * 2 - 1).to(gpu_device)
+    B, S, H, W, _ = shape
+    sources, targets = ops.image_pyramids(img, scales)
+    assert sorted(sources) == sorted(set(scales) | {1})
+    src_dense = img[:, :-1].contiguous()
+    tgt_dense = img[:, -1].contiguous()
+    for s in sources:
+        es = ops.resize_down(src_dense.reshape(B * (S - 1), H, W, 3), s).reshape(B, S - 1, H // s, W // s, 3)
+        et = ops.resize_down(tgt_dense, s)
+        assert torch.equal(sources[s], es), s
+        assert torch.equal(targets[s], et), s
+
+
 # ------------------------------------------------------------------------------------------------ K2+K3
 @pytest.mark.parametrize("B,N,h,w,scale", [(4, 4, 128, 416, 1), (2, 4, 32, 104, 4), (2, 1, 16, 52, 8), (1, 3, 5, 7, 1)])
 def test_warp_fwd_bwd(ops, gpu_device, B, N, h, w, scale):
@@ -343,6 +362,38 @@ def test_smoothness_fwd_bwd(ops, gpu_device, B, h, w, is_depth):
     frac_close(d.grad, d_ref.grad, 1e-5 * gs, rtol=1e-4, max_bad_frac=1e-5, what="dsmooth")
 
 
+@pytest.mark.parametrize("is_depth", [False, True])
+def test_smoothness_multi_scale_equals_per_scale(ops, gpu_device, is_depth):
+    """xpt_smooth_ms_* (all scales in one launch pair) == xpt_smooth_* scale by scale, bit for bit, with a scale
+    whose gradient is absent (no zero-filled stand-in is needed upstream)."""
+    g = gen(97)
+    B = 3
+    shapes = [(32, 104), (16, 52), (9, 27), (4, 13)]
+    imgs = [sd.smooth_noise((B, h, w, 3), g).to(gpu_device) for h, w in shapes]
+    depths = [sd.smooth_depth(B, h, w, g, lo=0.99, hi=100.0).to(gpu_device) for h, w in shapes]
+    gls = [torch.randn((B,), generator=g).to(gpu_device) for _ in shapes]
+    singles, grads = [], []
+    for d, im, gl in zip(depths, imgs, gls):
+        d = d.clone().requires_grad_(True)
+        loss = ops.smoothness(d, im, 4.0, is_depth)
+        loss.backward(gl)
+        singles.append(loss.detach())
+        grads.append(d.grad)
+    ds = [d.clone().requires_grad_(True) for d in depths]
+    multi = ops.smoothness_multi_scale(ds, imgs, 4.0, is_depth)
+    for a, b in zip(multi, singles):
+        assert torch.equal(a, b)
+    torch.autograd.backward(multi, gls)
+    for d, ge in zip(ds, grads):
+        assert torch.equal(d.grad, ge)
+    # one scale left out of the total: its depth gets an all-zero gradient, the others are unchanged
+    ds = [d.clone().requires_grad_(True) for d in depths]
+    multi = ops.smoothness_multi_scale(ds, imgs, 4.0, is_depth)
+    (multi[0] * gls[0] + multi[2] * gls[2]).sum().backward()
+    assert torch.equal(ds[0].grad, grads[0]) and torch.equal(ds[2].grad, grads[2])
+    assert ds[1].grad.abs().max().item() == 0 and ds[3].grad.abs().max().item() == 0
+
+
 # ------------------------------------------------------------------------------------------------ conv epilogues (a2/a3)
 @pytest.mark.parametrize("C,shape", [(44, (2, 16, 26)), (1, (2, 32, 52)), (3, (1, 5, 7)), (130, (1, 9, 11))])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -604,3 +655,37 @@ def test_inverse_sigmoid_depth(ops, gpu_device):
     x2r = x.clone().double().requires_grad_(True)
     uf.safe_reciprocal_number(uf.safe_reciprocal_number(torch.sigmoid(x2r) + 0.01)).sum().backward()
     assert torch.allclose(x2.grad.cpu().double(), x2r.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_inverse_sigmoid_depth_multi_equals_per_scale(ops, gpu_device):
+    """All prediction scales in one launch (xpt_depth_head_ms_*) == scale by scale, bit for bit, with outputs of some
+    scales left unused (their gradient slots are NULL at the boundary)."""
+    g = gen(501)
+    xs = [(torch.randn(shape, generator=g) * 4).to(gpu_device) for shape in [(2, 1, 16, 52), (2, 1, 8, 26), (2, 1, 4, 13), (2, 1, 2, 7)]]
+    gds = [torch.randn(x.shape, generator=g).to(gpu_device) for x in xs]
+    gss = [torch.randn(x.shape, generator=g).to(gpu_device) for x in xs]
+    use = [(True, True), (True, False), (False, True), (False, False)]
+    singles = []
+    for x, gd, gs, (ud, us) in zip(xs, gds, gss, use):
+        x = x.clone().requires_grad_(True)
+        depth, disp = ops.inverse_sigmoid_depth(x)
+        total = (depth * gd).sum() * float(ud) + (disp * gs).sum() * float(us) if (ud and us) else \
+            (depth * gd).sum() if ud else (disp * gs).sum() if us else None
+        if total is not None:
+            total.backward()
+        singles.append((depth.detach(), disp.detach(), x.grad))
+    xm = [x.clone().requires_grad_(True) for x in xs]
+    depths, disps = ops.inverse_sigmoid_depth_multi(xm)
+    total = 0
+    for depth, disp, gd, gs, (ud, us) in zip(depths, disps, gds, gss, use):
+        if ud:
+            total = total + (depth * gd).sum()
+        if us:
+            total = total + (disp * gs).sum()
+    total.backward()
+    for x, depth, disp, (d1, s1, g1) in zip(xm, depths, disps, singles):
+        assert torch.equal(depth, d1) and torch.equal(disp, s1)
+        if g1 is None:
+            assert x.grad.abs().max().item() == 0
+        else:
+            assert torch.equal(x.grad, g1)

@@ -211,9 +211,9 @@ __device__ inline float edge_weight(const float* __restrict__ a, const float* __
 }
 
 // part[b][blk][2] = (sum |gx wx|, sum |gy wy|)
-__global__ void smooth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ image,
-                                  float* __restrict__ part, int h, int w, float gf, int is_depth) {
-  __shared__ float red[4 * 2];
+__device__ __forceinline__ void smooth_fwd_body(const float* __restrict__ disp, const float* __restrict__ image,
+                                                float* __restrict__ part, int h, int w, float gf, int is_depth,
+                                                int nblk, float* red) {
   const int b = blockIdx.y;
   const int P = h * w;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,9 +234,35 @@ __global__ void smooth_fwd_kernel(const float* __restrict__ disp, const float* _
   }
   block_sum_n<2>(acc, red);
   if (threadIdx.x == 0) {
-    part[((long long)b * gridDim.x + blockIdx.x) * 2 + 0] = acc[0];
-    part[((long long)b * gridDim.x + blockIdx.x) * 2 + 1] = acc[1];
+    part[((long long)b * nblk + blockIdx.x) * 2 + 0] = acc[0];
+    part[((long long)b * nblk + blockIdx.x) * 2 + 1] = acc[1];
   }
+}
+
+__global__ void smooth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ image,
+                                  float* __restrict__ part, int h, int w, float gf, int is_depth) {
+  __shared__ float red[4 * 2];
+  smooth_fwd_body(disp, image, part, h, w, gf, is_depth, gridDim.x, red);
+}
+
+// All scales of the smoothness loss in one launch: blockIdx.z picks the scale, workgroups past a scale's own
+// block count leave at once (the grid is sized for the largest scale).
+struct SmoothMs {
+  const float* disp[4];
+  const float* image[4];
+  float* part[4];        // forward partials / backward: d(input)
+  const float* gloss[4];
+  float* loss[4];
+  int h[4], w[4], nblk[4];
+  float gf;
+  int is_depth, B;
+};
+
+__global__ void smooth_fwd_ms_kernel(SmoothMs a) {
+  __shared__ float red[4 * 2];
+  const int s = blockIdx.z;
+  if ((int)blockIdx.x >= a.nblk[s]) return;
+  smooth_fwd_body(a.disp[s], a.image[s], a.part[s], a.h[s], a.w[s], a.gf, a.is_depth, a.nblk[s], red);
 }
 
 __global__ void smooth_reduce_kernel(const float* __restrict__ part, float* __restrict__ loss, int B, int nblk,
@@ -251,11 +277,26 @@ __global__ void smooth_reduce_kernel(const float* __restrict__ part, float* __re
   loss[b] = 0.5f * (sx * inv_x) + 0.5f * (sy * inv_y);
 }
 
+__global__ void smooth_reduce_ms_kernel(SmoothMs a) {
+  const int s = blockIdx.y;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int nblk = a.nblk[s];
+  const float* part = a.part[s];
+  float sx = 0.f, sy = 0.f;
+  for (int k = 0; k < nblk; ++k) {
+    sx += part[((long long)b * nblk + k) * 2];
+    sy += part[((long long)b * nblk + k) * 2 + 1];
+  }
+  const float inv_x = 1.0f / ((float)a.h[s] * (float)(a.w[s] - 1)), inv_y = 1.0f / ((float)(a.h[s] - 1) * (float)a.w[s]);
+  a.loss[s][b] = 0.5f * (sx * inv_x) + 0.5f * (sy * inv_y);
+}
+
 __device__ inline float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 
-__global__ void smooth_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ image,
-                                  const float* __restrict__ gloss, float* __restrict__ dinput, int h, int w, float gf,
-                                  int is_depth, float inv_x, float inv_y) {
+__device__ __forceinline__ void smooth_bwd_body(const float* __restrict__ disp, const float* __restrict__ image,
+                                                const float* __restrict__ gloss, float* __restrict__ dinput, int h,
+                                                int w, float gf, int is_depth, float inv_x, float inv_y) {
   const int b = blockIdx.y;
   const int P = h * w;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,6 +326,19 @@ __global__ void smooth_bwd_kernel(const float* __restrict__ disp, const float* _
   float g = gloss[b] * 0.5f * (gxs * inv_x + gys * inv_y);
   if (is_depth) g = (raw > 0.00001f) ? -g / (raw * raw) : 0.f;
   dinput[(long long)b * P + p] = g;
+}
+
+__global__ void smooth_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ image,
+                                  const float* __restrict__ gloss, float* __restrict__ dinput, int h, int w, float gf,
+                                  int is_depth, float inv_x, float inv_y) {
+  smooth_bwd_body(disp, image, gloss, dinput, h, w, gf, is_depth, inv_x, inv_y);
+}
+
+__global__ void smooth_bwd_ms_kernel(SmoothMs a) {
+  const int s = blockIdx.z;
+  if ((int)blockIdx.x >= a.nblk[s]) return;
+  smooth_bwd_body(a.disp[s], a.image[s], a.gloss[s], a.part[s], a.h[s], a.w[s], a.gf, a.is_depth,
+                  1.0f / ((float)a.h[s] * (float)(a.w[s] - 1)), 1.0f / ((float)(a.h[s] - 1) * (float)a.w[s]));
 }
 
 // =================================================================== C ABI
@@ -374,6 +428,61 @@ int xpt_smooth_bwd(const float* disp, const float* image, const float* gloss, fl
   hipLaunchKernelGGL(smooth_bwd_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, disp, image, gloss, dinput,
                      h, w, grad_factor, input_is_depth, 1.0f / ((float)h * (float)(w - 1)),
                      1.0f / ((float)(h - 1) * (float)w));
+  return xpt_launch_status();
+}
+
+static int smooth_ms_fill(SmoothMs& a, int nscales, const float* const* disp, const float* const* image, int B,
+                          const int* h, const int* w, float grad_factor, int input_is_depth, int* max_blk) {
+  if (!disp || !image || !h || !w) return XPT_ERR_NULL;
+  if (nscales < 1 || nscales > 4 || B <= 0 || B > 65535) return XPT_ERR_SHAPE;
+  *max_blk = 0;
+  for (int s = 0; s < nscales; ++s) {
+    if (!disp[s] || !image[s]) return XPT_ERR_NULL;
+    if (h[s] < 2 || w[s] < 2) return XPT_ERR_SHAPE;
+    a.disp[s] = disp[s]; a.image[s] = image[s]; a.h[s] = h[s]; a.w[s] = w[s];
+    a.nblk[s] = (h[s] * w[s] + 255) / 256;
+    if (a.nblk[s] > *max_blk) *max_blk = a.nblk[s];
+  }
+  a.gf = grad_factor; a.is_depth = input_is_depth; a.B = B;
+  return XPT_OK;
+}
+
+int xpt_smooth_ms_fwd(int nscales, const float* const* disp, const float* const* image, float* losses,
+                      float* workspace, size_t workspace_floats, int B, const int* h, const int* w, float grad_factor,
+                      int input_is_depth, void* stream) {
+  XPT_CHECK_PTR(losses); XPT_CHECK_PTR(workspace);
+  SmoothMs a = {};
+  int max_blk = 0;
+  const int rc = smooth_ms_fill(a, nscales, disp, image, B, h, w, grad_factor, input_is_depth, &max_blk);
+  if (rc != XPT_OK) return rc;
+  size_t need = 0;
+  for (int s = 0; s < nscales; ++s) {
+    a.part[s] = workspace + need;
+    a.loss[s] = losses + (size_t)s * B;
+    need += xpt_smooth_workspace_floats(B, h[s], w[s]);
+  }
+  if (workspace_floats < need) return XPT_ERR_WORKSPACE;
+  XPT_BEGIN_LAUNCH();
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(smooth_fwd_ms_kernel, dim3(max_blk, B, nscales), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(smooth_reduce_ms_kernel, dim3((B + 63) / 64, nscales), dim3(64), 0, st, a);
+  return xpt_launch_status();
+}
+
+int xpt_smooth_ms_bwd(int nscales, const float* const* disp, const float* const* image, const float* const* gloss,
+                      float* const* dinput, int B, const int* h, const int* w, float grad_factor, int input_is_depth,
+                      void* stream) {
+  if (!gloss || !dinput) return XPT_ERR_NULL;
+  SmoothMs a = {};
+  int max_blk = 0;
+  const int rc = smooth_ms_fill(a, nscales, disp, image, B, h, w, grad_factor, input_is_depth, &max_blk);
+  if (rc != XPT_OK) return rc;
+  for (int s = 0; s < nscales; ++s) {
+    if (!gloss[s] || !dinput[s]) return XPT_ERR_NULL;
+    a.gloss[s] = gloss[s]; a.part[s] = dinput[s];
+  }
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(smooth_bwd_ms_kernel, dim3(max_blk, B, nscales), dim3(256), 0, (hipStream_t)stream, a);
   return xpt_launch_status();
 }
 

@@ -281,6 +281,49 @@ __global__ void depth_head_bwd_kernel(const float* __restrict__ x, const float* 
   }
 }
 
+// The four prediction scales of the decoder in one launch (blockIdx.y = scale; a grid-stride loop inside the scale).
+struct DepthHeadMs {
+  const float* x[4];
+  float* depth[4];       // backward: gx
+  float* disp[4];
+  const float* g_depth[4];
+  const float* g_disp[4];
+  long long n[4];
+};
+
+__global__ void depth_head_ms_fwd_kernel(DepthHeadMs a) {
+  const int s = blockIdx.y;
+  const float* __restrict__ x = a.x[s];
+  float* __restrict__ depth = a.depth[s];
+  float* __restrict__ disp = a.disp[s];
+  const long long n = a.n[s];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float sg = 1.f / (1.f + expf(-x[i]));
+    const float u = sg + 0.01f;
+    const float d = u > 1e-5f ? 1.f / u : 0.f;
+    depth[i] = d;
+    disp[i] = d > 1e-5f ? 1.f / d : 0.f;
+  }
+}
+
+__global__ void depth_head_ms_bwd_kernel(DepthHeadMs a) {
+  const int s = blockIdx.y;
+  const float* __restrict__ x = a.x[s];
+  const float* __restrict__ g_depth = a.g_depth[s];
+  const float* __restrict__ g_disp = a.g_disp[s];
+  float* __restrict__ gx = a.depth[s];
+  const long long n = a.n[s];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float sg = 1.f / (1.f + expf(-x[i]));
+    const float u = sg + 0.01f;
+    const float d = u > 1e-5f ? 1.f / u : 0.f;
+    float gd = g_depth ? g_depth[i] : 0.f;
+    if (g_disp && d > 1e-5f) gd -= g_disp[i] / (d * d);
+    const float gu = u > 1e-5f ? -gd / (u * u) : 0.f;
+    gx[i] = gu * sg * (1.f - sg);
+  }
+}
+
 // per channel c: S0 = sum_k part[k][0][c], S1 = sum_k part[k][1][c]; one wave (64 threads) per channel so that the
 // partial rows are fetched with few dependent round trips; fixed tree -> deterministic.
 __global__ void affine_finish_kernel(const float* __restrict__ part, Affine a, float* __restrict__ dbeta,
@@ -467,6 +510,41 @@ int xpt_depth_head_bwd(const float* x, const float* g_depth, const float* g_disp
   if (n <= 0) return XPT_ERR_SHAPE;
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(depth_head_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, g_depth, g_disp, gx, n);
+  return xpt_launch_status();
+}
+
+/* The same for nscales (1..4) prediction maps in one launch; a scale whose g_depth[s] and g_disp[s] are both NULL gets gx = 0. */
+int xpt_depth_head_ms_fwd(int nscales, const float* const* x, float* const* depth, float* const* disp, const long long* n,
+                          void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(depth); XPT_CHECK_PTR(disp); XPT_CHECK_PTR(n);
+  if (nscales < 1 || nscales > 4) return XPT_ERR_SHAPE;
+  DepthHeadMs a = {};
+  long long most = 0;
+  for (int s = 0; s < nscales; ++s) {
+    if (!x[s] || !depth[s] || !disp[s]) return XPT_ERR_NULL;
+    if (n[s] <= 0) return XPT_ERR_SHAPE;
+    a.x[s] = x[s]; a.depth[s] = depth[s]; a.disp[s] = disp[s]; a.n[s] = n[s];
+    if (n[s] > most) most = n[s];
+  }
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(depth_head_ms_fwd_kernel, dim3(grid_for(most), nscales), dim3(256), 0, (hipStream_t)stream, a);
+  return xpt_launch_status();
+}
+
+int xpt_depth_head_ms_bwd(int nscales, const float* const* x, const float* const* g_depth, const float* const* g_disp,
+                          float* const* gx, const long long* n, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(g_depth); XPT_CHECK_PTR(g_disp); XPT_CHECK_PTR(gx); XPT_CHECK_PTR(n);
+  if (nscales < 1 || nscales > 4) return XPT_ERR_SHAPE;
+  DepthHeadMs a = {};
+  long long most = 0;
+  for (int s = 0; s < nscales; ++s) {
+    if (!x[s] || !gx[s]) return XPT_ERR_NULL;
+    if (n[s] <= 0) return XPT_ERR_SHAPE;
+    a.x[s] = x[s]; a.depth[s] = gx[s]; a.g_depth[s] = g_depth[s]; a.g_disp[s] = g_disp[s]; a.n[s] = n[s];
+    if (n[s] > most) most = n[s];
+  }
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(depth_head_ms_bwd_kernel, dim3(grid_for(most), nscales), dim3(256), 0, (hipStream_t)stream, a);
   return xpt_launch_status();
 }
 

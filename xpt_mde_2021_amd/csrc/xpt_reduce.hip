@@ -54,6 +54,48 @@ __device__ inline void reduce_wide(const xpt_reduce_job& job, int first) {
   }
 }
 
+// Flat mode (wide-eligible jobs whose segments all have few splits: the large weights): the launch is bound by the
+// workgroup dispatch rate (~6 ns per workgroup measured, tools/reduce_breakdown.py), not by HBM, when a workgroup only
+// moves a few KiB, so here a workgroup owns 2048 consecutive outputs: every lane adds the splits of two float4 outputs
+// itself, in split order (all loads of a segment in flight together), no LDS.
+__device__ inline void reduce_flat(const xpt_reduce_job& job, int first) {
+  long long i[2];
+  bool live[2];
+  float4 sum[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    i[u] = (long long)first + 1024 * u + 4 * threadIdx.x;
+    live[u] = i[u] + 3 < job.n;                                        // n % 4 == 0 in this mode
+    sum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int g = 0; g < job.nseg; ++g) {
+    const long long stride = job.stride[g];
+    const int ns = job.nsplit[g];
+    for (int s0 = 0; s0 < ns; s0 += 8) {
+      float4 v[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float* src = job.src[g] + (live[u] ? i[u] : 0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float4 x = *(const float4*)(src + (long long)min(s0 + k, ns - 1) * stride);
+          const float keep = s0 + k < ns ? 1.f : 0.f;
+          v[u][k] = make_float4(x.x * keep, x.y * keep, x.z * keep, x.w * keep);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          sum[u].x += v[u][k].x; sum[u].y += v[u][k].y; sum[u].z += v[u][k].z; sum[u].w += v[u][k].w;
+        }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (live[u]) *(float4*)(job.dst + i[u]) = sum[u];
+}
+
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const xpt_reduce_job* __restrict__ jobs,
                                                                const int2* __restrict__ blockmap) {
   __shared__ float red[3][64];
@@ -61,6 +103,10 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const xpt_reduce_j
   const xpt_reduce_job job = jobs[bm.x];
   if (job.split_waves == 16) {                 // wide mode: 256 outputs per workgroup, 16-byte loads (below)
     reduce_wide(job, bm.y);
+    return;
+  }
+  if (job.split_waves == 32) {                 // flat mode: 2048 outputs per workgroup, few splits per segment
+    reduce_flat(job, bm.y);
     return;
   }
   const int SW = job.split_waves;              // 1 or 4 waves share one 64-output group

@@ -118,6 +118,66 @@ __global__ void resize_down_kernel(const float* __restrict__ img, float* __restr
   }
 }
 
+// Every image the loss stage reads, in one launch: the dense copies of the source frames and of the target frame of a
+// snippet batch image5d [B,S,H,W,3] (losses.py:57-66: TARGET FRAME LAST) and their resize_down pyramids.  A job =
+// (frames f0 .. f0+nf-1 of every snippet, factor s) -> out [B*nf, H/s, W/s, 3]; same arithmetic as resize_down_kernel.
+struct PyramidJob {
+  float* out;
+  long long total;     // outputs (float4 units when s == 1 and vec)
+  int f0, nf, s, block_off;
+};
+struct PyramidArgs {
+  PyramidJob job[10];
+  const float* img;
+  int njobs, S, H, W, vec;
+};
+
+__global__ void pyramid_kernel(PyramidArgs a) {
+  int j = 0;
+  while (j + 1 < a.njobs && (int)blockIdx.x >= a.job[j + 1].block_off) ++j;
+  const PyramidJob job = a.job[j];
+  const int nblk = (j + 1 < a.njobs ? a.job[j + 1].block_off : (int)gridDim.x) - job.block_off;
+  const long long first = (long long)(blockIdx.x - job.block_off) * blockDim.x + threadIdx.x;
+  const long long step = (long long)nblk * blockDim.x;
+  const int H = a.H, W = a.W, s = job.s;
+  if (s == 1) {
+    if (a.vec) {
+      const long long F4 = (long long)H * W * 3 / 4;
+      const float4* in4 = (const float4*)a.img;
+      float4* out4 = (float4*)job.out;
+      for (long long i = first; i < job.total; i += step) {
+        const long long m = i / F4, r = i - m * F4;
+        const long long b = m / job.nf, f = m - b * job.nf + job.f0;
+        out4[i] = in4[(b * a.S + f) * F4 + r];
+      }
+    } else {
+      const long long F = (long long)H * W * 3;
+      for (long long i = first; i < job.total; i += step) {
+        const long long m = i / F, r = i - m * F;
+        const long long b = m / job.nf, f = m - b * job.nf + job.f0;
+        job.out[i] = a.img[(b * a.S + f) * F + r];
+      }
+    }
+    return;
+  }
+  const int h = H / s, w = W / s;
+  const long long rowC = (long long)W * 3;
+  const int t = s / 2 - 1;
+  for (long long i = first; i < job.total; i += step) {
+    const int c = (int)(i % 3);
+    long long r = i / 3;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const long long m = r / h;
+    const long long b = m / job.nf, f = m - b * job.nf + job.f0;
+    const float* base = a.img + ((b * a.S + f) * H + (y * s + t)) * rowC + (long long)(x * s + t) * 3 + c;
+    const float tl = base[0], tr = base[3], bl = base[rowC], br = base[rowC + 3];
+    const float top = tl + (tr - tl) * 0.5f;
+    const float bot = bl + (br - bl) * 0.5f;
+    job.out[i] = top + (bot - top) * 0.5f;
+  }
+}
+
 // =================================================================== K2+K3: view synthesis (per-pixel form)
 // One thread per target pixel, looping over the N source views (depth / ray shared).
 __device__ inline void sample3(const float* __restrict__ img, int w, const Taps& t, float out[3], float tap[12]) {
@@ -333,6 +393,36 @@ int xpt_resize_down_fwd(const float* img, float* out, int M, int H, int W, int C
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(resize_down_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, img, out, M, H, W,
                      C, scale);
+  return xpt_launch_status();
+}
+
+int xpt_image_pyramids(const float* image5d, int B, int S, int H, int W, int njobs, const int* first_frame,
+                       const int* nframes, const int* scale, float* const* out, void* stream) {
+  XPT_CHECK_PTR(image5d); XPT_CHECK_PTR(first_frame); XPT_CHECK_PTR(nframes); XPT_CHECK_PTR(scale); XPT_CHECK_PTR(out);
+  if (B <= 0 || S <= 0 || H <= 0 || W <= 0 || njobs < 1 || njobs > 10) return XPT_ERR_SHAPE;
+  PyramidArgs a = {};
+  a.img = image5d; a.njobs = njobs; a.S = S; a.H = H; a.W = W;
+  a.vec = ((long long)H * W * 3) % 4 == 0 && ((uintptr_t)image5d) % 16 == 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (!out[j]) return XPT_ERR_NULL;
+    if (scale[j] == 1 && ((uintptr_t)out[j]) % 16 != 0) a.vec = 0;
+  }
+  long long blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    const int s = scale[j];
+    if (s <= 0 || (s != 1 && (s & 1)) || H % s || W % s) return XPT_ERR_SHAPE;
+    if (first_frame[j] < 0 || nframes[j] <= 0 || first_frame[j] + nframes[j] > S) return XPT_ERR_SHAPE;
+    PyramidJob& job = a.job[j];
+    job.out = out[j]; job.f0 = first_frame[j]; job.nf = nframes[j]; job.s = s;
+    job.total = (long long)B * nframes[j] * (H / s) * (W / s) * 3;
+    if (s == 1 && a.vec) job.total /= 4;
+    long long nb = (job.total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    job.block_off = (int)blocks;
+    blocks += nb;
+  }
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(pyramid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   return xpt_launch_status();
 }
 

@@ -29,6 +29,7 @@ SIGNATURES = {
     "xpt_pose_rvec2matr_fwd": (_i, [_p, _p, _i, _p]),
     "xpt_pose_rvec2matr_bwd": (_i, [_p, _p, _p, _i, _p]),
     "xpt_resize_down_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "xpt_image_pyramids": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "xpt_warp_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p]),
     "xpt_warp_bwd_workspace_floats": (_z, [_i, _i, _i, _i]),
     "xpt_warp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _f, _p]),
@@ -45,6 +46,8 @@ SIGNATURES = {
     "xpt_smooth_workspace_floats": (_z, [_i, _i, _i]),
     "xpt_smooth_fwd": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _f, _i, _p]),
     "xpt_smooth_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
+    "xpt_smooth_ms_fwd": (_i, [_i, _p, _p, _p, _p, _z, _i, _p, _p, _f, _i, _p]),
+    "xpt_smooth_ms_bwd": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _f, _i, _p]),
     "xpt_adam_step": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _f, _f, _f, _f, _f, _i, _p, _p]),
     "xpt_dwconv_fwd": (_i, [_p, _p, _p] + [_i] * 12 + [_p]),
     "xpt_dwconv_bwd_data": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p]),
@@ -84,6 +87,8 @@ SIGNATURES = {
     "xpt_corr_cost_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "xpt_depth_head_fwd": (_i, [_p, _p, _p, ctypes.c_longlong, _p]),
     "xpt_depth_head_bwd": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p]),
+    "xpt_depth_head_ms_fwd": (_i, [_i, _p, _p, _p, _p, _p]),
+    "xpt_depth_head_ms_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p]),
     "xpt_sum_rows": (_i, [_p, _p, _i, _p, ctypes.c_longlong, _i, _i, _p]),
     "xpt_photo_fused_ms_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),   # losses is one [2 n, B] buffer
     "xpt_photo_fused_ms_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),

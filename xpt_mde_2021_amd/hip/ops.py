@@ -67,6 +67,34 @@ def resize_down(img, scale):
     return out
 
 
+def image_pyramids(image5d, scales):
+    """Source frames (all but the last) and target frame (the last) of image5d [B,S,H,W,3] at every factor in `scales`
+    (1 = dense copy), in ONE launch: -> ({scale: [B,S-1,h,w,3]}, {scale: [B,h,w,3]}); no gradient.  Same values as
+    resize_down of the dense slices."""
+    import ctypes
+    lib = _lib.load()
+    img = _dev(image5d.detach(), "image5d")
+    if not img.is_contiguous():
+        raise _lib.XptHipError("image_pyramids: image5d must be contiguous")
+    B, S, H, W, C = img.shape
+    if C != 3 or S < 2:
+        raise _lib.XptHipError(f"image_pyramids: expected [B, S>=2, H, W, 3], got {tuple(img.shape)}")
+    scales = sorted({int(s) for s in scales} | {1})
+    sources, targets, first, count, factor, outs = {}, {}, [], [], [], []
+    for s in scales:
+        sources[s] = torch.empty((B, S - 1, H // s, W // s, 3), dtype=torch.float32, device=img.device)
+        targets[s] = torch.empty((B, H // s, W // s, 3), dtype=torch.float32, device=img.device)
+        first += [0, S - 1]
+        count += [S - 1, 1]
+        factor += [s, s]
+        outs += [sources[s], targets[s]]
+    n = len(outs)
+    _lib.check(lib.xpt_image_pyramids(_ptr(img), B, S, H, W, n, (ctypes.c_int * n)(*first), (ctypes.c_int * n)(*count),
+                                      (ctypes.c_int * n)(*factor), (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs]),
+                                      _stream()), "xpt_image_pyramids")
+    return sources, targets
+
+
 # ------------------------------------------------------------------------------- K2+K3 warp
 class _Warp(torch.autograd.Function):
     @staticmethod
@@ -359,6 +387,63 @@ def smoothness(disp, image, grad_factor, input_is_depth=False):
     return _Smooth.apply(disp, image, grad_factor, input_is_depth)
 
 
+class _SmoothMS(torch.autograd.Function):
+    """All scales of the smoothness loss in one forward pair and one backward launch (xpt_smooth_ms_*)."""
+
+    @staticmethod
+    def forward(ctx, grad_factor, input_is_depth, n, *tensors):
+        import ctypes
+        lib = _lib.load()
+        disps = [_dev(t, "disp") for t in tensors[:n]]
+        images = [_dev(t, "image") for t in tensors[n:]]
+        B = images[0].shape[0]
+        hs, ws_ = [int(t.shape[1]) for t in images], [int(t.shape[2]) for t in images]
+        for d, im in zip(disps, images):
+            if im.shape[0] != B or im.shape[3] != 3 or d.numel() != B * im.shape[1] * im.shape[2]:
+                raise _lib.XptHipError(f"smoothness_ms: disp {tuple(d.shape)} vs image {tuple(im.shape)}")
+        losses = torch.empty((n, B), dtype=torch.float32, device=images[0].device)
+        nws = sum(lib.xpt_smooth_workspace_floats(B, h, w) for h, w in zip(hs, ws_))
+        ws = torch.empty(nws, dtype=torch.float32, device=images[0].device)
+        P = ctypes.c_void_p * n
+        ptrs = lambda ts: P(*[t.data_ptr() for t in ts])       # noqa: E731
+        _lib.check(lib.xpt_smooth_ms_fwd(n, ptrs(disps), ptrs(images), _ptr(losses), _ptr(ws), nws, B,
+                                         (ctypes.c_int * n)(*hs), (ctypes.c_int * n)(*ws_), float(grad_factor),
+                                         int(input_is_depth), _stream()), "xpt_smooth_ms_fwd")
+        ctx.save_for_backward(*disps, *images)
+        ctx.cfg = (n, float(grad_factor), int(input_is_depth), hs, ws_)
+        ctx.set_materialize_grads(False)
+        return tuple(losses[i] for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        lib = _lib.load()
+        n, gf, is_depth, hs, ws_ = ctx.cfg
+        disps, images = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        B = images[0].shape[0]
+        zero = None
+        gs = []
+        for g in grads:
+            if g is None:
+                if zero is None:
+                    zero = torch.zeros(B, dtype=torch.float32, device=images[0].device)
+                g = zero
+            gs.append(_dev(g, "grad"))
+        dinputs = [torch.empty_like(d) for d in disps]
+        P = ctypes.c_void_p * n
+        ptrs = lambda ts: P(*[t.data_ptr() for t in ts])       # noqa: E731
+        _lib.check(lib.xpt_smooth_ms_bwd(n, ptrs(disps), ptrs(images), ptrs(gs), ptrs(dinputs), B,
+                                         (ctypes.c_int * n)(*hs), (ctypes.c_int * n)(*ws_), gf, is_depth, _stream()),
+                   "xpt_smooth_ms_bwd")
+        return (None, None, None, *dinputs, *([None] * n))
+
+
+def smoothness_multi_scale(disps, images, grad_factor, input_is_depth=False):
+    """[smoothness(disp_s, image_s) for every scale] in one launch pair (at most 4 scales)."""
+    n = len(disps)
+    return list(_SmoothMS.apply(grad_factor, input_is_depth, n, *disps, *images))
+
+
 # ------------------------------------------------------------------------------- deferred parameter gradients
 class GradSink:
     """Collects the split-K / per-workgroup partial sums of parameter gradients during one backward pass and finishes
@@ -431,7 +516,8 @@ class GradSink:
             _lib.check(lib.xpt_reduce_partials(_ptr(jobs), _ptr(blockmap), nblocks, _stream()), "xpt_reduce_partials")
 
     MAX_SPLITS = int(__import__('os').environ.get('XPT_SINK_MAX_SPLITS', '256'))   # per job and pass; more are folded by a first pass into groups of GROUP splits
-    GROUP = 64
+    GROUP = int(__import__('os').environ.get('XPT_SINK_GROUP', '256'))
+    FLAT_MAX = int(__import__('os').environ.get('XPT_SINK_FLAT_MAX', '32'))     # most splits served 2048 outputs per workgroup
 
     def _build(self, lib, pending):
         """Job tables of the finishing launches: [pass 1 (only when some job has > MAX_SPLITS splits), pass 2]."""
@@ -477,15 +563,17 @@ class GradSink:
         for j, (dst, n, segs) in enumerate(entries):
             waves = 1 if max(ns for _, ns, _ in segs) <= 8 else 4
             # wide mode (csrc/xpt_reduce.hip reduce_wide): whole 1 KiB rows per wave when every row is 16-byte aligned
-            wide = n >= 256 and n % 4 == 0 and dst % 16 == 0 and max(ns for _, ns, _ in segs) > 1 and \
-                all(ptr % 16 == 0 and st % 4 == 0 for ptr, _, st in segs)
+            wide = n >= 256 and n % 4 == 0 and dst % 16 == 0 and all(ptr % 16 == 0 and st % 4 == 0 for ptr, _, st in segs)
             if wide:
-                waves = 16
+                # <= 8 splits per segment (the large weights; a single split is a plain copy): 2048 outputs per
+                # workgroup (reduce_flat), the launch being bound by the workgroup dispatch rate when a workgroup
+                # moves only a few KiB
+                waves = 32 if max(ns for _, ns, _ in segs) <= GradSink.FLAT_MAX else 16
             job = jobs[j]
             job.dst, job.n, job.nseg, job.split_waves = dst, n, len(segs), waves
             for g, (ptr, ns, st) in enumerate(segs):
                 job.src[g], job.nsplit[g], job.stride[g] = ptr, ns, st
-            blockmap.extend((j, first) for first in range(0, n, 64 if waves == 4 else 256))
+            blockmap.extend((j, first) for first in range(0, n, {4: 64, 32: 2048}.get(waves, 256)))
         jobs_t = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
         map_t = torch.from_numpy(np.asarray(blockmap, dtype=np.int32).reshape(-1, 2)).to(dev)
         return jobs_t, map_t, len(blockmap)
@@ -780,6 +868,51 @@ class _DepthHead(torch.autograd.Function):
         gx = torch.empty_like(x)
         _lib.check(lib.xpt_depth_head_bwd(_ptr(x), _ptr(gd), _ptr(gs), _ptr(gx), x.numel(), _stream()), "xpt_depth_head_bwd")
         return gx
+
+
+class _DepthHeadMS(torch.autograd.Function):
+    """The depth activation of every prediction scale in one launch (and one for the backward: the gradients of all
+    scales come from the loss, so they are all there when the first decoder level is reached)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        import ctypes
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        xs = [_dev(x, "x") for x in xs]
+        n = len(xs)
+        depths, disps = [torch.empty_like(x) for x in xs], [torch.empty_like(x) for x in xs]
+        P = ctypes.c_void_p * n
+        ptrs = lambda ts: P(*[t.data_ptr() for t in ts])       # noqa: E731
+        _lib.check(lib.xpt_depth_head_ms_fwd(n, ptrs(xs), ptrs(depths), ptrs(disps),
+                                             (ctypes.c_longlong * n)(*[x.numel() for x in xs]), _stream()),
+                   "xpt_depth_head_ms_fwd")
+        ctx.save_for_backward(*xs)
+        return (*depths, *disps)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        lib = _lib.load()
+        xs = ctx.saved_tensors
+        n = len(xs)
+        if all(g is None for g in grads):
+            return (None,) * n
+        gs = [None if g is None else g.contiguous().float() for g in grads]
+        gxs = [torch.empty_like(x) for x in xs]
+        P = ctypes.c_void_p * n
+        ptrs = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])       # noqa: E731
+        _lib.check(lib.xpt_depth_head_ms_bwd(n, ptrs(xs), ptrs(gs[:n]), ptrs(gs[n:]), ptrs(gxs),
+                                             (ctypes.c_longlong * n)(*[x.numel() for x in xs]), _stream()),
+                   "xpt_depth_head_ms_bwd")
+        return tuple(gxs)
+
+
+def inverse_sigmoid_depth_multi(xs):
+    """([depth_s], [disp_s]) of inverse_sigmoid_depth for up to 4 prediction maps in one launch."""
+    n = len(xs)
+    out = _DepthHeadMS.apply(*xs)
+    return list(out[:n]), list(out[n:])
 
 
 def inverse_sigmoid_depth(x):

@@ -10,6 +10,9 @@ from ..model_util import layer_ops as lo
 from .pretrained_nets import PretrainedModel
 
 
+_BATCHED_HEADS = __import__("os").environ.get("XPT_DEBUG_PER_SCALE_LOSS", "0") != "1"     # A/B: one activation launch per scale
+
+
 class _ChannelsLastOne(torch.autograd.Function):
     """[B,1,H,W] contiguous -> the same memory with channels_last strides (a view); the gradient passes through as it
     comes (as_strided's own backward would materialise it with a zero fill and a copy)."""
@@ -68,13 +71,17 @@ class ScaledDepthHead(nn.Module):
         self.conv = conv2d(cin, 1, 3, activation="linear")
         self.predict_depth = pred_depth
 
-    def forward(self, src, dst_height, dst_width):
+    def forward(self, src, dst_height, dst_width, activate=True):
+        """activate=False: depth is None -- the caller applies the activation to all scales at once
+        (predict_depth.with_disparity_multi), the decoder itself only consuming the raw prediction."""
         with torch.autocast(device_type=src.device.type, enabled=False):
             if _conv.head_usable(src, self.conv.conv) and self.conv.slope == 1.0:
                 conv = _conv.head_conv(src, self.conv.conv.weight, self.conv.conv.bias)     # bf16 features in, fp32 prediction out
             else:
                 conv = self.conv(src.float())
-            if hasattr(self.predict_depth, "with_disparity"):
+            if not activate:
+                depth, self.last_disp = None, None
+            elif hasattr(self.predict_depth, "with_disparity"):
                 depth, self.last_disp = self.predict_depth.with_disparity(conv)
             else:
                 depth, self.last_disp = self.predict_depth(conv), None
@@ -111,22 +118,31 @@ class DepthNetPretrained(nn.Module):
         return outputs
 
     def decode(self, conv1, conv2, conv3, conv4, conv5, height, width):
+        heads = (self.depth0, self.depth1, self.depth2, self.depth3)
+        # the depth activation of all four scales runs as one launch after the decoder (only the raw predictions feed
+        # the next decoder level)
+        batched = _BATCHED_HEADS and conv5.is_cuda and hasattr(self.depth0.predict_depth, "with_disparity_multi")
         upconv4 = self.up4(conv5, [conv4])
         upconv3 = self.up3(upconv4, [conv3])
-        depth3, dpconv2_up, dpconv3 = self.depth3(upconv3, height // 4, width // 4)
+        depth3, dpconv2_up, dpconv3 = self.depth3(upconv3, height // 4, width // 4, not batched)
         upconv2 = self.up2(upconv3, [conv2, dpconv2_up])
-        depth2, dpconv1_up, dpconv2 = self.depth2(upconv2, height // 2, width // 2)
+        depth2, dpconv1_up, dpconv2 = self.depth2(upconv2, height // 2, width // 2, not batched)
         upconv1 = self.up1(upconv2, [conv1, dpconv1_up])
-        depth1, dpconv0_up, dpconv1 = self.depth1(upconv1, height, width)
+        depth1, dpconv0_up, dpconv1 = self.depth1(upconv1, height, width, not batched)
         upconv0 = self.up0(upconv1, [dpconv0_up])
-        depth0, _, dpconv0 = self.depth0(upconv0, height, width)
+        depth0, _, dpconv0 = self.depth0(upconv0, height, width, not batched)
+        if batched:
+            with torch.autocast(device_type=conv5.device.type, enabled=False):
+                (depth0, depth1, depth2, depth3), disps = self.depth0.predict_depth.with_disparity_multi(
+                    [dpconv0, dpconv1, dpconv2, dpconv3])
+            for h, d in zip(heads, disps):
+                h.last_disp = d
 
         def nhwc1(x):      # [B,1,h,w] -> [B,h,w,1]: same memory, the reference's axis order
             return x.contiguous().reshape(x.shape[0], x.shape[2], x.shape[3], 1)
 
         out = {"depth_ms": [nhwc1(depth0), nhwc1(depth1), nhwc1(depth2), nhwc1(depth3)],
                "debug_out": [dpconv0, upconv0, dpconv3, upconv3]}
-        heads = (self.depth0, self.depth1, self.depth2, self.depth3)
         disps = [h.last_disp for h in heads]
         for h in heads:        # hand the tensors over: a module attribute would keep this step's autograd graph (and its
             h.last_disp = None  # AccumulateGrad nodes with their stream) alive into the next step / a hipGraph capture

@@ -99,6 +99,14 @@ class InverseSigmoidActivation:
         depth = self(x)
         return depth, uf.safe_reciprocal_number(depth)
 
+    def with_disparity_multi(self, xs):
+        """with_disparity for every prediction scale of the decoder at once: ([depth_s], [disp_s])."""
+        if len(xs) <= 4 and all(x.is_cuda and x.dtype == torch.float32 for x in xs):
+            from ...hip import ops as _ops
+            return _ops.inverse_sigmoid_depth_multi(list(xs))
+        pairs = [self.with_disparity(x) for x in xs]
+        return [p[0] for p in pairs], [p[1] for p in pairs]
+
 
 class ExponentialActivation:
     """model_factory.py:141-145: depth = exp(sigmoid(x + 1) * 10 - 5)."""

@@ -14,7 +14,7 @@ from ...utils import convert_pose as cp
 from ...utils import util_funcs as uf
 from ...utils.util_class import WrongInputException
 from ..synthesize.flow_warping import FlowWarpMultiScale
-from ..synthesize.synthesize_base import SynthesizeMultiScale
+from ..synthesize.synthesize_base import SynthesizeMultiScale, _FUSED_MULTI_SCALE
 from . import loss_util as lsu
 
 
@@ -96,18 +96,28 @@ class TotalLoss:
         """losses.py:57-104: source/target split (TARGET FRAME LAST), multi-scale target, synthesized views."""
         image5d = features["image5d" + suffix]
         intrinsic = features["intrinsic" + suffix]
-        # one dense copy each, made here once: every scale would otherwise re-copy the strided slices (4 x 25 MB)
-        source_image = image5d[:, :-1].contiguous()
-        target_image = image5d[:, -1].contiguous()
+        rigid = ("depth_ms" + suffix in predictions) and ("pose" + suffix in predictions)
+        scales = self._pyramid_scales(image5d, predictions["depth_ms" + suffix]) if rigid else None
+        sources_ms = None
+        if scales:
+            # the dense copies of the source / target frames and their pyramids in one launch (xpt_image_pyramids)
+            sources, targets = _ops.image_pyramids(image5d, scales)
+            source_image, target_image = sources[1], targets[1]
+            sources_ms, target_ms = [sources[s] for s in scales], [targets[s] for s in scales]
+        else:
+            # one dense copy each, made here once: every scale would otherwise re-copy the strided slices (4 x 25 MB)
+            source_image = image5d[:, :-1].contiguous()
+            target_image = image5d[:, -1].contiguous()
         augm_data = {"source" + suffix: source_image, "target" + suffix: target_image}
-        if ("depth_ms" + suffix in predictions) and ("pose" + suffix in predictions):
+        if rigid:
             pred_depth_ms = predictions["depth_ms" + suffix]
             pred_pose = predictions["pose" + suffix]
-            target_ms = uf.multi_scale_like_depth(target_image, pred_depth_ms)
+            if not scales:
+                target_ms = uf.multi_scale_like_depth(target_image, pred_depth_ms)
             augm_data["target_ms" + suffix] = target_ms
             if self.use_fused(image5d):
                 augm_data["fused_photo_ms" + suffix] = SynthesizeMultiScale().photometric_losses(
-                    source_image, intrinsic, pred_depth_ms, pred_pose, target_ms)
+                    source_image, intrinsic, pred_depth_ms, pred_pose, target_ms, sources_ms)
             else:
                 augm_data["synth_target_ms" + suffix] = SynthesizeMultiScale()(source_image, intrinsic,
                                                                                 pred_depth_ms, pred_pose)
@@ -117,6 +127,22 @@ class TotalLoss:
             augm_data["flow_target_ms" + suffix] = uf.multi_scale_like_flow(target_image, pred_flow_ms)
             augm_data["warped_target_ms" + suffix] = FlowWarpMultiScale()(source_image, pred_flow_ms)
         return augm_data
+
+    @staticmethod
+    def _pyramid_scales(image5d, depth_ms):
+        """Integer factors of the depth scales when every one is an exact even (or unit) down-scale of a dense float32
+        device snippet batch (what xpt_image_pyramids serves), else None."""
+        if not (_FUSED_MULTI_SCALE and image5d.is_cuda and image5d.dtype == torch.float32 and image5d.is_contiguous()
+                and image5d.shape[1] >= 2 and image5d.shape[-1] == 3 and len(depth_ms) <= 4):
+            return None
+        H, W = image5d.shape[2:4]
+        scales = []
+        for depth in depth_ms:
+            hs, ws = depth.shape[1:3]
+            if H % hs or W % ws or H // hs != W // ws or (H // hs != 1 and (H // hs) % 2):
+                return None
+            scales.append(H // hs)
+        return scales if len(set(scales)) == len(scales) else None
 
     def synethesize_stereo(self, features, predictions, augm_data):
         """losses.py:106-140 (the reference's spelling is kept: logger.py:211-216 calls it by this name)."""
@@ -340,10 +366,11 @@ class SmoothenessLossMultiScale(LossBase):
         disp_ms = predictions["disp_ms" + self.key_suffix]
         target_ms = augm_data["target_ms" + self.key_suffix]
         orig_width = target_ms[0].shape[2]
-        losses, factors = [], []
-        for disp, image in zip(disp_ms, target_ms):
-            losses.append(self.smootheness_loss(disp, image))
-            factors.append(image.shape[2] / orig_width)              # each scale's loss divided by its scale factor
+        factors = [image.shape[2] / orig_width for image in target_ms]   # each scale's loss divided by its scale factor
+        if len(disp_ms) <= 4 and _FUSED_MULTI_SCALE:
+            losses = _ops.smoothness_multi_scale(list(disp_ms), list(target_ms), float(opts.IMAGE_GRADIENT_FACTOR))
+        else:
+            losses = [self.smootheness_loss(disp, image) for disp, image in zip(disp_ms, target_ms)]
         return self.merge_multi_scale_losses(losses, factors=factors)
 
     def smootheness_loss(self, disp, image):
