@@ -172,6 +172,14 @@ int xpt_smooth_ms_bwd(int nscales, const float* const* disp, const float* const*
                       float* const* dinput, int B, const int* h, const int* w, float grad_factor, int input_is_depth,
                       void* stream);
 
+/* ------------------------------------------------------------------ a13: the merge of TotalLoss.__call__ (losses.py:44-55)
+ * terms[t] [batch] (t < n <= 64: one per loss type and scale), c [n] (scale weight x type weight / global batch),
+ * amat [types][n] (per-type read-out) -> total [1] = sum_t c[t] sum_b terms[t][b], by_type [types]; one launch, fixed
+ * summation order.  bwd: g_total [1] -> grads [n][batch] = c[t] g_total. */
+int xpt_merge_total_fwd(int n, const float* const* terms, const float* c, const float* amat, float* total,
+                        float* by_type, int batch, int types, void* stream);
+int xpt_merge_total_bwd(int n, const float* c, const float* g_total, float* grads, int batch, void* stream);
+
 /* ------------------------------------------------------------------ a14: fused Adam (Keras semantics)
  * replaces tf.optimizers.Adam(lr).apply_gradients (model/model_util/optimizers.py:7-13,
  * model/train_val.py:86) over FLAT fp32 buffers of n elements (16-byte aligned):
@@ -330,6 +338,18 @@ int xpt_depth_head_ms_fwd(int nscales, const float* const* x, float* const* dept
                           void* stream);
 int xpt_depth_head_ms_bwd(int nscales, const float* const* x, const float* const* g_depth, const float* const* g_disp,
                           float* const* gx, const long long* n, void* stream);
+
+/* tf.keras.layers.GlobalAveragePooling2D closing PoseNet (model/build_model/pose_net.py:45) on an NHWC map x [B,HW,C]
+ * (dtype 0 float32 / 1 bfloat16) -> y float32 [B,C]; bwd: g float32 [B,C] -> dx [B,HW,C] of that dtype = g / HW. */
+int xpt_global_avgpool_fwd(const void* x, float* y, int B, int HW, int C, int dtype, void* stream);
+int xpt_global_avgpool_bwd(const float* g, void* dx, int B, int HW, int C, int dtype, void* stream);
+
+/* resize_image (model/model_util/layer_ops.py:43-50; tf.image.resize bilinear, half-pixel centres) at an exact factor 2 on
+ * the decoder's one-channel raw predictions (depth_net.py:87-92): src float32 [M,h,w] -> out [M,2h,2w] (dtype 0 float32 /
+ * 1 bfloat16: it is concatenated with bf16 features); bwd: g [M,2h,2w] read with a pixel pitch of g_pitch elements (a
+ * channel slice of the NHWC concatenation's gradient, in place) -> dsrc float32 [M,h,w] (gather form: no zero fill). */
+int xpt_upsample2x_fwd(const float* src, void* out, long long M, int h, int w, int dtype, void* stream);
+int xpt_upsample2x_bwd(const void* g, long long g_pitch, float* dsrc, long long M, int h, int w, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ f-4: PWC-Net correlation cost volume
  * tfa.layers.CorrelationCost(kernel_size=1, max_displacement=md, stride_1=1, stride_2=s2, pad=md, channels_last)

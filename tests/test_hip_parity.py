@@ -657,6 +657,69 @@ def test_inverse_sigmoid_depth(ops, gpu_device):
     assert torch.allclose(x2.grad.cpu().double(), x2r.grad, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 16, 52), (1, 1, 1, 1), (3, 1, 5, 7), (2, 3, 4, 6)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample2x_matches_interpolate(ops, gpu_device, shape, dtype):
+    """xpt_upsample2x_* (resize_image at an exact factor 2, layer_ops.py:43-50) vs F.interpolate(bilinear, half-pixel)
+    forward and backward, with the gradient arriving as a channel slice of an NHWC tensor (read in place)."""
+    import torch.nn.functional as F
+    g = gen(502)
+    B, C, h, w = shape
+    x = torch.randn(shape, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    yr = F.interpolate(xr, size=(2 * h, 2 * w), mode="bilinear", align_corners=False)
+    xg = x.to(gpu_device).requires_grad_(True)
+    y = ops.upsample2x(xg, dtype)
+    assert y.dtype == dtype and y.shape == yr.shape
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert torch.allclose(y.float().cpu().double(), yr.detach(), rtol=tol, atol=tol)
+    # the consumer is a concatenation in NHWC: the gradient of this operand is a strided channel slice
+    other = torch.randn((B, 5, 2 * h, 2 * w), generator=g).to(gpu_device).to(dtype).contiguous(memory_format=torch.channels_last)
+    wgt = torch.randn((B, 5 + C, 2 * h, 2 * w), generator=g)
+    cat = torch.cat([other, y.contiguous(memory_format=torch.channels_last)], dim=1)
+    (cat.float() * wgt.to(gpu_device)).sum().backward()
+    gy = wgt[:, 5:].to(dtype).double() if dtype == torch.bfloat16 else wgt[:, 5:].double()
+    yr.backward(gy)
+    assert torch.allclose(xg.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_global_avg_pool(ops, gpu_device, dtype):
+    """GlobalAveragePooling2D closing PoseNet (pose_net.py:45): value and gradient vs x.float().mean((2, 3))."""
+    g = gen(503)
+    x = torch.randn((3, 24, 2, 7), generator=g).to(dtype)
+    gy = torch.randn((3, 24), generator=g)
+    xr = x.double().requires_grad_(True)
+    xr.mean(dim=(2, 3)).backward(gy.double())
+    xg = x.to(gpu_device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = ops.global_avg_pool(xg)
+    y.backward(gy.to(gpu_device))
+    assert y.dtype == torch.float32
+    assert torch.allclose(y.cpu().double(), x.double().mean(dim=(2, 3)), rtol=1e-6, atol=1e-6)
+    assert xg.grad.dtype == dtype
+    assert torch.allclose(xg.grad.float().cpu().double(), xr.grad, rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-7)
+
+
+def test_merge_total_matches_the_tensor_op_chain(ops, gpu_device):
+    """xpt_merge_total_* == dot(c, rowsum(stack(terms))) and A rowsum(terms), with every term's gradient = c[t] g."""
+    g = gen(504)
+    n, batch, types = 12, 8, 3
+    terms = [torch.randn(batch, generator=g) for _ in range(n)]
+    c = torch.rand(n, generator=g)
+    a = torch.rand((types, n), generator=g)
+    tr = [t.clone().double().requires_grad_(True) for t in terms]
+    rs = torch.stack(tr).sum(dim=1)
+    total_r = torch.dot(c.double(), rs)
+    (total_r * 1.7).backward()
+    tg = [t.to(gpu_device).requires_grad_(True) for t in terms]
+    total, by_type = ops.merge_total(c.to(gpu_device), a.to(gpu_device), tg)
+    (total * 1.7).backward()
+    assert abs(total.item() - total_r.item()) < 1e-5
+    assert torch.allclose(by_type.cpu().double(), a.double() @ rs.detach(), rtol=1e-5, atol=1e-5)
+    for t, r in zip(tg, tr):
+        assert torch.allclose(t.grad.cpu().double(), r.grad, rtol=1e-6, atol=1e-7)
+
+
 def test_inverse_sigmoid_depth_multi_equals_per_scale(ops, gpu_device):
     """All prediction scales in one launch (xpt_depth_head_ms_*) == scale by scale, bit for bit, with outputs of some
     scales left unused (their gradient slots are NULL at the boundary)."""

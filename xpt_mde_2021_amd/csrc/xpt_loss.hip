@@ -341,8 +341,69 @@ __global__ void smooth_bwd_ms_kernel(SmoothMs a) {
                   1.0f / ((float)a.h[s] * (float)(a.w[s] - 1)), 1.0f / ((float)(a.h[s] - 1) * (float)a.w[s]));
 }
 
+// =================================================================== total-loss merge (TotalLoss.__call__, losses.py:44-55)
+// total = sum_t c[t] * rowsum_t,  by_type[k] = sum_t a[k][t] * rowsum_t,  rowsum_t = sum_b term_t[b]: one workgroup, fixed
+// order (what torch does with stack + sum + dot + mv: four launches); backward: grad_t[b] = c[t] * g_total.
+struct MergeTerms {
+  const float* term[64];
+  int n, batch, types;
+};
+
+__global__ void merge_total_fwd_kernel(MergeTerms a, const float* __restrict__ c, const float* __restrict__ amat,
+                                       float* __restrict__ total, float* __restrict__ by_type) {
+  __shared__ float rs[64];
+  const int t = threadIdx.x;
+  if (t < a.n) {
+    float s = 0.f;
+    for (int b = 0; b < a.batch; ++b) s += a.term[t][b];
+    rs[t] = s;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.f;
+    for (int j = 0; j < a.n; ++j) s += c[j] * rs[j];
+    total[0] = s;
+  }
+  if (t >= 64 && t - 64 < a.types) {
+    const int k = t - 64;
+    float s = 0.f;
+    for (int j = 0; j < a.n; ++j) s += amat[k * a.n + j] * rs[j];
+    by_type[k] = s;
+  }
+}
+
+__global__ void merge_total_bwd_kernel(const float* __restrict__ c, const float* __restrict__ g_total,
+                                       float* __restrict__ grads, int n, int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * batch) grads[i] = c[i / batch] * g_total[0];
+}
+
 // =================================================================== C ABI
 extern "C" {
+
+int xpt_merge_total_fwd(int n, const float* const* terms, const float* c, const float* amat, float* total,
+                        float* by_type, int batch, int types, void* stream) {
+  XPT_CHECK_PTR(terms); XPT_CHECK_PTR(c); XPT_CHECK_PTR(amat); XPT_CHECK_PTR(total); XPT_CHECK_PTR(by_type);
+  if (n < 1 || n > 64 || batch < 1 || types < 1 || types > 64) return XPT_ERR_SHAPE;
+  MergeTerms a = {};
+  for (int t = 0; t < n; ++t) {
+    if (!terms[t]) return XPT_ERR_NULL;
+    a.term[t] = terms[t];
+  }
+  a.n = n; a.batch = batch; a.types = types;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(merge_total_fwd_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, a, c, amat, total, by_type);
+  return xpt_launch_status();
+}
+
+int xpt_merge_total_bwd(int n, const float* c, const float* g_total, float* grads, int batch, void* stream) {
+  XPT_CHECK_PTR(c); XPT_CHECK_PTR(g_total); XPT_CHECK_PTR(grads);
+  if (n < 1 || n > 64 || batch < 1) return XPT_ERR_SHAPE;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(merge_total_bwd_kernel, dim3((n * batch + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, g_total,
+                     grads, n, batch);
+  return xpt_launch_status();
+}
 
 size_t xpt_photo_workspace_floats(int B, int N, int h, int w) {
   if (B <= 0 || N <= 0 || h <= 0 || w <= 0) return 0;

@@ -281,6 +281,97 @@ __global__ void depth_head_bwd_kernel(const float* __restrict__ x, const float* 
   }
 }
 
+// ---------------------------------------------------------------- GlobalAveragePooling2D of an NHWC map (PoseNet's tail)
+template <typename T>
+__global__ void gap_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, int total, int HW, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (b, c)
+  if (i >= total) return;
+  const int b = i / C, c = i - b * C;
+  const T* p = x + (long long)b * HW * C + c;
+  float s = 0.f;
+  for (int k = 0; k < HW; ++k) s += ldf<T>(p + (long long)k * C);
+  y[i] = s / (float)HW;
+}
+
+template <typename T>
+__global__ void gap_bwd_kernel(const float* __restrict__ g, T* __restrict__ dx, long long total, int HW, int C) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long b = i / ((long long)HW * C);
+    stf<T>(dx + i, g[b * C + c] / (float)HW);
+  }
+}
+
+// ---------------------------------------------------------------- exact 2x bilinear up-sampling of one-channel maps
+// tf.image.resize(bilinear, half-pixel centres) at an exact factor 2 = torch upsample_bilinear2d(align_corners=False):
+// source coordinate of output y is max(y / 2 - 0.25, 0): taps (i0, min(i0 + 1, h - 1)) with weights (1 - l, l).
+__device__ inline void up2_taps(int y, int h, int& i0, int& i1, float& l) {
+  const float src = fmaxf(0.5f * (float)y - 0.25f, 0.f);
+  i0 = (int)src;
+  i1 = min(i0 + 1, h - 1);
+  l = src - (float)i0;
+}
+
+template <typename T>
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ src, T* __restrict__ out, long long total, int h, int w) {
+  const int H = 2 * h, W = 2 * w;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    long long r = i / W;
+    const int y = (int)(r % H);
+    const long long m = r / H;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    up2_taps(y, h, y0, y1, ly);
+    up2_taps(x, w, x0, x1, lx);
+    const float* p = src + m * h * w;
+    const float top = (1.f - lx) * p[(long long)y0 * w + x0] + lx * p[(long long)y0 * w + x1];
+    const float bot = (1.f - lx) * p[(long long)y1 * w + x0] + lx * p[(long long)y1 * w + x1];
+    stf<T>(out + i, (1.f - ly) * top + ly * bot);
+  }
+}
+
+// weight of input i in output row y (0 when y is outside or i is not one of its taps); the adjoint of up2_taps
+__device__ inline float up2_weight(int y, int i, int h) {
+  if (y < 0 || y >= 2 * h) return 0.f;
+  int i0, i1;
+  float l;
+  up2_taps(y, h, i0, i1, l);
+  return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+}
+
+// gather form of the backward: input (i, j) collects its (at most) 4 x 4 outputs; g has a pixel pitch (a channel slice
+// of an NHWC concatenation gradient is read in place)
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ g, long long g_pitch, float* __restrict__ dsrc,
+                                      long long total, int h, int w) {
+  const int W = 2 * w, H = 2 * h;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % w);
+    long long r = idx / w;
+    const int i = (int)(r % h);
+    const long long m = r / h;
+    const T* gm = g + m * H * W * g_pitch;
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 2; ++dy) {
+      const int y = 2 * i + dy;
+      const float wy = up2_weight(y, i, h);
+      if (wy == 0.f) continue;
+      float row = 0.f;
+#pragma unroll
+      for (int dx = -1; dx <= 2; ++dx) {
+        const int x = 2 * j + dx;
+        const float wx = up2_weight(x, j, w);
+        if (wx != 0.f) row += wx * ldf<T>(gm + ((long long)y * W + x) * g_pitch);
+      }
+      acc += wy * row;
+    }
+    dsrc[idx] = acc;
+  }
+}
+
 // The four prediction scales of the decoder in one launch (blockIdx.y = scale; a grid-stride loop inside the scale).
 struct DepthHeadMs {
   const float* x[4];
@@ -510,6 +601,71 @@ int xpt_depth_head_bwd(const float* x, const float* g_depth, const float* g_disp
   if (n <= 0) return XPT_ERR_SHAPE;
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(depth_head_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, g_depth, g_disp, gx, n);
+  return xpt_launch_status();
+}
+
+/* GlobalAveragePooling2D (pose_net.py:45) of an NHWC map x [B,HW,C] (dtype 0 float32 / 1 bfloat16) -> y float32 [B,C];
+ * bwd: g float32 [B,C] -> dx [B,HW,C] of that dtype = g / HW. */
+int xpt_global_avgpool_fwd(const void* x, float* y, int B, int HW, int C, int dtype, void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(y);
+  if (B <= 0 || HW <= 0 || C <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  const int total = B * C;
+  XPT_BEGIN_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, y, total, HW, C);
+  else
+    hipLaunchKernelGGL(gap_fwd_kernel<__hip_bfloat16>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)x, y, total, HW, C);
+  return xpt_launch_status();
+}
+
+int xpt_global_avgpool_bwd(const float* g, void* dx, int B, int HW, int C, int dtype, void* stream) {
+  XPT_CHECK_PTR(g); XPT_CHECK_PTR(dx);
+  if (B <= 0 || HW <= 0 || C <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  const long long total = (long long)B * HW * C;
+  XPT_BEGIN_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, (float*)dx,
+                       total, HW, C);
+  else
+    hipLaunchKernelGGL(gap_bwd_kernel<__hip_bfloat16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g,
+                       (__hip_bfloat16*)dx, total, HW, C);
+  return xpt_launch_status();
+}
+
+/* lo.resize_image (layer_ops.py:43-50) at an exact factor 2 on one-channel maps: src float32 [M,h,w] -> out [M,2h,2w]
+ * (dtype 0 float32 / 1 bfloat16: the decoder concatenates it with bf16 features); bwd: g [M,2h,2w] with a pixel pitch of
+ * g_pitch elements (dtype as above) -> dsrc float32 [M,h,w]. */
+int xpt_upsample2x_fwd(const float* src, void* out, long long M, int h, int w, int dtype, void* stream) {
+  XPT_CHECK_PTR(src); XPT_CHECK_PTR(out);
+  if (M <= 0 || h <= 0 || w <= 0) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  const long long total = M * 4 * h * w;
+  XPT_BEGIN_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                       (float*)out, total, h, w);
+  else
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<__hip_bfloat16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       src, (__hip_bfloat16*)out, total, h, w);
+  return xpt_launch_status();
+}
+
+int xpt_upsample2x_bwd(const void* g, long long g_pitch, float* dsrc, long long M, int h, int w, int dtype, void* stream) {
+  XPT_CHECK_PTR(g); XPT_CHECK_PTR(dsrc);
+  if (M <= 0 || h <= 0 || w <= 0 || g_pitch < 1) return XPT_ERR_SHAPE;
+  if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
+  const long long total = M * h * w;
+  XPT_BEGIN_LAUNCH();
+  if (dtype == 0)
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)g, g_pitch, dsrc, total, h, w);
+  else
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<__hip_bfloat16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)g, g_pitch, dsrc, total, h, w);
   return xpt_launch_status();
 }
 

@@ -46,6 +46,8 @@ SIGNATURES = {
     "xpt_smooth_workspace_floats": (_z, [_i, _i, _i]),
     "xpt_smooth_fwd": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _f, _i, _p]),
     "xpt_smooth_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
+    "xpt_merge_total_fwd": (_i, [_i, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "xpt_merge_total_bwd": (_i, [_i, _p, _p, _p, _i, _p]),
     "xpt_smooth_ms_fwd": (_i, [_i, _p, _p, _p, _p, _z, _i, _p, _p, _f, _i, _p]),
     "xpt_smooth_ms_bwd": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _f, _i, _p]),
     "xpt_adam_step": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _f, _f, _f, _f, _f, _i, _p, _p]),
@@ -87,6 +89,10 @@ SIGNATURES = {
     "xpt_corr_cost_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "xpt_depth_head_fwd": (_i, [_p, _p, _p, ctypes.c_longlong, _p]),
     "xpt_depth_head_bwd": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p]),
+    "xpt_global_avgpool_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "xpt_global_avgpool_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "xpt_upsample2x_fwd": (_i, [_p, _p, ctypes.c_longlong, _i, _i, _i, _p]),
+    "xpt_upsample2x_bwd": (_i, [_p, ctypes.c_longlong, _p, ctypes.c_longlong, _i, _i, _i, _p]),
     "xpt_depth_head_ms_fwd": (_i, [_i, _p, _p, _p, _p, _p]),
     "xpt_depth_head_ms_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p]),
     "xpt_sum_rows": (_i, [_p, _p, _i, _p, ctypes.c_longlong, _i, _i, _p]),

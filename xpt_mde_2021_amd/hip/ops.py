@@ -387,6 +387,47 @@ def smoothness(disp, image, grad_factor, input_is_depth=False):
     return _Smooth.apply(disp, image, grad_factor, input_is_depth)
 
 
+class _MergeTotal(torch.autograd.Function):
+    """(total, by_type) of the total-loss merge in one launch; the backward hands every term one row of a dense
+    [terms, batch] matrix written by one launch."""
+
+    @staticmethod
+    def forward(ctx, c_vec, a_mat, *terms):
+        import ctypes
+        lib = _lib.load()
+        n, batch = len(terms), terms[0].numel()
+        terms = [_dev(t, "term") for t in terms]
+        if any(t.numel() != batch for t in terms) or a_mat.shape[1] != n or c_vec.numel() != n:
+            raise _lib.XptHipError("merge_total: inconsistent term / coefficient shapes")
+        c_vec, a_mat = _dev(c_vec, "c"), _dev(a_mat, "a")
+        total = torch.empty((), dtype=torch.float32, device=c_vec.device)
+        by_type = torch.empty((a_mat.shape[0],), dtype=torch.float32, device=c_vec.device)
+        _lib.check(lib.xpt_merge_total_fwd(n, (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms]), _ptr(c_vec),
+                                           _ptr(a_mat), _ptr(total), _ptr(by_type), batch, a_mat.shape[0], _stream()),
+                   "xpt_merge_total_fwd")
+        ctx.save_for_backward(c_vec)
+        ctx.shape = (n, batch)
+        ctx.mark_non_differentiable(by_type)
+        ctx.set_materialize_grads(False)
+        return total, by_type
+
+    @staticmethod
+    def backward(ctx, g_total, _):
+        lib = _lib.load()
+        c_vec, = ctx.saved_tensors
+        n, batch = ctx.shape
+        g_total = _dev(g_total, "grad")
+        grads = torch.empty((n, batch), dtype=torch.float32, device=c_vec.device)
+        _lib.check(lib.xpt_merge_total_bwd(n, _ptr(c_vec), _ptr(g_total), _ptr(grads), batch, _stream()),
+                   "xpt_merge_total_bwd")
+        return (None, None, *grads.unbind(0))
+
+
+def merge_total(c_vec, a_mat, terms):
+    """total = c . rowsum(terms), by_type = A rowsum(terms) (at most 64 float32 terms [batch] and 64 types)."""
+    return _MergeTotal.apply(c_vec, a_mat, *terms)
+
+
 class _SmoothMS(torch.autograd.Function):
     """All scales of the smoothness loss in one forward pair and one backward launch (xpt_smooth_ms_*)."""
 
@@ -868,6 +909,68 @@ class _DepthHead(torch.autograd.Function):
         gx = torch.empty_like(x)
         _lib.check(lib.xpt_depth_head_bwd(_ptr(x), _ptr(gd), _ptr(gs), _ptr(gx), x.numel(), _stream()), "xpt_depth_head_bwd")
         return gx
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = _nhwc(x, "x")
+        B, C, H, W = x.shape
+        y = torch.empty((B, C), dtype=torch.float32, device=x.device)
+        dt = 0 if x.dtype == torch.float32 else 1
+        _lib.check(lib.xpt_global_avgpool_fwd(_ptr(x), _ptr(y), B, H * W, C, dt, _stream()), "xpt_global_avgpool_fwd")
+        ctx.cfg = (B, C, H, W, x.dtype, dt)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, C, H, W, dtype, dt = ctx.cfg
+        g = _dev(g, "grad")
+        dx = torch.empty((B, C, H, W), dtype=dtype, device=g.device, memory_format=torch.channels_last)
+        _lib.check(lib.xpt_global_avgpool_bwd(_ptr(g), _ptr(dx), B, H * W, C, dt, _stream()), "xpt_global_avgpool_bwd")
+        return dx
+
+
+def global_avg_pool(x):
+    """GlobalAveragePooling2D of a channels_last [B,C,H,W] float32 / bfloat16 map -> float32 [B,C], one launch each way."""
+    return _GlobalAvgPool.apply(x)
+
+
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        lib = _lib.load()
+        x = _dev(x, "x")
+        B, C, h, w = x.shape
+        out = torch.empty((B, C, 2 * h, 2 * w), dtype=dtype, device=x.device)
+        _lib.check(lib.xpt_upsample2x_fwd(_ptr(x), _ptr(out), B * C, h, w, 0 if dtype == torch.float32 else 1, _stream()),
+                   "xpt_upsample2x_fwd")
+        ctx.shape = (B, C, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, C, h, w = ctx.shape
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        H, W = 2 * h, 2 * w
+        pitch = g.stride(3)
+        # a channel slice of an NHWC gradient (one map: C == 1) is read in place through its pixel pitch
+        if not (C == 1 and pitch >= 1 and g.stride(2) == pitch * W and g.stride(0) == pitch * W * H):
+            g, pitch = g.contiguous(), 1
+        dx = torch.empty((B, C, h, w), dtype=torch.float32, device=g.device)
+        _lib.check(lib.xpt_upsample2x_bwd(_ptr(g), pitch, _ptr(dx), B * C, h, w, 0 if g.dtype == torch.float32 else 1,
+                                          _stream()), "xpt_upsample2x_bwd")
+        return dx, None
+
+
+def upsample2x(x, dtype=torch.float32):
+    """Bilinear (half-pixel centres) 2x up-sampling of float32 [B,C,h,w] -> [B,C,2h,2w] of `dtype` (float32 / bfloat16)
+    in one launch; the backward gathers (one launch, no zero fill, reads a strided one-channel gradient in place)."""
+    return _Upsample2x.apply(x, dtype)
 
 
 class _DepthHeadMS(torch.autograd.Function):

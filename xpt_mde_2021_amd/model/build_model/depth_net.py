@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...hip import conv as _conv
+from ...hip import ops as _ops
 from ..model_util import layer_ops as lo
 from .pretrained_nets import PretrainedModel
 
@@ -85,7 +86,12 @@ class ScaledDepthHead(nn.Module):
                 depth, self.last_disp = self.predict_depth.with_disparity(conv)
             else:
                 depth, self.last_disp = self.predict_depth(conv), None
-            conv_up = lo.resize_image(conv, dst_height, dst_width)
+            if (_BATCHED_HEADS and conv.is_cuda and conv.dtype == torch.float32 and conv.is_contiguous()
+                    and src.dtype == torch.bfloat16 and (dst_height, dst_width) == (2 * conv.shape[2], 2 * conv.shape[3])):
+                # the exact 2x resize and the cast to the decoder's dtype in one launch (one more for the backward)
+                conv_up = _ops.upsample2x(conv, torch.bfloat16)
+            else:
+                conv_up = lo.resize_image(conv, dst_height, dst_width)
         return depth, conv_up, conv
 
 

@@ -40,7 +40,11 @@ class PoseNetBasic(nn.Module):
         else:
             x = restack_on_channels(image5d)
         x = self.head(self.convs(x))
-        poses = x.float().mean(dim=(2, 3))                     # GlobalAveragePooling2D
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+            from ...hip import ops as _ops
+            poses = _ops.global_avg_pool(x)                    # GlobalAveragePooling2D (cast included), one launch
+        else:
+            poses = x.float().mean(dim=(2, 3))                 # GlobalAveragePooling2D
         return {"pose": poses.reshape(-1, self.numsrc, 6)}
 
 

@@ -428,6 +428,8 @@ class SepConvBlock(nn.Module):
             x = F.relu(x)
             taps.offer(self.act_id1, x)
             x = self.conv1(x, bn=self.bn1)
+            if not taps.wants(self.act_id2):      # (NASNet-Mobile's skip taps are all first activations of a block)
+                return self.conv2(x, relu_in=True, bn=self.bn2, residual=residual)
             x = F.relu(x)
             taps.offer(self.act_id2, x)
             return self.conv2(x, bn=self.bn2, residual=residual)

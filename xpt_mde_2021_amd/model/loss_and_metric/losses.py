@@ -55,7 +55,7 @@ class TotalLoss:
         # Every loss object hands back its raw per-scale [batch] terms with their host-side weights instead of
         # combining them with a dozen tiny tensor ops each; all terms of all loss types are then reduced together:
         #   rs = rowsum(stack(terms));  total = <c, rs>;  loss_by_type = A rs      (c, A: constant device tensors)
-        # = 4 launches forward and 2 backward for the whole merge (losses.py:46-55 and :147-154 in one step).
+        # = 1 launch forward and 1 backward for the whole merge (xpt_merge_total_*) (losses.py:46-55 and :147-154 in one step).
         LossBase._collector = collected = []
         try:
             outputs = {name: obj(features, predictions, augm_data) for name, obj in self.loss_objects.items()}
@@ -72,8 +72,12 @@ class TotalLoss:
                 terms.append(tensor.reshape(-1))
             rows.append(row)
         c_vec, a_mat = self._merge_constants(coef, rows, terms[0].device)
-        total_loss, row_sums = _WeightedTotal.apply(c_vec, *terms)
-        by_type = torch.mv(a_mat, row_sums)
+        if (terms[0].is_cuda and len(terms) <= 64 and len(rows) <= 64
+                and all(t.dtype == torch.float32 and t.numel() == terms[0].numel() for t in terms)):
+            total_loss, by_type = _ops.merge_total(c_vec, a_mat, terms)          # one launch (and one backward)
+        else:
+            total_loss, row_sums = _WeightedTotal.apply(c_vec, *terms)
+            by_type = torch.mv(a_mat, row_sums)
         loss_by_type = {name: by_type[i] for i, name in enumerate(outputs)}
         return total_loss, loss_by_type
 
