@@ -273,6 +273,14 @@ def run(args):
                        "parallelism": f"dp{world}", "ranks": (dist.get_world_size() if world > 1 else 1),
                        "final_loss": round(loss, 6)},
         }
+        early = getattr(trainer, "_early_start", None)
+        if world > 1:
+            flat = trainer.optimizer.flat
+            # gradient exchange: the decoder / PoseNet bucket is all-reduced while the encoder's backward runs
+            result["config"]["grad_exchange"] = {
+                "buckets": 2 if early is not None else 1, "bytes": int(flat.numel) * 4,
+                "overlapped_bytes": (int(flat.numel) - int(early)) * 4 if early is not None else 0,
+                "how": "two-graph step, backward cut between decoder and encoder" if early is not None else "after the step"}
     note(f"timed region done: {elapsed:.3f} s")
     if rank == 0 and world == 1 and args.config != "c5" and not args.no_roofline:
         # the real loop (train_val.py:43-64 run_an_epoch): the same steps PLUS merge_results per step (abs-rel with two

@@ -103,6 +103,97 @@ def test_two_ranks_equal_one_process_full_batch():
         assert abs((a + b) - c) < 1e-5 * max(1.0, abs(c)), (a, b, c)
 
 
+class _DepthPoseLoss:
+    """A per-example loss over every depth scale and the poses, divided by the GLOBAL batch (losses.py:46-52)."""
+
+    def __init__(self, global_batch):
+        self.batch_size = global_batch
+
+    def __call__(self, predictions, features):
+        per_example = (predictions["pose"].float() ** 2).mean(dim=(1, 2))
+        for k, depth in enumerate(predictions["depth_ms"]):
+            per_example = per_example + (k + 1) * 0.01 * (1.0 / depth.float()).mean(dim=(1, 2, 3))
+        loss = per_example.sum() / self.batch_size
+        return loss, {"total": loss.detach()}
+
+
+def _build_rigid(global_batch, seed):
+    from xpt_mde_2021_amd.model.build_model.model_factory import ModelFactory
+    from xpt_mde_2021_amd.model.model_util.optimizers import optimizer_factory
+    from xpt_mde_2021_amd.utils import synthetic_data as sd
+    torch.manual_seed(seed)
+    feats = sd.make_features(4, 64, 96, 3, 7)
+    mf = ModelFactory(sd.tfr_config_for(feats), global_batch=global_batch,
+                      net_names={"depth": "NASNetMobile", "camera": "PoseNetImproved"}, pretrained_weight=False)
+    return mf.get_model(), feats, optimizer_factory("adam_constant", 1e-3)
+
+
+def _overlap_worker(rank, world, port, out_queue):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from xpt_mde_2021_amd.model import train_val as tv
+    from xpt_mde_2021_amd.model.model_util.distributer import DistributionStrategy
+    opts.CONV_DTYPE = "fp32"
+    opts.PER_REPLICA_BATCH = 2
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    DistributionStrategy.reset()
+    DistributionStrategy.get_strategy()
+    model, feats, optimizer = _build_rigid(opts.BATCH_SIZE, seed=100 + rank)
+    trainer, _ = tv.train_val_factory("distributed", model, _DepthPoseLoss(opts.BATCH_SIZE), 0, False, None, optimizer)
+    flat = optimizer.flat
+    # the cut exists: encoder parameters form the head of the flat buffers, decoder + PoseNet the (larger) tail
+    assert trainer._early_start is not None and 0 < trainer._early_start < flat.numel
+    started = []
+    plain = trainer.strategy.all_reduce_range
+    trainer.strategy.all_reduce_range = lambda g, a, b, async_op=False: (started.append((a, b, async_op)), plain(g, a, b, async_op))[1]
+    shard = {k: v[2 * rank:2 * rank + 2] for k, v in feats.items() if torch.is_tensor(v)}
+    losses = [float(trainer.run_a_batch(shard)[1]) for _ in range(2)]
+    # per step: the tail first (asynchronously, before the second backward phase), then the head; together everything once
+    assert started[:2] == [(trainer._early_start, flat.numel, True), (0, trainer._early_start, True)] and len(started) == 4
+    out_queue.put((rank, flat.data.numpy().copy(), losses, trainer._early_start))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_phase_backward_with_overlapped_all_reduce_equals_one_process():
+    """DepthNet + PoseNet on two gloo ranks with the backward cut between decoder and encoder (the decoder / PoseNet
+    gradients are all-reduced while the encoder's backward runs) == one process that sees the whole batch and runs the
+    ordinary single backward pass."""
+    from xpt_mde_2021_amd.model import train_val as tv
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, l0, cut), (_, w1, l1, _) = results
+    w0, w1 = torch.from_numpy(w0), torch.from_numpy(w1)
+    assert torch.equal(w0, w1), "replicas diverged"
+    saved = (opts.CONV_DTYPE, opts.PER_REPLICA_BATCH, opts.BATCH_SIZE)
+    opts.CONV_DTYPE = "fp32"
+    try:
+        model, feats, optimizer = _build_rigid(4, seed=100)
+        trainer, _ = tv.train_val_factory("eager", model, _DepthPoseLoss(4), 0, False, None, optimizer)
+        feats = {k: v for k, v in feats.items() if torch.is_tensor(v)}
+        ref_losses = [float(trainer.run_a_batch(feats)[1]) for _ in range(2)]
+    finally:
+        opts.CONV_DTYPE, opts.PER_REPLICA_BATCH, opts.BATCH_SIZE = saved
+    ref = optimizer.flat.data
+    # Adam's first steps move every weight by ~lr whatever the gradient's size, so a weight whose gradient is at the
+    # rounding level may differ by a step; the bar is on the bulk
+    close = torch.isclose(w0, ref, rtol=1e-3, atol=2e-5)
+    assert close.float().mean().item() > 0.999, float((w0 - ref).abs().max())
+    assert close[:cut].float().mean().item() > 0.999 and close[cut:].float().mean().item() > 0.999
+    for a, b, c in zip(l0, l1, ref_losses):
+        assert abs((a + b) - c) < 1e-4 * max(1.0, abs(c)), (a, b, c)
+
+
 def test_bench_launcher_starts_two_ranks():
     """`python bench.py --gpus 2` without a launcher around it must start the ranks itself (torch.distributed.run as a
     child process, before this process touches any GPU) and relay rank 0's JSON line -- exercised here on the CPU with

@@ -32,6 +32,9 @@ def test_two_ranks_on_one_card_train_in_step(gpu_device):
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["config"]["global_batch"] == 4
     assert out["config"]["mode"] == "distributed" and out["config"]["parallelism"] == "dp2"
     assert out["value"] > 0 and 0.0 < out["config"]["final_loss"] < 10.0
+    # the decoder / PoseNet gradients (the larger bucket) are exchanged while the encoder's backward runs
+    exchange = out["config"]["grad_exchange"]
+    assert exchange["buckets"] == 2 and 0.5 * exchange["bytes"] < exchange["overlapped_bytes"] < exchange["bytes"]
 
 
 def test_bench_launches_its_own_ranks(gpu_device):

@@ -34,10 +34,10 @@ def test_graph_replays_match_eager(gpu_device, nets, dtype):
     assert f"library path (executed eagerly by design): {dtype == 'fp32'}" in run.stdout, run.stdout[-1500:]
 
 
-def _loss_sequence(mode, aug, steps):
+def _loss_sequence(mode, aug, steps, **env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     run = subprocess.run([sys.executable, os.path.join(root, "tools", "determinism_train.py"), mode, aug, str(steps)],
-                         capture_output=True, text=True, timeout=900)
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
     assert run.returncode == 0, (run.stdout + run.stderr)[-2000:]
     losses = [l for l in run.stdout.splitlines() if l.startswith("LOSSES")]
     sums = [l for l in run.stdout.splitlines() if l.startswith("PARAMSUM")]
@@ -55,3 +55,14 @@ def test_captured_training_equals_eager_training_bit_for_bit(gpu_device):
     assert eager == graph, f"eager {eager}\ngraph {graph}"
     assert esum == gsum
     assert float(eager[-1]) < float(eager[0])          # and it trains
+
+
+def test_two_graph_step_with_cut_backward_equals_the_single_graph_step(gpu_device):
+    """The data-parallel trainer cuts the backward pass between decoder and encoder and captures the step as TWO graphs
+    sharing one memory pool (the all-reduce of the decoder / PoseNet gradients starts between their replays).  Without
+    other ranks (no collective) eight of its training steps must reproduce the single-graph trainer: same losses, same
+    final weights."""
+    single, ssum = _loss_sequence("graph", "noaug", 8)
+    double, dsum = _loss_sequence("distributed", "noaug", 8, XPT_DP_OVERLAP="1")
+    assert single == double, f"one graph  {single}\ntwo graphs {double}"
+    assert ssum == dsum

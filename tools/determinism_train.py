@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Loss sequence of K full training steps (forward, backward, fused Adam) from the seeded initial weights: two processes
-must print the same numbers.   python tools/determinism_train.py [eager|graph] [aug|noaug] [K]"""
+must print the same numbers.   python tools/determinism_train.py [eager|graph|distributed] [aug|noaug] [K]
+(distributed with XPT_DP_OVERLAP=1 and no other rank: the two-graph step of the data-parallel trainer)"""
 import os
 import sys
 
@@ -27,5 +28,7 @@ for i in range(K):
     losses.append(float(out[1]))
 torch.cuda.synchronize()
 flat = optimizer.flat
+if mode == "distributed":
+    print("TWO_PHASE", trainer._early_start is not None, type(trainer._graph.graph).__name__)
 print("LOSSES", mode, "aug" if use_aug else "noaug", " ".join(f"{v:.9f}" for v in losses))
 print("PARAMSUM", f"{float(flat.data.double().abs().sum()):.9f}" if hasattr(flat, "data") else "")

@@ -105,6 +105,8 @@ class DepthNetPretrained(nn.Module):
         self.total_shape = tuple(total_shape)
         self.high_res = high_res
         self.encoder = PretrainedModel(net_name, use_pt_weight).encoder()
+        self.cut_backward = False      # see forward()
+        self.cuts = []                 # [(encoder outputs, their detached stand-ins)] of the forward calls of this step
         c1, c2, c3, c4, c5 = self.encoder.TAP_CHANNELS
         self.up4 = UpconvWithSkip(conv2d, c5, c4, 256, upsample_iterp)            # 1/16
         self.up3 = UpconvWithSkip(conv2d, 256, c3, 128, upsample_iterp)           # 1/8
@@ -119,7 +121,15 @@ class DepthNetPretrained(nn.Module):
     def forward(self, image5d):
         target = image5d[:, -1].permute(0, 3, 1, 2)                               # [B,3,H,W] view of the NHWC frame
         height, width = target.shape[2:]
-        conv1, conv2, conv3, conv4, conv5 = self.encoder(target)
+        taps = self.encoder(target)
+        if self.cut_backward and torch.is_grad_enabled() and all(t.requires_grad for t in taps):
+            # the backward pass is cut between decoder and encoder (train_val.ModelTrainerDistrib: the gradients of
+            # everything behind the encoder are all-reduced while the encoder's backward still runs): the decoder reads
+            # detached leaves, whose gradients the trainer feeds into the encoder's graph in a second backward call
+            leaves = [t.detach().requires_grad_(True) for t in taps]
+            self.cuts.append((taps, leaves))
+            taps = leaves
+        conv1, conv2, conv3, conv4, conv5 = taps
         outputs = self.decode(conv1, conv2, conv3, conv4, conv5, height, width)
         return outputs
 

@@ -122,6 +122,28 @@ class ModelWrapper:
                     groups.extend(module.stack_groups())
         return groups
 
+    # ------------------------------------------------------------------ two-phase backward (data-parallel overlap)
+    def set_backward_cut(self, enabled):
+        """Cut every depth network's backward between decoder and encoder (depth_net.DepthNetPretrained.forward).
+        Returns the parameters whose gradients are only finished by the second phase (the encoders')."""
+        late = []
+        for model in self.models.values():
+            if hasattr(model, "cut_backward") and hasattr(model, "encoder"):
+                model.cut_backward = bool(enabled)
+                model.cuts = []
+                late.extend(p for p in model.encoder.parameters() if p.requires_grad)
+        return late
+
+    def take_backward_cuts(self):
+        """[(tensor, gradient)] to resume the backward pass from, after the first phase; clears the record."""
+        pairs = []
+        for model in self.models.values():
+            for taps, leaves in getattr(model, "cuts", []):
+                pairs.extend((t, leaf.grad) for t, leaf in zip(taps, leaves) if leaf.grad is not None)
+            if hasattr(model, "cuts"):
+                model.cuts = []
+        return pairs
+
     def weights_to_regularize(self):
         """model_wrappers.py:95-99: the FlowNet's trainable weights (for the flow_reg L2 term), else None."""
         if "flownet" in self.models:

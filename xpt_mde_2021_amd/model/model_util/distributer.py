@@ -58,6 +58,13 @@ class DistributionStrategy:
         for start in range(0, n, step):
             dist.all_reduce(flat_grad[start:start + step], op=dist.ReduceOp.SUM)
 
+    def all_reduce_range(self, flat_grad, start, stop, async_op=False):
+        """SUM flat_grad[start:stop] over all replicas; async_op: returns the work handle (the collective runs behind the
+        kernels already queued on the current stream, concurrently with whatever is queued after it)."""
+        if self.num_replicas_in_sync == 1 or stop <= start:
+            return None
+        return dist.all_reduce(flat_grad[start:stop], op=dist.ReduceOp.SUM, async_op=async_op)
+
     def broadcast_parameters(self, flat_data):
         """All replicas start from rank 0's weights (MirroredStrategy creates mirrored variables)."""
         if self.num_replicas_in_sync > 1:

@@ -196,11 +196,30 @@ class ModelTrainer(TrainValBase):
 _DEBUG_REPLAY = __import__("os").environ.get("XPT_DEBUG_REPLAY", "0") == "1"
 
 
+class _GraphPair:
+    """Two hipGraphs replayed back to back, with a host callback between them."""
+
+    def __init__(self, first, second):
+        self.first, self.second = first, second
+
+    def replay(self, between=None):
+        self.first.replay()
+        if between is not None:
+            between()
+        self.second.replay()
+
+
 class _StepGraph:
     """Captures fn(static_features) into a hipGraph; replays it after copying a new batch into the static buffers."""
 
-    def __init__(self, fn, warmup=3, state=None, describe=None, segments=None, repair=None, reference=False):
+    def __init__(self, fn, warmup=3, state=None, describe=None, segments=None, repair=None, reference=False,
+                 phases=None, between=None):
         self.fn = fn
+        # phases = (first, second): the step is captured as TWO graphs sharing one memory pool, first(features) ->
+        # (carry, outputs) and second(carry); `between` runs between their replays (the data-parallel trainer launches
+        # the all-reduce of the gradients the first phase finished there).  fn must be second(first(.)) without it.
+        self.phases = phases
+        self.between = between
         self.warmup = warmup
         self.state = state                     # callable -> list of tensors the warm-up runs must not change
         self.describe = describe               # (state index, bad-element mask) -> text for the replay-check message
@@ -237,7 +256,10 @@ class _StepGraph:
             self.signature = sig
             for k, v in self.static_in.items():
                 v.copy_(features[k], non_blocking=True)
-        self.graph.replay()
+        if isinstance(self.graph, _GraphPair):
+            self.graph.replay(self.between)
+        else:
+            self.graph.replay()
         return self.static_out
 
     def _capture(self, features, sig):
@@ -268,9 +290,18 @@ class _StepGraph:
             self.library_path = self.eager_fallback = True
             self.graph = None
             return
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.static_out = self.fn(self.static_in)
+        if self.phases is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static_out = self.fn(self.static_in)
+        else:
+            first, second = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(first):
+                carry, self.static_out = self.phases[0](self.static_in)
+            with torch.cuda.graph(second, pool=first.pool()):      # same capture stream (torch's default), same pool
+                self.phases[1](carry)
+            del carry
+            self.graph = _GraphPair(first, second)
         for t, s in zip(state, saved):
             t.copy_(s)
         self.signature = sig
@@ -475,18 +506,93 @@ class ModelTrainerDistrib(ModelTrainer):
                 flat.shadow.copy_(flat.data)     # (otherwise only the first Adam step would refresh them)
         weights = getattr(loss_object, "loss_weights", None) or {}           # see ModelTrainerGraph
         self.trains_flow_net = "flownet" in getattr(model, "models", {}) and any(k.startswith("flow") for k in weights)
+        # Overlap of the gradient exchange with the backward pass: the backward is cut between decoder and encoder; the
+        # gradients of everything behind the encoder (decoder, PoseNet: 60% of the bytes) are complete after the first
+        # phase and their all-reduce runs on RCCL's stream while the encoder's backward (the second phase) computes.
+        self._early_start = self._find_early_bucket() if self._overlap_wanted() else None
+        self._early_work = None
+        phases = (self.backward_first, self.backward_second) if self._early_start is not None else None
         self._graph = _StepGraph(self.forward_backward, state=self.optimizer_state, describe=self.describe_state,
                                  segments=self.state_segments, repair=self.repair_flagged,
-                                 reference=self.augmenter is None) \
+                                 reference=self.augmenter is None, phases=phases,
+                                 between=self.reduce_early if phases else None) \
             if getattr(opts, "DISTRIB_GRAPH", True) else None
 
+    def _overlap_wanted(self):
+        import os
+        forced = os.environ.get("XPT_DP_OVERLAP")
+        if forced is not None:
+            return forced == "1"
+        return self.strategy is not None and self.strategy.num_replicas_in_sync > 1 and not self.trains_flow_net
+
+    def _find_early_bucket(self):
+        """Offset in the flat buffers where the early gradients start: the encoders' parameters (finished by the second
+        backward phase) must form the head of the buffer, everything else its tail; None when there is no such cut."""
+        flat = getattr(self.optimizer, "flat", None)
+        if flat is None or not hasattr(self.model, "set_backward_cut"):
+            return None
+        late = {id(p) for p in self.model.set_backward_cut(True)}
+        flags = [id(p) in late for p in flat.params]
+        k = sum(flags)
+        if k == 0 or k == len(flags) or not all(flags[:k]):
+            self.model.set_backward_cut(False)
+            return None
+        return flat.offsets[k]
+
+    def backward_first(self, features):
+        """Forward pass and the backward of everything behind the encoders -> (carry for backward_second, outputs)."""
+        if self.augmenter is not None:
+            features = self.augmenter(features)
+        preds = self.model(features)
+        total_loss, loss_by_type = self.loss_object(preds, features)
+        total_loss.backward()
+        carry = self.model.take_backward_cuts()
+        if total_loss.is_cuda:
+            _ops.grad_sink.flush()
+        self.optimizer.flat.gather_grads()
+        return carry, (detach_tree(preds), total_loss.detach(), {k: v.detach() for k, v in loss_by_type.items()})
+
+    def backward_second(self, carry):
+        """The encoders' backward, resumed from the gradients the first phase left at the cut."""
+        if carry:
+            torch.autograd.backward([t for t, _ in carry], [g for _, g in carry])
+            if carry[0][0].is_cuda:
+                _ops.grad_sink.flush()
+            self.optimizer.flat.gather_grads()
+
+    def forward_backward(self, features):
+        if self._early_start is None:
+            return super().forward_backward(features)
+        carry, out = self.backward_first(features)
+        self.backward_second(carry)
+        return out
+
+    def reduce_early(self):
+        """Between the two phases: start the all-reduce of the gradients the first phase completed."""
+        if self.strategy is not None and self._early_start is not None:
+            grad = self.optimizer.flat.grad
+            self._early_work = self.strategy.all_reduce_range(grad, self._early_start, grad.numel(), async_op=True)
+
     def reduce_gradients(self):
-        if self.strategy is not None:
-            self.strategy.all_reduce_gradients(self.optimizer.flat.grad)
+        if self.strategy is None:
+            return
+        grad = self.optimizer.flat.grad
+        if self._early_work is not None:
+            rest = self.strategy.all_reduce_range(grad, 0, self._early_start, async_op=True)
+            self._early_work.wait()
+            self._early_work = None
+            if rest is not None:
+                rest.wait()
+        else:
+            self.strategy.all_reduce_gradients(grad)
 
     def run_a_batch(self, features):
         if self._graph is not None and features["image5d"].is_cuda and not self.trains_flow_net:
             out = self._graph(features)
+        elif self._early_start is not None:
+            carry, out = self.backward_first(features)
+            self.reduce_early()
+            self.backward_second(carry)
         else:
             out = self.forward_backward(features)
         self.reduce_gradients()
