@@ -422,10 +422,12 @@ class SepConvBlock(nn.Module):
         self.conv2 = SeparableConv(filters, filters, k, 1)
         self.bn2 = FrozenBatchNorm(filters)
 
-    def forward(self, x, taps, residual=None):
-        """residual: the other operand of the cell's `add` (fused into the last BatchNorm's epilogue)."""
+    def forward(self, x, taps, residual=None, rectified=False):
+        """residual: the other operand of the cell's `add` (fused into the last BatchNorm's epilogue).
+        rectified: x has been through the ReLU already (the very first cell shares one ReLU among all its branches)."""
         if taps.wants(self.act_id1) or taps.wants(self.act_id2):      # a tapped activation must be materialised
-            x = F.relu(x)
+            if not rectified:
+                x = F.relu(x)
             taps.offer(self.act_id1, x)
             x = self.conv1(x, bn=self.bn1)
             if not taps.wants(self.act_id2):      # (NASNet-Mobile's skip taps are all first activations of a block)
@@ -587,8 +589,14 @@ class ReductionCell(nn.Module):
     def forward(self, ip, p, taps):
         # h feeds the pooling pair and the left branch, p the stride-2 branches and the tapped right3 block: two aliases
         # each (their gradients are added inside the producing layer's weight-gradient launch where that layer is fused)
-        p, p_tap = self.adjust(p, taps, fan_out=2)
-        h = shared_relu(ip)
+        rectified = self.adjust.mode == "none" and p is ip and ip.is_cuda
+        if rectified:
+            # the very first cell: p IS ip and every branch starts with a ReLU, so one ReLU serves them all (the
+            # in-kernel ReLU of the separable convolutions is idempotent on it) and the raw stem output has ONE consumer
+            h, p, p_tap = _ops.fan_out(shared_relu(ip), 3)
+        else:
+            p, p_tap = self.adjust(p, taps, fan_out=2)
+            h = shared_relu(ip)
         taps.offer(self.act_id, h)
         h, h_pool = conv1x1_bn(h, self.conv.weight, self.bn, fan_out=2)
         if h.is_cuda and _CELL_TAIL and h.dtype in (torch.float32, torch.bfloat16):
@@ -621,7 +629,7 @@ class ReductionCell(nn.Module):
             outs = multi_conv1x1_bn(y2[1:], [b.conv2.pointwise.weight for b in blocks[1:]], [b.bn2 for b in blocks[1:]],
                                     [None, mp1] + ([ap] if wide3 else []))
             r1, x2 = outs[0], outs[1]
-            x3 = outs[2] if wide3 else self.right3(p_tap, taps, residual=ap)
+            x3 = outs[2] if wide3 else self.right3(p_tap, taps, residual=ap, rectified=rectified)
             x1 = conv1x1_bn(y2[0], self.left1.conv2.pointwise.weight, self.left1.bn2, residual=r1)
             x1a, x1b = _ops.fan_out(x1, 2)
             if _CELL_TAIL and x1.dtype == x2.dtype == x3.dtype:
@@ -639,7 +647,7 @@ class ReductionCell(nn.Module):
         x1a, x1b = _ops.fan_out(x1, 2)
         x2 = self.right2(p2, taps, residual=mp1)
         x2a, x2b = _ops.fan_out(x2, 2)
-        x3 = self.right3(p3, taps, residual=ap_h if ap_h is not None else F.avg_pool2d(h3, 3, 2))
+        x3 = self.right3(p3, taps, residual=ap_h if ap_h is not None else F.avg_pool2d(h3, 3, 2), rectified=rectified)
         x4 = x2a + avg_pool_same(x1a)
         x5 = self.left4(x1b, taps, residual=mp2)
         x2 = x2b
