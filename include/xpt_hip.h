@@ -496,6 +496,22 @@ int xpt_conv1x1_bn_multi_bwd_partials(int n, const void* const* dy, const long l
                                       const float* const* mean, float eps, void* const* g_out, float* const* w_partials,
                                       float* const* bn_partials, size_t w_partial_floats, size_t bn_partial_floats,
                                       long long M, int cout, int cin, long long pitch_x, void* stream);
+/* The whole backward of conv1x1 -> BatchNorm in ONE launch: the partials of xpt_conv1x1_bn_bwd_partials_sum plus, when
+ * dx is not NULL, the data gradient dx [M, cin] bf16 = ((dy + dy2 + dy3) * s) W (what torch.mm(g, W) did in a second
+ * launch; tape.gradient w.r.t. the layer input, model/train_val.py:85-86), computed by extra workgroups of the same
+ * launch straight from dy (g is not written).  w: the layer's bf16 weight [cout, cin], dense. */
+int xpt_conv1x1_bn_bwd_fused(const void* dy, const void* dy2, const void* dy3, const void* ypre, const void* x,
+                             const void* w, const float* gamma, const float* var, const float* mean, float eps, void* dx,
+                             float* w_partials, size_t w_partial_floats, float* bn_partials, size_t bn_partial_floats,
+                             long long M, int cout, int cin, long long pitch_dy, long long pitch_dy2, long long pitch_dy3,
+                             long long pitch_x, void* stream);
+/* The same for n (<= 6) layers of one shape; dx[j] NULL skips that layer's data gradient. */
+int xpt_conv1x1_bn_multi_bwd_fused(int n, const void* const* dy, const long long* pitch_dy, const void* const* ypre,
+                                   const void* const* x, const void* const* w, const float* const* gamma,
+                                   const float* const* var, const float* const* mean, float eps, void* const* dx,
+                                   float* const* w_partials, float* const* bn_partials, size_t w_partial_floats,
+                                   size_t bn_partial_floats, long long M, int cout, int cin, long long pitch_x,
+                                   void* stream);
 /* Several depthwise layers of one activation shape and stride in one launch (the mutually independent branch
  * convolutions of a NASNet cell stage): forward y[j] = dwconv(f(x[j]), w[j]) with kernel size k[j] in {3,5,7} and leading
  * padding (pad_t[j], pad_l[j]); backward: dxin[u] = gradient of the u-th DISTINCT input summed over the jobs reading it

@@ -196,6 +196,172 @@ struct WgradMulti {
   int n;                                                    // 0: single layer, the scalar arguments are used
 };
 
+// The DATA gradient of the same layer(s), dx = (dy * s) W, computed by EXTRA workgroups of the same launch (the first
+// `slices` blockIdx.z slices: they are short, so they are dispatched first and the weight-gradient workgroups of the
+// second round take over their compute units early): it needs nothing the weight-gradient workgroups produce (g = dy * s is formed on load), so the
+// two kinds of workgroup simply share the launch and run side by side -- one launch per layer group instead of a
+// weight-gradient launch followed by a library GEMM (104 GEMM launches, 0.88 ms per step at batch 8).
+struct DxFuse {
+  unsigned short* dx[WG_MAX_JOBS];          // [M, cin] bf16, dense
+  const unsigned short* w[WG_MAX_JOBS];     // [cout, cin] bf16, dense (the bf16 shadow of the weight)
+  int job[WG_MAX_JOBS];                     // index into WgradMulti of the layer this data gradient belongs to
+  int n;                                    // data gradients wanted
+  int slices;                               // leading blockIdx.z slices that belong to the data gradient (0: none)
+  int row_blocks, nsub;                     // a workgroup's tile: row_blocks x 32 rows by nsub x 32 input channels
+  int wgs_rows, wgs_ci;                     // workgroups per layer along the rows / the input channels
+  int vw;                                   // elements per global load of W (its rows and base are aligned to it)
+};
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define DX_KC 64          // rows of W staged per chunk
+#define DX_LD 132         // LDS row pitch of the staged W slice in 16-bit elements (8 rows apart = 16 banks apart)
+
+// One workgroup of 16 waves: wave = (row block rb, channel sub-tile ns); v_mfma_f32_32x32x16_bf16 with A = g rows read
+// straight from global (lane (r, h): row r, k = 8h..8h+7: consecutive channels of one gradient row), B = W staged in LDS.
+// Per chunk of DX_KC output channels every global load (the chunk's A vectors, the W slice) is issued before the first
+// wait, so a chunk costs one memory round trip, not one per k step.
+template <int VW> struct DxWRegs {
+  static constexpr int VPR = 128 / VW, PER = (DX_KC * VPR + 1023) / 1024;
+  typename StageVec<VW>::type reg[PER];
+};
+
+// global -> registers: this thread's share of W[kc0 .. kc0 + DX_KC)[ci_base .. ci_base + 128) (zeros outside the matrix)
+template <int VW>
+__device__ inline void dx_load_w(DxWRegs<VW>& t, const unsigned short* __restrict__ w, int kc0, int cout, int cin,
+                                 int ci_base) {
+  typedef typename StageVec<VW>::type vec_t;
+#pragma unroll
+  for (int i = 0; i < DxWRegs<VW>::PER; ++i) {
+    const int v = threadIdx.x + i * 1024;
+    const int k = v / DxWRegs<VW>::VPR, c = (v % DxWRegs<VW>::VPR) * VW;
+    const int co = kc0 + k, cc = ci_base + c;
+    const bool ok = k < DX_KC && co < cout && cc < cin;                    // cin % VW == 0: whole vectors
+    const vec_t val = *(const vec_t*)(w + (long long)(co < cout ? co : cout - 1) * cin + (cc < cin ? cc : cin - VW));
+    t.reg[i] = ok ? val : vec_t();
+  }
+}
+
+template <int VW>
+__device__ inline void dx_store_w(const DxWRegs<VW>& t, unsigned short* sW) {
+  typedef typename StageVec<VW>::type vec_t;
+#pragma unroll
+  for (int i = 0; i < DxWRegs<VW>::PER; ++i) {
+    const int v = threadIdx.x + i * 1024;
+    const int k = v / DxWRegs<VW>::VPR, c = (v % DxWRegs<VW>::VPR) * VW;
+    if (k < DX_KC) {
+      if constexpr (VW == 8) {                                             // LDS rows are 8-byte aligned
+        *(uint2*)(sW + k * DX_LD + c) = make_uint2(t.reg[i].x, t.reg[i].y);
+        *(uint2*)(sW + k * DX_LD + c + 4) = make_uint2(t.reg[i].z, t.reg[i].w);
+      } else {
+        *(vec_t*)(sW + k * DX_LD + c) = t.reg[i];
+      }
+    }
+  }
+}
+
+// One workgroup of 16 waves: wave = (row block rb, channel sub-tile ns); v_mfma_f32_32x32x16_bf16 with A = g rows read
+// straight from global (lane (r, h): row r, k = 8h..8h+7: consecutive channels of one gradient row), B = W staged in LDS
+// in chunks of DX_KC output channels.  Every global load of a chunk (its A vectors, its W slice) is issued before the
+// first wait; without fan-in pieces and up to 3 chunks (cout <= 192: all of NASNet-Mobile) ALL chunks' loads are issued
+// up front, so the workgroup pays one memory round trip in total.
+template <int VA, bool EX, int VW>
+__device__ inline void dgrad_body(const unsigned short* __restrict__ dy, long long pitch_dy, const BnFuse& bn,
+                                  const unsigned short* __restrict__ w, unsigned short* __restrict__ dx, long long M,
+                                  int cout, int cin, int rchunk, int cit, int row_blocks, int nsub,
+                                  unsigned char* smem) {
+  typedef typename StageVec<VA>::type vec_t;
+  constexpr int G = 8 / VA, KSTEPS = DX_KC / 16, HOIST = (EX || VW == 1) ? 1 : 3;   // chunks whose loads are in flight together
+  float* sScale = (float*)smem;                                   // [<= 256] BN scales (0 beyond cout)
+  unsigned short* sW = (unsigned short*)(smem + 1024);            // [DX_KC][DX_LD]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int rb = wave % row_blocks, ns = wave / row_blocks;
+  const bool active = ns < nsub;
+  const long long row0 = ((long long)rchunk * row_blocks + rb) * 32;
+  const long long row = row0 + r;
+  const long long rr = row < M ? row : M - 1;
+  const int ci_base = cit * nsub * 32;
+  const int ci = ci_base + ns * 32 + r;
+  const int kp = (cout + 15) / 16 * 16;
+  const int nx = EX ? bn.n_extra : 0;             // EX: the output gradient arrives in up to three pieces (fan-in)
+  for (int c = threadIdx.x; c < kp; c += blockDim.x)
+    sScale[c] = c < cout ? bn.gamma[c] * rsqrtf(bn.var[c] + bn.eps) : 0.f;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int kg0 = 0; kg0 < cout; kg0 += HOIST * DX_KC) {
+    // unconditional loads from clamped addresses (guarded loads would each get their own wait)
+    vec_t a0[HOIST][KSTEPS][G], a1[EX ? KSTEPS : 1][G], a2[EX ? KSTEPS : 1][G];
+    DxWRegs<VW> wr[HOIST];
+#pragma unroll
+    for (int q = 0; q < HOIST; ++q) {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int kg = kg0 + q * DX_KC + ks * 16 + 8 * h + g * VA;
+          const int kc = kg < cout ? kg : cout - VA;             // cout % VA == 0: a vector is inside or outside as a whole
+          a0[q][ks][g] = *(const vec_t*)(dy + rr * pitch_dy + kc);
+          if constexpr (EX) {
+            if (nx > 0) a1[ks][g] = *(const vec_t*)(bn.dy_extra[0] + rr * bn.pitch_extra[0] + kc);
+            if (nx > 1) a2[ks][g] = *(const vec_t*)(bn.dy_extra[1] + rr * bn.pitch_extra[1] + kc);
+          }
+        }
+      dx_load_w<VW>(wr[q], w, kg0 + q * DX_KC, cout, cin, ci_base);
+    }
+#pragma unroll
+    for (int q = 0; q < HOIST; ++q) {
+      const int kc0 = kg0 + q * DX_KC;
+      if (kc0 >= cout) break;                                     // uniform
+      __syncthreads();                                            // the previous chunk's reads are done (and sScale is set)
+      dx_store_w<VW>(wr[q], sW);
+      __syncthreads();
+      if (!active) continue;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int kbase = kc0 + ks * 16;
+        if (kbase < cout) {                                       // uniform
+          unsigned short a16[8];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int kg = kbase + 8 * h + g * VA;
+            const bool ok = kg < cout;
+#pragma unroll
+            for (int j = 0; j < VA; ++j) {
+              float f = bf16_bits_to_f32(((const unsigned short*)&a0[q][ks][g])[j]);
+              if constexpr (EX) {
+                if (nx > 0) {                                     // the fan-in sum, rounded once (as the weight part does)
+                  f += bf16_bits_to_f32(((const unsigned short*)&a1[ks][g])[j]);
+                  if (nx > 1) f += bf16_bits_to_f32(((const unsigned short*)&a2[ks][g])[j]);
+                  f = bf16_bits_to_f32(f32_to_bf16_bits(f));
+                }
+              }
+              a16[g * VA + j] = ok ? f32_to_bf16_bits(f * sScale[ok ? kg + j : 0]) : (unsigned short)0;
+            }
+          }
+          unsigned short b16[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) b16[j] = sW[(ks * 16 + 8 * h + j) * DX_LD + ns * 32 + r];
+          uint4 fa, fb;
+          fa.x = a16[0] | ((unsigned)a16[1] << 16); fa.y = a16[2] | ((unsigned)a16[3] << 16);
+          fa.z = a16[4] | ((unsigned)a16[5] << 16); fa.w = a16[6] | ((unsigned)a16[7] << 16);
+          fb.x = b16[0] | ((unsigned)b16[1] << 16); fb.y = b16[2] | ((unsigned)b16[3] << 16);
+          fb.z = b16[4] | ((unsigned)b16[5] << 16); fb.w = b16[6] | ((unsigned)b16[7] << 16);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
+                                                        acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (active && ci < cin) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long long orow = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (orow < M) dx[orow * cin + ci] = f32_to_bf16_bits(acc[i]);
+    }
+  }
+}
+
 template <int TCO, int TCI, int VA, int VB, bool BN>
 __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned short* __restrict__ dy_,
                                                               const unsigned short* __restrict__ x_,
@@ -203,16 +369,16 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
                                                               unsigned* __restrict__ counters, long long M, int cout,
                                                               int cin, long long pitch_dy_, long long pitch_x,
                                                               long long rows_per_block, int nsplit, int defer,
-                                                              BnFuse bn_, WgradMulti mj) {
+                                                              BnFuse bn_, WgradMulti mj, DxFuse dxf) {
   const unsigned short* __restrict__ dy = dy_;
   const unsigned short* __restrict__ x = x_;
   float* __restrict__ partial = partial_;
   long long pitch_dy = pitch_dy_;
   BnFuse bn = bn_;
-  int split = blockIdx.z;
-  if (BN && mj.n > 0) {
-    const int job = blockIdx.z / nsplit;
-    split = blockIdx.z - job * nsplit;
+  int split = (int)blockIdx.z - dxf.slices;                 // < 0: a data-gradient workgroup (below)
+  if (BN && mj.n > 0 && split >= 0) {
+    const int job = split / nsplit;
+    split -= job * nsplit;
     dy = mj.dy[job];
     x = mj.x[job];
     partial = mj.partial[job];
@@ -225,6 +391,34 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
   constexpr int RC = BN ? (Q == 1 ? 256 : 128) : (Q == 4 ? 128 : 256);
   constexpr int STAGE_BYTES = RC * (TCO + TCI + (BN ? TCO : 0)) * 2, RED_BYTES = (KS - 1) * Q * 4096;
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
+  if (BN && (int)blockIdx.z < dxf.slices) {                              // a data-gradient workgroup (see DxFuse)
+    static_assert(sizeof(smem) >= 1024 + DX_KC * DX_LD * 2, "the staged W slice must fit the staging buffers");
+    const int lid = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int per_job = dxf.wgs_rows * dxf.wgs_ci;
+    const int slot = lid / per_job;
+    if (slot >= dxf.n) return;
+    const int rem = lid - slot * per_job;
+    if (mj.n > 0) {
+      const int job = dxf.job[slot];
+      dy = mj.dy[job];
+      pitch_dy = mj.pitch_dy[job];
+      bn = mj.bn[job];
+    }
+#define XPT_DX(EX, VW)                                                                                               \
+  dgrad_body<VA, EX, VW>(dy, pitch_dy, bn, dxf.w[slot], dxf.dx[slot], M, cout, cin, rem / dxf.wgs_ci, rem % dxf.wgs_ci, \
+                         dxf.row_blocks, dxf.nsub, smem)
+    if (bn.n_extra > 0) {
+      if (dxf.vw == 8) XPT_DX(true, 8);
+      else if (dxf.vw == 4) XPT_DX(true, 4);
+      else XPT_DX(true, 1);
+    } else {
+      if (dxf.vw == 8) XPT_DX(false, 8);
+      else if (dxf.vw == 4) XPT_DX(false, 4);
+      else XPT_DX(false, 1);
+    }
+#undef XPT_DX
+    return;
+  }
   __shared__ unsigned last_flag;
   __shared__ float sS[BN ? TCO : 1];                        // BN scale of the tile's output channels
   __shared__ float bnred[BN ? KS * QA * 64 : 1];            // column sums of the k slices
@@ -286,7 +480,7 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
     if constexpr (BN) {
       if (bn_tile) {
         stage_store<VA, TCO, RC, NT>(sY, gy);
-        store_scaled<VA, TCO, RC, NT>(bn.g_out, sS, ga, cout, k0, k_end, co0, cout);
+        if (bn.g_out) store_scaled<VA, TCO, RC, NT>(bn.g_out, sS, ga, cout, k0, k_end, co0, cout);
       }
     }
     __syncthreads();
@@ -465,8 +659,26 @@ extern "C" int xpt_conv1x1_bwd_weight_counters(long long M, int cout, int cin) {
 
 static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspace, unsigned* counters, long long M,
                         int cout, int cin, long long pitch_dy, long long pitch_x, const WgradPlan& p, int defer,
-                        void* stream, const BnFuse* bn = nullptr, const WgradMulti* multi = nullptr) {
-  const dim3 grid(p.tiles_ci, p.tiles_co, p.nsplit * (multi ? multi->n : 1));
+                        void* stream, const BnFuse* bn = nullptr, const WgradMulti* multi = nullptr,
+                        const DxFuse* dx = nullptr) {
+  const int wz = p.nsplit * (multi ? multi->n : 1);
+  DxFuse dxf{};
+  if (dx && dx->n > 0) {
+    dxf = *dx;
+    dxf.nsub = (cin + 31) / 32 < 4 ? (cin + 31) / 32 : 4;
+    dxf.row_blocks = 16 / dxf.nsub;
+    dxf.wgs_rows = (int)((M + 32 * dxf.row_blocks - 1) / (32 * dxf.row_blocks));
+    dxf.wgs_ci = (cin + 32 * dxf.nsub - 1) / (32 * dxf.nsub);
+    dxf.vw = 8;
+    for (int j = 0; j < dxf.n; ++j)
+      while (dxf.vw > 1 && (cin % dxf.vw != 0 || ((uintptr_t)dxf.w[j]) % (2 * dxf.vw) != 0)) dxf.vw >>= 1;
+    if (dxf.vw == 2) dxf.vw = 1;            // (8, 4 and 1 are instantiated)
+    const long long per_slice = (long long)p.tiles_ci * p.tiles_co;
+    dxf.slices = (int)(((long long)dxf.n * dxf.wgs_rows * dxf.wgs_ci + per_slice - 1) / per_slice);
+  }
+  const long long dz = dxf.slices;
+  if (wz + dz > 65535) return XPT_ERR_SHAPE;
+  const dim3 grid(p.tiles_ci, p.tiles_co, (unsigned)(wz + dz));
   const dim3 block(1024);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* a = (const unsigned short*)dy;
@@ -505,10 +717,10 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
   do {                                                                                                                \
     if (bn)                                                                                                           \
       hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, true>), grid, block, 0, s, a, b, dw, workspace,        \
-                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, *bn, mj);      \
+                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, *bn, mj, dxf); \
     else                                                                                                              \
       hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, false>), grid, block, 0, s, a, b, dw, workspace,       \
-                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, none, mj);     \
+                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, none, mj, dxf); \
   } while (0)
 #define XPT_WGRAD_V(V)                                                                                               \
   do {                                                                                                               \
@@ -595,6 +807,35 @@ extern "C" int xpt_conv1x1_bn_bwd_partials_sum(const void* dy, const void* dy2, 
   return wgrad_launch(dy, x, nullptr, w_partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream, &bn);
 }
 
+/* The whole backward of conv1x1 -> BatchNorm in ONE launch: the partials above plus, when dx is not NULL, the data
+ * gradient dx [M, cin] bf16 = (dy (+ dy2 + dy3)) * s  W computed by extra workgroups of the same launch (w: the layer's
+ * bf16 weight [cout, cin], dense).  g is not written. */
+extern "C" int xpt_conv1x1_bn_bwd_fused(const void* dy, const void* dy2, const void* dy3, const void* ypre, const void* x,
+                                        const void* w, const float* gamma, const float* var, const float* mean, float eps,
+                                        void* dx, float* w_partials, size_t w_partial_floats, float* bn_partials,
+                                        size_t bn_partial_floats, long long M, int cout, int cin, long long pitch_dy,
+                                        long long pitch_dy2, long long pitch_dy3, long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(x); XPT_CHECK_PTR(gamma); XPT_CHECK_PTR(var);
+  XPT_CHECK_PTR(mean); XPT_CHECK_PTR(w_partials); XPT_CHECK_PTR(bn_partials);
+  if (dx != nullptr && w == nullptr) return XPT_ERR_NULL;
+  if (M <= 0 || cout <= 0 || cin <= 0 || pitch_dy < cout || pitch_x < cin) return XPT_ERR_SHAPE;
+  if (dy3 != nullptr && dy2 == nullptr) return XPT_ERR_NULL;
+  if ((dy2 && pitch_dy2 < cout) || (dy3 && pitch_dy3 < cout)) return XPT_ERR_SHAPE;
+  const WgradPlan p = wgrad_plan(M, cout, cin, true);
+  if (w_partial_floats < (size_t)p.nsplit * cout * cin) return XPT_ERR_WORKSPACE;
+  if (bn_partial_floats < (size_t)p.nsplit * 2 * cout) return XPT_ERR_WORKSPACE;
+  if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
+  BnFuse bn{gamma, var, mean, eps, (const unsigned short*)ypre, nullptr, bn_partials,
+            {(const unsigned short*)dy2, (const unsigned short*)dy3}, {pitch_dy2, pitch_dy3}, dy3 ? 2 : (dy2 ? 1 : 0)};
+  DxFuse d{};
+  if (dx) {
+    d.n = 1;
+    d.dx[0] = (unsigned short*)dx;
+    d.w[0] = (const unsigned short*)w;
+  }
+  return wgrad_launch(dy, x, nullptr, w_partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream, &bn, nullptr, &d);
+}
+
 extern "C" int xpt_conv1x1_bn_bwd_partials(const void* dy, const void* ypre, const void* x, const float* gamma,
                                            const float* var, const float* mean, float eps, void* g_out,
                                            float* w_partials, size_t w_partial_floats, float* bn_partials,
@@ -637,4 +878,45 @@ extern "C" int xpt_conv1x1_bn_multi_bwd_partials(int n, const void* const* dy, c
   }
   return wgrad_launch(dy[0], x[0], nullptr, w_partials[0], nullptr, M, cout, cin, pitch_dy[0], pitch_x, p, 1, stream,
                       &m.bn[0], &m);
+}
+
+/* ... and with the data gradients dx[j] [M, cin] bf16 = (dy_j * s_j) W_j of the layers whose dx[j] is not NULL computed
+ * by extra workgroups of the same launch (w[j]: bf16 weights [cout, cin], dense); g is not written. */
+extern "C" int xpt_conv1x1_bn_multi_bwd_fused(int n, const void* const* dy, const long long* pitch_dy,
+                                              const void* const* ypre, const void* const* x, const void* const* w,
+                                              const float* const* gamma, const float* const* var,
+                                              const float* const* mean, float eps, void* const* dx,
+                                              float* const* w_partials, float* const* bn_partials,
+                                              size_t w_partial_floats, size_t bn_partial_floats, long long M, int cout,
+                                              int cin, long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(pitch_dy); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(gamma);
+  XPT_CHECK_PTR(var); XPT_CHECK_PTR(mean); XPT_CHECK_PTR(dx); XPT_CHECK_PTR(w_partials); XPT_CHECK_PTR(bn_partials);
+  if (n < 1 || n > WG_MAX_JOBS) return XPT_ERR_ARG;
+  if (M <= 0 || cout <= 0 || cin <= 0 || pitch_x < cin) return XPT_ERR_SHAPE;
+  const WgradPlan p = wgrad_plan(M, cout, cin, true);
+  if (w_partial_floats < (size_t)p.nsplit * cout * cin || bn_partial_floats < (size_t)p.nsplit * 2 * cout)
+    return XPT_ERR_WORKSPACE;
+  if (p.tiles_co > 65535 || (long long)p.nsplit * n > 65535) return XPT_ERR_SHAPE;
+  WgradMulti m{};
+  DxFuse d{};
+  m.n = n;
+  for (int j = 0; j < n; ++j) {
+    if (!dy[j] || !ypre[j] || !x[j] || !gamma[j] || !var[j] || !mean[j] || !w_partials[j] || !bn_partials[j])
+      return XPT_ERR_NULL;
+    if (dx[j] && !w[j]) return XPT_ERR_NULL;
+    if (pitch_dy[j] < cout) return XPT_ERR_SHAPE;
+    m.dy[j] = (const unsigned short*)dy[j];
+    m.x[j] = (const unsigned short*)x[j];
+    m.partial[j] = w_partials[j];
+    m.pitch_dy[j] = pitch_dy[j];
+    m.bn[j] = BnFuse{gamma[j], var[j], mean[j], eps, (const unsigned short*)ypre[j], nullptr, bn_partials[j]};
+    if (dx[j]) {
+      d.dx[d.n] = (unsigned short*)dx[j];
+      d.w[d.n] = (const unsigned short*)w[j];
+      d.job[d.n] = j;
+      ++d.n;
+    }
+  }
+  return wgrad_launch(dy[0], x[0], nullptr, w_partials[0], nullptr, M, cout, cin, pitch_dy[0], pitch_x, p, 1, stream,
+                      &m.bn[0], &m, &d);
 }

@@ -183,7 +183,6 @@ def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx, ex
     dy2 = _ops.as_rows(dy.to(torch.bfloat16))
     more = [_ops.as_rows(e.to(torch.bfloat16)) for e in extra]
     M = dy2.shape[0]
-    g = torch.empty((M, cout), dtype=torch.bfloat16, device=dy.device)
     nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
     sink = _ops.grad_sink
     wpart = sink.partials(w_dst, "conv1x1", nsplit * cout * cin)
@@ -193,6 +192,20 @@ def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx, ex
     pitch_of = lambda t: t.stride(0) if M > 1 else cout           # noqa: E731
     e1 = more[0] if len(more) > 0 else None
     e2 = more[1] if len(more) > 1 else None
+    if _FUSED_DGRAD and ws.is_contiguous() and cout % 2 == 0:     # (odd widths: scalar loads, the kernel variant spills)
+        # the data gradient rides in the same launch (extra workgroups of the weight-gradient kernel): no g, no GEMM launch
+        dx = torch.empty((M, cin), dtype=torch.bfloat16, device=dy.device) if need_dx else None
+        _ops._lib.check(lib.xpt_conv1x1_bn_bwd_fused(dy2.data_ptr(), _ops._ptr(e1), _ops._ptr(e2), ypre.data_ptr(),
+                                                     x2.data_ptr(), ws.data_ptr(), gamma.data_ptr(), var.data_ptr(),
+                                                     mean.data_ptr(), eps, _ops._ptr(dx), wpart.data_ptr(), wpart.numel(),
+                                                     bpart.data_ptr(), bpart.numel(), M, cout, cin, pitch_dy,
+                                                     0 if e1 is None else pitch_of(e1), 0 if e2 is None else pitch_of(e2),
+                                                     pitch_x, _ops._stream()), "xpt_conv1x1_bn_bwd_fused")
+        sink.add(w_dst, wpart, 0, cout * cin, nsplit, cout * cin)
+        sink.add(b_dst, bpart, 0, cout, nsplit, 2 * cout)
+        sink.add(g_dst, bpart, cout, cout, nsplit, 2 * cout)
+        return dx.view(B, H, W, cin).permute(0, 3, 1, 2) if need_dx else None
+    g = torch.empty((M, cout), dtype=torch.bfloat16, device=dy.device)
     _ops._lib.check(lib.xpt_conv1x1_bn_bwd_partials_sum(dy2.data_ptr(), _ops._ptr(e1), _ops._ptr(e2), ypre.data_ptr(),
                                                         x2.data_ptr(), gamma.data_ptr(), var.data_ptr(), mean.data_ptr(),
                                                         eps, g.data_ptr(), wpart.data_ptr(), wpart.numel(),
@@ -257,7 +270,6 @@ class _MultiConv1x1Bn(torch.autograd.Function):
         dy2s = [_ops.as_rows(d.to(torch.bfloat16)) for d in dys]
         M = dy2s[0].shape[0]
         nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
-        g_all = torch.empty((n, M, cout), dtype=torch.bfloat16, device=dys[0].device)
         wparts, bparts = [], []
         for w_dst, g_dst, b_dst in ctx.dsts:
             wparts.append(sink.partials(w_dst, "conv1x1", nsplit * cout * cin))
@@ -265,6 +277,22 @@ class _MultiConv1x1Bn(torch.autograd.Function):
         P, LL = ctypes.c_void_p * n, ctypes.c_longlong * n
         ptr = lambda ts: P(*[x.data_ptr() for x in ts])
         pitch_x = x2s[0].stride(0) if M > 1 else cin
+        need = [ctx.needs_input_grad[2 + j] for j in range(n)]
+        if _FUSED_DGRAD and cout % 2 == 0 and all(s.is_contiguous() for s in shadows):
+            # ... and the n data gradients in the same launch (extra workgroups): no g, no batched GEMM launch
+            dx_all = torch.empty((n, M, cin), dtype=torch.bfloat16, device=dys[0].device)
+            _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_fused(
+                n, ptr(dy2s), LL(*[(d.stride(0) if M > 1 else cout) for d in dy2s]), ptr(ypres), ptr(x2s), ptr(shadows),
+                ptr(gs), ptr(vs), ptr(ms), eps, P(*[dx_all[j].data_ptr() if need[j] else None for j in range(n)]),
+                ptr(wparts), ptr(bparts), wparts[0].numel(), bparts[0].numel(), M, cout, cin, pitch_x, _ops._stream()),
+                "xpt_conv1x1_bn_multi_bwd_fused")
+            for j, (w_dst, g_dst, b_dst) in enumerate(ctx.dsts):
+                sink.add(w_dst, wparts[j], 0, cout * cin, nsplit, cout * cin)
+                sink.add(b_dst, bparts[j], 0, cout, nsplit, 2 * cout)
+                sink.add(g_dst, bparts[j], cout, cout, nsplit, 2 * cout)
+            dxs = [dx_all[j].view(B, H, W, cin).permute(0, 3, 1, 2) if need[j] else None for j in range(n)]
+            return (None, None, *dxs, *none, *none, *none, *none, *none, *dres)
+        g_all = torch.empty((n, M, cout), dtype=torch.bfloat16, device=dys[0].device)
         _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_partials(
             n, ptr(dy2s), LL(*[(d.stride(0) if M > 1 else cout) for d in dy2s]), ptr(ypres), ptr(x2s), ptr(gs), ptr(vs),
             ptr(ms), eps, P(*[g_all[j].data_ptr() for j in range(n)]), ptr(wparts), ptr(bparts), wparts[0].numel(),
@@ -273,7 +301,6 @@ class _MultiConv1x1Bn(torch.autograd.Function):
             sink.add(w_dst, wparts[j], 0, cout * cin, nsplit, cout * cin)
             sink.add(b_dst, bparts[j], 0, cout, nsplit, 2 * cout)
             sink.add(g_dst, bparts[j], cout, cout, nsplit, 2 * cout)
-        need = [ctx.needs_input_grad[2 + j] for j in range(n)]
         if n >= 2 and all(need) and (n >= 3 or _is_stacked(shadows)):
             # data gradients of all layers as ONE strided-batched GEMM: the g_j are already one [n, M, cout] buffer and the
             # weights sit equally spaced in the flat shadow buffer (FlatParameters groups them: stack_groups()), so the
@@ -335,6 +362,7 @@ def multi_conv1x1_bn(xs, weights, bns, residuals=None):
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
 _WIDE_CELL = __import__("os").environ.get("XPT_DEBUG_NARROW_CELL", "0") != "1"          # A/B: per-branch depthwise launches
 _FUSE_FAN_IN = __import__("os").environ.get("XPT_DEBUG_SEPARATE_FAN_IN", "0") != "1"     # A/B: gradient fan-in as its own launch
+_FUSED_DGRAD = __import__("os").environ.get("XPT_DEBUG_GEMM_DGRAD", "0") != "1"     # A/B: data gradient of conv1x1+BN as a library GEMM launch
 _CELL_TAIL = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CELL_TAIL", "0") != "1"     # A/B: pools / add / concat / relu as separate launches
 
 
