@@ -182,7 +182,8 @@ def test_fused_conv1x1_bn_backward(gpu_device, shape, with_residual, library_for
 
 
 @pytest.mark.parametrize("shape,n_alias,live", [((2, 264, 44, 16, 52), 3, (0, 1, 2)), ((1, 528, 88, 8, 26), 3, (0, 2)),
-                                                ((2, 36, 33, 3, 5), 2, (0, 1)), ((1, 44, 44, 9, 13), 4, (0, 1, 2, 3))])
+                                                ((2, 36, 33, 3, 5), 2, (0, 1)), ((1, 44, 44, 9, 13), 4, (0, 1, 2, 3)),
+                                                ((1, 1056, 176, 4, 13), 3, (0, 1, 2))])
 def test_conv1x1_bn_fan_in_inside_the_backward_launch(gpu_device, shape, n_alias, live, monkeypatch):
     """conv1x1_bn(..., fan_out=n): the gradients of the n consumers are added inside the weight-gradient launch
     (xpt_conv1x1_bn_bwd_partials_sum) -- bit for bit what the separate gradient fan-in launch (xpt_sum_rows) produced:
@@ -220,6 +221,53 @@ def test_conv1x1_bn_fan_in_inside_the_backward_launch(gpu_device, shape, n_alias
 
     a, b = run(True), run(False)
     for u, v, what in zip(a, b, ("y", "dx", "dW", "dgamma", "dbeta")):
+        assert torch.equal(u, v), what
+
+
+@pytest.mark.parametrize("shape,n_alias", [((2, 44, 44, 16, 52), 1), ((1, 264, 44, 16, 52), 3), ((2, 88, 88, 8, 26), 1),
+                                           ((1, 1056, 176, 4, 13), 2), ((3, 176, 176, 4, 13), 1), ((2, 22, 22, 9, 13), 1),
+                                           ((1, 300, 200, 5, 7), 1)])
+def test_data_gradient_inside_the_weight_gradient_launch(gpu_device, shape, n_alias, monkeypatch):
+    """The data gradient of conv1x1 + BatchNorm computed by extra workgroups of the weight-gradient launch
+    (xpt_conv1x1_bn_bwd_fused: dx = ((dy + dy2 + ...) * s) W on the bf16 matrix cores, straight from dy) against the
+    two-launch path it replaces (g = dy * s written by the weight-gradient kernel, then a library GEMM): same bf16
+    operands, fp32 accumulation in a different order -> equal to bf16 rounding; everything else bit for bit.
+    Shapes: one / several input-channel tiles, one / two / three (and four) 64-channel chunks of W, ragged rows."""
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
+    B, cin, cout, H, W = shape
+    dev = gpu_device
+    g = torch.Generator().manual_seed(cin * 5 + cout)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).bfloat16()
+    gys = [torch.randn(B, cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+           for _ in range(n_alias)]
+
+    def run(fused):
+        monkeypatch.setattr(pn, "_FUSED_DGRAD", fused)
+        weight = torch.nn.Parameter(w.float().to(dev))
+        weight.shadow_bf16 = w.to(dev)
+        weight.flat_grad = torch.zeros(cout, cin, 1, 1, device=dev)
+        bn = pn.FrozenBatchNorm(cout).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, cout)); bn.bias.fill_(0.1)
+            bn.running_mean.copy_(torch.linspace(-0.2, 0.2, cout)); bn.running_var.copy_(torch.linspace(0.4, 1.3, cout))
+        bn.weight.flat_grad = torch.zeros(cout, device=dev)
+        bn.bias.flat_grad = torch.zeros(cout, device=dev)
+        xg = x.clone().requires_grad_(True)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            ys = pn.conv1x1_bn(xg, weight, bn, fan_out=n_alias)
+        ys = ys if isinstance(ys, tuple) else (ys,)
+        torch.autograd.backward(list(ys), gys)
+        ops.grad_sink.flush()
+        torch.cuda.synchronize()
+        return xg.grad, weight.flat_grad, bn.weight.flat_grad, bn.bias.flat_grad
+
+    a, b = run(True), run(False)
+    scale = b[0].float().abs().max().item()
+    assert (a[0].float() - b[0].float()).abs().max().item() <= 2 ** -7 * scale, "dx"      # one bf16 ulp at the largest value
+    assert ((a[0].float() - b[0].float()).abs() > 2 ** -8 * b[0].float().abs() + 1e-3 * scale).float().mean().item() < 1e-3
+    for u, v, what in zip(a[1:], b[1:], ("dW", "dgamma", "dbeta")):
         assert torch.equal(u, v), what
 
 
