@@ -29,8 +29,8 @@ struct WgradPlan {
 };
 
 // tuning knobs (xpt_conv1x1_bwd_weight_tune; defaults measured on MI355X)
-int g_waves = 16;             // waves per workgroup
-int g_pairs_per_wave = 8;     // row pairs (MFMAs) each wave should at least get (in-step sweep: 16 -> 8.70 ms, 8 -> 8.59 ms, 4 -> 8.74 ms)
+int g_waves = 8;              // waves per workgroup (8: two workgroups per CU at <= 128 VGPRs; in-step 16/8 pairs -> 7.17 ms, 8/16 -> 7.05 ms)
+int g_pairs_per_wave = 16;    // row pairs (MFMAs) each wave should at least get (in-step sweep with 8 waves: 8 / 12 / 16 / 20 / 24 -> 7.20 / 7.09 / 7.05 / 7.21 / 7.19 ms)
 int g_max_blocks = 1024;      // workgroups per launch
 int g_max_partial_kib = 512;  // partial tiles the finishing workgroup adds, per output tile
 int g_defer_cap_mib = 8;      // deferred mode: bytes of split partials one layer may leave for xpt_reduce_partials
@@ -216,24 +216,24 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define DX_KC 64          // rows of W staged per chunk
 #define DX_LD 132         // LDS row pitch of the staged W slice in 16-bit elements (8 rows apart = 16 banks apart)
 
-// One workgroup of 16 waves: wave = (row block rb, channel sub-tile ns); v_mfma_f32_32x32x16_bf16 with A = g rows read
+// One workgroup of NT / 64 waves: wave = (row block rb, channel sub-tile ns); v_mfma_f32_32x32x16_bf16 with A = g rows read
 // straight from global (lane (r, h): row r, k = 8h..8h+7: consecutive channels of one gradient row), B = W staged in LDS.
 // Per chunk of DX_KC output channels every global load (the chunk's A vectors, the W slice) is issued before the first
 // wait, so a chunk costs one memory round trip, not one per k step.
-template <int VW> struct DxWRegs {
-  static constexpr int VPR = 128 / VW, PER = (DX_KC * VPR + 1023) / 1024;
+template <int VW, int NT> struct DxWRegs {
+  static constexpr int VPR = 128 / VW, PER = (DX_KC * VPR + NT - 1) / NT;
   typename StageVec<VW>::type reg[PER];
 };
 
 // global -> registers: this thread's share of W[kc0 .. kc0 + DX_KC)[ci_base .. ci_base + 128) (zeros outside the matrix)
-template <int VW>
-__device__ inline void dx_load_w(DxWRegs<VW>& t, const unsigned short* __restrict__ w, int kc0, int cout, int cin,
+template <int VW, int NT>
+__device__ inline void dx_load_w(DxWRegs<VW, NT>& t, const unsigned short* __restrict__ w, int kc0, int cout, int cin,
                                  int ci_base) {
   typedef typename StageVec<VW>::type vec_t;
 #pragma unroll
-  for (int i = 0; i < DxWRegs<VW>::PER; ++i) {
-    const int v = threadIdx.x + i * 1024;
-    const int k = v / DxWRegs<VW>::VPR, c = (v % DxWRegs<VW>::VPR) * VW;
+  for (int i = 0; i < DxWRegs<VW, NT>::PER; ++i) {
+    const int v = threadIdx.x + i * NT;
+    const int k = v / DxWRegs<VW, NT>::VPR, c = (v % DxWRegs<VW, NT>::VPR) * VW;
     const int co = kc0 + k, cc = ci_base + c;
     const bool ok = k < DX_KC && co < cout && cc < cin;                    // cin % VW == 0: whole vectors
     const vec_t val = *(const vec_t*)(w + (long long)(co < cout ? co : cout - 1) * cin + (cc < cin ? cc : cin - VW));
@@ -241,13 +241,13 @@ __device__ inline void dx_load_w(DxWRegs<VW>& t, const unsigned short* __restric
   }
 }
 
-template <int VW>
-__device__ inline void dx_store_w(const DxWRegs<VW>& t, unsigned short* sW) {
+template <int VW, int NT>
+__device__ inline void dx_store_w(const DxWRegs<VW, NT>& t, unsigned short* sW) {
   typedef typename StageVec<VW>::type vec_t;
 #pragma unroll
-  for (int i = 0; i < DxWRegs<VW>::PER; ++i) {
-    const int v = threadIdx.x + i * 1024;
-    const int k = v / DxWRegs<VW>::VPR, c = (v % DxWRegs<VW>::VPR) * VW;
+  for (int i = 0; i < DxWRegs<VW, NT>::PER; ++i) {
+    const int v = threadIdx.x + i * NT;
+    const int k = v / DxWRegs<VW, NT>::VPR, c = (v % DxWRegs<VW, NT>::VPR) * VW;
     if (k < DX_KC) {
       if constexpr (VW == 8) {                                             // LDS rows are 8-byte aligned
         *(uint2*)(sW + k * DX_LD + c) = make_uint2(t.reg[i].x, t.reg[i].y);
@@ -259,18 +259,18 @@ __device__ inline void dx_store_w(const DxWRegs<VW>& t, unsigned short* sW) {
   }
 }
 
-// One workgroup of 16 waves: wave = (row block rb, channel sub-tile ns); v_mfma_f32_32x32x16_bf16 with A = g rows read
+// One workgroup of NT / 64 waves: wave = (row block rb, channel sub-tile ns); v_mfma_f32_32x32x16_bf16 with A = g rows read
 // straight from global (lane (r, h): row r, k = 8h..8h+7: consecutive channels of one gradient row), B = W staged in LDS
 // in chunks of DX_KC output channels.  Every global load of a chunk (its A vectors, its W slice) is issued before the
 // first wait; without fan-in pieces and up to 3 chunks (cout <= 192: all of NASNet-Mobile) ALL chunks' loads are issued
 // up front, so the workgroup pays one memory round trip in total.
-template <int VA, bool EX, int VW>
+template <int VA, bool EX, int VW, int NT>
 __device__ inline void dgrad_body(const unsigned short* __restrict__ dy, long long pitch_dy, const BnFuse& bn,
                                   const unsigned short* __restrict__ w, unsigned short* __restrict__ dx, long long M,
                                   int cout, int cin, int rchunk, int cit, int row_blocks, int nsub,
                                   unsigned char* smem) {
   typedef typename StageVec<VA>::type vec_t;
-  constexpr int G = 8 / VA, KSTEPS = DX_KC / 16, HOIST = (EX || VW == 1) ? 1 : 3;   // chunks whose loads are in flight together
+  constexpr int G = 8 / VA, KSTEPS = DX_KC / 16, HOIST = (EX || VW == 1) ? 1 : (NT >= 1024 ? 3 : 2);   // chunks whose loads are in flight together
   float* sScale = (float*)smem;                                   // [<= 256] BN scales (0 beyond cout)
   unsigned short* sW = (unsigned short*)(smem + 1024);            // [DX_KC][DX_LD]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -292,7 +292,7 @@ __device__ inline void dgrad_body(const unsigned short* __restrict__ dy, long lo
   for (int kg0 = 0; kg0 < cout; kg0 += HOIST * DX_KC) {
     // unconditional loads from clamped addresses (guarded loads would each get their own wait)
     vec_t a0[HOIST][KSTEPS][G], a1[EX ? KSTEPS : 1][G], a2[EX ? KSTEPS : 1][G];
-    DxWRegs<VW> wr[HOIST];
+    DxWRegs<VW, NT> wr[HOIST];
 #pragma unroll
     for (int q = 0; q < HOIST; ++q) {
 #pragma unroll
@@ -307,14 +307,14 @@ __device__ inline void dgrad_body(const unsigned short* __restrict__ dy, long lo
             if (nx > 1) a2[ks][g] = *(const vec_t*)(bn.dy_extra[1] + rr * bn.pitch_extra[1] + kc);
           }
         }
-      dx_load_w<VW>(wr[q], w, kg0 + q * DX_KC, cout, cin, ci_base);
+      dx_load_w<VW, NT>(wr[q], w, kg0 + q * DX_KC, cout, cin, ci_base);
     }
 #pragma unroll
     for (int q = 0; q < HOIST; ++q) {
       const int kc0 = kg0 + q * DX_KC;
       if (kc0 >= cout) break;                                     // uniform
       __syncthreads();                                            // the previous chunk's reads are done (and sScale is set)
-      dx_store_w<VW>(wr[q], sW);
+      dx_store_w<VW, NT>(wr[q], sW);
       __syncthreads();
       if (!active) continue;
 #pragma unroll
@@ -362,8 +362,8 @@ __device__ inline void dgrad_body(const unsigned short* __restrict__ dy, long lo
   }
 }
 
-template <int TCO, int TCI, int VA, int VB, bool BN>
-__global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned short* __restrict__ dy_,
+template <int TCO, int TCI, int VA, int VB, bool BN, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgrad_kernel(const unsigned short* __restrict__ dy_,
                                                               const unsigned short* __restrict__ x_,
                                                               float* __restrict__ dw, float* __restrict__ partial_,
                                                               unsigned* __restrict__ counters, long long M, int cout,
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
     pitch_dy = mj.pitch_dy[job];
     bn = mj.bn[job];
   }
-  constexpr int NW = 16, QA = TCO / 32, QB = TCI / 32, Q = QA * QB, KS = NW / Q, NT = NW * 64;
+  constexpr int NW = NWAVES, QA = TCO / 32, QB = TCI / 32, Q = QA * QB, KS = NW / Q, NT = NW * 64;
   constexpr int TILE = TCO * TCI;
   // rows staged per chunk: 32 / 48 / 32 KiB of LDS (BN fusion: a third buffer for ypre, 48 / 40 / 48 KiB)
   constexpr int RC = BN ? (Q == 1 ? 256 : 128) : (Q == 4 ? 128 : 256);
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
       bn = mj.bn[job];
     }
 #define XPT_DX(EX, VW)                                                                                               \
-  dgrad_body<VA, EX, VW>(dy, pitch_dy, bn, dxf.w[slot], dxf.dx[slot], M, cout, cin, rem / dxf.wgs_ci, rem % dxf.wgs_ci, \
+  dgrad_body<VA, EX, VW, NT>(dy, pitch_dy, bn, dxf.w[slot], dxf.dx[slot], M, cout, cin, rem / dxf.wgs_ci, rem % dxf.wgs_ci, \
                          dxf.row_blocks, dxf.nsub, smem)
     if (bn.n_extra > 0) {
       if (dxf.vw == 8) XPT_DX(true, 8);
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(1024) void conv1x1_wgrad_kernel(const unsigned shor
 }  // namespace
 
 extern "C" int xpt_conv1x1_bwd_weight_tune(int waves, int pairs_per_wave, int max_blocks, int max_partial_kib) {
-  if (waves != 16 || pairs_per_wave < 1 || max_blocks < 1 || max_partial_kib < 16) return XPT_ERR_ARG;
+  if ((waves != 16 && waves != 8) || pairs_per_wave < 1 || max_blocks < 1 || max_partial_kib < 16) return XPT_ERR_ARG;
   g_waves = waves;
   g_pairs_per_wave = pairs_per_wave;
   g_max_blocks = max_blocks;
@@ -666,7 +666,7 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
   if (dx && dx->n > 0) {
     dxf = *dx;
     dxf.nsub = (cin + 31) / 32 < 4 ? (cin + 31) / 32 : 4;
-    dxf.row_blocks = 16 / dxf.nsub;
+    dxf.row_blocks = p.waves / dxf.nsub;
     dxf.wgs_rows = (int)((M + 32 * dxf.row_blocks - 1) / (32 * dxf.row_blocks));
     dxf.wgs_ci = (cin + 32 * dxf.nsub - 1) / (32 * dxf.nsub);
     dxf.vw = 8;
@@ -679,7 +679,7 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
   const long long dz = dxf.slices;
   if (wz + dz > 65535) return XPT_ERR_SHAPE;
   const dim3 grid(p.tiles_ci, p.tiles_co, (unsigned)(wz + dz));
-  const dim3 block(1024);
+  const dim3 block(p.waves * 64);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* a = (const unsigned short*)dy;
   const unsigned short* b = (const unsigned short*)x;
@@ -713,14 +713,21 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
   }
   const BnFuse none{};
   XPT_BEGIN_LAUNCH();
-#define XPT_WGRAD(TCO, TCI, V)                                                                                        \
+#define XPT_WGRAD_W(TCO, TCI, V, NWV)                                                                                 \
   do {                                                                                                                \
     if (bn)                                                                                                           \
-      hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, true>), grid, block, 0, s, a, b, dw, workspace,        \
+      hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, true, NWV>), grid, block, 0, s, a, b, dw, workspace,   \
                          counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, *bn, mj, dxf); \
     else                                                                                                              \
-      hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, false>), grid, block, 0, s, a, b, dw, workspace,       \
+      hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, false, NWV>), grid, block, 0, s, a, b, dw, workspace,  \
                          counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, none, mj, dxf); \
+  } while (0)
+#define XPT_WGRAD(TCO, TCI, V)                                                                                        \
+  do {                                                                                                                \
+    if (p.waves == 8)                                                                                                 \
+      XPT_WGRAD_W(TCO, TCI, V, 8);                                                                                    \
+    else                                                                                                              \
+      XPT_WGRAD_W(TCO, TCI, V, 16);                                                                                   \
   } while (0)
 #define XPT_WGRAD_V(V)                                                                                               \
   do {                                                                                                               \
@@ -743,6 +750,7 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
     XPT_WGRAD_V(1);
 #undef XPT_WGRAD_V
 #undef XPT_WGRAD
+#undef XPT_WGRAD_W
   return xpt_launch_status();
 }
 
