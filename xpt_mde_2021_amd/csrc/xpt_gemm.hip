@@ -661,25 +661,6 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
                         int cout, int cin, long long pitch_dy, long long pitch_x, const WgradPlan& p, int defer,
                         void* stream, const BnFuse* bn = nullptr, const WgradMulti* multi = nullptr,
                         const DxFuse* dx = nullptr) {
-  const int wz = p.nsplit * (multi ? multi->n : 1);
-  DxFuse dxf{};
-  if (dx && dx->n > 0) {
-    dxf = *dx;
-    dxf.nsub = (cin + 31) / 32 < 4 ? (cin + 31) / 32 : 4;
-    dxf.row_blocks = p.waves / dxf.nsub;
-    dxf.wgs_rows = (int)((M + 32 * dxf.row_blocks - 1) / (32 * dxf.row_blocks));
-    dxf.wgs_ci = (cin + 32 * dxf.nsub - 1) / (32 * dxf.nsub);
-    dxf.vw = 8;
-    for (int j = 0; j < dxf.n; ++j)
-      while (dxf.vw > 1 && (cin % dxf.vw != 0 || ((uintptr_t)dxf.w[j]) % (2 * dxf.vw) != 0)) dxf.vw >>= 1;
-    if (dxf.vw == 2) dxf.vw = 1;            // (8, 4 and 1 are instantiated)
-    const long long per_slice = (long long)p.tiles_ci * p.tiles_co;
-    dxf.slices = (int)(((long long)dxf.n * dxf.wgs_rows * dxf.wgs_ci + per_slice - 1) / per_slice);
-  }
-  const long long dz = dxf.slices;
-  if (wz + dz > 65535) return XPT_ERR_SHAPE;
-  const dim3 grid(p.tiles_ci, p.tiles_co, (unsigned)(wz + dz));
-  const dim3 block(p.waves * 64);
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* a = (const unsigned short*)dy;
   const unsigned short* b = (const unsigned short*)x;
@@ -711,6 +692,27 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
         if (c[q] < v) v = c[q];
     }
   }
+  // scalar staging (odd channel counts): the 8-wave instantiation spills at its 128-register cap; 16 waves there
+  const int waves = v == 1 ? 16 : p.waves;
+  const int wz = p.nsplit * (multi ? multi->n : 1);
+  DxFuse dxf{};
+  if (dx && dx->n > 0) {
+    dxf = *dx;
+    dxf.nsub = (cin + 31) / 32 < 4 ? (cin + 31) / 32 : 4;
+    dxf.row_blocks = waves / dxf.nsub;
+    dxf.wgs_rows = (int)((M + 32 * dxf.row_blocks - 1) / (32 * dxf.row_blocks));
+    dxf.wgs_ci = (cin + 32 * dxf.nsub - 1) / (32 * dxf.nsub);
+    dxf.vw = 8;
+    for (int j = 0; j < dxf.n; ++j)
+      while (dxf.vw > 1 && (cin % dxf.vw != 0 || ((uintptr_t)dxf.w[j]) % (2 * dxf.vw) != 0)) dxf.vw >>= 1;
+    if (dxf.vw == 2) dxf.vw = 1;            // (8, 4 and 1 are instantiated)
+    const long long per_slice = (long long)p.tiles_ci * p.tiles_co;
+    dxf.slices = (int)(((long long)dxf.n * dxf.wgs_rows * dxf.wgs_ci + per_slice - 1) / per_slice);
+  }
+  const long long dz = dxf.slices;
+  if (wz + dz > 65535) return XPT_ERR_SHAPE;
+  const dim3 grid(p.tiles_ci, p.tiles_co, (unsigned)(wz + dz));
+  const dim3 block(waves * 64);
   const BnFuse none{};
   XPT_BEGIN_LAUNCH();
 #define XPT_WGRAD_W(TCO, TCI, V, NWV)                                                                                 \
@@ -724,7 +726,7 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
   } while (0)
 #define XPT_WGRAD(TCO, TCI, V)                                                                                        \
   do {                                                                                                                \
-    if (p.waves == 8)                                                                                                 \
+    if (waves == 8)                                                                                                   \
       XPT_WGRAD_W(TCO, TCI, V, 8);                                                                                    \
     else                                                                                                              \
       XPT_WGRAD_W(TCO, TCI, V, 16);                                                                                   \
