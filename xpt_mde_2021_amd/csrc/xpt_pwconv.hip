@@ -74,6 +74,19 @@ __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, 
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+  // the epilogue's operands (BatchNorm parameters of this lane's output channel, the residual elements of its 16 output
+  // rows) are fetched FIRST, from clamped addresses: their round trip then overlaps the first batch of operand loads
+  // instead of following the last MFMA
+  const int bc = col_ok ? bn_ : cout - 1;
+  const float e_gamma = bn.gamma[bc], e_var = bn.var[bc], e_beta = bn.beta[bc], e_mean = bn.mean[bc];
+  unsigned short res_raw[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const long long m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+    const long long mc = m < M ? m : M - 1;
+    res_raw[i] = residual ? residual[mc * cout + bc] : (unsigned short)0;
+  }
+
   const int ksteps = (cin + 15) / 16;
   for (int s0 = 0; s0 < ksteps; s0 += PW_G) {
     uint4 fa[PW_G], fb[PW_G];
@@ -97,15 +110,11 @@ __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, 
 
   // accumulator (reg i, lane): output row m0 + (i & 3) + 8 (i >> 2) + 4 h, column n0 + r
   if (!col_ok) return;
-  const float sc = bn.gamma[bn_] * rsqrtf(bn.var[bn_] + bn.eps);
-  const float sh = bn.beta[bn_] - bn.mean[bn_] * sc;
+  const float sc = e_gamma * rsqrtf(e_var + bn.eps);
+  const float sh = e_beta - e_mean * sc;
   float res[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const long long m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-    const long long mc = m < M ? m : M - 1;
-    res[i] = residual ? bf16_bits_to_f32(residual[mc * cout + bn_]) : 0.f;
-  }
+  for (int i = 0; i < 16; ++i) res[i] = bf16_bits_to_f32(res_raw[i]);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const long long m = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;

@@ -129,6 +129,10 @@ def _apply_env_tuning():
     for code in os.environ.get("XPT_DW_TUNE", "").split(","):     # depthwise knobs (xpt_dwconv_tune codes, see xpt_hip.h)
         if code:
             _lib.load().xpt_dwconv_tune(int(code))
+    plan = os.environ.get("XPT_CONV_TUNE")                 # dense convolution plan (xpt_conv2d_tune: -1000 - n = LDS-kernel threshold)
+    if plan:
+        for code in plan.split(","):
+            _lib.load().xpt_conv2d_tune(int(code))
     cap = os.environ.get("XPT_PW_DEFER_CAP_MIB")           # pointwise weight gradient: MiB of split partials per layer
     if cap:
         _lib.load().xpt_conv1x1_bwd_weight_defer_cap(int(cap))
