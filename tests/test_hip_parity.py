@@ -487,13 +487,14 @@ def test_batchnorm_residual_and_sliced_gradient(ops, gpu_device, C, shape, dtype
 
 # ------------------------------------------------------------------------------------------------ depthwise conv (a2)
 DW_SMALL = (2, 44, 16, 26)          # scalar kernels (small maps)
-DW_LARGE = (2, 40, 96, 280)         # >= 2^21 elements: the vectorised LDS-tap stencil (forward, stride-1 data gradient)
+DW_LARGE = (2, 40, 96, 280)         # >= 2^21 elements: the vectorised LDS-tap stencil (forward, stride-1 data gradient) and
+                                    # the vectorised stride-2 data gradient
 DW_LARGE_ODD = (1, 22, 301, 330)    # V = 2 vectors, odd extents
 
 
 @pytest.mark.parametrize("k,stride,shape", [(3, 1, DW_SMALL), (5, 1, DW_SMALL), (7, 1, DW_SMALL), (3, 2, DW_SMALL),
                                             (5, 2, DW_SMALL), (7, 2, DW_SMALL), (3, 1, DW_LARGE), (5, 1, DW_LARGE),
-                                            (7, 2, DW_LARGE), (5, 2, DW_LARGE_ODD), (7, 1, DW_LARGE_ODD)])
+                                            (7, 2, DW_LARGE), (3, 2, DW_LARGE), (5, 2, DW_LARGE_ODD), (7, 1, DW_LARGE_ODD)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("relu_in", [False, True])
 def test_depthwise_conv_fwd_bwd(ops, gpu_device, k, stride, shape, dtype, relu_in):

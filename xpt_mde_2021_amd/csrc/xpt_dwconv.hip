@@ -361,6 +361,61 @@ __global__ void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restr
   dw_bwd_data_body<T, K, S>(x, w, dy, dx, d, relu_in, blockIdx.x, gridDim.x);
 }
 
+// Stride-2 data gradient with V channels per thread (the reduction cells' first layers on the 64x208 / 32x104 maps: a
+// 2-byte load per lane and tap costs the address path what a 16-byte one costs): the taps sit in LDS as [tap][channel],
+// a thread owns V consecutive channels of one input pixel and visits the (K+1)/2 x (K+1)/2 taps of its parity class.
+template <typename T, int K, int V>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_vec_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                                  const T* __restrict__ dy, T* __restrict__ dx, DwDims d,
+                                                                  int relu_in) {
+  extern __shared__ __attribute__((aligned(16))) float sWt[];     // [K*K][C]
+  dw_stage_taps(sWt, w, d.C, K * K, false);
+  __syncthreads();
+  constexpr int KT = (K + 1) / 2;
+  const int CG = d.C / V;
+  const long long total = (long long)d.B * d.H * d.W * CG;
+  for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += 256LL * gridDim.x) {
+    const int c0 = (int)(idx % CG) * V;
+    long long r = idx / CG;
+    const int ix = (int)(r % d.W); r /= d.W;
+    const int iy = (int)(r % d.H);
+    const int b = (int)(r / d.H);
+    float acc[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) acc[u] = 0.f;
+    const int py = (iy + d.pad_t) & 1, px = (ix + d.pad_l) & 1;
+#pragma unroll
+    for (int jy = 0; jy < KT; ++jy) {
+      const int ky = py + 2 * jy;
+      const int ty = iy + d.pad_t - ky;                // even by construction
+      const int oy = ty >> 1;
+      const bool row_ok = ky < K && ty >= 0 && oy < d.OH;
+      const T* row = dy + (((long long)b * d.OH + min(max(oy, 0), d.OH - 1)) * d.OW) * d.C + c0;
+#pragma unroll
+      for (int jx = 0; jx < KT; ++jx) {
+        const int kx = px + 2 * jx;
+        const int tx = ix + d.pad_l - kx;
+        const int ox = tx >> 1;
+        const bool ok = row_ok && kx < K && tx >= 0 && ox < d.OW;
+        float v[V];
+        load_chan<T, V>(row + (long long)min(max(ox, 0), d.OW - 1) * d.C, v);      // unconditional, zeroed by select
+        const float* wt = sWt + (min(ky, K - 1) * K + min(kx, K - 1)) * d.C + c0;
+#pragma unroll
+        for (int u = 0; u < V; ++u) acc[u] += ok ? v[u] * wt[u] : 0.f;
+      }
+    }
+    const long long o = (((long long)b * d.H + iy) * d.W + ix) * d.C + c0;
+    if (relu_in) {
+      float m[V];
+      load_chan<T, V>(x + o, m);
+#pragma unroll
+      for (int u = 0; u < V; ++u)
+        if (!(m[u] > 0.f)) acc[u] = 0.f;
+    }
+    store_chan<T, V>(dx + o, acc);
+  }
+}
+
 // ---------------------------------------------------------------- weight gradient
 // dw[c,ky,kx] = sum_{b,oy,ox} dy[b,oy,ox,c] * f(x[b,oy*S+ky-pad_t,ox*S+kx-pad_l,c])
 // Work item = OXT neighbouring outputs of one row ("group"); grid (channel chunks of 64, chunks of GRP groups).
@@ -637,6 +692,7 @@ inline unsigned grid_for(long long total) {
 }
 
 int g_dw_multi_vec = 1;     // 0: the scalar multi-layer kernels (A/B, xpt_dwconv_tune(-1) / (-2))
+int g_dw_s2_vec = 1;        // 0: the scalar stride-2 data gradient (A/B, xpt_dwconv_tune(-3) / (-4))
 
 // channel vector width of the vectorised multi-layer kernels: 8 / 4 / 2 bf16 or 4 / 2 floats dividing C; 1 = none
 inline int multi_vec_width(int dtype, int C, std::initializer_list<const void*>) {
@@ -704,6 +760,23 @@ int launch_bwd_data(const void* x, const float* w, const void* dy, void* dx, con
     const int v = chan_vec<T>(t, K, {dy, dx, relu_in ? x : nullptr});
     if (v > 1 && t.pad_t >= 0 && t.pad_l >= 0) {
       launch_stencil<T, K, 1, 4, 1>(v, dy, w, x, dx, t, relu_in, s);
+      return xpt_launch_status();
+    }
+  }
+  if (S == 2 && g_dw_s2_vec) {
+    const int v = chan_vec<T>(d, K, {dy, dx, relu_in ? x : nullptr});
+    if (v > 1) {
+      const long long groups = (long long)d.B * d.H * d.W * (d.C / v);
+      const size_t lds = (size_t)K * K * d.C * sizeof(float);
+      const dim3 grid(grid_for(groups));
+#define XPT_S2V(V) \
+  hipLaunchKernelGGL((dw_bwd_data_s2_vec_kernel<T, K, V>), grid, dim3(256), lds, s, (const T*)x, w, (const T*)dy, (T*)dx, d, relu_in)
+      if constexpr (sizeof(T) == 2) {
+        if (v == 8) XPT_S2V(8); else if (v == 4) XPT_S2V(4); else XPT_S2V(2);
+      } else {
+        if (v == 4) XPT_S2V(4); else XPT_S2V(2);
+      }
+#undef XPT_S2V
       return xpt_launch_status();
     }
   }
@@ -820,6 +893,10 @@ int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* works
 int xpt_dwconv_tune(int wrw_groups) {
   if (wrw_groups == -1 || wrw_groups == -2) {        // -1: scalar multi-layer kernels, -2: vectorised (default)
     g_dw_multi_vec = wrw_groups == -2;
+    return XPT_OK;
+  }
+  if (wrw_groups == -3 || wrw_groups == -4) {        // -3: scalar stride-2 data gradient, -4: vectorised (default)
+    g_dw_s2_vec = wrw_groups == -4;
     return XPT_OK;
   }
   if (wrw_groups != 0 && wrw_groups != 4 && wrw_groups != 8 && wrw_groups != 16 && wrw_groups != 32) return XPT_ERR_ARG;
