@@ -80,7 +80,7 @@ __device__ inline void dw_fwd_body(const T* __restrict__ x, const float* __restr
 }
 
 template <typename T, int K, int S, int OXT>
-__global__ void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, DwDims d,
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, DwDims d,
                               int relu_in) {
   dw_fwd_body<T, K, S, OXT>(x, w, y, d, relu_in, blockIdx.x, gridDim.x);
 }
@@ -356,7 +356,7 @@ __device__ inline void dw_bwd_data_body(const T* __restrict__ x, const float* __
 }
 
 template <typename T, int K, int S>
-__global__ void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy,
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy,
                                    T* __restrict__ dx, DwDims d, int relu_in) {
   dw_bwd_data_body<T, K, S>(x, w, dy, dx, d, relu_in, blockIdx.x, gridDim.x);
 }
@@ -518,7 +518,7 @@ __device__ inline void dw_bwd_weight_body(const T* __restrict__ x, const T* __re
 }
 
 template <typename T, int K, int S>
-__global__ void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part,
                                      DwDims d, int relu_in, int RG, int GRP) {
   dw_bwd_weight_body<T, K, S>(x, dy, part, d, relu_in, RG, GRP, blockIdx.x, blockIdx.y);
 }
@@ -745,8 +745,9 @@ int launch_fwd(const void* x, const float* w, void* y, const DwDims& d, int relu
     launch_stencil<T, K, S, OXT, 0>(v, x, w, nullptr, y, d, relu_in, s);
     return xpt_launch_status();
   }
-  const long long total = (long long)d.B * d.OH * ((d.OW + OXT - 1) / OXT) * d.C;
-  hipLaunchKernelGGL((dw_fwd_kernel<T, K, S, OXT>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, w, (T*)y, d,
+  constexpr int OXS = OXT;
+  const long long total = (long long)d.B * d.OH * ((d.OW + OXS - 1) / OXS) * d.C;
+  hipLaunchKernelGGL((dw_fwd_kernel<T, K, S, OXS>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, w, (T*)y, d,
                      relu_in);
   return xpt_launch_status();
 }

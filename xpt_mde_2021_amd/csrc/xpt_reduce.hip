@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const xpt_reduce_j
                                                                const int2* __restrict__ blockmap) {
   __shared__ float red[3][64];
   const int2 bm = blockmap[blockIdx.x];
-  const xpt_reduce_job job = jobs[bm.x];
+  // by reference: the segment arrays are indexed with a loop variable, a by-value copy of the job would live in scratch
+  const xpt_reduce_job& job = jobs[bm.x];
   if (job.split_waves == 16) {                 // wide mode: 256 outputs per workgroup, 16-byte loads (below)
     reduce_wide(job, bm.y);
     return;
