@@ -60,6 +60,47 @@ def test_bad_arguments_are_rejected_without_gpu(lib):
     assert lib.xpt_photo_workspace_floats(2, 4, 8, 8) == 2 * 4 * 64 * 9
 
 
+def test_round2_entry_points_reject_bad_arguments_without_gpu(lib):
+    """The multi-scale / fused entry points added in round 2: argument checks come before any launch."""
+    null = None
+    one = ctypes.c_void_p(16)
+    four = (ctypes.c_void_p * 4)(16, 16, 16, 16)
+    hw = (ctypes.c_int * 4)(8, 8, 8, 8)
+    n64 = (ctypes.c_longlong * 4)(8, 8, 8, 8)
+    # smoothness, all scales: at most 4 scales, h and w >= 2, workspace large enough
+    assert lib.xpt_smooth_ms_fwd(5, four, four, one, one, 10 ** 6, 1, hw, hw, 4.0, 0, null) == -2
+    assert lib.xpt_smooth_ms_fwd(2, four, four, one, one, 1, 1, hw, hw, 4.0, 0, null) == -4
+    assert lib.xpt_smooth_ms_fwd(2, four, four, null, one, 10 ** 6, 1, hw, hw, 4.0, 0, null) == -1
+    assert lib.xpt_smooth_ms_bwd(2, four, four, null, four, 1, hw, hw, 4.0, 0, null) == -1
+    # depth activation, all scales
+    assert lib.xpt_depth_head_ms_fwd(0, four, four, four, n64, null) == -2
+    assert lib.xpt_depth_head_ms_bwd(2, four, null, four, four, n64, null) == -1
+    # image pyramids: at most 10 jobs, frames inside the snippet, even factors that divide the image
+    jobs = (ctypes.c_int * 2)
+    outs = (ctypes.c_void_p * 2)(16, 16)
+    assert lib.xpt_image_pyramids(one, 1, 5, 8, 8, 11, jobs(0, 4), jobs(4, 1), jobs(1, 1), outs, null) == -2
+    assert lib.xpt_image_pyramids(one, 1, 5, 8, 8, 2, jobs(0, 4), jobs(4, 2), jobs(1, 1), outs, null) == -2      # frame 5 of 5
+    assert lib.xpt_image_pyramids(one, 1, 5, 8, 8, 2, jobs(0, 4), jobs(4, 1), jobs(3, 1), outs, null) == -2      # odd factor
+    assert lib.xpt_image_pyramids(null, 1, 5, 8, 8, 2, jobs(0, 4), jobs(4, 1), jobs(1, 1), outs, null) == -1
+    # total-loss merge: at most 64 terms and types
+    assert lib.xpt_merge_total_fwd(65, one, one, one, one, one, 8, 3, null) == -2
+    assert lib.xpt_merge_total_fwd(2, null, one, one, one, one, 8, 3, null) == -1
+    assert lib.xpt_merge_total_bwd(2, one, one, one, 0, null) == -2
+    # exact 2x up-sampling / global average pooling: dtype 0 or 1
+    assert lib.xpt_upsample2x_fwd(one, one, 1, 4, 4, 2, null) == -3
+    assert lib.xpt_upsample2x_bwd(one, 0, one, 1, 4, 4, 0, null) == -2        # pixel pitch < 1
+    assert lib.xpt_global_avgpool_fwd(one, one, 1, 4, 8, 5, null) == -3
+    assert lib.xpt_global_avgpool_bwd(null, one, 1, 4, 8, 0, null) == -1
+    # fused pointwise backward: a data gradient needs the weight; partial buffers must hold every split
+    args = (one, null, null, one, one)
+    assert lib.xpt_conv1x1_bn_bwd_fused(*args, null, one, one, one, 1e-3, one, one, 10 ** 9, one, 10 ** 9, 64, 8, 8, 8, 0, 0,
+                                        8, null) == -1
+    assert lib.xpt_conv1x1_bn_bwd_fused(*args, one, one, one, one, 1e-3, one, one, 1, one, 10 ** 9, 64, 8, 8, 8, 0, 0, 8,
+                                        null) == -4
+    assert lib.xpt_conv1x1_bn_bwd_fused(*args, one, one, one, one, 1e-3, one, one, 10 ** 9, one, 10 ** 9, 64, 8, 8, 4, 0, 0,
+                                        8, null) == -2                          # gradient row pitch < channels
+
+
 def test_ops_refuse_cpu_tensors(lib):
     import torch
     from xpt_mde_2021_amd.hip import ops
