@@ -391,7 +391,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
   constexpr int RC = BN ? (Q == 1 ? 256 : 128) : (Q == 4 ? 128 : 256);
   constexpr int STAGE_BYTES = RC * (TCO + TCI + (BN ? TCO : 0)) * 2, RED_BYTES = (KS - 1) * Q * 4096;
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
-  if (BN && (int)blockIdx.z < dxf.slices) {                              // a data-gradient workgroup (see DxFuse)
+  if constexpr (BN && VA > 1)        // (scalar staging = odd channel counts: the host never asks for a data gradient)
+  if ((int)blockIdx.z < dxf.slices) {                                    // a data-gradient workgroup (see DxFuse)
     static_assert(sizeof(smem) >= 1024 + DX_KC * DX_LD * 2, "the staged W slice must fit the staging buffers");
     const int lid = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const int per_job = dxf.wgs_rows * dxf.wgs_ci;
@@ -694,6 +695,7 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
   }
   // scalar staging (odd channel counts): the 8-wave instantiation spills at its 128-register cap; 16 waves there
   const int waves = v == 1 ? 16 : p.waves;
+  if (v == 1 && dx && dx->n > 0) return XPT_ERR_ARG;      // data gradients ride only in the vector-staged instantiations
   const int wz = p.nsplit * (multi ? multi->n : 1);
   DxFuse dxf{};
   if (dx && dx->n > 0) {

@@ -192,7 +192,10 @@ def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx, ex
     pitch_of = lambda t: t.stride(0) if M > 1 else cout           # noqa: E731
     e1 = more[0] if len(more) > 0 else None
     e2 = more[1] if len(more) > 1 else None
-    if _FUSED_DGRAD and ws.is_contiguous() and cout % 2 == 0:     # (odd widths: scalar loads, the kernel variant spills)
+    even = lambda t, pitch: pitch % 2 == 0 and t.data_ptr() % 4 == 0           # noqa: E731
+    vector_rows = (cout % 2 == 0 and cin % 2 == 0 and even(dy2, pitch_dy) and even(x2, pitch_x)
+                   and all(even(e, pitch_of(e)) for e in more))
+    if _FUSED_DGRAD and ws.is_contiguous() and vector_rows:     # (odd widths: scalar staging, no data-gradient workgroups)
         # the data gradient rides in the same launch (extra workgroups of the weight-gradient kernel): no g, no GEMM launch
         dx = torch.empty((M, cin), dtype=torch.bfloat16, device=dy.device) if need_dx else None
         _ops._lib.check(lib.xpt_conv1x1_bn_bwd_fused(dy2.data_ptr(), _ops._ptr(e1), _ops._ptr(e2), ypre.data_ptr(),
@@ -278,7 +281,10 @@ class _MultiConv1x1Bn(torch.autograd.Function):
         ptr = lambda ts: P(*[x.data_ptr() for x in ts])
         pitch_x = x2s[0].stride(0) if M > 1 else cin
         need = [ctx.needs_input_grad[2 + j] for j in range(n)]
-        if _FUSED_DGRAD and cout % 2 == 0 and all(s.is_contiguous() for s in shadows):
+        vector_rows = (cout % 2 == 0 and cin % 2 == 0 and pitch_x % 2 == 0
+                       and all(d.data_ptr() % 4 == 0 and (d.stride(0) if M > 1 else cout) % 2 == 0 for d in dy2s)
+                       and all(x.data_ptr() % 4 == 0 for x in x2s))
+        if _FUSED_DGRAD and vector_rows and all(s.is_contiguous() for s in shadows):
             # ... and the n data gradients in the same launch (extra workgroups): no g, no batched GEMM launch
             dx_all = torch.empty((n, M, cin), dtype=torch.bfloat16, device=dys[0].device)
             _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_fused(
