@@ -500,6 +500,9 @@ int xpt_conv1x1_bn_multi_bwd_partials(int n, const void* const* dy, const long l
  * dx is not NULL, the data gradient dx [M, cin] bf16 = ((dy + dy2 + dy3) * s) W (what torch.mm(g, W) did in a second
  * launch; tape.gradient w.r.t. the layer input, model/train_val.py:85-86), computed by extra workgroups of the same
  * launch straight from dy (g is not written).  w: the layer's bf16 weight [cout, cin], dense. */
+int xpt_conv1x1_bwd_fused(const void* dy, const void* x, const void* w, void* dx, float* partials,
+                          size_t partial_floats, long long M, int cout, int cin, long long pitch_dy, long long pitch_x,
+                          void* stream);   /* no BatchNorm behind the convolution: dx = dy W */
 int xpt_conv1x1_bn_bwd_fused(const void* dy, const void* dy2, const void* dy3, const void* ypre, const void* x,
                              const void* w, const float* gamma, const float* var, const float* mean, float eps, void* dx,
                              float* w_partials, size_t w_partial_floats, float* bn_partials, size_t bn_partial_floats,

@@ -271,6 +271,41 @@ def test_data_gradient_inside_the_weight_gradient_launch(gpu_device, shape, n_al
         assert torch.equal(u, v), what
 
 
+@pytest.mark.parametrize("shape", [(2, 44, 22, 8, 26), (1, 264, 132, 4, 13), (2, 88, 44, 5, 7), (1, 32, 11, 9, 13)])
+def test_plain_conv1x1_backward_in_one_launch(gpu_device, shape, monkeypatch):
+    """conv1x1 WITHOUT a BatchNorm behind it (the adjust block's two half-width projections): weight-gradient partials and
+    the data gradient dx = dy W in one launch (xpt_conv1x1_bwd_fused) against partials + library GEMM; an odd output width
+    (last shape) keeps the two-launch path."""
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
+    B, cin, cout, H, W = shape
+    dev = gpu_device
+    g = torch.Generator().manual_seed(cin + 7 * cout)
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).bfloat16()
+    gy = torch.randn(B, cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+
+    def run(fused):
+        monkeypatch.setattr(pn, "_FUSED_DGRAD", fused)
+        weight = torch.nn.Parameter(w.float().to(dev))
+        weight.shadow_bf16 = w.to(dev)
+        weight.flat_grad = torch.zeros(cout, cin, 1, 1, device=dev)
+        xg = x.clone().requires_grad_(True)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            y = pn.conv1x1(xg, weight)
+        y.backward(gy)
+        ops.grad_sink.flush()
+        torch.cuda.synchronize()
+        return xg.grad, weight.flat_grad
+
+    a, b = run(True), run(False)
+    ref = torch.einsum("bohw,oi->bihw", gy.float(), w.float().to(dev).reshape(cout, cin))
+    scale = ref.abs().max().item()
+    assert (a[0].float() - ref).abs().max().item() <= 2 ** -7 * scale
+    assert (b[0].float() - ref).abs().max().item() <= 2 ** -7 * scale
+    assert torch.equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("k,stride,C", [(3, 1, 44), (5, 1, 88), (7, 2, 22), (5, 2, 11), (3, 1, 176)])
 @pytest.mark.parametrize("relu_in", [False, True])
 def test_depthwise_backward_in_one_launch(gpu_device, k, stride, C, relu_in):

@@ -285,7 +285,7 @@ __device__ inline void dgrad_body(const unsigned short* __restrict__ dy, long lo
   const int kp = (cout + 15) / 16 * 16;
   const int nx = EX ? bn.n_extra : 0;             // EX: the output gradient arrives in up to three pieces (fan-in)
   for (int c = threadIdx.x; c < kp; c += blockDim.x)
-    sScale[c] = c < cout ? bn.gamma[c] * rsqrtf(bn.var[c] + bn.eps) : 0.f;
+    sScale[c] = c < cout ? (bn.gamma ? bn.gamma[c] * rsqrtf(bn.var[c] + bn.eps) : 1.f) : 0.f;   // no BatchNorm: scale 1
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
   constexpr int RC = BN ? (Q == 1 ? 256 : 128) : (Q == 4 ? 128 : 256);
   constexpr int STAGE_BYTES = RC * (TCO + TCI + (BN ? TCO : 0)) * 2, RED_BYTES = (KS - 1) * Q * 4096;
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
-  if constexpr (BN && VA > 1)        // (scalar staging = odd channel counts: the host never asks for a data gradient)
+  if constexpr (VA > 1)              // (scalar staging = odd channel counts: the host never asks for a data gradient)
   if ((int)blockIdx.z < dxf.slices) {                                    // a data-gradient workgroup (see DxFuse)
     static_assert(sizeof(smem) >= 1024 + DX_KC * DX_LD * 2, "the staged W slice must fit the staging buffers");
     const int lid = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
     const int slot = lid / per_job;
     if (slot >= dxf.n) return;
     const int rem = lid - slot * per_job;
-    if (mj.n > 0) {
+    if (BN && mj.n > 0) {
       const int job = dxf.job[slot];
       dy = mj.dy[job];
       pitch_dy = mj.pitch_dy[job];
@@ -792,6 +792,28 @@ extern "C" int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, fl
   if (partial_floats < (size_t)p.nsplit * cout * cin) return XPT_ERR_WORKSPACE;
   if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
   return wgrad_launch(dy, x, nullptr, partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream);
+}
+
+/* The same partials plus, when dx is not NULL, the data gradient dx [M, cin] bf16 = dy W (w: bf16 [cout, cin], dense)
+ * computed by extra workgroups of the same launch (a pointwise convolution WITHOUT a BatchNorm behind it). */
+extern "C" int xpt_conv1x1_bwd_fused(const void* dy, const void* x, const void* w, void* dx, float* partials,
+                                     size_t partial_floats, long long M, int cout, int cin, long long pitch_dy,
+                                     long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(dy);
+  XPT_CHECK_PTR(x);
+  XPT_CHECK_PTR(partials);
+  if (dx != nullptr && w == nullptr) return XPT_ERR_NULL;
+  if (M <= 0 || cout <= 0 || cin <= 0 || pitch_dy < cout || pitch_x < cin) return XPT_ERR_SHAPE;
+  const WgradPlan p = wgrad_plan(M, cout, cin, true);
+  if (partial_floats < (size_t)p.nsplit * cout * cin) return XPT_ERR_WORKSPACE;
+  if (p.tiles_co > 65535 || p.nsplit > 65535) return XPT_ERR_SHAPE;
+  DxFuse d{};
+  if (dx) {
+    d.n = 1;
+    d.dx[0] = (unsigned short*)dx;
+    d.w[0] = (const unsigned short*)w;
+  }
+  return wgrad_launch(dy, x, nullptr, partials, nullptr, M, cout, cin, pitch_dy, pitch_x, p, 1, stream, nullptr, nullptr, &d);
 }
 
 /* conv -> BatchNorm backward in one launch (see BnFuse): dy is the gradient of the BN output.

@@ -1333,9 +1333,10 @@ def conv1x1_weight_grad(dy2, x2):
     return dw
 
 
-def conv1x1_weight_grad_deferred(dy2, x2, dst):
+def conv1x1_weight_grad_deferred(dy2, x2, dst, w=None):
     """Same product as conv1x1_weight_grad, left as split-K partials for grad_sink.flush() to add into `dst`
-    (the weight's flat-gradient view, [cout, cin(,1,1)] contiguous)."""
+    (the weight's flat-gradient view, [cout, cin(,1,1)] contiguous).  w (the bf16 weight [cout, cin], dense): also
+    returns the data gradient dx = dy2 w [M, cin] bf16, computed by extra workgroups of the same launch."""
     lib = _lib.load()
     if not (dy2.is_cuda and x2.is_cuda) or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16:
         raise _lib.XptHipError("conv1x1_weight_grad: expected bfloat16 CUDA/HIP matrices (no CPU fallback)")
@@ -1348,9 +1349,23 @@ def conv1x1_weight_grad_deferred(dy2, x2, dst):
     pitch_x = x2.stride(0) if M > 1 else cin
     nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
     ws = grad_sink.partials(dst, "conv1x1", nsplit * cout * cin)
-    _lib.check(lib.xpt_conv1x1_bwd_weight_partials(_ptr(dy2), _ptr(x2), _ptr(ws), ws.numel(), M, cout, cin, pitch_dy,
-                                                   pitch_x, _stream()), "xpt_conv1x1_bwd_weight_partials")
+    dx = None
+    if w is not None:
+        dx = torch.empty((M, cin), dtype=torch.bfloat16, device=dy2.device)
+        _lib.check(lib.xpt_conv1x1_bwd_fused(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(dx), _ptr(ws), ws.numel(), M, cout, cin,
+                                             pitch_dy, pitch_x, _stream()), "xpt_conv1x1_bwd_fused")
+    else:
+        _lib.check(lib.xpt_conv1x1_bwd_weight_partials(_ptr(dy2), _ptr(x2), _ptr(ws), ws.numel(), M, cout, cin, pitch_dy,
+                                                       pitch_x, _stream()), "xpt_conv1x1_bwd_weight_partials")
     grad_sink.add(dst, ws, 0, cout * cin, nsplit, cout * cin)
+    return dx
+
+
+def vector_rows(t, channels):
+    """Rows of a [M, channels] bf16 view start on 4-byte boundaries and hold an even number of channels (what the fused
+    data gradient of the pointwise backward kernels needs: their scalar-staged instantiations carry no such code)."""
+    pitch = t.stride(0) if t.shape[0] > 1 else channels
+    return channels % 2 == 0 and pitch % 2 == 0 and t.data_ptr() % 4 == 0
 
 
 # ------------------------------------------------------------------------------- PWC-Net correlation cost volume

@@ -88,6 +88,11 @@ class _Conv1x1Bf16(torch.autograd.Function):
         B, cin, H, W, cout, wshape = ctx.dims
         dy2 = _ops.as_rows(dy.to(torch.bfloat16))
         dx = dw = None
+        if (_FUSED_DGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.sink_dst is not None
+                and ws.is_contiguous() and _ops.vector_rows(dy2, cout) and _ops.vector_rows(x2, cin)):
+            # weight-gradient partials and the data gradient in ONE launch (extra workgroups; no GEMM launch)
+            dx = _ops.conv1x1_weight_grad_deferred(dy2, x2, ctx.sink_dst, ws).view(B, H, W, cin).permute(0, 3, 1, 2)
+            return dx, None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dy2, ws).view(B, H, W, cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1] and ctx.sink_dst is not None:
