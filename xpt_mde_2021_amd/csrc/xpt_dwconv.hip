@@ -556,6 +556,9 @@ struct DwMultiBwd {
 template <typename T, int S>
 __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims d, int relu_in, int RG, int GRP,
                                                            int data_blocks, int cchunks, int wblocks_per_job) {
+  // the weight-gradient workgroups' fold buffer, sized by the host for the largest kernel among the jobs (one static
+  // buffer per kernel size added up to 63.7 KB and held the launch at two workgroups per CU)
+  extern __shared__ __attribute__((aligned(16))) float sFold[];
   const int ndata = m.n_inputs * data_blocks;
   if ((int)blockIdx.x < ndata) {
     const int u = blockIdx.x / data_blocks, blk = blockIdx.x - u * data_blocks;
@@ -595,11 +598,11 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims 
   const T* x = (const T*)m.xin[m.input_of[job]];
   const T* dy = (const T*)m.dy[job];
   if (m.k[job] == 3)
-    dw_bwd_weight_body<T, 3, S>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
+    dw_bwd_weight_body<T, 3, S, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, sFold);
   else if (m.k[job] == 5)
-    dw_bwd_weight_body<T, 5, S>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
+    dw_bwd_weight_body<T, 5, S, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, sFold);
   else
-    dw_bwd_weight_body<T, 7, S>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks);
+    dw_bwd_weight_body<T, 7, S, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, sFold);
 }
 
 // The same launch with the data-gradient part vectorised (stride 1): dx_u = [x_u > 0] * sum over the jobs j reading input u
@@ -1054,9 +1057,14 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
   }
   const int data_blocks = (int)grid_for((long long)B * H * W * C);
   const dim3 grid(n_inputs * data_blocks + n * wbpj);
+  size_t fold_bytes = 0;
+  for (int j = 0; j < n; ++j) {
+    const size_t f = (size_t)3 * 64 * k[j] * k[j] * sizeof(float);
+    fold_bytes = f > fold_bytes ? f : fold_bytes;
+  }
   XPT_BEGIN_LAUNCH();
 #define XPT_MULTI(T, S) \
-  hipLaunchKernelGGL((dw_multi_bwd_kernel<T, S>), grid, dim3(256), 0, s, m, d, relu_in, RG, GRP, data_blocks, cchunks, wbpj)
+  hipLaunchKernelGGL((dw_multi_bwd_kernel<T, S>), grid, dim3(256), fold_bytes, s, m, d, relu_in, RG, GRP, data_blocks, cchunks, wbpj)
   if (dtype == 0) {
     if (stride == 1) XPT_MULTI(float, 1); else XPT_MULTI(float, 2);
   } else {
