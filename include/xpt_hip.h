@@ -206,7 +206,8 @@ int xpt_dwconv_fwd(const void* x, const float* w, void* y, int B, int H, int W, 
                    int pad_l, int OH, int OW, int relu_in, int dtype, void* stream);
 int xpt_dwconv_bwd_data(const void* x, const float* w, const void* dy, void* dx, int B, int H, int W, int C, int k,
                         int stride, int pad_t, int pad_l, int OH, int OW, int relu_in, int dtype, void* stream);
-/* launch-plan knob (process-wide, for benchmarking): output groups per workgroup of the weight-gradient kernel */
+/* launch-plan knob (process-wide, for benchmarking): output groups per workgroup of the weight-gradient kernel (0, 4, 8,
+ * 16, 32); -1 / -2: scalar / vectorised multi-layer kernels; -3 / -4: scalar / vectorised stride-2 data gradient */
 int xpt_dwconv_tune(int wrw_groups);
 size_t xpt_dwconv_bwd_weight_workspace_floats(int B, int OH, int OW, int C, int k);
 int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_floats,
