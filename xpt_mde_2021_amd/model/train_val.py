@@ -290,6 +290,12 @@ class _StepGraph:
             self.library_path = self.eager_fallback = True
             self.graph = None
             return
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            # let the collective library's watchdog thread retire the (completed) start-up collectives before the capture
+            # begins: an event query from another thread during a global-mode capture would invalidate it
+            import time
+            time.sleep(0.3)
         if self.phases is None:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
