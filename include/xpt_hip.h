@@ -321,6 +321,7 @@ int xpt_restack_bf16(const float* image5d, void* out, int B, int S, int H, int W
  * and its tape.gradient: pre [B,H,W] fp32 = bias + conv3x3_same(x [B,H,W,C] bf16 with pixel pitch xpitch, w [3][3][C] fp32),
  * C in {16, 32, 64, 128}.  bwd: g [B,H,W] fp32 -> dx [B,H,W,C] bf16 dense and per-workgroup partials
  * [xpt_headconv_bwd_blocks()][9 C + 1] fp32 (dW [3][3][C], then dbias), finished by xpt_reduce_partials. */
+int xpt_headconv_tune(int passes, int max_blocks);   /* launch-plan knob of xpt_headconv_bwd (pixel passes per workgroup, most workgroups) */
 int xpt_headconv_bwd_blocks(int B, int H, int W, int C);
 int xpt_headconv_fwd(const void* x, long long xpitch, const float* w, const float* bias, float* pre, int B, int H, int W,
                      int C, void* stream);

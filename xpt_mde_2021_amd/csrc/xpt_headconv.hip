@@ -152,15 +152,24 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned short* __r
     partials[(long long)blockIdx.x * (9 * C + 1) + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
 }
 
+int g_head_passes = 4, g_head_max_blocks = 512;   // in-step sweep (passes, blocks): 8,256 6.726 ms; 4,512 6.706; 2,1024 6.723; 1,2048 6.744
+
 int head_blocks(long long P, int C) {
   const long long ppb = 4 * (64 / (C / 8));            // pixels per workgroup pass
-  long long blocks = (P + ppb * 8 - 1) / (ppb * 8);    // about 8 passes per workgroup
-  if (blocks > 256) blocks = 256;                      // one finishing pass of xpt_reduce_partials
+  long long blocks = (P + ppb * g_head_passes - 1) / (ppb * g_head_passes);    // passes per workgroup
+  if (blocks > g_head_max_blocks) blocks = g_head_max_blocks;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
 
 }  // namespace
+
+extern "C" int xpt_headconv_tune(int passes, int max_blocks) {
+  if (passes < 1 || max_blocks < 1) return XPT_ERR_ARG;
+  g_head_passes = passes;
+  g_head_max_blocks = max_blocks;
+  return XPT_OK;
+}
 
 extern "C" int xpt_headconv_bwd_blocks(int B, int H, int W, int C) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;

@@ -133,6 +133,9 @@ def _apply_env_tuning():
     if plan:
         for code in plan.split(","):
             _lib.load().xpt_conv2d_tune(int(code))
+    spec = os.environ.get("XPT_HEAD_TUNE")                 # depth-head convolution backward: pixel passes per workgroup, most workgroups
+    if spec:
+        _lib.load().xpt_headconv_tune(*[int(v) for v in spec.split(",")])
     cap = os.environ.get("XPT_PW_DEFER_CAP_MIB")           # pointwise weight gradient: MiB of split partials per layer
     if cap:
         _lib.load().xpt_conv1x1_bwd_weight_defer_cap(int(cap))
