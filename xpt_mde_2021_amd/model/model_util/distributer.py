@@ -5,8 +5,10 @@
 Semantics kept from the reference: the per-example losses are summed and divided by the GLOBAL batch
 (losses.py:49), so the gradient reduction across replicas is a SUM; the global batch is
 replicas x PER_REPLICA_BATCH (distributer.py:12); BatchNorm statistics are frozen, so nothing else is exchanged.
-The collective is one all-reduce(SUM) per flat gradient bucket (GRAD_BUCKETS chunks of the FlatParameters.grad
-buffer: 41 MB fp32 for NASNet-Mobile + PoseNetImproved; xGMI rings are per-link bound, so few large messages).
+The collective is an all-reduce(SUM) of the flat gradient buffer (FlatParameters.grad: 42 MB fp32 for NASNet-Mobile +
+PoseNetImproved; xGMI rings are per-link bound, so few large messages): in TWO pieces when the trainer cuts the
+backward pass between decoder and encoder (train_val.ModelTrainerDistrib: the decoder / PoseNet piece is exchanged
+asynchronously while the encoder's backward runs, all_reduce_range), else in GRAD_BUCKETS chunks after the step.
 """
 import os
 
