@@ -262,8 +262,7 @@ int xpt_conv1x1_bwd_weight(const void* dy, const void* x, float* dw, float* work
  * mode) and the `layers.add` that follow it inside tf.keras.applications.NASNetMobile (pretrained_nets.py:36-44):
  *   x [M, cin] bf16 rows (pitch_x elements apart), w [cout, cin] bf16 ->
  *   ypre [M, cout] bf16 = x w^T (fp32 accumulation on the matrix cores), y [M, cout] bf16 = BN(ypre) (+ residual [M, cout]).
- * cin and pitch_x must be multiples of 4 and the bases 8-byte aligned (XPT_ERR_ARG otherwise: use a GEMM library and
- * xpt_affine_act_fwd). */
+ * Rows are read with the widest loads cin, pitch_x and the bases allow (16 bytes down to 2: 11-channel layers). */
 int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const float* beta, const float* mean,
                       const float* var, float eps, const void* residual, void* ypre, void* y, long long M, int cin,
                       int cout, long long pitch_x, void* stream);

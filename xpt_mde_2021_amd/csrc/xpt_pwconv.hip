@@ -11,8 +11,8 @@
 // no LDS staging and no transposition.  A wave owns a 32x32 output tile; the 4 waves of a workgroup stack along the
 // pixel axis and share the filter rows through the L1.  The k loop issues the loads of up to 8 k steps (16 per lane)
 // before the MFMAs that consume them.  ypre is kept because the fused conv+BN backward (xpt_gemm.hip, BnFuse) needs it
-// for dgamma.  Layouts whose rows are not 8-byte aligned (cin not a multiple of 4) are rejected (the host then uses
-// the GEMM library and the stand-alone epilogue kernel).
+// for dgamma.  Rows that are only 4- or 2-byte aligned (22 / 11 channels: the stem cells) are read with
+// narrower loads (load_frag).
 #include "xpt_common.h"
 
 namespace {
@@ -27,21 +27,33 @@ __device__ inline unsigned short f32_to_bf16_bits(float f) {   // round to neare
   return (unsigned short)(u >> 16);
 }
 
-// 8 consecutive bf16 of one row starting at element k (k < K guaranteed for the first V elements; the rest zero)
+// 8 consecutive bf16 of one row starting at element k (k < K); elements at or past K read as zero.  V = elements per
+// load: rows whose pitch / base only allow 8-, 4- or 2-byte loads (44, 22 or 11 channels) take 2, 4 or 8 loads per fragment.
+template <int V> struct FragVec;
+template <> struct FragVec<4> { typedef uint2 type; };
+template <> struct FragVec<2> { typedef unsigned type; };
+template <> struct FragVec<1> { typedef unsigned short type; };
+
 template <int V>
 __device__ inline uint4 load_frag(const unsigned short* __restrict__ row, int k, int K) {
-  uint4 f;
-  if (V == 8) {
-    f = *(const uint4*)(row + k);
-  } else {   // V == 4: rows are only 8-byte aligned; the second half may lie past the end of the row
-    const uint2 lo = *(const uint2*)(row + k);
-    const int k2 = k + 4 < K ? k + 4 : k;
-    const uint2 hi = *(const uint2*)(row + k2);
-    f.x = lo.x; f.y = lo.y;
-    f.z = k + 4 < K ? hi.x : 0u;
-    f.w = k + 4 < K ? hi.y : 0u;
+  if constexpr (V == 8) {
+    return *(const uint4*)(row + k);
+  } else {
+    typedef typename FragVec<V>::type vec_t;
+    unsigned short e[8];
+#pragma unroll
+    for (int g = 0; g < 8 / V; ++g) {               // unconditional loads from a clamped k, zeroed by select
+      const int kg = k + g * V;
+      const bool ok = kg < K;                        // K % V == 0: a vector is inside or outside as a whole
+      const vec_t raw = *(const vec_t*)(row + (ok ? kg : k));
+#pragma unroll
+      for (int u = 0; u < V; ++u) e[g * V + u] = ok ? ((const unsigned short*)&raw)[u] : (unsigned short)0;
+    }
+    uint4 f;
+    f.x = e[0] | ((unsigned)e[1] << 16); f.y = e[2] | ((unsigned)e[3] << 16);
+    f.z = e[4] | ((unsigned)e[5] << 16); f.w = e[6] | ((unsigned)e[7] << 16);
+    return f;
   }
-  return f;
 }
 
 struct PwBn {
@@ -169,8 +181,8 @@ extern "C" int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* 
   PwMulti m{};
   for (int j = 0; j < n; ++j) {
     if (!x[j] || !w[j] || !gamma[j] || !beta[j] || !mean[j] || !var[j] || !ypre[j] || !y[j]) return XPT_ERR_NULL;
-    while (v >= 4 && (cin % v != 0 || pitch_x % v != 0 || ((uintptr_t)x[j]) % (2 * v) != 0 ||
-                      ((uintptr_t)w[j]) % (2 * v) != 0))
+    while (v > 1 && (cin % v != 0 || pitch_x % v != 0 || ((uintptr_t)x[j]) % (2 * v) != 0 ||
+                     ((uintptr_t)w[j]) % (2 * v) != 0))
       v >>= 1;
     m.x[j] = (const unsigned short*)x[j];
     m.w[j] = (const unsigned short*)w[j];
@@ -179,7 +191,6 @@ extern "C" int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* 
     m.y[j] = (unsigned short*)y[j];
     m.bn[j] = PwBn{gamma[j], beta[j], mean[j], var[j], eps};
   }
-  if (v < 4) return XPT_ERR_ARG;
   const long long mblocks = (M + 127) / 128;
   if (mblocks > 65535) return XPT_ERR_SHAPE;
   const dim3 grid((cout + 31) / 32, (unsigned)mblocks, n);
@@ -187,8 +198,12 @@ extern "C" int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* 
   XPT_BEGIN_LAUNCH();
   if (v == 8)
     hipLaunchKernelGGL(pwconv_bn_multi_fwd_kernel<8>, grid, dim3(256), 0, s, m, M, cin, cout, pitch_x);
-  else
+  else if (v == 4)
     hipLaunchKernelGGL(pwconv_bn_multi_fwd_kernel<4>, grid, dim3(256), 0, s, m, M, cin, cout, pitch_x);
+  else if (v == 2)
+    hipLaunchKernelGGL(pwconv_bn_multi_fwd_kernel<2>, grid, dim3(256), 0, s, m, M, cin, cout, pitch_x);
+  else
+    hipLaunchKernelGGL(pwconv_bn_multi_fwd_kernel<1>, grid, dim3(256), 0, s, m, M, cin, cout, pitch_x);
   return xpt_launch_status();
 }
 
@@ -198,11 +213,10 @@ extern "C" int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamm
   XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(gamma); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(mean);
   XPT_CHECK_PTR(var); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(y);
   if (M <= 0 || cin <= 0 || cout <= 0 || pitch_x < cin) return XPT_ERR_SHAPE;
-  // operand rows must start on an 8-byte boundary (16 for the wide path)
+  // widest operand load (elements) the row pitch, the channel count and the bases allow
   int v = 8;
-  while (v >= 4 && (cin % v != 0 || pitch_x % v != 0 || ((uintptr_t)x) % (2 * v) != 0 || ((uintptr_t)w) % (2 * v) != 0))
+  while (v > 1 && (cin % v != 0 || pitch_x % v != 0 || ((uintptr_t)x) % (2 * v) != 0 || ((uintptr_t)w) % (2 * v) != 0))
     v >>= 1;
-  if (v < 4) return XPT_ERR_ARG;
   const long long mblocks = (M + 127) / 128;
   if (mblocks > 65535) return XPT_ERR_SHAPE;
   const dim3 grid((cout + 31) / 32, (unsigned)mblocks);
@@ -213,8 +227,16 @@ extern "C" int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamm
     hipLaunchKernelGGL(pwconv_bn_fwd_kernel<8>, grid, dim3(256), 0, s, (const unsigned short*)x,
                        (const unsigned short*)w, bn, (const unsigned short*)residual, (unsigned short*)ypre,
                        (unsigned short*)y, M, cin, cout, pitch_x);
-  else
+  else if (v == 4)
     hipLaunchKernelGGL(pwconv_bn_fwd_kernel<4>, grid, dim3(256), 0, s, (const unsigned short*)x,
+                       (const unsigned short*)w, bn, (const unsigned short*)residual, (unsigned short*)ypre,
+                       (unsigned short*)y, M, cin, cout, pitch_x);
+  else if (v == 2)
+    hipLaunchKernelGGL(pwconv_bn_fwd_kernel<2>, grid, dim3(256), 0, s, (const unsigned short*)x,
+                       (const unsigned short*)w, bn, (const unsigned short*)residual, (unsigned short*)ypre,
+                       (unsigned short*)y, M, cin, cout, pitch_x);
+  else
+    hipLaunchKernelGGL(pwconv_bn_fwd_kernel<1>, grid, dim3(256), 0, s, (const unsigned short*)x,
                        (const unsigned short*)w, bn, (const unsigned short*)residual, (unsigned short*)ypre,
                        (unsigned short*)y, M, cin, cout, pitch_x);
   return xpt_launch_status();

@@ -142,8 +142,7 @@ class _Conv1x1BnBf16(torch.autograd.Function):
         # one wave walks the whole reduction: for the deepest ones (cin 1056, on 4x13 maps with too few tiles to fill the
         # chip) the library's split kernels win (tools/bench_pwconv.py); up to 528 channels the fused launch is as fast
         # as GEMM + epilogue launch inside the step and one launch fewer
-        if (not _LIBRARY_PWCONV and cin <= _PWCONV_MAX_CIN and cin % 4 == 0 and pitch_x % 4 == 0
-                and x2.data_ptr() % 8 == 0 and ws.data_ptr() % 8 == 0):
+        if not _LIBRARY_PWCONV and cin <= _PWCONV_MAX_CIN:
             # GEMM + BatchNorm (+ branch add) in one gfx950 launch (csrc/xpt_pwconv.hip)
             ypre = torch.empty((M, cout), dtype=torch.bfloat16, device=x.device)
             _ops._lib.check(lib.xpt_pwconv_bn_fwd(x2.data_ptr(), ws.data_ptr(), g_.data_ptr(), b_.data_ptr(),
@@ -356,14 +355,13 @@ def multi_conv1x1_bn(xs, weights, bns, residuals=None):
     cin = w0.shape[1]
     ok = (_FUSE_CONV_BN and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD and 1 < n <= 6 and x0.is_cuda
           and x0.dtype == torch.bfloat16 and torch.is_autocast_enabled() and torch.is_grad_enabled()
-          and cin <= _PWCONV_MAX_CIN and cin % 4 == 0
+          and cin <= _PWCONV_MAX_CIN
           and all(x.shape == x0.shape and x.dtype == x0.dtype for x in xs)
-          and all(w.shape == w0.shape and hasattr(w, "shadow_bf16") and sink.wants(w) and w.shadow_bf16.data_ptr() % 8 == 0
-                  for w in weights)
+          and all(w.shape == w0.shape and hasattr(w, "shadow_bf16") and sink.wants(w) for w in weights)
           and all(sink.wants(b.weight) and sink.wants(b.bias) for b in bns))
     if ok:
         rows = [_ops.as_rows(x) for x in xs]
-        ok = all(r.stride(0) == rows[0].stride(0) and r.stride(0) % 4 == 0 and r.data_ptr() % 8 == 0 for r in rows)
+        ok = all(r.stride(0) == rows[0].stride(0) for r in rows)
     if not ok:
         return [conv1x1_bn(x, w, b, r) for x, w, b, r in zip(xs, weights, bns, residuals)]
     return list(_MultiConv1x1Bn.apply(n, BN_EPS, *xs, *weights, *[b.weight for b in bns], *[b.bias for b in bns],
