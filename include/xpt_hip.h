@@ -263,6 +263,9 @@ int xpt_conv1x1_bwd_weight(const void* dy, const void* x, float* dw, float* work
  *   x [M, cin] bf16 rows (pitch_x elements apart), w [cout, cin] bf16 ->
  *   ypre [M, cout] bf16 = x w^T (fp32 accumulation on the matrix cores), y [M, cout] bf16 = BN(ypre) (+ residual [M, cout]).
  * Rows are read with the widest loads cin, pitch_x and the bases allow (16 bytes down to 2: 11-channel layers). */
+int xpt_pwconv_tune(int ksplit_min_cin, int ksplit_max_tiles);   /* launch-plan knob: split the k loop over the 4 waves of a
+                                                                   * workgroup from this many input channels on, up to this
+                                                                   * many 32x32 output tiles (0 tiles: never) */
 int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const float* beta, const float* mean,
                       const float* var, float eps, const void* residual, void* ypre, void* y, long long M, int cin,
                       int cout, long long pitch_x, void* stream);

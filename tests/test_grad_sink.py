@@ -123,7 +123,7 @@ def test_deferred_equals_immediate(gpu_device, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("shape", [(2, 44, 88, 5, 7), (1, 264, 44, 16, 52), (3, 22, 11, 9, 13), (2, 176, 176, 4, 13),
-                                   (1, 1056, 176, 4, 13), (2, 36, 33, 3, 5), (2, 11, 11, 7, 9), (1, 22, 22, 16, 13)])
+                                   (1, 1056, 176, 4, 13), (2, 36, 33, 3, 5), (2, 11, 11, 7, 9), (1, 22, 22, 16, 13), (1, 528, 88, 8, 26), (2, 400, 40, 3, 5)])
 @pytest.mark.parametrize("with_residual", [False, True])
 @pytest.mark.parametrize("library_forward", [False, True])
 def test_fused_conv1x1_bn_backward(gpu_device, shape, with_residual, library_forward, monkeypatch):

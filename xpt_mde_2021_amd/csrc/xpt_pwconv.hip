@@ -66,16 +66,19 @@ struct PwBn {
 
 constexpr int PW_G = 8;   // k steps (of 16) whose loads are issued together
 
-template <int V>
+// KW = 1: the 4 waves of a workgroup own 4 tiles stacked along the pixel axis.  KW = 4 (deep reductions on small maps:
+// too few tiles to fill the chip, and one wave walking 66 k steps is 9 dependent batches of loads): the 4 waves share ONE
+// tile and split its k steps into 4 contiguous ranges, summed through LDS in wave order before the epilogue.
+template <int V, int KW = 1>
 __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
                                           const PwBn& bn, const unsigned short* __restrict__ residual,
                                           unsigned short* __restrict__ ypre, unsigned short* __restrict__ y,
                                           long long M, int cin, int cout, long long pitch_x) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const long long m0 = ((long long)blockIdx.y * 4 + wave) * 32;
+  const long long m0 = (KW == 1 ? (long long)blockIdx.y * 4 + wave : (long long)blockIdx.y) * 32;
   const int n0 = blockIdx.x * 32;
-  if (m0 >= M) return;                                   // wave-uniform; no block-level synchronisation below
+  if (m0 >= M) return;                                   // wave-uniform (KW = 4: workgroup-uniform, barriers below)
   const long long am = m0 + r < M ? m0 + r : M - 1;      // rows past the end re-read the last row (never stored)
   const int bn_ = n0 + r;
   const bool col_ok = bn_ < cout;
@@ -99,8 +102,11 @@ __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, 
     res_raw[i] = residual ? residual[mc * cout + bc] : (unsigned short)0;
   }
 
-  const int ksteps = (cin + 15) / 16;
-  for (int s0 = 0; s0 < ksteps; s0 += PW_G) {
+  const int ksteps_all = (cin + 15) / 16;
+  const int per_wave = (ksteps_all + KW - 1) / KW;
+  const int s_begin = KW == 1 ? 0 : wave * per_wave;
+  const int ksteps = KW == 1 ? ksteps_all : (s_begin + per_wave < ksteps_all ? s_begin + per_wave : ksteps_all);
+  for (int s0 = s_begin; s0 < ksteps; s0 += PW_G) {
     uint4 fa[PW_G], fb[PW_G];
 #pragma unroll
     for (int g = 0; g < PW_G; ++g) {                     // unconditional loads from clamped k, zeroed by select
@@ -120,6 +126,19 @@ __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, 
                                                       __builtin_bit_cast(bf16x8, fb[g]), acc, 0, 0, 0);
   }
 
+  if constexpr (KW > 1) {                                // the k ranges of the 4 waves, added in wave order
+    __shared__ float red[KW - 1][16][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int q = 0; q < KW - 1; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] += red[q][i][lane];
+  }
   // accumulator (reg i, lane): output row m0 + (i & 3) + 8 (i >> 2) + 4 h, column n0 + r
   if (!col_ok) return;
   const float sc = e_gamma * rsqrtf(e_var + bn.eps);
@@ -139,14 +158,14 @@ __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, 
   }
 }
 
-template <int V>
+template <int V, int KW = 1>
 __global__ __launch_bounds__(256) void pwconv_bn_fwd_kernel(const unsigned short* __restrict__ x,
                                                              const unsigned short* __restrict__ w, PwBn bn,
                                                              const unsigned short* __restrict__ residual,
                                                              unsigned short* __restrict__ ypre,
                                                              unsigned short* __restrict__ y, long long M, int cin,
                                                              int cout, long long pitch_x) {
-  pwconv_bn_fwd_body<V>(x, w, bn, residual, ypre, y, M, cin, cout, pitch_x);
+  pwconv_bn_fwd_body<V, KW>(x, w, bn, residual, ypre, y, M, cin, cout, pitch_x);
 }
 
 // up to 6 independent layers of one shape (the branch convolutions of a cell stage): job = blockIdx.z
@@ -167,7 +186,16 @@ __global__ __launch_bounds__(256) void pwconv_bn_multi_fwd_kernel(PwMulti m, lon
   pwconv_bn_fwd_body<V>(m.x[j], m.w[j], m.bn[j], m.residual[j], m.ypre[j], m.y[j], M, cin, cout, pitch_x);
 }
 
+int g_pw_ksplit_min_cin = 256, g_pw_ksplit_max_tiles = 512;   // in-step sweep: (384,0) 6.66 ms, (384,512) 6.63, (256,512) 6.61-6.62, (256,2048) 6.62
+
 }  // namespace
+
+extern "C" int xpt_pwconv_tune(int ksplit_min_cin, int ksplit_max_tiles) {
+  if (ksplit_min_cin < 16 || ksplit_max_tiles < 0) return XPT_ERR_ARG;
+  g_pw_ksplit_min_cin = ksplit_min_cin;
+  g_pw_ksplit_max_tiles = ksplit_max_tiles;
+  return XPT_OK;
+}
 
 extern "C" int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* const* w, const float* const* gamma,
                                        const float* const* beta, const float* const* mean, const float* const* var,
@@ -217,11 +245,21 @@ extern "C" int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamm
   int v = 8;
   while (v > 1 && (cin % v != 0 || pitch_x % v != 0 || ((uintptr_t)x) % (2 * v) != 0 || ((uintptr_t)w) % (2 * v) != 0))
     v >>= 1;
+  const PwBn bn{gamma, beta, mean, var, eps};
+  hipStream_t s = (hipStream_t)stream;
+  // deep reduction, few tiles: the 4 waves of a workgroup split the k steps of one tile (pwconv_bn_fwd_body, KW = 4)
+  const long long tiles = ((M + 31) / 32) * ((cout + 31) / 32);
+  if (v == 8 && cin >= g_pw_ksplit_min_cin && tiles <= g_pw_ksplit_max_tiles && (M + 31) / 32 <= 65535) {
+    const dim3 gridk((cout + 31) / 32, (unsigned)((M + 31) / 32));
+    XPT_BEGIN_LAUNCH();
+    hipLaunchKernelGGL((pwconv_bn_fwd_kernel<8, 4>), gridk, dim3(256), 0, s, (const unsigned short*)x,
+                       (const unsigned short*)w, bn, (const unsigned short*)residual, (unsigned short*)ypre,
+                       (unsigned short*)y, M, cin, cout, pitch_x);
+    return xpt_launch_status();
+  }
   const long long mblocks = (M + 127) / 128;
   if (mblocks > 65535) return XPT_ERR_SHAPE;
   const dim3 grid((cout + 31) / 32, (unsigned)mblocks);
-  const PwBn bn{gamma, beta, mean, var, eps};
-  hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
   if (v == 8)
     hipLaunchKernelGGL(pwconv_bn_fwd_kernel<8>, grid, dim3(256), 0, s, (const unsigned short*)x,

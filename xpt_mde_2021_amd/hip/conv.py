@@ -133,6 +133,9 @@ def _apply_env_tuning():
     if plan:
         for code in plan.split(","):
             _lib.load().xpt_conv2d_tune(int(code))
+    spec = os.environ.get("XPT_PWCONV_TUNE")               # fused pointwise forward: k split from this cin on, up to this many tiles
+    if spec:
+        _lib.load().xpt_pwconv_tune(*[int(v) for v in spec.split(",")])
     spec = os.environ.get("XPT_HEAD_TUNE")                 # depth-head convolution backward: pixel passes per workgroup, most workgroups
     if spec:
         _lib.load().xpt_headconv_tune(*[int(v) for v in spec.split(",")])

@@ -93,6 +93,7 @@ SIGNATURES = {
     "xpt_corr_cost_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "xpt_corr_cost_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "xpt_headconv_tune": (_i, [_i, _i]),
+    "xpt_pwconv_tune": (_i, [_i, _i]),
     "xpt_depth_head_fwd": (_i, [_p, _p, _p, ctypes.c_longlong, _p]),
     "xpt_depth_head_bwd": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p]),
     "xpt_global_avgpool_fwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),

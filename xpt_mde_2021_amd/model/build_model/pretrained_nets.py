@@ -139,9 +139,9 @@ class _Conv1x1BnBf16(torch.autograd.Function):
         if residual is not None:
             residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         g_, b_ = gamma.detach(), beta.detach()
-        # one wave walks the whole reduction: for the deepest ones (cin 1056, on 4x13 maps with too few tiles to fill the
-        # chip) the library's split kernels win (tools/bench_pwconv.py); up to 528 channels the fused launch is as fast
-        # as GEMM + epilogue launch inside the step and one launch fewer
+        # deep reductions on small maps (cin >= 256, few tiles) split the k loop over the 4 waves of a workgroup inside
+        # the kernel (xpt_pwconv.hip, KW = 4): with that the fused launch beats GEMM + epilogue launch up to the widest
+        # layer (1056 channels) too
         if not _LIBRARY_PWCONV and cin <= _PWCONV_MAX_CIN:
             # GEMM + BatchNorm (+ branch add) in one gfx950 launch (csrc/xpt_pwconv.hip)
             ypre = torch.empty((M, cout), dtype=torch.bfloat16, device=x.device)
@@ -383,7 +383,7 @@ def _rectified_concat(spec, inputs):
     head = outs[0]
     head._xpt_relu_aliases = outs[1:]        # (not the head itself: a tensor -> list -> tensor cycle would outlive the step)
     return head
-_PWCONV_MAX_CIN = int(__import__("os").environ.get("XPT_PWCONV_MAX_CIN", "528"))     # deeper reductions: library GEMM + epilogue launch
+_PWCONV_MAX_CIN = int(__import__("os").environ.get("XPT_PWCONV_MAX_CIN", "1056"))    # deeper reductions: library GEMM + epilogue launch
 _LIBRARY_PWCONV = __import__("os").environ.get("XPT_DEBUG_LIBRARY_PWCONV", "0") == "1"    # A/B: rocBLAS GEMM + epilogue launch
 
 
