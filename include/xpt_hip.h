@@ -150,6 +150,27 @@ int xpt_photo_fused_ms_bwd(int nscales, const float* const* src, const float* co
                            float* const* ddepth, float* dT, float* workspace, size_t workspace_floats, int B, int N,
                            const int* h, const int* w, const float* scale, void* stream);
 
+/* Second generation of the multi-scale march launches (csrc/xpt_march.hip): same arguments, same results to fp32
+ * rounding (losses 1e-6 relative, gradients 1e-5 of their scale), same workspace size as xpt_photo_fused_ms_*; the row
+ * body is re-written for the instruction classes gfx950 issues at full rate and the workgroups are numbered XCD by XCD.
+ * Replaces the same reference callables (synthesize_base.py:13-20, 88-178; bilinear_interp.py:7-147;
+ * loss_util.py:6-25, 52-96; losses.py:179-195).  xpt_photo_march_tune: launch-plan knobs as xpt_photo_fused_tune. */
+int xpt_photo_march_tune(int fwd_min_waves, int bwd_min_waves, int min_rows);
+int xpt_photo_march_ms_fwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
+                           const float* const* target, float* losses, float* workspace, size_t workspace_floats,
+                           int B, int N, const int* h, const int* w, const float* scale, void* stream);
+/* backward AND forward values of a training step in one pass: losses [2 nscales][B] as xpt_photo_fused_ms_fwd writes them
+ * (NULL: gradients only); the upstream gradients g_l1 / g_ssim must be known when it is launched (they are loss weights
+ * over the batch size: TotalLoss.__call__, losses.py:44-55). */
+int xpt_photo_march_ms_fwdbwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
+                              const float* const* target, const float* const* g_l1, const float* const* g_ssim,
+                              float* losses, float* const* ddepth, float* dT, float* workspace, size_t workspace_floats,
+                              int B, int N, const int* h, const int* w, const float* scale, void* stream);
+int xpt_photo_march_ms_bwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
+                           const float* const* target, const float* const* g_l1, const float* const* g_ssim,
+                           float* const* ddepth, float* dT, float* workspace, size_t workspace_floats, int B, int N,
+                           const int* h, const int* w, const float* scale, void* stream);
+
 /* ------------------------------------------------------------------ K6 (+a4): edge-aware smoothness
  * replaces SmoothenessLossMultiScale.smootheness_loss (losses.py:409-440) for one scale
  * (the caller divides by the scale, losses.py:401-402).
