@@ -263,12 +263,35 @@ def photo_fused(src, depth, T, K, target, scale):
     return _PhotoFused.apply(src, depth, T, K, target, scale)
 
 
+_MARCH_V1 = __import__("os").environ.get("XPT_DEBUG_MARCH_V1", "0") == "1"      # A/B: the first-generation march kernels (xpt_fused.hip)
+_ONE_PASS = __import__("os").environ.get("XPT_DEBUG_TWO_PASS_LOSS", "0") != "1"   # A/B: forward and backward march as two launches
+_grad_constants = {}
+
+
+def _constant_rows(values, batch, device):
+    """[len(values), batch] float32 rows, row i filled with values[i]: the upstream gradients a loss module announces
+    for its fused terms.  Built once per configuration (outside graph capture when the trainer warms up eagerly)."""
+    key = (tuple(values), int(batch), str(device))
+    t = _grad_constants.get(key)
+    if t is None:
+        t = torch.tensor(values, dtype=torch.float32).reshape(-1, 1).repeat(1, batch).to(device)
+        _grad_constants[key] = t
+    return t
+
+
 class _PhotoFusedMS(torch.autograd.Function):
     """photo_fused for every scale of the pyramid in ONE march launch (+ one finishing launch) forward and backward;
-    the pose gradient comes back already summed over the scales.  args = (T, K, scales, src_0.., depth_0.., target_0..)."""
+    the pose gradient comes back already summed over the scales.
+    args = (T, K, scales, grad_hint, src_0.., depth_0.., target_0..).
+
+    grad_hint (2 n floats or None): the gradients the caller's loss will send back for (l1 of every scale, ssim of every
+    scale) -- they are loss weights over the batch size (TotalLoss.__call__, losses.py:44-55), known before the forward
+    runs.  With a hint the forward IS the backward: xpt_photo_march_ms_fwdbwd leaves losses, d_depth and dT in one pass
+    (csrc/xpt_march.hip) and backward() hands the stored gradients out after checking the hint against what actually
+    arrived (outside graph capture; a mismatch recomputes with the real gradients)."""
 
     @staticmethod
-    def forward(ctx, T, K, scales, *tensors):
+    def forward(ctx, T, K, scales, grad_hint, *tensors):
         import ctypes
         lib = _lib.load()
         n = len(scales)
@@ -290,10 +313,25 @@ class _PhotoFusedMS(torch.autograd.Function):
         ws = torch.empty(nws, dtype=torch.float32, device=T.device)
         P = ctypes.c_void_p * n
         ptrs = lambda ts: P(*[t.data_ptr() for t in ts])       # noqa: E731
-        _lib.check(lib.xpt_photo_fused_ms_fwd(n, ptrs(srcs), ptrs(depths), _ptr(T), _ptr(K), ptrs(targets), _ptr(losses),
-                                              _ptr(ws), nws, B, N, (ctypes.c_int * n)(*hs), (ctypes.c_int * n)(*ws_),
-                                              (ctypes.c_float * n)(*[float(s) for s in scales]), _stream()),
-                   "xpt_photo_fused_ms_fwd")
+        ci, cf = (ctypes.c_int * n)(*hs), (ctypes.c_float * n)(*[float(s) for s in scales])
+        cw = (ctypes.c_int * n)(*ws_)
+        needs_grad = any(ctx.needs_input_grad[i] for i in (0,) + tuple(range(4 + n, 4 + 2 * n)))
+        one_pass = (grad_hint is not None and needs_grad and _ONE_PASS and not _MARCH_V1 and len(grad_hint) == 2 * n)
+        ctx.stash = None
+        if one_pass:
+            hint = _constant_rows(grad_hint, B, T.device)
+            ddepths = [torch.empty_like(d) for d in depths]
+            dT = torch.empty_like(T)
+            _lib.check(lib.xpt_photo_march_ms_fwdbwd(n, ptrs(srcs), ptrs(depths), _ptr(T), _ptr(K), ptrs(targets),
+                                                     ptrs([hint[i] for i in range(n)]),
+                                                     ptrs([hint[n + i] for i in range(n)]), _ptr(losses), ptrs(ddepths),
+                                                     _ptr(dT), _ptr(ws), nws, B, N, ci, cw, cf, _stream()),
+                       "xpt_photo_march_ms_fwdbwd")
+            ctx.stash = (hint, ddepths, dT)
+        else:
+            fwd = lib.xpt_photo_fused_ms_fwd if _MARCH_V1 else lib.xpt_photo_march_ms_fwd
+            _lib.check(fwd(n, ptrs(srcs), ptrs(depths), _ptr(T), _ptr(K), ptrs(targets), _ptr(losses), _ptr(ws), nws, B, N,
+                           ci, cw, cf, _stream()), "xpt_photo_march_ms_fwd")
         ctx.save_for_backward(T, K, *srcs, *depths, *targets)
         ctx.cfg = (n, tuple(float(s) for s in scales), hs, ws_, nws)
         ctx.set_materialize_grads(False)
@@ -308,6 +346,16 @@ class _PhotoFusedMS(torch.autograd.Function):
         T, K = saved[0], saved[1]
         srcs, depths, targets = saved[2:2 + n], saved[2 + n:2 + 2 * n], saved[2 + 2 * n:2 + 3 * n]
         B, N = srcs[0].shape[:2]
+        if ctx.stash is not None:
+            hint, ddepths, dT = ctx.stash
+            ctx.stash = None
+            # the announced gradients against the ones that arrived (a device comparison + one fetch: only outside graph
+            # capture; the trainers' eager warm-up steps run it before every capture)
+            if torch.cuda.is_current_stream_capturing() or PHOTO_HINT_CHECK is False or all(
+                    (g is None and not bool(hint[i].any())) or (g is not None and torch.equal(g.reshape(-1), hint[i]))
+                    for i, g in enumerate(grads)):
+                return (dT, None, None, None, *([None] * n), *ddepths, *([None] * n))
+            PHOTO_HINT_MISSES.append(tuple(None if g is None else float(g.reshape(-1)[0]) for g in grads))
         zero = None
         gs = []
         for g in grads:
@@ -321,17 +369,26 @@ class _PhotoFusedMS(torch.autograd.Function):
         ws = torch.empty(nws, dtype=torch.float32, device=T.device)
         P = ctypes.c_void_p * n
         ptrs = lambda ts: P(*[t.data_ptr() for t in ts])       # noqa: E731
-        _lib.check(lib.xpt_photo_fused_ms_bwd(n, ptrs(srcs), ptrs(depths), _ptr(T), _ptr(K), ptrs(targets), ptrs(gs[:n]),
-                                              ptrs(gs[n:]), ptrs(ddepths), _ptr(dT), _ptr(ws), nws, B, N,
-                                              (ctypes.c_int * n)(*hs), (ctypes.c_int * n)(*ws_),
-                                              (ctypes.c_float * n)(*scales), _stream()), "xpt_photo_fused_ms_bwd")
-        return (dT, None, None, *([None] * n), *ddepths, *([None] * n))
+        bwd = lib.xpt_photo_fused_ms_bwd if _MARCH_V1 else lib.xpt_photo_march_ms_bwd
+        _lib.check(bwd(n, ptrs(srcs), ptrs(depths), _ptr(T), _ptr(K), ptrs(targets), ptrs(gs[:n]), ptrs(gs[n:]),
+                       ptrs(ddepths), _ptr(dT), _ptr(ws), nws, B, N, (ctypes.c_int * n)(*hs), (ctypes.c_int * n)(*ws_),
+                       (ctypes.c_float * n)(*scales), _stream()), "xpt_photo_march_ms_bwd")
+        return (dT, None, None, None, *([None] * n), *ddepths, *([None] * n))
 
 
-def photo_fused_multi_scale(srcs, depths, T, K, targets, scales):
-    """[(l1 [B], ssim [B]) per scale] of photo_fused, all scales in one launch (N must be 4 or 1, at most 4 scales)."""
+PHOTO_HINT_CHECK = True       # False: trust the announced gradients (no device fetch in eager steps)
+PHOTO_HINT_MISSES = []        # announced-vs-actual mismatches seen by backward() (each one fell back to the two-pass path)
+
+
+def photo_fused_multi_scale(srcs, depths, T, K, targets, scales, grad_hint=None):
+    """[(l1 [B], ssim [B]) per scale] of photo_fused, all scales in one launch (N must be 4 or 1, at most 4 scales).
+    grad_hint: ([d total / d l1_s] per scale, [d total / d ssim_s] per scale) as floats when the caller knows them (loss
+    weights over the batch size): forward and backward then run as ONE pass (see _PhotoFusedMS)."""
     n = len(scales)
-    out = _PhotoFusedMS.apply(T, K, tuple(scales), *srcs, *depths, *targets)
+    hint = None
+    if grad_hint is not None:
+        hint = tuple(float(v) for v in grad_hint[0]) + tuple(float(v) for v in grad_hint[1])
+    out = _PhotoFusedMS.apply(T, K, tuple(scales), hint, *srcs, *depths, *targets)
     return [(out[i], out[n + i]) for i in range(n)]
 
 

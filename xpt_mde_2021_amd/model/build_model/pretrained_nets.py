@@ -5,10 +5,13 @@ third-party dependency that is NOT part of the reference checkout) and taps the 
 scaled_layers.json ("NASNetMobile": activation_7 / _18 / _77 / _136 / _187 at 1/2 ... 1/32).  This file
 restates the published NASNet-A (4 @ 1056) architecture of that Keras application as torch modules.
 
-PARITY UNPINNED: no golden activations, tap channel counts or ImageNet weights exist offline.  Structural pins
-that tests/test_nets.py checks: (i) creation-order index of the unnamed Activation layers reproduces exactly the
-five tap names above with the spatial sizes scaled_layers.json records; (ii) the parameter count equals Keras'
-published 4,269,716 (include_top=False).
+PARITY UNPINNED against TensorFlow itself: no golden activations or ImageNet weights exist offline.  What is pinned:
+(i) creation-order index of the unnamed Activation layers reproduces exactly the five tap names above with the spatial
+sizes scaled_layers.json records; (ii) the parameter count equals Keras' published 4,269,716 (include_top=False)
+(tests/test_nasnet_pins.py); (iii) an independent second restatement in the framework's own conventions
+(oracle/ref_nasnet.py: NHWC, HWIO, Keras variable names) yields the same five taps on the same weights, on the CPU and
+through the gfx950 kernels (tests/test_ref_nasnet.py); (iv) every Keras variable of the no-top model lands on exactly one
+parameter / buffer of this module (load_keras_weights below, tests/golden/nasnet_mobile_manifest.json).
 
 Bug-compatible details kept (SURVEY 7 "Hard parts" h, i):
   * `preprocess_input` (x/127.5 - 1) is applied to images that are ALREADY in [-1, 1] (pretrained_nets.py:40),
@@ -786,6 +789,133 @@ class NASNetMobileEncoder(nn.Module):
         return [taps.found[k] for k in self.TAP_ACTIVATIONS]
 
 
+# ------------------------------------------------------------------------------------------ Keras weights
+# tf.keras.applications.NASNetMobile addresses its variables by LAYER NAME / VARIABLE NAME (stem_conv1/kernel,
+# separable_conv_1_normal_left1_0/depthwise_kernel, separable_conv_1_bn_normal_left1_0/moving_mean, ...).  The map below
+# gives every parameter / buffer of NASNetMobileEncoder its Keras name and layout; tests/golden/nasnet_mobile_manifest.json
+# (names + shapes of the published architecture, written by tools/make_nasnet_manifest.py from the independent
+# restatement oracle/ref_nasnet.py) must be covered exactly: every variable lands on one tensor, every tensor is filled.
+CELL_BLOCK_IDS = ("stem_1", "stem_2", "0", "1", "2", "3", "reduce_4", "5", "6", "7", "8", "reduce_8", "9", "10", "11", "12")
+
+
+def _to_keras(kind, t):
+    """torch layout -> keras layout: conv OIHW -> HWIO, depthwise [C,1,k,k] -> [k,k,C,1]."""
+    if kind == "conv":
+        return t.permute(2, 3, 1, 0)
+    if kind == "depthwise":
+        return t.permute(2, 3, 0, 1)
+    return t
+
+
+def _from_keras(kind, a):
+    if kind == "conv":
+        return a.permute(3, 2, 0, 1)
+    if kind == "depthwise":
+        return a.permute(2, 3, 0, 1)
+    return a
+
+
+def keras_variable_map(encoder):
+    """{keras variable name: (tensor of the encoder, kind)} with kind in {"conv", "depthwise", "vector"}."""
+    out = {}
+
+    def conv(name, module):
+        out[f"{name}/kernel"] = (module.weight, "conv")
+
+    def bn(name, module):
+        out[f"{name}/gamma"] = (module.weight, "vector")
+        out[f"{name}/beta"] = (module.bias, "vector")
+        out[f"{name}/moving_mean"] = (module.running_mean, "vector")
+        out[f"{name}/moving_variance"] = (module.running_var, "vector")
+
+    def sep_block(block_id, block):
+        for k, (sep, norm) in enumerate(((block.conv1, block.bn1), (block.conv2, block.bn2)), start=1):
+            out[f"separable_conv_{k}_{block_id}/depthwise_kernel"] = (sep.depthwise.weight, "depthwise")
+            out[f"separable_conv_{k}_{block_id}/pointwise_kernel"] = (sep.pointwise.weight, "conv")
+            bn(f"separable_conv_{k}_bn_{block_id}", norm)
+
+    conv("stem_conv1", encoder.stem_conv)
+    bn("stem_bn1", encoder.stem_bn)
+    if len(encoder.cells) != len(CELL_BLOCK_IDS):
+        raise WrongInputException("keras_variable_map: not the NASNet-Mobile cell sequence")
+    for bid, cell in zip(CELL_BLOCK_IDS, encoder.cells):
+        adj = cell.adjust
+        if adj.mode == "spatial":
+            conv(f"adjust_conv_1_{bid}", adj.conv1)
+            conv(f"adjust_conv_2_{bid}", adj.conv2)
+            bn(f"adjust_bn_{bid}", adj.bn)
+        elif adj.mode == "project":
+            conv(f"adjust_conv_projection_{bid}", adj.conv)
+            bn(f"adjust_bn_{bid}", adj.bn)
+        if isinstance(cell, NormalCell):
+            conv(f"normal_conv_1_{bid}", cell.conv)
+            bn(f"normal_bn_1_{bid}", cell.bn)
+            for side in ("left1", "right1", "left2", "right2", "left5"):
+                sep_block(f"normal_{side}_{bid}", getattr(cell, side))
+        else:
+            conv(f"reduction_conv_1_{bid}", cell.conv)
+            bn(f"reduction_bn_1_{bid}", cell.bn)
+            for side in ("left1", "right1", "right2", "right3", "left4"):
+                sep_block(f"reduction_{side}_{bid}", getattr(cell, side))
+    return out
+
+
+def export_keras_weights(encoder):
+    """{keras variable name: float32 array in the keras layout} of the encoder's current weights."""
+    return {name: _to_keras(kind, t.detach()).contiguous().float().cpu() for name, (t, kind) in keras_variable_map(encoder).items()}
+
+
+def read_keras_weight_file(path):
+    """{variable name: numpy array} from an .npz keyed by keras variable names (INTEGRATION.md has the one-line export to
+    run where Keras is installed) or from Keras' own NASNet-mobile-no-top.h5 when h5py is importable."""
+    import numpy as np
+    if str(path).endswith(".npz"):
+        with np.load(path) as z:
+            return {k[:-2] if k.endswith(":0") else k: z[k] for k in z.files}
+    if str(path).endswith((".h5", ".hdf5")):
+        try:
+            import h5py
+        except ImportError as e:
+            raise WrongInputException("reading a Keras .h5 file needs h5py (not installed): convert it to .npz, "
+                                      "INTEGRATION.md") from e
+        out = {}
+        with h5py.File(path, "r") as f:
+            root = f["model_weights"] if "model_weights" in f else f
+
+            def visit(name, obj):
+                if isinstance(obj, h5py.Dataset):
+                    parts = name.split("/")
+                    var = parts[-1][:-2] if parts[-1].endswith(":0") else parts[-1]
+                    out[f"{parts[-2]}/{var}"] = obj[()]
+            root.visititems(visit)
+        return out
+    raise WrongInputException(f"unknown weight file type: {path}")
+
+
+def load_keras_weights(encoder, weights):
+    """Fills the encoder from Keras NASNetMobile(include_top=False) variables (a path or a {name: array} dict).  Strict: a
+    missing, unknown or mis-shaped variable raises; nothing is loaded partially."""
+    if not isinstance(weights, dict):
+        weights = read_keras_weight_file(weights)
+    table = keras_variable_map(encoder)
+    missing = sorted(set(table) - set(weights))
+    unknown = sorted(set(weights) - set(table))
+    if missing or unknown:
+        raise WrongInputException(f"NASNet-Mobile weights: {len(missing)} variables missing (e.g. {missing[:3]}), "
+                                  f"{len(unknown)} not part of the no-top model (e.g. {unknown[:3]})")
+    staged = {}
+    for name, (t, kind) in table.items():
+        a = torch.as_tensor(weights[name])
+        if tuple(a.shape) != tuple(_to_keras(kind, t).shape):
+            raise WrongInputException(f"{name}: file has shape {tuple(a.shape)}, the model expects "
+                                      f"{tuple(_to_keras(kind, t).shape)}")
+        staged[name] = _from_keras(kind, a)
+    with torch.no_grad():
+        for name, (t, kind) in table.items():
+            t.copy_(staged[name].to(device=t.device, dtype=t.dtype))
+    return len(staged)
+
+
 class PretrainedModel:
     """pretrained_nets.py:11-117 interface: PretrainedModel(net_name, use_pt_weight).encoder() builds the module
     whose forward is the reference's `.encode(input_image)`."""
@@ -795,10 +925,19 @@ class PretrainedModel:
         if net_name not in self.SUPPORTED:
             raise WrongInputException(f"Pretrained backbone '{net_name}' is outside this build's hot path "
                                       f"(available: {self.SUPPORTED})")
+        self.weight_file = None
         if use_pt_weight:
-            raise WrongInputException("ImageNet weights (Keras storage bucket download, pretrained_nets.py:23) are not "
-                                      "obtainable offline; set opts.PRETRAINED_WEIGHT = False")
+            # weights="imagenet" (pretrained_nets.py:23) downloads from the Keras storage bucket; offline the user
+            # supplies the same variables as a file (one-line export where Keras is installed)
+            self.weight_file = __import__("os").environ.get("XPT_NASNET_WEIGHTS", "")
+            if not self.weight_file:
+                raise WrongInputException("ImageNet weights (Keras storage bucket download, pretrained_nets.py:23) are not "
+                                          "obtainable offline: point XPT_NASNET_WEIGHTS at an .npz / .h5 of the Keras "
+                                          "NASNetMobile(include_top=False) variables, or set opts.PRETRAINED_WEIGHT = False")
         self.net_name = net_name
 
     def encoder(self):
-        return NASNetMobileEncoder()
+        net = NASNetMobileEncoder()
+        if self.weight_file:
+            load_keras_weights(net, self.weight_file)
+        return net

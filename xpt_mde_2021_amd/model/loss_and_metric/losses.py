@@ -41,6 +41,24 @@ class TotalLoss:
                     for o in (self.loss_objects or {}).values() if isinstance(o, PhotometricLoss))
         return want and plain and tensor.is_cuda
 
+    def _photo_grad_hint(self, cls, suffix, nscales):
+        """(d total / d L1_s, d total / d SSIM_s) per scale for the fused photometric terms a loss object of class `cls`
+        with this key suffix reads: weight of the loss type x scale weight / global batch (the coefficients __call__
+        applies below), or None when they cannot be told in advance."""
+        out = {"L1": [0.0] * nscales, "SSIM": [0.0] * nscales}
+        try:
+            for name, obj in (self.loss_objects or {}).items():
+                if type(obj) is not cls or getattr(obj, "key_suffix", "") != suffix or obj.method not in out:
+                    continue
+                weights = [float(w) for w in np.asarray(obj.scale_weights, dtype=np.float64).reshape(-1)]
+                if len(weights) < nscales:
+                    return None
+                for i in range(nscales):
+                    out[obj.method][i] += float(self.loss_weights[name]) * weights[i] / self.batch_size
+        except (KeyError, TypeError, ValueError):
+            return None
+        return out["L1"], out["SSIM"]
+
     def __call__(self, predictions, features):
         """
         :param predictions: {"depth_ms": .., "disp_ms": .., "pose": ..}
@@ -121,7 +139,8 @@ class TotalLoss:
             augm_data["target_ms" + suffix] = target_ms
             if self.use_fused(image5d):
                 augm_data["fused_photo_ms" + suffix] = SynthesizeMultiScale().photometric_losses(
-                    source_image, intrinsic, pred_depth_ms, pred_pose, target_ms, sources_ms)
+                    source_image, intrinsic, pred_depth_ms, pred_pose, target_ms, sources_ms,
+                    grad_hint=self._photo_grad_hint(PhotometricLossMultiScale, suffix, len(pred_depth_ms)))
             else:
                 augm_data["synth_target_ms" + suffix] = SynthesizeMultiScale()(source_image, intrinsic,
                                                                                 pred_depth_ms, pred_pose)
@@ -158,10 +177,12 @@ class TotalLoss:
         pose_T_LR = cp.pose_matr2rvec_batch(features["stereo_T_LR"].unsqueeze(1))
         left_src, right_src = augm_data["target_R"].unsqueeze(1), augm_data["target"].unsqueeze(1)
         if self.use_fused(left_src):
+            hint = self._photo_grad_hint(StereoDepthLoss, "", len(predictions["depth_ms"]))   # left and right: same weights
             synth_stereo["fused_stereo_ms"] = SynthesizeMultiScale().photometric_losses(
-                left_src, features["intrinsic"], predictions["depth_ms"], pose_T_RL, augm_data["target_ms"])
+                left_src, features["intrinsic"], predictions["depth_ms"], pose_T_RL, augm_data["target_ms"], grad_hint=hint)
             synth_stereo["fused_stereo_ms_R"] = SynthesizeMultiScale().photometric_losses(
-                right_src, features["intrinsic"], predictions["depth_ms_R"], pose_T_LR, augm_data["target_ms_R"])
+                right_src, features["intrinsic"], predictions["depth_ms_R"], pose_T_LR, augm_data["target_ms_R"],
+                grad_hint=hint)
             return synth_stereo
         synth_stereo["stereo_synth_ms"] = SynthesizeMultiScale()(left_src, features["intrinsic"],
                                                                  predictions["depth_ms"], pose_T_RL)

@@ -20,20 +20,23 @@ class SynthesizeMultiScale:
         poses_matr = pose_rvec2matr_batch_tf(pred_pose)
         return [SynthesizeSingleScale()(source_image, intrinsic, depth_sc, poses_matr) for depth_sc in pred_depth_ms]
 
-    def photometric_losses(self, source_image, intrinsic, pred_depth_ms, pred_pose, target_ms, sources_ms=None):
+    def photometric_losses(self, source_image, intrinsic, pred_depth_ms, pred_pose, target_ms, sources_ms=None,
+                           grad_hint=None):
         """Fused fast path: per scale (photometric L1 [batch], photometric SSIM [batch]) of the synthesized views
         against target_ms, computed by the warp+L1+SSIM march kernel without materialising the views.
-        sources_ms: the sources already resized to every scale (hip/ops.py image_pyramids), else resized here."""
+        sources_ms: the sources already resized to every scale (hip/ops.py image_pyramids), else resized here.
+        grad_hint: (d total / d L1 per scale, d total / d SSIM per scale) when the caller knows its loss weights: the
+        march then leaves the gradients in the same pass as the loss values (hip/ops.py _PhotoFusedMS)."""
         poses_matr = pose_rvec2matr_batch_tf(pred_pose)
         if source_image.shape[1] in (1, 4) and len(pred_depth_ms) <= 4 and _FUSED_MULTI_SCALE:
-            # every scale in one march launch (csrc/xpt_fused.hip: fused_fwd_ms_kernel / fused_bwd_ms_kernel)
+            # every scale in one march launch (csrc/xpt_march.hip)
             singles = [SynthesizeSingleScale() for _ in pred_depth_ms]
             sources = []
             for i, (single, depth_sc) in enumerate(zip(singles, pred_depth_ms)):
                 single.read_shape(source_image, depth_sc)
                 sources.append(sources_ms[i] if sources_ms is not None else single.resize_source_images(source_image))
             return _ops.photo_fused_multi_scale(sources, list(pred_depth_ms), poses_matr, intrinsic, list(target_ms),
-                                                [s.scale for s in singles])
+                                                [s.scale for s in singles], grad_hint=grad_hint)
         return [SynthesizeSingleScale().photometric_losses(source_image, intrinsic, depth_sc, poses_matr, target_sc)
                 for depth_sc, target_sc in zip(pred_depth_ms, target_ms)]
 
