@@ -60,27 +60,37 @@ def test_hip_kernels_reproduce_golden(gpu_device, path):
     p = z["pose"].clone().requires_grad_(True)
     T = ops.pose_rvec2matr(p)
     synth = ops.warp(z["src"], d, T, z["intrinsic"], 1)
-    bad = ((synth - z["synth"]).abs() > 1e-4).float().mean().item()
-    assert bad < 1e-3, bad                       # strict validity test: a rounding-level coordinate may flip single pixels
+    # (flip-aware fixtures: tools/make_golden.py moves the depth of the pixels whose projection fp32 rounding could carry across
+    # an integer coordinate or the validity border, so every bar below holds with ZERO outliers)
+    assert float((synth - z["synth"]).abs().max()) <= 1e-4
     l1 = ops.photometric("L1", synth, z["target"])
     ss = ops.photometric("SSIM", synth, z["target"])
     assert torch.allclose(l1, z["l1"], atol=1e-4) and torch.allclose(ss, z["ssim"], atol=1e-4)
     if "l1_map" in z:
         m1 = ops.photometric("L1", synth, z["target"], reduce=False)
         m2 = ops.photometric("SSIM", synth, z["target"], reduce=False)
-        assert ((m1 - z["l1_map"]).abs() > 1e-4).float().mean().item() < 2e-3
-        assert ((m2 - z["ssim_map"]).abs() > 1e-4).float().mean().item() < 5e-3
+        assert float((m1 - z["l1_map"]).abs().max()) <= 1e-4
+        assert float((m2 - z["ssim_map"]).abs().max()) <= 2e-4
     (l1.sum() + ss.sum()).backward()
     scale_d, scale_p = z["d_depth"].abs().max().item(), z["d_pose"].abs().max().item()
-    assert ((d.grad - z["d_depth"]).abs() > 1e-3 * scale_d).float().mean().item() < 5e-3
-    assert (p.grad - z["d_pose"]).abs().max().item() < 2e-2 * scale_p
+    assert float((d.grad - z["d_depth"]).abs().max()) <= 1e-3 * scale_d
+    assert float((p.grad - z["d_pose"]).abs().max()) <= 1e-3 * scale_p
     # the fused march kernels (the training path): same numbers without materialising the views
     d2 = z["depth"].clone().requires_grad_(True)
     p2 = z["pose"].clone().requires_grad_(True)
     f1, f2 = ops.photo_fused(z["src"], d2, ops.pose_rvec2matr(p2), z["intrinsic"], z["target"], 1)
     assert torch.allclose(f1, z["l1"], atol=1e-4) and torch.allclose(f2, z["ssim"], atol=1e-4)
     (f1.sum() + f2.sum()).backward()
-    assert (p2.grad - z["d_pose"]).abs().max().item() < 2e-2 * scale_p
+    assert float((d2.grad - z["d_depth"]).abs().max()) <= 1e-3 * scale_d
+    assert float((p2.grad - z["d_pose"]).abs().max()) <= 1e-3 * scale_p
+    # ... and the second-generation march (all scales in one launch; here one scale)
+    d3 = z["depth"].clone().requires_grad_(True)
+    p3 = z["pose"].clone().requires_grad_(True)
+    (m1_, m2_), = ops.photo_fused_multi_scale([z["src"]], [d3], ops.pose_rvec2matr(p3), z["intrinsic"], [z["target"]], [1])
+    assert torch.allclose(m1_, z["l1"], atol=1e-4) and torch.allclose(m2_, z["ssim"], atol=1e-4)
+    (m1_.sum() + m2_.sum()).backward()
+    assert float((d3.grad - z["d_depth"]).abs().max()) <= 1e-3 * scale_d
+    assert float((p3.grad - z["d_pose"]).abs().max()) <= 1e-3 * scale_p
     smooth = ops.smoothness(z["depth"], z["target"], 4.0, input_is_depth=True)
     assert torch.allclose(smooth, z["smooth"], atol=1e-5)
 
