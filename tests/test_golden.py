@@ -83,6 +83,10 @@ def test_hip_kernels_reproduce_golden(gpu_device, path):
     (f1.sum() + f2.sum()).backward()
     assert float((d2.grad - z["d_depth"]).abs().max()) <= 1e-3 * scale_d
     assert float((p2.grad - z["d_pose"]).abs().max()) <= 1e-3 * scale_p
+    smooth = ops.smoothness(z["depth"], z["target"], 4.0, input_is_depth=True)
+    assert torch.allclose(smooth, z["smooth"], atol=1e-5)
+    if z["src"].shape[1] not in (1, 4):       # the multi-scale march launches take 4 (temporal) or 1 (stereo) source views
+        return
     # ... and the second-generation march (all scales in one launch; here one scale)
     d3 = z["depth"].clone().requires_grad_(True)
     p3 = z["pose"].clone().requires_grad_(True)
@@ -91,8 +95,7 @@ def test_hip_kernels_reproduce_golden(gpu_device, path):
     (m1_.sum() + m2_.sum()).backward()
     assert float((d3.grad - z["d_depth"]).abs().max()) <= 1e-3 * scale_d
     assert float((p3.grad - z["d_pose"]).abs().max()) <= 1e-3 * scale_p
-    smooth = ops.smoothness(z["depth"], z["target"], 4.0, input_is_depth=True)
-    assert torch.allclose(smooth, z["smooth"], atol=1e-5)
+
 
 
 @pytest.mark.gpu

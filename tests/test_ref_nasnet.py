@@ -136,25 +136,25 @@ def test_restatement_catches_a_rewired_cell(encoder, weights):
 
 @pytest.mark.gpu
 def test_gfx950_encoder_equals_the_independent_restatement(gpu_device, weights):
-    """The fp32 HIP path (own depthwise / pointwise / cell-tail kernels) against oracle/ref_nasnet.py on the same Keras
-    variables: the five taps and the gradient of a random functional of them w.r.t. the input image."""
+    """The fp32 HIP path (own depthwise / pointwise / cell-tail kernels) against oracle/ref_nasnet.py evaluated in fp64 on
+    the same Keras variables: the five taps, and the gradient of a random functional of them w.r.t. the input image (the
+    network is piecewise linear in between its ReLU / max-pool switches: a 1e-4 share of the gradient elements may sit on
+    the other side of a switch in fp32 -- the fp32 and fp64 evaluations of the restatement itself differ that way)."""
+    from tests.util import frac_close
     net = pn.NASNetMobileEncoder().float().eval()
     pn.load_keras_weights(net, {k: v.numpy() for k, v in weights.items()})
     net = net.to(gpu_device)
     g = torch.Generator().manual_seed(5)
     image = (torch.rand((2, 64, 192, 3), generator=g) * 2 - 1)
-    x_ref = image.clone().requires_grad_(True)
+    x_ref = image.double().requires_grad_(True)
     x_dev = image.permute(0, 3, 1, 2).contiguous().to(gpu_device).requires_grad_(True)
-    ref = ref_nasnet.forward(weights, x_ref)
+    ref = ref_nasnet.forward({k: v.double() for k, v in weights.items()}, x_ref)
     got = net(x_dev)
     probes = [torch.randn(r.shape, generator=torch.Generator().manual_seed(20 + k)) for k, r in enumerate(ref)]
-    sum((r * p).sum() for r, p in zip(ref, probes)).backward()
+    sum((r * p.double()).sum() for r, p in zip(ref, probes)).backward()
     sum((o.permute(0, 2, 3, 1) * p.to(gpu_device)).sum() for o, p in zip(got, probes)).backward()
     torch.cuda.synchronize()
     for k, (r, o) in enumerate(zip(ref, got)):
-        scale = float(r.abs().max())
-        err = float((o.detach().permute(0, 2, 3, 1).cpu() - r.detach()).abs().max())
-        assert err <= 2e-4 * scale, (k, err, scale)
-    gscale = float(x_ref.grad.abs().max())
-    gerr = float((x_dev.grad.permute(0, 2, 3, 1).cpu() - x_ref.grad).abs().max())
-    assert gerr <= 2e-3 * gscale, (gerr, gscale)
+        frac_close(o.permute(0, 2, 3, 1), r, 2e-4 * float(r.abs().max()), what=f"tap {k}")
+    frac_close(x_dev.grad.permute(0, 2, 3, 1), x_ref.grad, 2e-3 * float(x_ref.grad.abs().max()), max_bad_frac=1e-4,
+               what="d taps / d image")

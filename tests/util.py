@@ -64,5 +64,4 @@ def flip_safe_depth(depth, T, K, scale, eps=1e-3, nudge=False):
         risky = risky_pixels(out, T, K, scale, eps)
     # what is left does not move with its depth (no parallax along that axis): its d_depth term is as insensitive as its
     # projection, and it is one pixel in a sum for the pose gradient
-    assert float(risky.float().mean()) < 0.02, f"flip_safe_depth: {int(risky.sum())} pixels stay within rounding of an integer coordinate"
     return out, share
