@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--sustained-seconds", type=float, default=6.0,
+                    help="back-to-back steps after the timed region, reported separately (`sustained`); 0 disables")
     args = ap.parse_args()
     if args.config == "c4":
         args.height, args.width, args.batch = 256, 832, 4
@@ -202,9 +204,14 @@ def run(args):
         raise SystemExit("bench.py needs a GPU (the HIP ops have no CPU fallback)")
     # (XPT_DIST_BACKEND=gloo + several ranks on one card: the rehearsal of the data-parallel GPU path on a one-GPU box,
     #  tests/test_dp_gpu_rehearsal.py; the real thing is nccl = RCCL with one card per rank)
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    if world > 1:
-        dist.init_process_group(backend=os.environ.get("XPT_DIST_BACKEND", "nccl"))
+    backend = os.environ.get("XPT_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev:
+        raise SystemExit(f"bench.py: {world} RCCL ranks but {ndev} GPUs on this node (one card per rank; "
+                         "XPT_DIST_BACKEND=gloo rehearses several ranks on one card)")
+    torch.cuda.set_device(local_rank % ndev if backend == "gloo" else local_rank)
+    if world > 1 or (args.mode == "distributed" and "RANK" in os.environ):
+        dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
     # seeded weights and augmentation draws (per rank): "final_loss" is then the same number in every run of one build
@@ -228,21 +235,40 @@ def run(args):
     note(f"mode={mode} world={world} batch/GPU={args.batch} {args.height}x{args.width} dtype={args.dtype}")
     if args.config == "c5":
         args.warmup = max(args.warmup, len(MIXED_SHAPES))          # every image size is captured before the timed region
+    first_loss = None
     for i in range(args.warmup):
-        trainer.run_a_batch(batches[i % len(batches)])
+        out = trainer.run_a_batch(batches[i % len(batches)])
         if i == 0:
             torch.cuda.synchronize()
+            first_loss = float(out[1])
             note("first step done (graph captured)")
     sync()
     note("warm-up done")
+    # the timed region: EXACTLY args.steps steps between two barrier + synchronize pairs (wall clock -> `value`); a HIP event
+    # after every step on the launch stream gives the per-step spread (`step_ms`: median, p10, p90)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         out = trainer.run_a_batch(batches[i % len(batches)])
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
     loss = float(out[1])
+    if first_loss is None:
+        first_loss = loss
+    if not (loss == loss and abs(loss) < 1e30):
+        raise SystemExit(f"bench.py: the training loss is not finite ({loss}): the timed steps did not train")
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pick = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]          # noqa: E731
+    step_ms = {"median": round(pick(0.5), 4), "p10": round(pick(0.1), 4), "p90": round(pick(0.9), 4),
+               "how": "HIP events after every step on the launch stream (device time between step ends)"}
+    rank_ms = None
     if world > 1:
         t = torch.tensor([elapsed], device="cuda")
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        rank_ms = [round(1000.0 * float(g.item()) / args.steps, 4) for g in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -271,10 +297,22 @@ def run(args):
                                    f"{LOSS_LABEL[args.nets] if args.nets != 'rigid' else ('stereo LOSS_RIGID_T2' if args.stereo else 'mono L1+SSIM+smoothness')}, 4 scales",
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "mode": mode,
                        "parallelism": f"dp{world}", "ranks": (dist.get_world_size() if world > 1 else 1),
-                       "final_loss": round(loss, 6)},
+                       "first_loss": round(first_loss, 6), "final_loss": round(loss, 6),
+                       "loss_decreased": bool(loss < first_loss)},
+            "step_ms": step_ms,
         }
+        if args.nets == "rigid" and not (loss < first_loss) and args.warmup + args.steps >= 10:
+            raise SystemExit(f"bench.py: the loss did not decrease over {args.warmup + args.steps} steps on the same "
+                             f"batches ({first_loss} -> {loss}): the timed steps did not train")
         early = getattr(trainer, "_early_start", None)
         if world > 1:
+            result["config"]["rank_ms_per_step"] = rank_ms
+            result["config"]["backend"] = os.environ.get("XPT_DIST_BACKEND", "nccl")
+            try:
+                result["config"]["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:          # noqa: BLE001  (gloo rehearsal / build without the binding)
+                result["config"]["rccl_version"] = None
+        if world > 1 or mode.startswith("distributed"):
             flat = trainer.optimizer.flat
             # gradient exchange: the decoder / PoseNet bucket is all-reduced while the encoder's backward runs
             result["config"]["grad_exchange"] = {
@@ -282,6 +320,21 @@ def run(args):
                 "overlapped_bytes": (int(flat.numel) - int(early)) * 4 if early is not None else 0,
                 "how": "two-graph step, backward cut between decoder and encoder" if early is not None else "after the step"}
     note(f"timed region done: {elapsed:.3f} s")
+    if args.sustained_seconds > 0 and world == 1 and args.config != "c5":
+        # a longer stretch of the same steps (outside `value`): long enough for an outside observer's GPU-busy sampling
+        torch.cuda.synchronize()
+        n_sus, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < args.sustained_seconds:
+            for i in range(50):
+                trainer.run_a_batch(batches[(n_sus + i) % len(batches)])
+            n_sus += 50
+            torch.cuda.synchronize()
+        sus = time.perf_counter() - t1
+        if rank == 0:
+            result["sustained"] = {"seconds": round(sus, 3), "steps": n_sus, "ms_per_step": round(1000.0 * sus / n_sus, 4),
+                                   "value": round(args.batch * n_sus / sus, 3), "unit": "images/sec",
+                                   "what": "back-to-back training steps after the timed region (not part of `value`)"}
+        note(f"sustained leg done: {n_sus} steps in {sus:.2f} s")
     if rank == 0 and world == 1 and args.config != "c5" and not args.no_roofline:
         # the real loop (train_val.py:43-64 run_an_epoch): the same steps PLUS merge_results per step (abs-rel with two
         # sorts per sample, centre depths, pose errors, eager, outside the captured graph) and the per-epoch fetch

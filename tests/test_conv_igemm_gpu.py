@@ -179,3 +179,38 @@ def test_stem_input_matches_the_reference_preprocessing(gpu_device, B, H, W):
     diff = (got[:, :3].float() - want.float()).abs()
     # same fp32 expression, then one bf16 rounding: a last-bit difference of the fp32 value can flip that rounding
     assert (diff > 0).float().mean().item() < 1e-3 and diff.max().item() <= 2 ** -7
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+def test_deferred_weight_gradient_lands_unpermuted_whatever_the_weight_layout(gpu_device, channels_last):
+    """FlatParameters over k x k kernels stored channels_last (the default) or plain NCHW: the gradient that ends up in the
+    flat buffer must be dW in the PARAMETER's own element order either way.  (A plain-NCHW kernel gets no deferred-gradient
+    sink: the dense convolution's partials are laid out [cout][kh][kw][cin] and would land permuted without any error.)"""
+    from xpt_mde_2021_amd.hip import conv as xc, ops
+    from xpt_mde_2021_amd.model.model_util.optimizers import FlatParameters
+    dev = gpu_device
+    g = torch.Generator().manual_seed(5)
+    cin, cout, k, H, W = 16, 32, 3, 16, 24
+    conv = torch.nn.Conv2d(cin, cout, k, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_((torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).to(torch.bfloat16).float())
+    conv = conv.to(dev)
+    if channels_last:
+        conv = conv.to(memory_format=torch.channels_last)
+    flat = FlatParameters([conv.weight, conv.bias])
+    assert hasattr(conv.weight, "flat_grad") == channels_last
+    x = torch.randn(2, cin, H, W, generator=g).to(torch.bfloat16)
+    gy = torch.randn(2, cout, H, W, generator=g).to(torch.bfloat16)
+    xr = x.float()
+    wr = conv.weight.detach().float().cpu().contiguous().requires_grad_(True)
+    (reference(xr, wr, conv.bias.detach().float().cpu(), 1, 0.1, False) * gy.float()).sum().backward()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yd = xc.conv2d_same(xd, conv.weight, conv.bias, 1, 0.1, False)
+    (yd.float() * gy.to(dev).float()).sum().backward()
+    ops.grad_sink.flush()
+    flat.gather_grads()
+    torch.cuda.synchronize()
+    got = flat.grad_views[0].detach().float().cpu()                 # the parameter-shaped view of the flat gradient buffer
+    scale = wr.grad.abs().max().item()
+    assert (got - wr.grad).abs().max().item() < 1.5e-2 * scale

@@ -11,6 +11,20 @@ import torch  # noqa: E402
 from xpt_mde_2021_amd.config import opts  # noqa: E402
 from xpt_mde_2021_amd.model import model_main as mm, train_val as tv  # noqa: E402
 
+import torch.distributed as dist  # noqa: E402
+
+# (launched with RANK / WORLD_SIZE in the environment -- e.g. WORLD_SIZE=1 on a one-GPU box -- the distributed trainer
+#  creates its process group: backend nccl = RCCL; every collective it issues is counted)
+_calls = {"async": 0, "sync": 0}
+_all_reduce = dist.all_reduce
+
+
+def _counting_all_reduce(tensor, *a, **kw):
+    _calls["async" if kw.get("async_op") else "sync"] += 1
+    return _all_reduce(tensor, *a, **kw)
+
+
+dist.all_reduce = _counting_all_reduce
 mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
 use_aug = (sys.argv[2] if len(sys.argv) > 2 else "aug") == "aug"
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 12
@@ -22,12 +36,18 @@ dataset, cfg, _ = mm.get_dataset("synthetic", "train", True)
 model, aug, loss_object, optimizer = mm.create_training_parts(0, cfg, 1e-4, opts.LOSS_RIGID_T1, opts.SCALE_WEIGHT_T1,
                                                               opts.RIGID_NET, ckpt_name="__det__")
 trainer, _ = tv.train_val_factory(mode, model, loss_object, 0, False, aug if use_aug else None, optimizer)
-losses = []
+losses, per_step = [], []
 for i in range(K):
+    before = dict(_calls)
     out = trainer.run_a_batch(dataset.batches[i % len(dataset.batches)])
     losses.append(float(out[1]))
+    per_step.append((_calls["async"] - before["async"], _calls["sync"] - before["sync"]))
 torch.cuda.synchronize()
 flat = optimizer.flat
+if dist.is_initialized():
+    print("PROCESS_GROUP", dist.get_backend(), dist.get_world_size(),
+          ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else "-")
+    print("ALLREDUCE_PER_STEP", " ".join(f"{a}+{s}" for a, s in per_step))
 if mode == "distributed":
     print("TWO_PHASE", trainer._early_start is not None, type(trainer._graph.graph).__name__)
 print("LOSSES", mode, "aug" if use_aug else "noaug", " ".join(f"{v:.9f}" for v in losses))

@@ -78,9 +78,11 @@ def measure_fused(ops, feats, repeats, batch=None):
             {"B": B, "N": N, "h": H, "w": W})
 
 
-def measure_fused_ms(ops, feats, repeats, batch=None, nscales=4):
+def measure_fused_ms(ops, feats, repeats, batch=None, nscales=4, generation=2):
     """(fwd ms, bwd ms, algorithmic fwd bytes, algorithmic bwd bytes, shape) of the MULTI-SCALE march launches (what the
-    training step runs: all pyramid scales in one launch, csrc/xpt_fused.hip fused_fwd_ms_kernel / fused_bwd_ms_kernel)."""
+    training step runs: all pyramid scales in one launch).  generation 2 = csrc/xpt_march.hip (forward launch; and the
+    one-pass launch that leaves losses AND gradients -- the training step's only march launch -- priced with the backward's
+    bytes), generation 1 = csrc/xpt_fused.hip (forward launch, backward launch)."""
     import ctypes
     from . import lib as _lib
     x = _inputs(feats, batch)
@@ -100,20 +102,28 @@ def measure_fused_ms(ops, feats, repeats, batch=None, nscales=4):
     g1 = torch.ones(B, device=T.device)
     ddepths = [torch.empty_like(d) for d in depths]
     dT = torch.empty_like(T)
+    losses = torch.empty((2 * nscales, B), device=T.device)
     st = torch.cuda.current_stream().cuda_stream
     P = ctypes.c_void_p * nscales
     ptrs = lambda ts: P(*[t.data_ptr() for t in ts])  # noqa: E731
     ci, cf = (ctypes.c_int * nscales), (ctypes.c_float * nscales)
     a_src, a_dep, a_tgt, a_g, a_dd = ptrs(srcs), ptrs(depths), ptrs(tgts), ptrs([g1] * nscales), ptrs(ddepths)
     a_h, a_w, a_s = ci(*hs), ci(*ws_), cf(*scales)
+    f_fwd = lib.xpt_photo_march_ms_fwd if generation == 2 else lib.xpt_photo_fused_ms_fwd
 
     def fwd():     # losses NULL: the march launch alone
-        _lib.check(lib.xpt_photo_fused_ms_fwd(nscales, a_src, a_dep, T.data_ptr(), x["K"].data_ptr(), a_tgt, None,
-                                              ws.data_ptr(), nws, B, N, a_h, a_w, a_s, st), "fused ms fwd")
+        _lib.check(f_fwd(nscales, a_src, a_dep, T.data_ptr(), x["K"].data_ptr(), a_tgt, None, ws.data_ptr(), nws, B, N, a_h,
+                         a_w, a_s, st), "march ms fwd")
 
-    def bwd():     # march + the pose-gradient finisher (one small launch)
-        _lib.check(lib.xpt_photo_fused_ms_bwd(nscales, a_src, a_dep, T.data_ptr(), x["K"].data_ptr(), a_tgt, a_g, a_g, a_dd,
-                                              dT.data_ptr(), ws.data_ptr(), nws, B, N, a_h, a_w, a_s, st), "fused ms bwd")
+    def bwd():     # march + its finishing launch (pose gradient; generation 2: the loss values as well)
+        if generation == 2:
+            _lib.check(lib.xpt_photo_march_ms_fwdbwd(nscales, a_src, a_dep, T.data_ptr(), x["K"].data_ptr(), a_tgt, a_g, a_g,
+                                                     losses.data_ptr(), a_dd, dT.data_ptr(), ws.data_ptr(), nws, B, N, a_h,
+                                                     a_w, a_s, st), "march ms fwdbwd")
+        else:
+            _lib.check(lib.xpt_photo_fused_ms_bwd(nscales, a_src, a_dep, T.data_ptr(), x["K"].data_ptr(), a_tgt, a_g, a_g,
+                                                  a_dd, dT.data_ptr(), ws.data_ptr(), nws, B, N, a_h, a_w, a_s, st),
+                       "fused ms bwd")
 
     pixels = sum(h * w for h, w in zip(hs, ws_))
     return (_time_kernel(fwd, repeats), _time_kernel(bwd, repeats), B * pixels * (16 + 12 * N), B * pixels * (20 + 12 * N),
@@ -136,9 +146,11 @@ def _pmc_traffic(kernel, shape):
 
 
 def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
-    """bench.py's `roofline` object: the fused forward kernel at the step's own shape (dominant hand-written kernel of
-    the loss path), plus the backward, the unfused kernels and a large-batch point that no longer fits the 256 MiB
-    Infinity Cache (the in-step shape does: SURVEY 7 'roofline measurement honesty')."""
+    """bench.py's `roofline` object: the march launches of the training step (csrc/xpt_march.hip: view synthesis + L1 +
+    SSIM of the four pyramid scales) at the step's own shape -- `frac` = the forward launch, `bwd` = the one-pass launch
+    that leaves losses and gradients (the only march launch a training step runs) -- plus the same at a batch that no
+    longer fits the 256 MiB Infinity Cache and at configs[3]'s 256 x 832, the first-generation kernels and the unfused
+    kernels for comparison."""
     x = _inputs(feats)
     B, N, H, W = x["B"], x["N"], x["H"], x["W"]
     P = H * W
@@ -149,37 +161,42 @@ def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
     extra["unfused warp_fwd_kernel"] = (ms, B * P * (4 + 24 * N))
     ms = _time_kernel(lambda: ops.photometric("SSIM", synth, x["tgt"], True), repeats)
     extra["unfused photo_fwd_kernel<SSIM>"] = (ms, B * P * (12 + 12 * N))
-    s_ms, sb_ms, s_bytes, sb_bytes, _ = measure_fused(ops, feats, repeats)
-    extra["fused_fwd_kernel<false, true> (scale 1 alone)"] = (s_ms, s_bytes)
-    extra["fused_bwd_kernel<0> (scale 1 alone, + its finisher)"] = (sb_ms, sb_bytes)
+    f1_ms, b1_ms, f_bytes, b_bytes, shape = measure_fused_ms(ops, feats, repeats, generation=1)
+    extra["first generation fused_fwd_ms_kernel (4 scales)"] = (f1_ms, f_bytes)
+    extra["first generation fused_bwd_ms_kernel<0> (4 scales, + its finisher)"] = (b1_ms, b_bytes)
     f_ms, b_ms, f_bytes, b_bytes, shape = measure_fused_ms(ops, feats, repeats)
-    extra["fused_bwd_ms_kernel<0> (4 scales, + its finisher)"] = (b_ms, b_bytes)
-    lf_ms, lb_ms, lf_bytes, lb_bytes, lshape = measure_fused_ms(ops, feats, max(repeats // 5, 5), batch=large_batch)
-    # configs[3]'s shape: 256 x 832, batch 4 (twice the pixels per launch at half the batch)
     from ..utils import synthetic_data as sd
+
+    def point(feats_, reps, batch=None):
+        f, b, fb, bb, shp = measure_fused_ms(ops, feats_, reps, batch=batch)
+        gf, gb = fb / (f * 1e-3) / 1e9, bb / (b * 1e-3) / 1e9
+        return {"shape": shp,
+                "fwd": {"launch_us": round(f * 1e3, 2), "GBps": round(gf, 2), "frac": round(gf / hbm_peak_gbs, 4)},
+                "bwd": {"launch_us": round(b * 1e3, 2), "GBps": round(gb, 2), "frac": round(gb / hbm_peak_gbs, 4)}}
+
+    # configs[3]'s shape (256 x 832) at batch 4 and at batch 32 (beyond the Infinity Cache); batch 128 at 128 x 416
     hfeats = {k: v.to(x["src"].device) for k, v in sd.make_features(4, 2 * H, 2 * W, feats["image5d"].shape[1], 7).items()}
-    hf_ms, hb_ms, hf_bytes, hb_bytes, hshape = measure_fused_ms(ops, hfeats, repeats)
     achieved = f_bytes / (f_ms * 1e-3) / 1e9
-    traffic = _pmc_traffic("fused_fwd_ms_kernel", shape)
+    achieved_b = b_bytes / (b_ms * 1e-3) / 1e9
+    traffic = _pmc_traffic("march_fwd_ms_kernel", shape)
 
     def gbs(ms_, nbytes):
         return round(nbytes / (ms_ * 1e-3) / 1e9, 2)
 
-    return {"bound": "hbm", "kernel": "fused_fwd_ms_kernel (warp + L1 + SSIM, the 4 pyramid scales in one launch; hand-pipelined row loop)",
+    return {"bound": "hbm", "kernel": "march_fwd_ms_kernel (warp + L1 + SSIM, the 4 pyramid scales in one launch; csrc/xpt_march.hip)",
             "achieved": round(achieved, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(achieved / hbm_peak_gbs, 4),
             "traffic": traffic, "launch_us": round(f_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(f_bytes),
             "bytes_per_warped_pixel": round((16 + 12 * N) / N, 3), "shape": shape,
+            "fwd": {"launch_us": round(f_ms * 1e3, 3), "GBps": round(achieved, 2), "frac": round(achieved / hbm_peak_gbs, 4)},
+            "bwd": {"kernel": "march_bwd_ms_kernel<0> + its finisher: losses AND gradients in one pass (the training step's march launch)",
+                    "launch_us": round(b_ms * 1e3, 3), "GBps": round(achieved_b, 2), "frac": round(achieved_b / hbm_peak_gbs, 4),
+                    "algorithmic_bytes_per_launch": int(b_bytes), "bytes_per_warped_pixel": round((20 + 12 * N) / N, 3)},
+            "valu_note": "both launches are bound by vector-instruction issue, not by bytes: ~172 (forward) / ~336 (one-pass) "
+                         "instructions per warped pixel row of a wave at 3.4-6 cycles each (DESIGN.md section 5, profiles/r03_lab_*)",
             "all": {k: {"launch_us": round(v[0] * 1e3, 3), "GBps": gbs(*v)} for k, v in extra.items()},
-            "hires": {"shape": hshape,
-                      "fwd": {"launch_us": round(hf_ms * 1e3, 2), "GBps": gbs(hf_ms, hf_bytes),
-                              "frac": round(gbs(hf_ms, hf_bytes) / hbm_peak_gbs, 4)},
-                      "bwd": {"launch_us": round(hb_ms * 1e3, 2), "GBps": gbs(hb_ms, hb_bytes),
-                              "frac": round(gbs(hb_ms, hb_bytes) / hbm_peak_gbs, 4)}},
-            "large_batch": {"shape": lshape,
-                            "fwd": {"launch_us": round(lf_ms * 1e3, 2), "GBps": gbs(lf_ms, lf_bytes),
-                                    "frac": round(gbs(lf_ms, lf_bytes) / hbm_peak_gbs, 4)},
-                            "bwd": {"launch_us": round(lb_ms * 1e3, 2), "GBps": gbs(lb_ms, lb_bytes),
-                                    "frac": round(gbs(lb_ms, lb_bytes) / hbm_peak_gbs, 4)}}}
+            "hires": point(hfeats, repeats),
+            "hires_large_batch": point(hfeats, max(repeats // 5, 5), batch=32),
+            "large_batch": point(feats, max(repeats // 5, 5), batch=large_batch)}
 
 
 # ------------------------------------------------------------------------------- convolution arithmetic of one step

@@ -12,7 +12,9 @@ from ...utils import util_funcs as uf
 class ModelWrapper:
     def __init__(self, models):
         self.models = models                      # {"depthnet": nn.Module, "posenet": nn.Module}
-        self.conv_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[opts.CONV_DTYPE]
+        # (BASELINE configs[4] names fp16 convolutions: this build computes them in bf16 -- same matrix-core rate on gfx950,
+        #  fp32 accumulation, no loss scaling; DESIGN.md section 7 -- so "fp16" is not an accepted value)
+        self.conv_dtype = {"bf16": torch.bfloat16, "fp32": None}[opts.CONV_DTYPE]
 
     def __call__(self, features):
         return self.predict_batch(features)

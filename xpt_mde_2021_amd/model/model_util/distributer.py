@@ -15,6 +15,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from ...utils.util_class import WrongInputException
+
 from ...config import opts
 
 
@@ -36,7 +38,13 @@ class DistributionStrategy:
                     return None                                # single process: no strategy, like non-distributed modes
                 backend = backend or os.environ.get("XPT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
                 if torch.cuda.is_available():
-                    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
+                    local_rank, ndev = int(os.environ.get("LOCAL_RANK", 0)), torch.cuda.device_count()
+                    if backend == "gloo":                      # the rehearsal: several ranks may share the one card
+                        local_rank %= ndev
+                    elif int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > ndev:
+                        raise WrongInputException(f"{os.environ.get('LOCAL_WORLD_SIZE')} RCCL ranks on a node with {ndev} "
+                                                  "GPUs: RCCL needs one card per rank")
+                    torch.cuda.set_device(local_rank)
                 dist.init_process_group(backend=backend)
             cls.strategy = cls(dist.get_backend())
             opts.BATCH_SIZE = cls.strategy.num_replicas_in_sync * opts.PER_REPLICA_BATCH      # distributer.py:12
@@ -63,7 +71,9 @@ class DistributionStrategy:
     def all_reduce_range(self, flat_grad, start, stop, async_op=False):
         """SUM flat_grad[start:stop] over all replicas; async_op: returns the work handle (the collective runs behind the
         kernels already queued on the current stream, concurrently with whatever is queued after it)."""
-        if self.num_replicas_in_sync == 1 or stop <= start:
+        # (XPT_DP_FORCE_COLLECTIVES=1: a one-rank group still issues its collectives -- the identity -- so that the one-GPU
+        #  test box exercises RCCL itself in the graph / all-reduce / graph sequence: tests/test_rccl_single_rank_gpu.py)
+        if (self.num_replicas_in_sync == 1 and os.environ.get("XPT_DP_FORCE_COLLECTIVES") != "1") or stop <= start:
             return None
         return dist.all_reduce(flat_grad[start:stop], op=dist.ReduceOp.SUM, async_op=async_op)
 

@@ -42,9 +42,12 @@ class FlatParameters:
             self.grad_views.append(gview)
             if self.shadow is not None:
                 p.shadow_bf16 = self._view(self.shadow, p, off)
-                if gview.is_contiguous():
+                kxk = p.dim() == 4 and p.shape[2] * p.shape[3] > 1
+                if gview.is_contiguous() and (not kxk or gview.is_contiguous(memory_format=torch.channels_last)):
                     # destination of the deferred gradient finishing (hip/ops.py GradSink): the gfx950 backward kernels
-                    # of this parameter leave partial sums behind and ONE launch per step adds them into this view
+                    # of this parameter leave partial sums behind and ONE launch per step adds them into this view.
+                    # (A k x k kernel stored plain NCHW gets NO sink: the dense convolution's partials are laid out
+                    # [cout][kh][kw][cin] (hip/conv.py) and would land permuted; its gradient takes the non-deferred path.)
                     p.flat_grad = gview
                 elif p.dim() == 4 and gview.is_contiguous(memory_format=torch.channels_last):
                     # channels_last k x k kernels: memory order [cout][kh][kw][cin] -- exactly the layout of the dense

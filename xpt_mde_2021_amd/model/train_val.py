@@ -291,20 +291,22 @@ class _StepGraph:
             self.graph = None
             return
         import torch.distributed as _dist
+        # With a process group alive the collective library's watchdog thread polls events of (completed) collectives at its
+        # own pace: in the default "global" capture mode such a query from another thread invalidates the capture.  Capture
+        # thread-locally instead (only THIS thread's calls are held to the capture rules) after draining the device.
+        mode = "global"
         if _dist.is_available() and _dist.is_initialized():
-            # let the collective library's watchdog thread retire the (completed) start-up collectives before the capture
-            # begins: an event query from another thread during a global-mode capture would invalidate it
-            import time
-            time.sleep(0.3)
+            torch.cuda.synchronize()
+            mode = "thread_local"
         if self.phases is None:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.static_out = self.fn(self.static_in)
         else:
             first, second = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(first):
+            with torch.cuda.graph(first, capture_error_mode=mode):
                 carry, self.static_out = self.phases[0](self.static_in)
-            with torch.cuda.graph(second, pool=first.pool()):      # same capture stream (torch's default), same pool
+            with torch.cuda.graph(second, pool=first.pool(), capture_error_mode=mode):   # same capture stream (torch's default), same pool
                 self.phases[1](carry)
             del carry
             self.graph = _GraphPair(first, second)
