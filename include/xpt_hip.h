@@ -578,6 +578,13 @@ int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, float* partia
  * (tf.data.TFRecordDataset); masked value = ((crc >> 15) | (crc << 17)) + 0xa282ead8. */
 uint32_t xpt_crc32c(const void* data, size_t nbytes);
 
+/* ------------------------------------------------------------------ captured-step audit (no reference counterpart)
+ * Node census of a captured hipGraph (hipGraph_t as torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph() hands it out),
+ * child graphs included: counts[6] = kernel, memcpy, memset, host, other nodes, total.  The trainers that replace the
+ * reference's @tf.function step (model/train_val.py:95-102) refuse a captured step with a memset node: such nodes replay
+ * wrongly on this runtime. */
+int xpt_graph_node_census(void* hip_graph, int* counts);
+
 #ifdef __cplusplus
 }
 #endif

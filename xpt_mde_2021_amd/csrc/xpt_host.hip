@@ -55,3 +55,44 @@ extern "C" uint32_t xpt_crc32c(const void* data, size_t nbytes) {
 #endif
   return crc_sw(crc, p, nbytes) ^ 0xFFFFFFFFu;
 }
+
+// ---------------------------------------------------------------------------------------------- hipGraph node census
+// A captured training step must not contain memset nodes: on this runtime a hipMemsetAsync captured into a hipGraph
+// writes garbage from the second replay on (tools/replay_probe_memset.py).  The trainers walk every
+// captured graph with this helper (train_val._StepGraph) and refuse one that has such a node, instead of relying on the
+// convention "no memset inside the step".  counts[6] = kernel, memcpy, memset, host, other (empty / event / ...) nodes and
+// the total, child graphs included.
+#include <hip/hip_runtime.h>
+#include <vector>
+
+namespace {
+int census_walk(hipGraph_t graph, int* counts, int depth) {
+  size_t n = 0;
+  if (hipGraphGetNodes(graph, nullptr, &n) != hipSuccess) return XPT_ERR_LAUNCH;
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n && hipGraphGetNodes(graph, nodes.data(), &n) != hipSuccess) return XPT_ERR_LAUNCH;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) return XPT_ERR_LAUNCH;
+    if (t == hipGraphNodeTypeGraph && depth < 8) {
+      hipGraph_t child;
+      if (hipGraphChildGraphNodeGetGraph(nodes[i], &child) != hipSuccess) return XPT_ERR_LAUNCH;
+      const int rc = census_walk(child, counts, depth + 1);
+      if (rc != XPT_OK) return rc;
+      continue;
+    }
+    const int slot = t == hipGraphNodeTypeKernel ? 0 : t == hipGraphNodeTypeMemcpy ? 1 : t == hipGraphNodeTypeMemset ? 2
+                     : t == hipGraphNodeTypeHost ? 3 : 4;
+    counts[slot] += 1;
+    counts[5] += 1;
+  }
+  return XPT_OK;
+}
+}  // namespace
+
+extern "C" int xpt_graph_node_census(void* hip_graph, int* counts) {
+  if (hip_graph == nullptr || counts == nullptr) return XPT_ERR_NULL;
+  for (int i = 0; i < 6; ++i) counts[i] = 0;
+  (void)hipGetLastError();
+  return census_walk((hipGraph_t)hip_graph, counts, 0);
+}

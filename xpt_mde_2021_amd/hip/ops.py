@@ -480,6 +480,15 @@ class _MergeTotal(torch.autograd.Function):
         return (None, None, *grads.unbind(0))
 
 
+def graph_census(graph):
+    """{"kernel", "memcpy", "memset", "host", "other", "total"} node counts of a captured torch.cuda.CUDAGraph that was
+    created with keep_graph=True (xpt_graph_node_census walks the hipGraph_t, child graphs included)."""
+    import ctypes
+    counts = (ctypes.c_int * 6)()
+    _lib.check(_lib.load().xpt_graph_node_census(ctypes.c_void_p(graph.raw_cuda_graph()), counts), "xpt_graph_node_census")
+    return dict(zip(("kernel", "memcpy", "memset", "host", "other", "total"), [int(c) for c in counts]))
+
+
 def merge_total(c_vec, a_mat, terms):
     """total = c . rowsum(terms), by_type = A rowsum(terms) (at most 64 float32 terms [batch] and 64 types)."""
     return _MergeTotal.apply(c_vec, a_mat, *terms)

@@ -254,8 +254,14 @@ class _StepGraph:
         else:
             self.graph, self.static_in, self.static_out = entry
             self.signature = sig
-            for k, v in self.static_in.items():
-                v.copy_(features[k], non_blocking=True)
+            # the new batch into the graph's static inputs: ONE multi-tensor copy launch instead of one copy per feature
+            dst = [v for k, v in self.static_in.items() if features[k].is_cuda and features[k].dtype == v.dtype]
+            src = [features[k] for k, v in self.static_in.items() if features[k].is_cuda and features[k].dtype == v.dtype]
+            if len(dst) > 1:
+                torch._foreach_copy_(dst, src)
+            rest = [k for k, v in self.static_in.items() if not (features[k].is_cuda and features[k].dtype == v.dtype)]
+            for k in (rest if len(dst) > 1 else self.static_in):
+                self.static_in[k].copy_(features[k], non_blocking=True)
         if isinstance(self.graph, _GraphPair):
             self.graph.replay(self.between)
         else:
@@ -298,18 +304,38 @@ class _StepGraph:
         if _dist.is_available() and _dist.is_initialized():
             torch.cuda.synchronize()
             mode = "thread_local"
+        # keep_graph: the hipGraph_t stays available, so that the capture can be AUDITED before it is instantiated
         if self.phases is None:
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.static_out = self.fn(self.static_in)
+            captured = [self.graph]
         else:
-            first, second = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            first, second = torch.cuda.CUDAGraph(keep_graph=True), torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(first, capture_error_mode=mode):
                 carry, self.static_out = self.phases[0](self.static_in)
             with torch.cuda.graph(second, pool=first.pool(), capture_error_mode=mode):   # same capture stream (torch's default), same pool
                 self.phases[1](carry)
             del carry
             self.graph = _GraphPair(first, second)
+            captured = [first, second]
+        # Node audit: a memset node replays wrongly on this runtime -- the invariant "nothing inside a
+        # captured step depends on a memset" is ENFORCED here, not remembered: one torch.zeros / multi-block sum / library
+        # workspace clear inside the step and the capture is refused.
+        self.census = {}
+        for g in captured:
+            for k, v in _ops.graph_census(g).items():
+                self.census[k] = self.census.get(k, 0) + v
+        if self.census.get("memset", 0) and not getattr(opts, "ALLOW_MEMSET_NODES", False):
+            for t, s_ in zip(state, saved):
+                t.copy_(s_)
+            self.graph = None
+            raise RuntimeError(f"[StepGraph] the captured step contains {self.census['memset']} memset node(s) "
+                               f"({self.census}): memset nodes of a hipGraph write garbage from the second replay on with "
+                               "this runtime -- replace the zero-fill (torch.zeros / sum over several blocks / library "
+                               "workspace clear) by a kernel, or run the step eagerly")
+        for g in captured:
+            g.instantiate()
         for t, s in zip(state, saved):
             t.copy_(s)
         self.signature = sig
@@ -458,10 +484,14 @@ class _MetricsGraph:
                 merge_results(static_in, preds, loss, loss_by_type, self.stereo)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
+            graph = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(graph):
                 res = merge_results(static_in, preds, loss, loss_by_type, self.stereo)
                 out = torch.stack([res[k].reshape(()).float() for k in keys])
+            census = _ops.graph_census(graph)          # the same audit as the training step's graph (no memset nodes)
+            if census["memset"]:
+                raise RuntimeError(f"[MetricsGraph] the captured per-step metrics contain memset nodes: {census}")
+            graph.instantiate()
             self.cache[key] = (graph, keys, out)
             return first
         graph, keys, out = entry
