@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -61,6 +62,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=20.0)
+    ap.add_argument("--data", default="resident", choices=["resident", "tfrecord"],
+                    help="tfrecord: ALSO write a synthetic shard set with the repo's TFRecord writer and train from it through the "
+                         "prefetching reader (`host_fed`: reader alone, and the step fed from the host; never `value`)")
     ap.add_argument("--sustained-seconds", type=float, default=6.0,
                     help="back-to-back steps after the timed region, reported separately (`sustained`); 0 disables")
     args = ap.parse_args()
@@ -146,6 +150,63 @@ def roofline_leg(args, dataset, repeats=50):
     from xpt_mde_2021_amd.hip import roofline as rf
     feats = dataset.batches[0]
     return rf.measure(ops, feats, repeats, HBM_PEAK_GBS)
+
+
+def host_fed_leg(args, trainer, dataset, note):
+    """--data tfrecord: the input contract end to end.  Writes `n` KITTI-shaped snippets (uint8 image 5H x W x 3, intrinsic,
+    depth_gt, pose_gt: what tfrecords/tfr_util.py serialises) with the repo's own TFRecord writer, then (a) drains the
+    prefetching reader alone -> reader_snippets_per_s, (b) trains from it -> value_host_fed.  tfrecord_reader.py:61-108."""
+    import shutil
+    import tempfile
+    from xpt_mde_2021_amd.tfrecords.tfrecord_reader import TfrecordReader, TfrecordWriter
+    n = 64 * args.batch
+    feats = dataset.batches[0]
+    root = tempfile.mkdtemp(prefix="xpt_bench_tfr_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        host = {k: v.detach().cpu() for k, v in feats.items() if k in ("image", "intrinsic", "depth_gt", "pose_gt")}
+        writer = TfrecordWriter(root, shard_size=128)
+        B = host["image"].shape[0]
+        for i in range(n):
+            b = i % B
+            img = ((host["image"][b] + 1.0) * 127.5).round().clamp(0, 255).to(torch.uint8).numpy()
+            img = np.roll(img, i // B, axis=1)                       # distinct snippets
+            writer.write({"image": img, "intrinsic": host["intrinsic"][b].numpy(), "depth_gt": host["depth_gt"][b].numpy(),
+                          "pose_gt": host["pose_gt"][b].numpy()})
+        writer.close([feats["image5d"].shape[1], args.height, args.width, 3])
+        nbytes = sum(os.path.getsize(os.path.join(root, f)) for f in os.listdir(root))
+        note(f"host-fed leg: {n} snippets, {nbytes / 1e6:.0f} MB of TFRecord shards in {root}")
+        workers = min(8, max(2, (os.cpu_count() or 4) // 2))
+        kw = dict(shuffle=True, batch_size=args.batch, device="cuda", prefetch=3, workers=workers)
+        # (a) the reader alone
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        count = 0
+        for batch in TfrecordReader(root, epochs=3, **kw).get_dataset():
+            count += batch["image5d"].shape[0]
+        torch.cuda.synchronize()
+        reader_rate = count / (time.perf_counter() - t0)
+        # (b) the training step fed by it (same captured graph: the batch is copied into its static inputs)
+        ds = TfrecordReader(root, epochs=6, **kw).get_dataset()
+        it = iter(ds)
+        for _ in range(8):
+            trainer.run_a_batch(next(it))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        steps = 0
+        for batch in it:
+            trainer.run_a_batch(batch)
+            steps += 1
+        torch.cuda.synchronize()
+        fed = time.perf_counter() - t0
+        return {"reader_snippets_per_s": round(reader_rate, 1), "value_host_fed": round(args.batch * steps / fed, 3),
+                "unit": "images/sec", "steps": steps, "ms_per_step": round(1000.0 * fed / steps, 4),
+                "wait_for_reader_ms_per_step": round(1000.0 * ds.reader_seconds / max(steps + 8, 1), 4),
+                "shard_bytes": int(nbytes), "snippets": n, "decode_workers": workers, "prefetch": 3,
+                "what": "synthetic KITTI-shaped snippets written with the repo's TFRecord writer, read back (framing, masked "
+                        "CRC32C, hand-parsed tf.train.Example, uint8 -> float on the device), shuffled, batched, uploaded from "
+                        "pinned memory on a side stream and trained on; `value` itself is measured on HBM-resident inputs"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def cpu_baseline(args, seconds):
@@ -354,6 +415,10 @@ def run(args):
                                 "ms_per_step": round(1000.0 * loop / args.steps, 4),
                                 "what": "run_an_epoch over the same batches: training step + per-step metrics (merge_results)"}
         note(f"epoch loop done: {loop:.3f} s")
+    if rank == 0 and world == 1 and args.data == "tfrecord" and args.config != "c5" and args.nets == "rigid" and not args.stereo:
+        result["host_fed"] = host_fed_leg(args, trainer, dataset, note)
+        result["host_fed"]["vs_resident"] = round(result["host_fed"]["value_host_fed"] / result["value"], 4)
+        note("host-fed leg done")
     if rank == 0 and not args.no_roofline:
         result["roofline"] = roofline_leg(args, dataset)
         note("roofline leg done")

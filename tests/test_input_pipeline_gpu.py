@@ -78,3 +78,23 @@ def test_tfrecords_augment_graph_train(gpu_device, tmp_path):
         opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE = saved[:3]
         opts.IMAGE_SIZES.clear()
         opts.IMAGE_SIZES.update(saved[3])
+
+
+def test_prefetching_reader_uploads_the_same_batches(gpu_device, tmp_path):
+    """prefetch > 0 on the device: memory-mapped shards, decode workers writing into pinned staging rows, upload and
+    uint8 -> float conversion on a side stream -- the batches the step receives must equal the synchronous reader's bit
+    for bit (tfrecord_reader.py:61-108 hands the step a tf.data pipeline; this is its background half)."""
+    from xpt_mde_2021_amd.tfrecords.tfrecord_reader import TfrecordReader
+    _write_shards(tmp_path, 14, 32, 96)
+    kw = dict(shuffle=True, batch_size=3, device=gpu_device, epochs=2, shuffle_buffer=5, seed=4)
+    plain = list(TfrecordReader(str(tmp_path), **kw).get_dataset())
+    ahead = []
+    for feats in TfrecordReader(str(tmp_path), prefetch=2, workers=3, **kw).get_dataset():
+        assert all(v.is_cuda for v in feats.values())
+        ahead.append({k: v.clone() for k, v in feats.items()})     # (consumed on the current stream, as a training step would)
+    torch.cuda.synchronize()
+    assert len(plain) == len(ahead) == (14 * 2) // 3
+    for a, b in zip(plain, ahead):
+        assert sorted(a) == sorted(b)
+        for k in a:
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k

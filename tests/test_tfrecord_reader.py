@@ -121,3 +121,37 @@ def test_bad_config_rejected(tmp_path):
     json.dump(cfg, open(tmp_path / "tfr_config.txt", "w"))
     with pytest.raises(TypeError):
         tr.TfrecordReader(str(tmp_path), batch_size=1)
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_prefetching_reader_yields_the_same_batches(tmp_path, shuffle):
+    """prefetch > 0: a producer thread (with decode workers) reads ahead -- tf.data's role in tfrecord_reader.py:61-108 --
+    and must hand out exactly the batches of the synchronous generator: same order, same keys, same values."""
+    _write(tmp_path, 23, shard_size=6, stereo=True)
+    kw = dict(shuffle=shuffle, epochs=2, batch_size=4, shuffle_buffer=5, seed=3)
+    plain = list(tr.TfrecordReader(str(tmp_path), **kw).get_dataset())
+    ahead = list(tr.TfrecordReader(str(tmp_path), prefetch=2, workers=3, **kw).get_dataset())
+    assert len(plain) == len(ahead) == (23 * 2) // 4
+    for a, b in zip(plain, ahead):
+        assert sorted(a) == sorted(b)
+        for k in a:
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), k
+
+
+def test_prefetching_reader_propagates_errors_and_stops_early(tmp_path):
+    _write(tmp_path, 6)
+    fn = tmp_path / "shard_000.tfrecord"
+    raw = bytearray(fn.read_bytes())
+    raw[len(raw) // 2] ^= 0xFF
+    fn.write_bytes(bytes(raw))
+    with pytest.raises(IOError):
+        list(tr.TfrecordReader(str(tmp_path), batch_size=1, prefetch=2).get_dataset())
+    _write(tmp_path, 40)
+    it = iter(tr.TfrecordReader(str(tmp_path), batch_size=2, prefetch=1, epochs=50).get_dataset())
+    first = next(it)
+    assert first["index"].tolist() == [0, 1]
+    it.close()                                   # the producer thread is told to stop (no leak of a blocked thread)
+    import threading
+    import time
+    time.sleep(0.5)
+    assert not [t for t in threading.enumerate() if t.name == "xpt-tfrecord-prefetch" and t.is_alive()]

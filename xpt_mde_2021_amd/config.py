@@ -154,6 +154,8 @@ class VodeOptions(LossOptions):
     # ---- other options (:258-266)
     ENABLE_SHAPE_DECOR = False
     LOG_LOSS = True
+    READER_PREFETCH = 2      # batches the TFRecord reader keeps ready ahead of the step (0: synchronous generator)
+    READER_WORKERS = 4       # decode threads of the prefetching reader
     TRAIN_MODE = "graph"                      # "eager" | "graph" (hipGraph replay) | "distributed" (RCCL DP)
     RAW_IMAGE_RES = {"kitti_raw": (375, 1242)}
 

@@ -144,8 +144,10 @@ def get_dataset(dataset_name, split, shuffle, batch_size=None):
     print("tfr path : ", tfr_path)
     assert op.isdir(tfr_path), tfr_path
     rank, world = (0, 1) if strategy is None else (strategy.rank, strategy.num_replicas_in_sync)
+    # background read / decode / pinned staging / side-stream upload (tf.data's role, tfrecord_reader.py:61-108)
     reader = TfrecordReader(tfr_path, shuffle=shuffle, batch_size=per_replica, rank=rank, world_size=world,
-                            device=device())
+                            device=device(), prefetch=int(getattr(opts, "READER_PREFETCH", 2)),
+                            workers=int(getattr(opts, "READER_WORKERS", 4)))
     return reader.get_dataset(), reader.get_tfr_config(), reader.get_total_steps()
 
 

@@ -13,13 +13,23 @@ get_dataset() yields feature dicts of torch tensors with the reference's keys / 
 [B, 5H, W, 3] in [-1, 1] (uint8/255*2-1, utils/util_funcs.py:79-80), `image5d` [B, 5, H, W, 3], `intrinsic` [B,3,3],
 `depth_gt` [B,H,W,1], `pose_gt` [B,4,4,4] and, when present, the `_R` variants and `stereo_T_LR`; shuffle buffer 200,
 `batch(drop_remainder=True)`.  In data-parallel runs every rank reads the examples `rank, rank+world, ...`.
+
+`prefetch=n > 0` is the counterpart of tf.data's background threads (tfrecord_reader.py:61-108 hands the step a
+`tf.data` pipeline): a producer thread reads, CRC-checks, parses and decodes ahead of the training step (`workers`
+decode threads: the CRC, the buffer copies and the tensor ops release the GIL), keeps the images uint8 until the batch is
+assembled in PINNED host memory, sends it to the device on a side stream (a quarter of the float bytes) and converts it
+there; the consumer finds up to n ready batches and only waits on an event.  Same batches, same order, same values as
+the synchronous generator (tests/test_tfrecord_reader.py).
 """
+import concurrent.futures
 import ctypes
 import glob
 import json
 import os.path as op
+import queue
 import random
 import struct
+import threading
 
 import numpy as np
 import torch
@@ -30,7 +40,11 @@ _MASK_DELTA = 0xA282EAD8
 
 
 def masked_crc32c(data):
-    crc = _lib.load().xpt_crc32c(ctypes.c_char_p(bytes(data)), len(data))
+    if isinstance(data, memoryview):             # zero-copy: the address of the (memory-mapped) bytes
+        arr = np.frombuffer(data, dtype=np.uint8)
+        crc = _lib.load().xpt_crc32c(ctypes.c_void_p(arr.ctypes.data), arr.size) if arr.size else 0
+    else:
+        crc = _lib.load().xpt_crc32c(ctypes.c_char_p(bytes(data)), len(data))
     return ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + _MASK_DELTA) & 0xFFFFFFFF
 
 
@@ -183,8 +197,10 @@ class TfrecordWriter:
             json.dump(cfg, fw)
 
 
-def iterate_records(filename, verify_crc=True):
-    with open(filename, "rb") as f:
+def iterate_records(filename, verify_crc=True, deferred=False):
+    """Payloads of one shard.  deferred=True: yields (payload, check) and leaves the payload's CRC to check() -- the
+    prefetching reader runs it in its decode workers, off the sequential read path."""
+    with open(filename, "rb", buffering=1 << 22) as f:
         while True:
             header = f.read(8)
             if len(header) < 8:
@@ -193,14 +209,22 @@ def iterate_records(filename, verify_crc=True):
             (hcrc,) = struct.unpack("<I", f.read(4))
             payload = f.read(length)
             (pcrc,) = struct.unpack("<I", f.read(4))
-            if verify_crc and (hcrc != masked_crc32c(header) or pcrc != masked_crc32c(payload)):
+            if verify_crc and hcrc != masked_crc32c(header):
                 raise IOError(f"corrupted TFRecord in {filename} (CRC32C mismatch)")
-            yield payload
+
+            def check(payload=payload, pcrc=pcrc):
+                if verify_crc and pcrc != masked_crc32c(payload):
+                    raise IOError(f"corrupted TFRecord in {filename} (CRC32C mismatch)")
+            if deferred:
+                yield payload, check
+            else:
+                check()
+                yield payload
 
 
 class TfrecordReader:
     def __init__(self, tfrpath, shuffle=False, epochs=1, batch_size=None, rank=0, world_size=1, device="cpu",
-                 verify_crc=True, shuffle_buffer=200, seed=0):
+                 verify_crc=True, shuffle_buffer=200, seed=0, prefetch=0, workers=4):
         from ..config import opts
         self.tfrpath = tfrpath
         self.shuffle = shuffle
@@ -211,6 +235,7 @@ class TfrecordReader:
         self.verify_crc = verify_crc
         self.shuffle_buffer = shuffle_buffer
         self.rng = random.Random(seed + rank)
+        self.prefetch, self.workers = int(prefetch), max(int(workers), 1)
         self.config = self.read_tfrecord_config(tfrpath)
 
     def read_tfrecord_config(self, tfrpath):
@@ -226,8 +251,9 @@ class TfrecordReader:
                 raise TypeError("[read_tfrecord_config] invalid decode_type")
         return config
 
-    def decode_example(self, payload):
-        """tfrecord_reader.py:77-98: parse, decode_raw, reshape, uint8 image -> float [-1, 1], add image5d."""
+    def decode_example(self, payload, raw_images=False):
+        """tfrecord_reader.py:77-98: parse, decode_raw, reshape, uint8 image -> float [-1, 1], add image5d.
+        raw_images: leave the images uint8 (finish_images converts the assembled batch, on the device when there is one)."""
         parsed = parse_example(payload)
         decoded = {}
         for key, feat_conf in self.config.items():
@@ -240,27 +266,38 @@ class TfrecordReader:
             arr = np.frombuffer(parsed[key], dtype=dtype)
             if feat_conf["shape"] is not None:
                 arr = arr.reshape(feat_conf["shape"])
-            decoded[key] = torch.from_numpy(arr.copy())
-        for sfx in ("", "_R"):
-            if "image" + sfx in decoded:
-                img = decoded["image" + sfx].to(torch.float32) * (2.0 / 255.0) - 1.0
-                decoded["image" + sfx] = img
-                decoded["image5d" + sfx] = img.reshape(self.config["imshape"])
-        return decoded
+            decoded[key] = torch.from_numpy(arr.copy())          # (the payload buffer is read-only and short-lived)
+        return decoded if raw_images else self.finish_images(decoded)
 
-    def _examples(self):
+    def finish_images(self, feats):
+        """uint8 image -> float32 in [-1, 1] (util_funcs.py:79-80) + the image5d view; works on one example or a batch."""
+        for sfx in ("", "_R"):
+            img = feats.get("image" + sfx)
+            if img is not None:
+                if img.dtype == torch.uint8:
+                    img = img.to(torch.float32) * (2.0 / 255.0) - 1.0
+                    feats["image" + sfx] = img
+                lead = tuple(img.shape[:img.dim() - 3])
+                feats["image5d" + sfx] = img.reshape(lead + tuple(self.config["imshape"]))
+        return feats
+
+    def _payloads(self, deferred=False):
         filenames = sorted(glob.glob(op.join(self.tfrpath, "*.tfrecord")))
         index = 0
         for _ in range(self.epochs):
             for filename in filenames:
-                for payload in iterate_records(filename, self.verify_crc):
+                for payload in iterate_records(filename, self.verify_crc, deferred):
                     if index % self.world_size == self.rank:
-                        yield self.decode_example(payload)
+                        yield payload
                     index += 1
+
+    def _examples(self):
+        for payload in self._payloads():
+            yield self.decode_example(payload)
 
     def get_dataset(self):
         """Generator of batched feature dicts on `device` (tfrecord_reader.py:61-108)."""
-        return _BatchedDataset(self)
+        return _PrefetchedDataset(self) if self.prefetch > 0 else _BatchedDataset(self)
 
     def get_total_steps(self):
         return self.config["length"] // (self.batch_size * self.world_size)
@@ -299,3 +336,169 @@ class _BatchedDataset:
             out = emit(buffer.pop(rd.rng.randrange(len(buffer))))
             if out is not None:
                 yield out                                           # a trailing partial batch is dropped
+
+
+class _PrefetchedDataset:
+    """The same batches as _BatchedDataset, produced ahead of the consumer by a background thread (module docstring).
+
+    Bytes move ONCE on the host: the shards are memory-mapped, the shuffle buffer holds references (payload views), and a
+    decode worker checks the CRC of its record and copies the decoded arrays straight into the record's row of the batch's
+    pinned staging buffers; the upload and the uint8 -> float conversion run on a side stream."""
+
+    def __init__(self, reader):
+        self.reader = reader
+        self.reader_seconds = 0.0             # time the consumer spent waiting for a batch (diagnostics)
+        self._maps = []
+
+    def _refs(self):
+        """(payload view, record name) of this rank's records in file order; nothing is copied."""
+        import mmap
+        rd = self.reader
+        filenames = sorted(glob.glob(op.join(rd.tfrpath, "*.tfrecord")))
+        index = 0
+        for _ in range(rd.epochs):
+            for filename in filenames:
+                with open(filename, "rb") as f:
+                    size = f.seek(0, 2)
+                    if size == 0:
+                        continue
+                    mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+                self._maps.append(mm)
+                view = memoryview(mm)
+                pos = 0
+                while pos + 12 <= size:
+                    header = view[pos:pos + 8]
+                    (length,) = struct.unpack("<Q", header)
+                    (hcrc,) = struct.unpack("<I", view[pos + 8:pos + 12])
+                    if rd.verify_crc and hcrc != masked_crc32c(header):
+                        raise IOError(f"corrupted TFRecord in {filename} (CRC32C mismatch)")
+                    end = pos + 12 + length
+                    if end + 4 > size:
+                        raise IOError(f"truncated TFRecord in {filename}")
+                    if index % rd.world_size == rd.rank:
+                        yield view[pos + 12:end], struct.unpack("<I", view[end:end + 4])[0], filename
+                    index += 1
+                    pos = end + 4
+
+    def _batched_refs(self):
+        rd = self.reader
+        buffer, batch = [], []
+        for ref in self._refs():
+            if rd.shuffle:
+                buffer.append(ref)
+                if len(buffer) < rd.shuffle_buffer:
+                    continue
+                ref = buffer.pop(rd.rng.randrange(len(buffer)))
+            batch.append(ref)
+            if len(batch) == rd.batch_size:
+                yield batch
+                batch = []
+        while buffer:
+            batch.append(buffer.pop(rd.rng.randrange(len(buffer))))
+            if len(batch) == rd.batch_size:
+                yield batch
+                batch = []                                          # a trailing partial batch is dropped
+
+    def _staging(self, pinned):
+        """Host buffers of one batch: [batch, *shape] per feature of the side-car config (uint8 images stay uint8)."""
+        rd = self.reader
+        bufs = {}
+        for key, conf in rd.config.items():
+            if not isinstance(conf, dict):
+                continue
+            if conf["parse_type"] == "tf.int64":
+                t = torch.empty((rd.batch_size,), dtype=torch.int64)
+            else:
+                dtype = torch.uint8 if conf["decode_type"] == "tf.uint8" else torch.float32
+                t = torch.empty((rd.batch_size,) + tuple(conf["shape"] or ()), dtype=dtype)
+            bufs[key] = t.pin_memory() if pinned else t
+        return bufs
+
+    def _decode_into(self, ref, bufs, row):
+        rd = self.reader
+        payload, pcrc, filename = ref
+        if rd.verify_crc and pcrc != masked_crc32c(payload):
+            raise IOError(f"corrupted TFRecord in {filename} (CRC32C mismatch)")
+        parsed = parse_example(payload)
+        for key, conf in rd.config.items():
+            if not isinstance(conf, dict):
+                continue
+            if key not in parsed:
+                raise IOError(f"record without feature '{key}' in {filename}")
+            if conf["parse_type"] == "tf.int64":
+                bufs[key][row] = int(parsed[key])
+                continue
+            dst = bufs[key][row].numpy()
+            src = np.frombuffer(parsed[key], dtype=dst.dtype)
+            np.copyto(dst, src.reshape(dst.shape))                  # the one host copy of the record's bytes
+
+    def _produce(self, out, stop):
+        rd = self.reader
+        on_gpu = torch.device(rd.device).type == "cuda"
+        stream = torch.cuda.Stream(device=rd.device) if on_gpu else None
+        nslots = rd.prefetch + 3                                    # a slot is reused only after its batch was consumed
+        staging = [None] * nslots
+        inflight = []                                               # (futures, slot) of batches being decoded
+
+        def finish(futures, slot):
+            for fut in futures:
+                fut.result()                                        # re-raises a worker's exception
+            host = staging[slot]
+            if on_gpu:
+                with torch.cuda.stream(stream):
+                    feats = rd.finish_images({k: v.to(rd.device, non_blocking=True) for k, v in host.items()})
+                    ready = torch.cuda.Event()
+                    ready.record(stream)
+                item = (feats, ready)
+            else:
+                item = (rd.finish_images({k: v.clone() for k, v in host.items()}), None)
+            while not stop.is_set():
+                try:
+                    out.put(item, timeout=0.1)
+                    return
+                except queue.Full:
+                    continue
+
+        try:
+            with concurrent.futures.ThreadPoolExecutor(max_workers=rd.workers) as pool:
+                slot = 0
+                for refs in self._batched_refs():
+                    if stop.is_set():
+                        return
+                    if staging[slot] is None:
+                        staging[slot] = self._staging(on_gpu)
+                    inflight.append(([pool.submit(self._decode_into, ref, staging[slot], i) for i, ref in enumerate(refs)], slot))
+                    slot = (slot + 1) % nslots
+                    if len(inflight) > 1:                           # the next batch decodes while this one is uploaded
+                        finish(*inflight.pop(0))
+                for job in inflight:
+                    finish(*job)
+            out.put(None)
+        except BaseException as e:             # noqa: BLE001  (handed to the consumer, which re-raises it)
+            out.put(e)
+
+    def __iter__(self):
+        import time
+        rd = self.reader
+        out = queue.Queue(maxsize=rd.prefetch)
+        stop = threading.Event()
+        thread = threading.Thread(target=self._produce, args=(out, stop), daemon=True, name="xpt-tfrecord-prefetch")
+        thread.start()
+        try:
+            while True:
+                t0 = time.perf_counter()
+                item = out.get()
+                self.reader_seconds += time.perf_counter() - t0
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                feats, ready = item
+                if ready is not None:
+                    torch.cuda.current_stream().wait_event(ready)
+                    for v in feats.values():
+                        v.record_stream(torch.cuda.current_stream())
+                yield feats
+        finally:
+            stop.set()
+            thread.join(timeout=5.0)
