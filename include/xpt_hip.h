@@ -578,6 +578,21 @@ int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, float* partia
  * (tf.data.TFRecordDataset); masked value = ((crc >> 15) | (crc << 17)) + 0xa282ead8. */
 uint32_t xpt_crc32c(const void* data, size_t nbytes);
 
+/* ------------------------------------------------------------------ NASNet branch stage in one launch (xpt_sepconv.hip)
+ * keras nasnet._separable_conv_block halves (Activation('relu') -> SeparableConv2D(k, stride 1, 'same') ->
+ * BatchNormalization, inference statistics) of up to 6 branches of one cell stage, optionally with the sibling branch of
+ * the cell's `add` (_normal_a_cell) or a residual: tensorflow.keras.applications NASNetMobile as instantiated at
+ * model/build_model/pretrained_nets.py:36-44.  Arrays of n entries; *_b = the sibling branch of job j (x_b[j] NULL: none).
+ * Same results, bit for bit, as xpt_dwconv_multi_fwd followed by xpt_pwconv_bn_multi_fwd (right branches first). */
+int xpt_sepconv_bn_multi_fwd(int n, const void* const* x, const float* const* wdw, const void* const* wpw,
+                             const float* const* gamma, const float* const* beta, const float* const* mean,
+                             const float* const* var, const int* k, void* const* ydw, void* const* ypre,
+                             const void* const* x_b, const float* const* wdw_b, const void* const* wpw_b,
+                             const float* const* gamma_b, const float* const* beta_b, const float* const* mean_b,
+                             const float* const* var_b, const int* k_b, void* const* ydw_b, void* const* ypre_b,
+                             void* const* yb, const void* const* residual, void* const* y, float eps, int B, int H, int W,
+                             int C, int cout, void* stream);
+
 /* ------------------------------------------------------------------ captured-step audit (no reference counterpart)
  * Node census of a captured hipGraph (hipGraph_t as torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph() hands it out),
  * child graphs included: counts[6] = kernel, memcpy, memset, host, other nodes, total.  The trainers that replace the

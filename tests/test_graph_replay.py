@@ -66,3 +66,13 @@ def test_two_graph_step_with_cut_backward_equals_the_single_graph_step(gpu_devic
     double, dsum = _loss_sequence("distributed", "noaug", 8, XPT_DP_OVERLAP="1")
     assert single == double, f"one graph  {single}\ntwo graphs {double}"
     assert ssum == dsum
+
+
+def test_one_launch_branch_stage_equals_the_two_launch_path_bit_for_bit(gpu_device):
+    """csrc/xpt_sepconv.hip (ReLU -> depthwise -> pointwise -> BatchNorm [+ sibling branch / residual] of a NASNet cell
+    stage in ONE launch; opt-in, XPT_FUSED_SEPCONV=1) against the separate depthwise and pointwise launches it replaces:
+    the same arithmetic in the same order, so six full training steps must give the SAME losses and final weights."""
+    fused, fsum = _loss_sequence("graph", "noaug", 6, XPT_FUSED_SEPCONV="1")
+    unfused, usum = _loss_sequence("graph", "noaug", 6)
+    assert fused == unfused, f"one launch  {fused}\ntwo launches {unfused}"
+    assert fsum == usum

@@ -106,6 +106,7 @@ SIGNATURES = {
     "xpt_photo_fused_ms_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),   # losses is one [2 n, B] buffer
     "xpt_photo_fused_ms_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),
     "xpt_graph_node_census": (_i, [_p, _p]),
+    "xpt_sepconv_bn_multi_fwd": (_i, [_i] + [_p] * 23 + [_f, _i, _i, _i, _i, _i, _p]),
     "xpt_photo_march_tune": (_i, [_i, _i, _i]),
     "xpt_photo_march_ms_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),
     "xpt_photo_march_ms_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),

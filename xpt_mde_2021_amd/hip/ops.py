@@ -776,6 +776,8 @@ class _MultiDepthwise(torch.autograd.Function):
     (top, bottom, left, right); inputs may repeat: the gradient of a repeated input is returned once, already summed
     over its jobs."""
 
+    precomputed = None      # outputs a fused launch already produced (pretrained_nets.fused_sep_stage): consumed by the next forward
+
     @staticmethod
     def forward(ctx, relu_in, stride, pads, *tensors):
         import ctypes
@@ -783,6 +785,7 @@ class _MultiDepthwise(torch.autograd.Function):
         n = len(tensors) // 2
         xs = [_nhwc(t, "x") for t in tensors[:n]]
         ws = [t.detach().contiguous() for t in tensors[n:]]
+        pre, _MultiDepthwise.precomputed = _MultiDepthwise.precomputed, None
         B, C, H, W = xs[0].shape
         ks = [int(w.shape[-1]) for w in ws]
         outs = {((H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1) for k, (pt, pb, pl, pr) in zip(ks, pads)}
@@ -792,14 +795,17 @@ class _MultiDepthwise(torch.autograd.Function):
         if len(outs) != 1:
             raise _lib.XptHipError(f"multi_depthwise: the layers disagree on the output size: {outs}")
         OH, OW = outs.pop()
-        ys = [torch.empty((B, C, OH, OW), dtype=xs[0].dtype, device=xs[0].device, memory_format=torch.channels_last)
-              for _ in range(n)]
         pts, pls = [int(p[0]) for p in pads], [int(p[2]) for p in pads]
         dt = 0 if xs[0].dtype == torch.float32 else 1
-        P, I = ctypes.c_void_p * n, ctypes.c_int * n
-        _lib.check(lib.xpt_dwconv_multi_fwd(P(*[x.data_ptr() for x in xs]), P(*[w.data_ptr() for w in ws]),
-                                            P(*[y.data_ptr() for y in ys]), I(*ks), I(*pts), I(*pls), n, B, H, W, C,
-                                            int(stride), OH, OW, int(relu_in), dt, _stream()), "xpt_dwconv_multi_fwd")
+        if pre is not None:                    # the fused branch-stage launch wrote the depthwise outputs already
+            ys = list(pre)
+        else:
+            ys = [torch.empty((B, C, OH, OW), dtype=xs[0].dtype, device=xs[0].device, memory_format=torch.channels_last)
+                  for _ in range(n)]
+            P, I = ctypes.c_void_p * n, ctypes.c_int * n
+            _lib.check(lib.xpt_dwconv_multi_fwd(P(*[x.data_ptr() for x in xs]), P(*[w.data_ptr() for w in ws]),
+                                                P(*[y.data_ptr() for y in ys]), I(*ks), I(*pts), I(*pls), n, B, H, W, C,
+                                                int(stride), OH, OW, int(relu_in), dt, _stream()), "xpt_dwconv_multi_fwd")
         # distinct inputs (by storage), in order of first use
         ptrs, input_of = [], []
         for x in xs:

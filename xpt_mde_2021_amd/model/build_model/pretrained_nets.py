@@ -233,10 +233,13 @@ class _MultiConv1x1Bn(torch.autograd.Function):
     the backward runs the fused per-layer kernels of _Conv1x1BnBf16.  args = (n, eps, xs..., weights..., gammas...,
     betas..., means..., vars..., residuals-or-None...)."""
 
+    precomputed = None      # (ypres, ys) a fused branch-stage launch already produced (fused_sep_stage): consumed by the next forward
+
     @staticmethod
     def forward(ctx, n, eps, *a):
         import ctypes
         lib = _ops._lib.load()
+        pre, _MultiConv1x1Bn.precomputed = _MultiConv1x1Bn.precomputed, None
         xs, ws_, gs, bs, ms, vs, rs = (a[i * n:(i + 1) * n] for i in range(7))
         B, cin, H, W = xs[0].shape
         cout = ws_[0].shape[0]
@@ -245,15 +248,18 @@ class _MultiConv1x1Bn(torch.autograd.Function):
         pitch = x2s[0].stride(0) if M > 1 else cin
         shadows = [w.shadow_bf16.reshape(cout, cin) for w in ws_]
         res = [None if r is None else r.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for r in rs]
-        ypres = [torch.empty((M, cout), dtype=torch.bfloat16, device=xs[0].device) for _ in range(n)]
-        ys = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=xs[0].device, memory_format=torch.channels_last)
-              for _ in range(n)]
-        P = ctypes.c_void_p * n
-        ptr = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])
-        _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd(n, ptr(x2s), ptr(shadows), ptr([g.detach() for g in gs]),
-                                                    ptr([b.detach() for b in bs]), ptr(ms), ptr(vs), float(eps), ptr(res),
-                                                    ptr(ypres), ptr(ys), M, cin, cout, pitch, _ops._stream()),
-                        "xpt_pwconv_bn_multi_fwd")
+        if pre is not None:                    # the fused branch-stage launch computed this stage already
+            ypres, ys = list(pre[0]), list(pre[1])
+        else:
+            ypres = [torch.empty((M, cout), dtype=torch.bfloat16, device=xs[0].device) for _ in range(n)]
+            ys = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=xs[0].device, memory_format=torch.channels_last)
+                  for _ in range(n)]
+            P = ctypes.c_void_p * n
+            ptr = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])
+            _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd(n, ptr(x2s), ptr(shadows), ptr([g.detach() for g in gs]),
+                                                        ptr([b.detach() for b in bs]), ptr(ms), ptr(vs), float(eps), ptr(res),
+                                                        ptr(ypres), ptr(ys), M, cin, cout, pitch, _ops._stream()),
+                            "xpt_pwconv_bn_multi_fwd")
         ctx.save_for_backward(*x2s, *shadows, *ypres, *[g.detach() for g in gs], *ms, *vs)
         ctx.n = n
         ctx.dims = (B, cin, H, W, cout, float(eps))
@@ -530,6 +536,88 @@ def avg_pool_same(x, scale=1.0):
     return y if scale == 1.0 else y * scale
 
 
+# The one-launch branch stage (csrc/xpt_sepconv.hip) is bit-identical to the two / three launches it replaces and removes 36
+# launches from the step, but it is SLOWER at batch 8 (measured, profiles/r03_c_*: 6.67 against 6.56 ms per step): with 32
+# pixels per workgroup a stage is 39-1040 workgroups whose critical path -- taps to LDS, the depthwise loads, the filter
+# rows, the stores: four dependent memory round trips and four barriers -- is as long as the separate launches' paths
+# together, and on the 4 x 13 maps only 39-65 of the 256 CUs have work.  Off by default; XPT_FUSED_SEPCONV=1 turns it on.
+_FUSED_SEP_STAGE = __import__("os").environ.get("XPT_FUSED_SEPCONV", "0") == "1"
+
+
+def _sep_stage_usable(xs, seps, bns):
+    """The one-launch branch stage (csrc/xpt_sepconv.hip) applies: training in bf16 on flat (deferred-gradient) parameters,
+    stride-1 separable convolutions of one activation shape with equally many input and output channels."""
+    sink = _ops.grad_sink
+    x0 = xs[0]
+    return (_FUSED_SEP_STAGE and _FUSE_CONV_BN and _WIDE_CELL and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD
+            and not _DISABLE_HIP_DWCONV and x0.is_cuda and x0.dtype == torch.bfloat16 and torch.is_autocast_enabled()
+            and torch.is_grad_enabled() and x0.shape[1] % 2 == 0
+            and all(x.shape == x0.shape and x.dtype == x0.dtype and x.is_contiguous(memory_format=torch.channels_last) for x in xs)
+            and all(sp.stride == 1 and sp.k in (3, 5, 7) and sp.pointwise.weight.shape[:2] == (x0.shape[1], x0.shape[1])
+                    and hasattr(sp.pointwise.weight, "shadow_bf16") and sink.wants(sp.pointwise.weight)
+                    and sp.depthwise.weight.dtype == torch.float32 for sp in seps)
+            and all(sink.wants(b.weight) and sink.wants(b.bias) for b in bns))
+
+
+def fused_sep_stage(main, siblings=None, residuals=None):
+    """One branch stage of a cell in ONE forward launch.  main / siblings: lists of (x, SeparableConv, FrozenBatchNorm);
+    job j computes  BN_j(pw_j(dw_j(relu(x_j))))  [+ BN(pw(dw(relu(x)))) of siblings[j]]  [+ residuals[j]].
+    Returns (results per job, the siblings' own outputs or None).  The autograd graph is that of the unfused path
+    (_MultiDepthwise followed by _MultiConv1x1Bn, the sibling branches first): the launch only pre-computes their outputs,
+    their backward kernels run unchanged."""
+    import ctypes
+    n = len(main)
+    siblings = siblings or [None] * n
+    residuals = residuals or [None] * n
+    lib = _ops._lib.load()
+    x0 = main[0][0]
+    B, C, H, W = x0.shape
+    M = B * H * W
+    dev = x0.device
+    new_map = lambda: torch.empty((B, C, H, W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)   # noqa: E731
+    new_rows = lambda: torch.empty((M, C), dtype=torch.bfloat16, device=dev)                                           # noqa: E731
+    sib = [j for j in range(n) if siblings[j] is not None]
+    ydw_a, ypre_a, y_a = [new_map() for _ in range(n)], [new_rows() for _ in range(n)], [new_map() for _ in range(n)]
+    ydw_b, ypre_b, y_b = {j: new_map() for j in sib}, {j: new_rows() for j in sib}, {j: new_map() for j in sib}
+    res = [None if r is None else r.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for r in residuals]
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    ptr = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])                                             # noqa: E731
+
+    def columns(entries):
+        xs = [None if e is None else e[0] for e in entries]
+        sp = [None if e is None else e[1] for e in entries]
+        bn = [None if e is None else e[2] for e in entries]
+        pick = lambda f: [None if e is None else f(e) for e in entries]                                                 # noqa: E731
+        return (ptr(xs), ptr(pick(lambda e: e[1].depthwise.weight.detach())),
+                ptr(pick(lambda e: e[1].pointwise.weight.shadow_bf16)), ptr(pick(lambda e: e[2].weight.detach())),
+                ptr(pick(lambda e: e[2].bias.detach())), ptr(pick(lambda e: e[2].running_mean)),
+                ptr(pick(lambda e: e[2].running_var)), I(*[0 if e is None else int(e[1].k) for e in entries]))
+
+    a, b = columns(main), columns(siblings)
+    _ops._lib.check(lib.xpt_sepconv_bn_multi_fwd(
+        n, *a, ptr(ydw_a), ptr(ypre_a), *b, ptr([ydw_b.get(j) for j in range(n)]), ptr([ypre_b.get(j) for j in range(n)]),
+        ptr([y_b.get(j) for j in range(n)]), ptr(res), ptr(y_a), float(BN_EPS), B, H, W, C, C, _ops._stream()),
+        "xpt_sepconv_bn_multi_fwd")
+    # ---- the unfused path's autograd graph around the pre-computed outputs
+    entries = list(main) + [siblings[j] for j in sib]
+    _ops._MultiDepthwise.precomputed = ydw_a + [ydw_b[j] for j in sib]
+    ys_dw = _ops.multi_depthwise([e[0] for e in entries], [e[1].depthwise.weight for e in entries])
+    sib_out = {}
+    if sib:
+        _MultiConv1x1Bn.precomputed = ([ypre_b[j] for j in sib], [y_b[j] for j in sib])
+        outs = _MultiConv1x1Bn.apply(len(sib), BN_EPS, *ys_dw[n:], *[siblings[j][1].pointwise.weight for j in sib],
+                                     *[siblings[j][2].weight for j in sib], *[siblings[j][2].bias for j in sib],
+                                     *[siblings[j][2].running_mean for j in sib], *[siblings[j][2].running_var for j in sib],
+                                     *([None] * len(sib)))
+        sib_out = dict(zip(sib, outs))
+    adds = [sib_out.get(j, residuals[j]) for j in range(n)]
+    _MultiConv1x1Bn.precomputed = (ypre_a, y_a)
+    outs = _MultiConv1x1Bn.apply(n, BN_EPS, *ys_dw[:n], *[e[1].pointwise.weight for e in main], *[e[2].weight for e in main],
+                                 *[e[2].bias for e in main], *[e[2].running_mean for e in main],
+                                 *[e[2].running_var for e in main], *adds)
+    return list(outs), [sib_out.get(j) for j in range(n)]
+
+
 class NormalCell(nn.Module):
     """_normal_a_cell -> concat([p, x1, x2, x3, x4, x5]) = 6 * filters channels."""
 
@@ -573,16 +661,29 @@ class NormalCell(nn.Module):
             fused_tail = _CELL_TAIL and hs[0].dtype == ps[0].dtype and hs[0].shape == ps[0].shape
             if not fused_tail and len(ps) < 4:
                 ps = (ps[0],) + tuple(_ops.fan_out(ps[1], 3))
-            y1 = _ops.multi_depthwise([hs[0], hs[0], ps[0], ps[0], ps[0]], [b.conv1.depthwise.weight for b in blocks])
-            z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
-            y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
-            # second pointwise stage in two launches: the right branches first, then the left ones with their adds
-            r1, r2 = multi_conv1x1_bn([y2[2], y2[4]], [self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight],
-                                      [self.right1.bn2, self.right2.bn2])
-            x1, x2, x5 = multi_conv1x1_bn([y2[0], y2[3], y2[1]],
-                                          [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight,
-                                           self.left5.conv2.pointwise.weight],
-                                          [self.left1.bn2, self.left2.bn2, self.left5.bn2], [r1, r2, hs[2]])
+            stage1_in = [hs[0], hs[0], ps[0], ps[0], ps[0]]
+            if _sep_stage_usable(stage1_in, [b.conv1 for b in blocks] + [b.conv2 for b in blocks],
+                                 [b.bn1 for b in blocks] + [b.bn2 for b in blocks]):
+                # each stage of the five branches is ONE launch (csrc/xpt_sepconv.hip): depthwise tile -> LDS -> matrix
+                # cores -> BatchNorm; the second stage adds the sibling branches (x1 = left1 + right1, x2 = left2 + right2)
+                # and h (x5 = left5 + h) in its epilogue
+                z1, _ = fused_sep_stage([(x, b.conv1, b.bn1) for x, b in zip(stage1_in, blocks)])
+                (x1, x2, x5), _ = fused_sep_stage(
+                    [(z1[0], self.left1.conv2, self.left1.bn2), (z1[3], self.left2.conv2, self.left2.bn2),
+                     (z1[1], self.left5.conv2, self.left5.bn2)],
+                    siblings=[(z1[2], self.right1.conv2, self.right1.bn2), (z1[4], self.right2.conv2, self.right2.bn2), None],
+                    residuals=[None, None, hs[2]])
+            else:
+                y1 = _ops.multi_depthwise(stage1_in, [b.conv1.depthwise.weight for b in blocks])
+                z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
+                y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
+                # second pointwise stage in two launches: the right branches first, then the left ones with their adds
+                r1, r2 = multi_conv1x1_bn([y2[2], y2[4]], [self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight],
+                                          [self.right1.bn2, self.right2.bn2])
+                x1, x2, x5 = multi_conv1x1_bn([y2[0], y2[3], y2[1]],
+                                              [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight,
+                                               self.left5.conv2.pointwise.weight],
+                                              [self.left1.bn2, self.left2.bn2, self.left5.bn2], [r1, r2, hs[2]])
             if fused_tail:
                 # concat([p, x1, x2, avg(h) + p, avg(p) + avg(p), x5]) and the consumers' relu: inputs (p, x1, x2, h, x5)
                 spec = (((0, 0, 1.0),), ((1, 0, 1.0),), ((2, 0, 1.0),), ((3, 1, 1.0), (0, 0, 1.0)), ((0, 1, 2.0),),
