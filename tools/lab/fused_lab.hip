@@ -79,6 +79,19 @@ __global__ void subsample(const float* __restrict__ in, float* __restrict__ out,
   out[i] = in[((long long)n * h + (long long)y * s) * w + (long long)x * s];
 }
 
+// calibration launches for PMC passes (FETCH_SIZE / WRITE_SIZE): known byte counts in this kernel family's access widths
+__global__ void calib_copy16(const float4* __restrict__ in, float4* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void calib_read12(const float* __restrict__ in, float* __restrict__ out, long long npix) {   // 12-byte pixels, one per lane
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < npix) {
+    const float a = in[3 * i], b = in[3 * i + 1], c = in[3 * i + 2];
+    if (a + b + c == 12345.678f) out[i] = a;
+  }
+}
+
 struct Run { std::vector<float> losses, dT; std::vector<std::vector<float>> dd; float fwd_us, bwd_us; };
 
 int main(int argc, char** argv) {
@@ -168,6 +181,18 @@ int main(int argc, char** argv) {
     fflush(stdout);
     return r;
   };
+  if (getenv("LAB_CALIB")) {
+    const long long n = 16LL << 20;                       // 256 MiB of float4
+    float4 *ci, *co;
+    CK(hipMalloc(&ci, n * 16)); CK(hipMalloc(&co, n * 16));
+    CK(hipMemset(ci, 0, n * 16));
+    for (int i = 0; i < 3; ++i) {
+      hipLaunchKernelGGL(calib_copy16, dim3((unsigned)(n / 256)), dim3(256), 0, 0, ci, co, n);
+      hipLaunchKernelGGL(calib_read12, dim3((unsigned)((n * 4 / 3 + 255) / 256)), dim3(256), 0, 0, (const float*)ci, (float*)co, n * 4 / 3);
+    }
+    CK(hipDeviceSynchronize());
+    printf("calibration: calib_copy16 reads %lld B and writes %lld B; calib_read12 reads %lld B\n", n * 16, n * 16, (n * 4 / 3) * 12);
+  }
   Run a, b;
   const bool do_old = strcmp(mode, "new") != 0, do_new = strcmp(mode, "old") != 0;
   if (do_old) a = run(false);
