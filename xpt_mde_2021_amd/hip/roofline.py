@@ -190,7 +190,8 @@ def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
             "fwd": {"launch_us": round(f_ms * 1e3, 3), "GBps": round(achieved, 2), "frac": round(achieved / hbm_peak_gbs, 4)},
             "bwd": {"kernel": "march_bwd_ms_kernel<0> + its finisher: losses AND gradients in one pass (the training step's march launch)",
                     "launch_us": round(b_ms * 1e3, 3), "GBps": round(achieved_b, 2), "frac": round(achieved_b / hbm_peak_gbs, 4),
-                    "algorithmic_bytes_per_launch": int(b_bytes), "bytes_per_warped_pixel": round((20 + 12 * N) / N, 3)},
+                    "algorithmic_bytes_per_launch": int(b_bytes), "bytes_per_warped_pixel": round((20 + 12 * N) / N, 3),
+                    "traffic": _pmc_traffic("march_bwd_ms_kernel<0>", shape)},
             "valu_note": "both launches are bound by vector-instruction issue, not by bytes: ~172 (forward) / ~336 (one-pass) "
                          "instructions per warped pixel row of a wave at 3.4-6 cycles each (DESIGN.md section 5, profiles/r03_lab_*)",
             "all": {k: {"launch_us": round(v[0] * 1e3, 3), "GBps": gbs(*v)} for k, v in extra.items()},
