@@ -335,8 +335,10 @@ def run(args):
 
     result = None
     step_graph = getattr(trainer, "_graph", None)
-    if step_graph is not None and getattr(step_graph, "library_path", False):
-        mode += " (library convolutions on the path: executed eagerly by design, DESIGN.md section 6)"
+    if step_graph is not None and getattr(step_graph, "library_path", False) and getattr(step_graph, "eager_fallback", False):
+        mode += " (library convolutions on the path and memset nodes in its capture: executed eagerly, DESIGN.md section 6)"
+    elif step_graph is not None and getattr(step_graph, "library_path", False):
+        mode += " (library convolutions on the path; captured: the graph audit found no memset node)"
     elif step_graph is not None and getattr(step_graph, "eager_fallback", False):
         mode += " (eager fallback: no captured step passed the replay check)"
     if getattr(trainer, "trains_flow_net", False):
@@ -358,6 +360,7 @@ def run(args):
                                    f"{LOSS_LABEL[args.nets] if args.nets != 'rigid' else ('stereo LOSS_RIGID_T2' if args.stereo else 'mono L1+SSIM+smoothness')}, 4 scales",
                        "global_batch": global_batch, "per_gpu_batch": args.batch, "mode": mode,
                        "parallelism": f"dp{world}", "ranks": (dist.get_world_size() if world > 1 else 1),
+                       "graph_nodes": getattr(step_graph, "census", None),
                        "first_loss": round(first_loss, 6), "final_loss": round(loss, 6),
                        "loss_decreased": bool(loss < first_loss)},
             "step_ms": step_ms,

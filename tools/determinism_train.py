@@ -28,7 +28,7 @@ dist.all_reduce = _counting_all_reduce
 mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
 use_aug = (sys.argv[2] if len(sys.argv) > 2 else "aug") == "aug"
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 12
-opts.CONV_DTYPE = "bf16"
+opts.CONV_DTYPE = os.environ.get("XPT_DET_DTYPE", "bf16")
 opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 8
 opts.TRAIN_MODE = mode
 torch.manual_seed(0)
@@ -48,6 +48,9 @@ if dist.is_initialized():
     print("PROCESS_GROUP", dist.get_backend(), dist.get_world_size(),
           ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else "-")
     print("ALLREDUCE_PER_STEP", " ".join(f"{a}+{s}" for a, s in per_step))
+graph = getattr(trainer, "_graph", None)
+print("CAPTURED", graph is not None and graph.graph is not None, "library" if getattr(graph, "library_path", False) else "own-kernels",
+      getattr(graph, "census", None))
 if mode == "distributed":
     print("TWO_PHASE", trainer._early_start is not None, type(trainer._graph.graph).__name__)
 print("LOSSES", mode, "aug" if use_aug else "noaug", " ".join(f"{v:.9f}" for v in losses))

@@ -87,7 +87,7 @@ for it in range(replays):
     total_bad += len(bad)
     print(f"[diff] replay {it}: loss {float(loss):.6f} (eager {loss_ref:.6f}); {len(bad)} of {len(names)} gradients off"
           + (": " + " ".join(bad[:12]) + " ... " + " ".join(bad[-4:]) if bad else ""), flush=True)
-print(f"[diff] library path (executed eagerly by design): {graph.library_path}")
+print(f"[diff] library path: {graph.library_path}; captured: {graph.graph is not None}; graph nodes: {getattr(graph, 'census', None)}")
 print(f"[diff] RESULT: {total_bad} gradient mismatches over {replays} replays; eager fallback: {graph.eager_fallback and not graph.library_path}; "
       f"repairs: {graph.repairs}", flush=True)
 sys.exit(4 if total_bad else 0)

@@ -281,20 +281,26 @@ class _StepGraph:
                 self.fn(self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if _lo.LIBRARY_CONV_CALLS[0] > library_before and not getattr(opts, "CAPTURE_LIBRARY_STEPS", False):
-            # The step went through MIOpen (fp32 mode, PWC-Net's dilated / transposed convolutions): such steps are NOT
-            # captured.  Solvers that zero a workspace do it with a memset node, and memset nodes of a captured graph
-            # write garbage from the second replay on with this runtime -- which solver the library
-            # picks varies from run to run, the failure can appear after the replay check, and it can be silent (a net
-            # whose gradient is all zeros).  Eager execution of the same step is correct; opts.CAPTURE_LIBRARY_STEPS = True
-            # restores the capture (with the replay check) for those who accept that.
+        self.library_path = _lo.LIBRARY_CONV_CALLS[0] > library_before
+        policy = getattr(opts, "CAPTURE_LIBRARY_STEPS", "audit")
+
+        def run_eagerly(why):
             import sys
             for t, s in zip(state, saved):
                 t.copy_(s)
-            print("[StepGraph] the step contains library (MIOpen) convolutions: it is executed eagerly, not captured",
+            print(f"[StepGraph] the step contains library (MIOpen) convolutions {why}: it is executed eagerly, not captured",
                   file=sys.stderr, flush=True)
-            self.library_path = self.eager_fallback = True
+            self.eager_fallback = True
             self.graph = None
+
+        if self.library_path and policy is False:
+            # The step went through MIOpen (fp32 mode, PWC-Net's dilated / transposed convolutions).  Solvers that zero a
+            # workspace do it with a memset node, and memset nodes of a captured graph write garbage from the second replay on
+            # with this runtime; which solver the library picks varies from run to run.  Round 2 therefore
+            # never captured such steps; since round 3 the captured graph is AUDITED (below) and a library step is captured
+            # exactly when its graph holds no memset node ("audit", the default).  False restores round 2's rule, True
+            # captures whatever the audit says.
+            run_eagerly("and opts.CAPTURE_LIBRARY_STEPS is False")
             return
         import torch.distributed as _dist
         # With a process group alive the collective library's watchdog thread polls events of (completed) collectives at its
@@ -326,7 +332,13 @@ class _StepGraph:
         for g in captured:
             for k, v in _ops.graph_census(g).items():
                 self.census[k] = self.census.get(k, 0) + v
-        if self.census.get("memset", 0) and not getattr(opts, "ALLOW_MEMSET_NODES", False):
+        if self.census.get("memset", 0) and self.library_path and policy != True:      # noqa: E712
+            # a library solver that clears its workspace with a memset was picked this time: this step is not replayable
+            del captured
+            self.static_out = None
+            run_eagerly(f"whose capture holds {self.census['memset']} memset node(s) ({self.census})")
+            return
+        if self.census.get("memset", 0) and not self.library_path and not getattr(opts, "ALLOW_MEMSET_NODES", False):
             for t, s_ in zip(state, saved):
                 t.copy_(s_)
             self.graph = None
