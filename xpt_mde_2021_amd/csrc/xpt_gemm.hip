@@ -5,10 +5,10 @@
 // The output is tiny (11x32 ... 1056x1056) and the reduction long, the shape the BLAS library serves worst (one or a
 // few workgroups walk the whole K loop: 19-67 us per call, 4.8 ms of a 26 ms step).  This kernel splits the reduction
 // over enough workgroups to fill the chip and finishes in the same launch:
-//   * one wave owns a 32x32 tile of dW and issues v_mfma_f32_32x32x2_f32 (f32 operands, f32 accumulate): its A operand
-//     is dy[k+h][co0 + r], its B operand x[k+h][ci0 + r] (r = lane & 31, h = lane >> 5), i.e. both are read straight
-//     from the row-major activations, coalesced, with no transposition and no LDS; bf16 -> f32 is a 16-bit shift, so
-//     the products are exact and only the accumulation rounds (tighter than a bf16 GEMM);
+//   * one wave owns a 32x32 tile of dW and issues v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate: the products
+//     of two bf16 are exact in f32, only the accumulation rounds).  The reduction index (pixels) is the slow axis of both
+//     row-major activations, so the rows are staged in LDS as they lie in memory (coalesced 16-byte loads) and read back
+//     transposed (ds_read_b64_tr_b16): lane (r, h) gets pixels 8h .. 8h+7 of channel r for A = dy and for B = x;
 //   * a workgroup = 4 waves = up to 4 tile quadrants (64x64, 64x32, 32x64) or, for narrow outputs, several interleaved
 //     slices of the reduction that are combined through LDS;
 //   * the reduction is split over gridDim.z workgroups per tile; each writes its partial tile to the workspace, and the
@@ -213,6 +213,20 @@ struct DxFuse {
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// two transposed LDS reads = one bf16 MFMA fragment: per 16-lane group ds_read_b64_tr_b16 takes 4 rows x 16 columns and
+// hands lane i the 4 rows of column i (csrc/xpt_conv_wgrad.hip uses the same reads for the k x k weight gradient)
+__device__ inline bf16x8 tr_pair(const char* lds, unsigned off0, unsigned off1) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + off1));
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
 #define DX_KC 64          // rows of W staged per chunk
 #define DX_LD 132         // LDS row pitch of the staged W slice in 16-bit elements (8 rows apart = 16 banks apart)
 
@@ -388,9 +402,12 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
   constexpr int NW = NWAVES, QA = TCO / 32, QB = TCI / 32, Q = QA * QB, KS = NW / Q, NT = NW * 64;
   constexpr int TILE = TCO * TCI;
   // rows staged per chunk: 32 / 48 / 32 KiB of LDS (BN fusion: a third buffer for ypre, 48 / 40 / 48 KiB)
-  constexpr int RC = BN ? (Q == 1 ? 256 : 128) : (Q == 4 ? 128 : 256);
+  // (a 64 x 64 tile on 8 waves = 2 k slices x 16 rows x XPT_PW_WGRAD pairs: the plan's 64 rows per workgroup are one chunk)
+  constexpr int RC = Q == 4 ? 64 : (BN ? (Q == 1 ? 256 : 128) : 256);
   constexpr int STAGE_BYTES = RC * (TCO + TCI + (BN ? TCO : 0)) * 2, RED_BYTES = (KS - 1) * Q * 4096;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES];
+  constexpr int DX_BYTES = VA > 1 ? 1024 + DX_KC * DX_LD * 2 : 0;
+  constexpr int SMEM_A = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_A > DX_BYTES ? SMEM_A : DX_BYTES];
   if constexpr (VA > 1)              // (scalar staging = odd channel counts: the host never asks for a data gradient)
   if ((int)blockIdx.z < dxf.slices) {                                    // a data-gradient workgroup (see DxFuse)
     static_assert(sizeof(smem) >= 1024 + DX_KC * DX_LD * 2, "the staged W slice must fit the staging buffers");
@@ -470,10 +487,17 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
     }
     __syncthreads();
   }
-  const float a_scale = BN ? sS[qa * 32 + r] : 1.f;
-  const unsigned short* myA = sA + h * TCO + qa * 32 + r;
-  const unsigned short* myB = sB + h * TCI + qb * 32 + r;
-  const unsigned short* myY = sY + h * TCO + qa * 32 + r;
+  // lane roles of the transposed reads: every lane supplies the address of 4 elements of one staged row
+  unsigned a_off[2], b_off[2];
+  {
+    const int li = lane & 15, q = li >> 2, p = li & 3, half = (lane >> 4) & 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pr = 8 * h + 4 * i + q;                     // row of the 16-row step
+      a_off[i] = (unsigned)((pr * TCO + qa * 32 + 16 * half + 4 * p) * 2);
+      b_off[i] = (unsigned)((pr * TCI + qb * 32 + 16 * half + 4 * p) * 2);
+    }
+  }
   for (long long k0 = k_begin; k0 < k_end; k0 += RC) {
     __syncthreads();                                        // the previous chunk's operand reads are done
     stage_store<VA, TCO, RC, NT>(sA, ga);
@@ -494,17 +518,26 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
         if (bn_tile) stage_load<VA, TCO, RC, NT>(gy, bn.ypre, cout, k0 + RC, k_end, co0, cout);
       }
     }
-    // row pairs ksub, ksub + KS, ... of the chunk (rows past k_end hold zeros); bounds are wave-uniform
+    // 16-row steps ksub, ksub + KS, ... of the chunk (rows past k_end hold zeros); bounds are wave-uniform.  Both
+    // operands come out of LDS transposed (ds_read_b64_tr_b16, see tr_pair): lane (r, h) gets rows 8h .. 8h+7 of column r,
+    // the fragment v_mfma_f32_32x32x16_bf16 wants -- RAW bf16 gradients: the BatchNorm scale is applied to the
+    // accumulator rows once, behind the loop.
     const long long left = k_end - k0;
-    const int pairs = left >= RC ? RC / 2 : (int)((left + 1) / 2);
-    for (int j = ksub; j < pairs; j += KS) {
-      const float a_raw = bf16_bits_to_f32(myA[2 * j * TCO]);
-      const float b = bf16_bits_to_f32(myB[2 * j * TCI]);
+    const int steps = left >= RC ? RC / 16 : (int)((left + 15) / 16);
+    for (int j = ksub; j < steps; j += KS) {
+      const bf16x8 fa = tr_pair((const char*)sA, a_off[0] + j * (32 * TCO), a_off[1] + j * (32 * TCO));
+      const bf16x8 fb = tr_pair((const char*)sB, b_off[0] + j * (32 * TCI), b_off[1] + j * (32 * TCI));
       if (BN && bn_sums) {
-        sum_dy += a_raw;
-        sum_dyy += a_raw * bf16_bits_to_f32(myY[2 * j * TCO]);
+        const s16x8 ua = __builtin_bit_cast(s16x8, fa);
+        const s16x8 uy = __builtin_bit_cast(s16x8, tr_pair((const char*)sY, a_off[0] + j * (32 * TCO), a_off[1] + j * (32 * TCO)));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float a_raw = bf16_bits_to_f32((unsigned short)ua[i]);
+          sum_dy += a_raw;
+          sum_dyy += a_raw * bf16_bits_to_f32((unsigned short)uy[i]);
+        }
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(BN ? a_raw * a_scale : a_raw, b, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
     }
   }
   if (BN && bn_sums) {       // fold the two row halves of the wave, park the k slice's column sums
@@ -550,6 +583,10 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
   }
 
   // accumulator element (reg i, lane) = dW[co0 + qa*32 + (i&3) + 8*(i>>2) + 4*h][ci0 + qb*32 + r]
+  if (BN && ksub == 0) {                                     // g = dy * s: the scale of the accumulator's row
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] *= sS[qa * 32 + (i & 3) + 8 * (i >> 2) + 4 * h];
+  }
   if (defer) {   // partial[split][cout][cin]: added up later, together with every other layer's, by xpt_reduce_partials
     if (ksub == 0 && ci_ok) {
       float* mine = partial + (long long)split * cout * cin;
