@@ -313,6 +313,7 @@ def run(args):
     for i in range(args.steps):
         out = trainer.run_a_batch(batches[i % len(batches)])
         marks[i + 1].record()
+    host_elapsed = time.perf_counter() - t0          # the host is done enqueueing here; the device may still be running
     sync()
     elapsed = time.perf_counter() - t0
     loss = float(out[1])
@@ -364,6 +365,7 @@ def run(args):
                        "first_loss": round(first_loss, 6), "final_loss": round(loss, 6),
                        "loss_decreased": bool(loss < first_loss)},
             "step_ms": step_ms,
+            "host_enqueue_ms_per_step": round(1000.0 * host_elapsed / args.steps, 4),
         }
         if args.nets == "rigid" and not (loss < first_loss) and args.warmup + args.steps >= 10:
             raise SystemExit(f"bench.py: the loss did not decrease over {args.warmup + args.steps} steps on the same "

@@ -401,6 +401,18 @@ int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* const* w, c
                             const float* const* beta, const float* const* mean, const float* const* var, float eps,
                             const void* const* residual, void* const* ypre, void* const* y, long long M, int cin, int cout,
                             long long pitch_x, void* stream);
+/* ... with SIBLING layers (keras nasnet._normal_a_cell: x1 = add([left1, right1]), both ending in a pointwise convolution
+ * + BatchNormalization of one shape): where sib_x[j] is not NULL job j computes
+ *   y_j = bn_j(x_j w_j^T) + bf16(bn'_j(sib_x_j sib_w_j^T)) (+ residual_j)
+ * in the same workgroups -- the sum never goes through memory -- and sib_ypre[j] receives the sibling's convolution output
+ * (its BatchNorm backward needs it).  Bit for bit what two launches (siblings first, then the main layers with the sibling
+ * outputs as residuals) produce.  The sib_* arrays hold n entries; entries of jobs without a sibling are NULL. */
+int xpt_pwconv_bn_multi_fwd_sib(int n, const void* const* x, const void* const* w, const float* const* gamma,
+                                const float* const* beta, const float* const* mean, const float* const* var, float eps,
+                                const void* const* residual, void* const* ypre, void* const* y, const void* const* sib_x,
+                                const void* const* sib_w, const float* const* sib_gamma, const float* const* sib_beta,
+                                const float* const* sib_mean, const float* const* sib_var, void* const* sib_ypre,
+                                long long M, int cin, int cout, long long pitch_x, void* stream);
 
 /* ------------------------------------------------------------------ a2: gradient fan-in of a multiply used activation
  * out [rows, C] = sum_i inputs[i] [rows, C] (row pitch pitches[i] >= C elements; n = 2..8; dtype 0 float32 / 1 bfloat16,

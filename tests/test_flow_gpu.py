@@ -149,8 +149,8 @@ def small_shapes():
 
 def test_flow_net_trains(gpu_device, small_shapes):
     """FLOW_NET with LOSS_FLOW (flowL2 + flow_reg, config-example.py:110-113): loss decreases, the L2 term reports
-    sum(w^2) / 2 and its gradient reaches the weights through the optimizer; the "graph" trainer runs this step eagerly
-    (ModelTrainerGraph.trains_flow_net) and must give the eager trainer's numbers."""
+    sum(w^2) / 2 and its gradient reaches the weights through the optimizer; the "graph" trainer captures this step when
+    the audit of its graph finds no memset node (else it runs it eagerly) and must follow the eager trainer's numbers."""
     losses = {}
     for mode, dtype in (("eager", "fp32"), ("graph", "fp32"), ("graph", "bf16")):
         hist, types, model, optimizer = _train(mode, dtype, opts.FLOW_NET, opts.LOSS_FLOW)

@@ -440,3 +440,63 @@ def test_multi_conv1x1_bn_matches_single_layers(gpu_device):
         assert torch.equal(a, b)
     for a, b in zip(pa, pb):
         assert torch.allclose(a, b, atol=1e-5 * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.parametrize("C,H,W", [(44, 8, 13), (88, 4, 7), (176, 4, 13), (22, 8, 13)])
+def test_sibling_pointwise_layers_ride_in_the_main_launch(gpu_device, C, H, W, monkeypatch):
+    """multi_conv1x1_bn(..., siblings=...): x1 = bn(pw(left1)) + bn(pw(right1)), x2 likewise, x5 = bn(pw(left5)) + h in ONE
+    forward launch and ONE backward launch == the right layers first and their outputs as residuals of the left ones
+    (keras nasnet._normal_a_cell): outputs, input gradients and parameter gradients bit for bit."""
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
+    dev = gpu_device
+    g = torch.Generator().manual_seed(C + W)
+    B, n = 2, 5
+
+    def make():
+        layers = []
+        gg = torch.Generator().manual_seed(11)
+        for _ in range(n):
+            w = torch.nn.Parameter((torch.randn(C, C, 1, 1, generator=gg) * 0.2).to(dev))
+            w.shadow_bf16 = w.detach().bfloat16()
+            w.flat_grad = torch.zeros_like(w)
+            bn = pn.FrozenBatchNorm(C).to(dev)
+            with torch.no_grad():
+                bn.weight.copy_(torch.rand(C, generator=gg) + 0.5); bn.bias.copy_(torch.randn(C, generator=gg) * 0.3)
+                bn.running_mean.copy_(torch.randn(C, generator=gg) * 0.2); bn.running_var.copy_(torch.rand(C, generator=gg) + 0.3)
+            bn.weight.flat_grad = torch.zeros(C, device=dev)
+            bn.bias.flat_grad = torch.zeros(C, device=dev)
+            layers.append((w, bn))
+        return layers
+
+    rnd = lambda: torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    xs0, h0, gys = [rnd() for _ in range(n)], rnd(), [rnd() for _ in range(3)]
+
+    def run(siblings):
+        layers = make()
+        xs = [x.clone().requires_grad_(True) for x in xs0]
+        h = h0.clone().requires_grad_(True)
+        (l1, l2, l5, r1, r2) = layers
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            if siblings:
+                ys = pn.multi_conv1x1_bn(xs[:3], [l1[0], l2[0], l5[0]], [l1[1], l2[1], l5[1]], [None, None, h],
+                                         siblings=[(xs[3], r1[0], r1[1]), (xs[4], r2[0], r2[1]), None])
+                assert "MultiConv1x1Bn" in type(ys[0].grad_fn).__name__
+            else:
+                rs = pn.multi_conv1x1_bn(xs[3:], [r1[0], r2[0]], [r1[1], r2[1]])
+                ys = pn.multi_conv1x1_bn(xs[:3], [l1[0], l2[0], l5[0]], [l1[1], l2[1], l5[1]], [rs[0], rs[1], h])
+        torch.autograd.backward(ys, gys)
+        ops.grad_sink.flush()
+        torch.cuda.synchronize()
+        grads = [x.grad.float() for x in xs] + [h.grad.float()]
+        params = [t.flat_grad.clone() for w, b in layers for t in (w, b.weight, b.bias)]
+        return [y.detach().float() for y in ys], grads, params
+
+    ya, ga, pa = run(True)
+    yb, gb, pb = run(False)
+    for a, b in zip(ya, yb):
+        assert torch.equal(a, b)
+    for a, b in zip(ga, gb):
+        assert torch.equal(a, b)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)

@@ -157,6 +157,10 @@ class VodeOptions(LossOptions):
     READER_PREFETCH = 2      # batches the TFRecord reader keeps ready ahead of the step (0: synchronous generator)
     READER_WORKERS = 4       # decode threads of the prefetching reader
     TRAIN_MODE = "graph"                      # "eager" | "graph" (hipGraph replay) | "distributed" (RCCL DP)
+    # steps with library (MIOpen) convolutions on the path -- fp32 mode, PWC-Net: "audit" = captured when the node audit of
+    # the captured graph finds no memset node (memset nodes replay wrongly on this runtime), True = captured regardless,
+    # False = always eager (round 2's rule)
+    CAPTURE_LIBRARY_STEPS = "audit"
     RAW_IMAGE_RES = {"kitti_raw": (375, 1242)}
 
     # ---- MI355X build switches (new; nothing to mirror in the reference)

@@ -229,18 +229,23 @@ def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx, ex
 
 
 class _MultiConv1x1Bn(torch.autograd.Function):
-    """n independent conv1x1 + BatchNorm (+ residual) layers of one shape: ONE forward launch (xpt_pwconv_bn_multi_fwd);
-    the backward runs the fused per-layer kernels of _Conv1x1BnBf16.  args = (n, eps, xs..., weights..., gammas...,
-    betas..., means..., vars..., residuals-or-None...)."""
+    """n independent conv1x1 + BatchNorm (+ residual) layers of one shape: ONE forward launch (xpt_pwconv_bn_multi_fwd) and
+    ONE backward launch.  Optionally some of them have a SIBLING: a further layer of the same shape whose BatchNorm output is
+    added to theirs (the two operands of a NASNet cell's `add`), evaluated inside the same launch
+    (xpt_pwconv_bn_multi_fwd_sib); the backward then runs all n + ns layers as one launch, a sibling with its main layer's
+    output gradient.  args = (n, eps, sib_of, xs..., weights..., gammas..., betas..., means..., vars... (n + ns each, the
+    siblings behind the main layers), residuals-or-None... (n)); sib_of[k] = the main layer sibling k adds to."""
 
     precomputed = None      # (ypres, ys) a fused branch-stage launch already produced (fused_sep_stage): consumed by the next forward
 
     @staticmethod
-    def forward(ctx, n, eps, *a):
+    def forward(ctx, n, eps, sib_of, *a):
         import ctypes
         lib = _ops._lib.load()
         pre, _MultiConv1x1Bn.precomputed = _MultiConv1x1Bn.precomputed, None
-        xs, ws_, gs, bs, ms, vs, rs = (a[i * n:(i + 1) * n] for i in range(7))
+        L = n + len(sib_of)
+        xs, ws_, gs, bs, ms, vs = (a[i * L:(i + 1) * L] for i in range(6))
+        rs = a[6 * L:6 * L + n]
         B, cin, H, W = xs[0].shape
         cout = ws_[0].shape[0]
         x2s = [_ops.as_rows(x) for x in xs]
@@ -251,17 +256,25 @@ class _MultiConv1x1Bn(torch.autograd.Function):
         if pre is not None:                    # the fused branch-stage launch computed this stage already
             ypres, ys = list(pre[0]), list(pre[1])
         else:
-            ypres = [torch.empty((M, cout), dtype=torch.bfloat16, device=xs[0].device) for _ in range(n)]
+            ypres = [torch.empty((M, cout), dtype=torch.bfloat16, device=xs[0].device) for _ in range(L)]
             ys = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=xs[0].device, memory_format=torch.channels_last)
                   for _ in range(n)]
             P = ctypes.c_void_p * n
-            ptr = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])
-            _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd(n, ptr(x2s), ptr(shadows), ptr([g.detach() for g in gs]),
-                                                        ptr([b.detach() for b in bs]), ptr(ms), ptr(vs), float(eps), ptr(res),
-                                                        ptr(ypres), ptr(ys), M, cin, cout, pitch, _ops._stream()),
-                            "xpt_pwconv_bn_multi_fwd")
+            ptr = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])           # noqa: E731
+            det = lambda ts: [None if t is None else t.detach() for t in ts]                # noqa: E731
+            main = (ptr(x2s[:n]), ptr(shadows[:n]), ptr(det(gs[:n])), ptr(det(bs[:n])), ptr(ms[:n]), ptr(vs[:n]), float(eps),
+                    ptr(res), ptr(ypres[:n]), ptr(ys))
+            if sib_of:
+                at = {j: n + k for k, j in enumerate(sib_of)}                                # main layer -> its sibling
+                pick = lambda ts: [ts[at[j]] if j in at else None for j in range(n)]         # noqa: E731
+                _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd_sib(
+                    n, *main, ptr(pick(x2s)), ptr(pick(shadows)), ptr(det(pick(gs))), ptr(det(pick(bs))), ptr(pick(ms)),
+                    ptr(pick(vs)), ptr(pick(ypres)), M, cin, cout, pitch, _ops._stream()), "xpt_pwconv_bn_multi_fwd_sib")
+            else:
+                _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd(n, *main, M, cin, cout, pitch, _ops._stream()),
+                                "xpt_pwconv_bn_multi_fwd")
         ctx.save_for_backward(*x2s, *shadows, *ypres, *[g.detach() for g in gs], *ms, *vs)
-        ctx.n = n
+        ctx.n, ctx.sib_of = n, tuple(sib_of)
         ctx.dims = (B, cin, H, W, cout, float(eps))
         ctx.dsts = [(w.flat_grad, g.flat_grad, b.flat_grad) for w, g, b in zip(ws_, gs, bs)]
         return tuple(ys)
@@ -269,18 +282,21 @@ class _MultiConv1x1Bn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *dys):
         import ctypes
-        n = ctx.n
+        n, sib_of = ctx.n, ctx.sib_of
+        L = n + len(sib_of)
         t = ctx.saved_tensors
-        x2s, shadows, ypres, gs, ms, vs = (t[i * n:(i + 1) * n] for i in range(6))
+        x2s, shadows, ypres, gs, ms, vs = (t[i * L:(i + 1) * L] for i in range(6))
         B, cin, H, W, cout, eps = ctx.dims
-        none = [None] * n
-        dres = [dys[j] if (dys[j] is not None and ctx.needs_input_grad[2 + 6 * n + j]) else None for j in range(n)]
+        none = [None] * L
+        dres = [dys[j] if (dys[j] is not None and ctx.needs_input_grad[3 + 6 * L + j]) else None for j in range(n)]
+        dys = list(dys) + [dys[j] for j in sib_of]            # a sibling sees its main layer's output gradient
+        need = [ctx.needs_input_grad[3 + j] for j in range(L)]
         if any(d is None for d in dys):                      # a branch without gradient: per-layer path
             dxs = [None if dys[j] is None else
                    _conv_bn_backward(x2s[j], shadows[j], ypres[j], gs[j], ms[j], vs[j], ctx.dims, ctx.dsts[j], dys[j],
-                                     ctx.needs_input_grad[2 + j]) for j in range(n)]
-            return (None, None, *dxs, *none, *none, *none, *none, *none, *dres)
-        # ONE launch for the n layers: g_j = dy_j * s_j, split-K partials of dW_j / dgamma_j / dbeta_j
+                                     need[j]) for j in range(L)]
+            return (None, None, None, *dxs, *none, *none, *none, *none, *none, *dres)
+        # ONE launch for the L layers: g_j = dy_j * s_j, split-K partials of dW_j / dgamma_j / dbeta_j
         lib = _ops._lib.load()
         sink = _ops.grad_sink
         dy2s = [_ops.as_rows(d.to(torch.bfloat16)) for d in dys]
@@ -290,46 +306,45 @@ class _MultiConv1x1Bn(torch.autograd.Function):
         for w_dst, g_dst, b_dst in ctx.dsts:
             wparts.append(sink.partials(w_dst, "conv1x1", nsplit * cout * cin))
             bparts.append(sink.partials(b_dst, "bnfuse", nsplit * 2 * cout))
-        P, LL = ctypes.c_void_p * n, ctypes.c_longlong * n
-        ptr = lambda ts: P(*[x.data_ptr() for x in ts])
+        P, LL = ctypes.c_void_p * L, ctypes.c_longlong * L
+        ptr = lambda ts: P(*[x.data_ptr() for x in ts])       # noqa: E731
         pitch_x = x2s[0].stride(0) if M > 1 else cin
-        need = [ctx.needs_input_grad[2 + j] for j in range(n)]
         vector_rows = (cout % 2 == 0 and cin % 2 == 0 and pitch_x % 2 == 0
                        and all(d.data_ptr() % 4 == 0 and (d.stride(0) if M > 1 else cout) % 2 == 0 for d in dy2s)
                        and all(x.data_ptr() % 4 == 0 for x in x2s))
         if _FUSED_DGRAD and vector_rows and all(s.is_contiguous() for s in shadows):
-            # ... and the n data gradients in the same launch (extra workgroups): no g, no batched GEMM launch
-            dx_all = torch.empty((n, M, cin), dtype=torch.bfloat16, device=dys[0].device)
+            # ... and the L data gradients in the same launch (extra workgroups): no g, no batched GEMM launch
+            dx_all = torch.empty((L, M, cin), dtype=torch.bfloat16, device=dys[0].device)
             _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_fused(
-                n, ptr(dy2s), LL(*[(d.stride(0) if M > 1 else cout) for d in dy2s]), ptr(ypres), ptr(x2s), ptr(shadows),
-                ptr(gs), ptr(vs), ptr(ms), eps, P(*[dx_all[j].data_ptr() if need[j] else None for j in range(n)]),
+                L, ptr(dy2s), LL(*[(d.stride(0) if M > 1 else cout) for d in dy2s]), ptr(ypres), ptr(x2s), ptr(shadows),
+                ptr(gs), ptr(vs), ptr(ms), eps, P(*[dx_all[j].data_ptr() if need[j] else None for j in range(L)]),
                 ptr(wparts), ptr(bparts), wparts[0].numel(), bparts[0].numel(), M, cout, cin, pitch_x, _ops._stream()),
                 "xpt_conv1x1_bn_multi_bwd_fused")
             for j, (w_dst, g_dst, b_dst) in enumerate(ctx.dsts):
                 sink.add(w_dst, wparts[j], 0, cout * cin, nsplit, cout * cin)
                 sink.add(b_dst, bparts[j], 0, cout, nsplit, 2 * cout)
                 sink.add(g_dst, bparts[j], cout, cout, nsplit, 2 * cout)
-            dxs = [dx_all[j].view(B, H, W, cin).permute(0, 3, 1, 2) if need[j] else None for j in range(n)]
-            return (None, None, *dxs, *none, *none, *none, *none, *none, *dres)
-        g_all = torch.empty((n, M, cout), dtype=torch.bfloat16, device=dys[0].device)
+            dxs = [dx_all[j].view(B, H, W, cin).permute(0, 3, 1, 2) if need[j] else None for j in range(L)]
+            return (None, None, None, *dxs, *none, *none, *none, *none, *none, *dres)
+        g_all = torch.empty((L, M, cout), dtype=torch.bfloat16, device=dys[0].device)
         _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_partials(
-            n, ptr(dy2s), LL(*[(d.stride(0) if M > 1 else cout) for d in dy2s]), ptr(ypres), ptr(x2s), ptr(gs), ptr(vs),
-            ptr(ms), eps, P(*[g_all[j].data_ptr() for j in range(n)]), ptr(wparts), ptr(bparts), wparts[0].numel(),
+            L, ptr(dy2s), LL(*[(d.stride(0) if M > 1 else cout) for d in dy2s]), ptr(ypres), ptr(x2s), ptr(gs), ptr(vs),
+            ptr(ms), eps, P(*[g_all[j].data_ptr() for j in range(L)]), ptr(wparts), ptr(bparts), wparts[0].numel(),
             bparts[0].numel(), M, cout, cin, pitch_x, _ops._stream()), "xpt_conv1x1_bn_multi_bwd_partials")
         for j, (w_dst, g_dst, b_dst) in enumerate(ctx.dsts):
             sink.add(w_dst, wparts[j], 0, cout * cin, nsplit, cout * cin)
             sink.add(b_dst, bparts[j], 0, cout, nsplit, 2 * cout)
             sink.add(g_dst, bparts[j], cout, cout, nsplit, 2 * cout)
-        if n >= 2 and all(need) and (n >= 3 or _is_stacked(shadows)):
-            # data gradients of all layers as ONE strided-batched GEMM: the g_j are already one [n, M, cout] buffer and the
+        if L >= 2 and all(need) and (L >= 3 or _is_stacked(shadows)):
+            # data gradients of all layers as ONE strided-batched GEMM: the g_j are already one [L, M, cout] buffer and the
             # weights sit equally spaced in the flat shadow buffer (FlatParameters groups them: stack_groups()), so the
-            # [n, cout, cin] operand is a strided view; one stack launch otherwise
-            dx_all = torch.bmm(g_all, _stacked_view(shadows))              # [n, M, cin]
-            dxs = [dx_all[j].view(B, H, W, cin).permute(0, 3, 1, 2) for j in range(n)]
+            # [L, cout, cin] operand is a strided view; one stack launch otherwise
+            dx_all = torch.bmm(g_all, _stacked_view(shadows))              # [L, M, cin]
+            dxs = [dx_all[j].view(B, H, W, cin).permute(0, 3, 1, 2) for j in range(L)]
         else:
             dxs = [torch.mm(g_all[j], shadows[j]).view(B, H, W, cin).permute(0, 3, 1, 2) if need[j] else None
-                   for j in range(n)]
-        return (None, None, *dxs, *none, *none, *none, *none, *none, *dres)
+                   for j in range(L)]
+        return (None, None, None, *dxs, *none, *none, *none, *none, *none, *dres)
 
 
 def _is_stacked(mats):
@@ -354,27 +369,49 @@ def _stacked_view(mats):
     return torch.stack(list(mats))
 
 
-def multi_conv1x1_bn(xs, weights, bns, residuals=None):
+def multi_conv1x1_bn(xs, weights, bns, residuals=None, siblings=None):
     """[bn_j(conv1x1(x_j, w_j)) (+ residual_j)] for layers of one shape: one forward launch when the fused path applies
-    (same conditions as conv1x1_bn), the per-layer calls otherwise."""
+    (same conditions as conv1x1_bn), the per-layer calls otherwise.  siblings[j] = (x, weight, bn) or None: a further layer
+    of the same shape whose result is added to layer j's (evaluated inside the same launches, forward and backward)."""
     n = len(xs)
     residuals = [None] * n if residuals is None else residuals
+    siblings = [None] * n if siblings is None else siblings
+    sib_of = tuple(j for j in range(n) if siblings[j] is not None)
+    sibs = [siblings[j] for j in sib_of]
+    all_x = list(xs) + [q[0] for q in sibs]
+    all_w = list(weights) + [q[1] for q in sibs]
+    all_bn = list(bns) + [q[2] for q in sibs]
     sink = _ops.grad_sink
     x0, w0 = xs[0], weights[0]
     cin = w0.shape[1]
-    ok = (_FUSE_CONV_BN and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD and 1 < n <= 6 and x0.is_cuda
+    ok = (_FUSE_CONV_BN and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD and 1 < len(all_x) <= 6 and x0.is_cuda
           and x0.dtype == torch.bfloat16 and torch.is_autocast_enabled() and torch.is_grad_enabled()
           and cin <= _PWCONV_MAX_CIN
-          and all(x.shape == x0.shape and x.dtype == x0.dtype for x in xs)
-          and all(w.shape == w0.shape and hasattr(w, "shadow_bf16") and sink.wants(w) for w in weights)
-          and all(sink.wants(b.weight) and sink.wants(b.bias) for b in bns))
+          and all(x.shape == x0.shape and x.dtype == x0.dtype for x in all_x)
+          and all(w.shape == w0.shape and hasattr(w, "shadow_bf16") and sink.wants(w) for w in all_w)
+          and all(sink.wants(b.weight) and sink.wants(b.bias) for b in all_bn))
     if ok:
-        rows = [_ops.as_rows(x) for x in xs]
+        rows = [_ops.as_rows(x) for x in all_x]
         ok = all(r.stride(0) == rows[0].stride(0) for r in rows)
+    if ok and sib_of and _MultiConv1x1Bn.precomputed is not None:
+        ok = False
     if not ok:
+        if sib_of:           # the siblings first, their outputs as residuals of the main layers (the same sums)
+            if any(residuals[j] is not None for j in sib_of):
+                raise WrongInputException("multi_conv1x1_bn: a layer with a sibling cannot take a residual as well")
+            outs = multi_conv1x1_bn([q[0] for q in sibs], [q[1] for q in sibs], [q[2] for q in sibs]) if len(sibs) > 1 \
+                else [conv1x1_bn(*sibs[0])]
+            residuals = list(residuals)
+            for j, r in zip(sib_of, outs):
+                residuals[j] = r
+            return multi_conv1x1_bn(xs, weights, bns, residuals)
+        if n == 1:
+            return [conv1x1_bn(xs[0], weights[0], bns[0], residuals[0])]
         return [conv1x1_bn(x, w, b, r) for x, w, b, r in zip(xs, weights, bns, residuals)]
-    return list(_MultiConv1x1Bn.apply(n, BN_EPS, *xs, *weights, *[b.weight for b in bns], *[b.bias for b in bns],
-                                      *[b.running_mean for b in bns], *[b.running_var for b in bns], *residuals))
+    if any(residuals[j] is not None for j in sib_of):
+        raise WrongInputException("multi_conv1x1_bn: a layer with a sibling cannot take a residual as well")
+    return list(_MultiConv1x1Bn.apply(n, BN_EPS, sib_of, *all_x, *all_w, *[b.weight for b in all_bn], *[b.bias for b in all_bn],
+                                      *[b.running_mean for b in all_bn], *[b.running_var for b in all_bn], *residuals))
 
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
@@ -382,6 +419,7 @@ _WIDE_CELL = __import__("os").environ.get("XPT_DEBUG_NARROW_CELL", "0") != "1"  
 _FUSE_FAN_IN = __import__("os").environ.get("XPT_DEBUG_SEPARATE_FAN_IN", "0") != "1"     # A/B: gradient fan-in as its own launch
 _FUSED_DGRAD = __import__("os").environ.get("XPT_DEBUG_GEMM_DGRAD", "0") != "1"     # A/B: data gradient of conv1x1+BN as a library GEMM launch
 _CELL_TAIL = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CELL_TAIL", "0") != "1"     # A/B: pools / add / concat / relu as separate launches
+_SIBLING_PW = __import__("os").environ.get("XPT_DEBUG_SEPARATE_SIBLINGS", "0") != "1"     # A/B: right branches' last pointwise layers as their own launch
 
 
 def _rectified_concat(spec, inputs):
@@ -640,8 +678,8 @@ class NormalCell(nn.Module):
         """Pointwise weights the wide cell consumes as one strided batch (order = the multi_conv1x1_bn calls below)."""
         blocks = (self.left1, self.left5, self.right1, self.left2, self.right2)
         return [[b.conv1.pointwise.weight for b in blocks],
-                [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight, self.left5.conv2.pointwise.weight],
-                [self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight]]
+                [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight, self.left5.conv2.pointwise.weight,
+                 self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight]]
 
     def forward(self, ip, p, taps):
         blocks = (self.left1, self.left5, self.right1, self.left2, self.right2)
@@ -677,13 +715,17 @@ class NormalCell(nn.Module):
                 y1 = _ops.multi_depthwise(stage1_in, [b.conv1.depthwise.weight for b in blocks])
                 z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
                 y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
-                # second pointwise stage in two launches: the right branches first, then the left ones with their adds
-                r1, r2 = multi_conv1x1_bn([y2[2], y2[4]], [self.right1.conv2.pointwise.weight, self.right2.conv2.pointwise.weight],
-                                          [self.right1.bn2, self.right2.bn2])
-                x1, x2, x5 = multi_conv1x1_bn([y2[0], y2[3], y2[1]],
-                                              [self.left1.conv2.pointwise.weight, self.left2.conv2.pointwise.weight,
-                                               self.left5.conv2.pointwise.weight],
-                                              [self.left1.bn2, self.left2.bn2, self.left5.bn2], [r1, r2, hs[2]])
+                # second pointwise stage in ONE launch: the right branches are the siblings of the left ones they are added
+                # to (x1 = left1 + right1, x2 = left2 + right2), x5 = left5 + h takes h as a residual
+                lefts = (self.left1, self.left2, self.left5)
+                rights = [(y2[2], self.right1.conv2.pointwise.weight, self.right1.bn2),
+                          (y2[4], self.right2.conv2.pointwise.weight, self.right2.bn2), None]
+                if not _SIBLING_PW:                      # A/B: the right branches first, as a launch of their own
+                    r1, r2 = multi_conv1x1_bn([q[0] for q in rights[:2]], [q[1] for q in rights[:2]],
+                                              [q[2] for q in rights[:2]])
+                x1, x2, x5 = multi_conv1x1_bn([y2[0], y2[3], y2[1]], [b.conv2.pointwise.weight for b in lefts],
+                                              [b.bn2 for b in lefts], [None, None, hs[2]] if _SIBLING_PW else [r1, r2, hs[2]],
+                                              siblings=rights if _SIBLING_PW else None)
             if fused_tail:
                 # concat([p, x1, x2, avg(h) + p, avg(p) + avg(p), x5]) and the consumers' relu: inputs (p, x1, x2, h, x5)
                 spec = (((0, 0, 1.0),), ((1, 0, 1.0),), ((2, 0, 1.0),), ((3, 1, 1.0), (0, 0, 1.0)), ((0, 1, 2.0),),

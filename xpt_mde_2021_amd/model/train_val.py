@@ -374,12 +374,13 @@ class _StepGraph:
                 self.graph = None
                 return self._capture(features, sig)
             self.graph = None
-            if not bool(int(__import__("os").environ.get("XPT_ALLOW_EAGER_FALLBACK", "0"))):
+            if not self.library_path and not bool(int(__import__("os").environ.get("XPT_ALLOW_EAGER_FALLBACK", "0"))):
                 # a captured step that does not reproduce its own eager execution is a defect, not an operating mode:
                 # stop (tests and bench.py fail on this); XPT_ALLOW_EAGER_FALLBACK=1 trades that for a ~4x slower run
                 raise RuntimeError(f"[StepGraph] the captured training step fails the replay check: {report}")
-            print(f"[StepGraph] captured step fails the replay check again ({report}): XPT_ALLOW_EAGER_FALLBACK=1, running "
-                  f"the step EAGERLY (about 4x slower)", file=sys.stderr, flush=True)
+            why = "library convolutions on the path" if self.library_path else "XPT_ALLOW_EAGER_FALLBACK=1"
+            print(f"[StepGraph] captured step fails the replay check again ({report}): {why}, running the step EAGERLY",
+                  file=sys.stderr, flush=True)
             self.eager_fallback = True
 
     def _replay_report(self, state, saved, replays=3):
@@ -517,13 +518,14 @@ class ModelTrainerGraph(ModelTrainer):
         super().__init__(model, loss_object, steps_per_epoch, stereo, augmenter, optimizer)
         self.set_name("Train (graph)")
         self._metrics = _MetricsGraph(stereo)
-        # Training PWC-Net itself (flowL2 / flow_reg) stays eager: the backward of its small pyramid levels goes through
-        # library solvers that do not survive hipGraph replay on this stack -- the replay check below catches them, but
-        # intermittently the step was found corrupted even after the fallback -- and the step is
-        # bound by MIOpen's dense convolutions, not by launches (24.1 ms captured vs 24.0 ms eager at batch 8, 128x384).
-        # JOINT_NET steps with the combined loss only run PWC-Net forward and are captured like the rigid step.
+        # Steps that TRAIN PWC-Net (flowL2 / flow_reg) run MIOpen's backward solvers on its small pyramid levels.  Round 2 kept
+        # them out of capture altogether (some solvers clear a workspace with a memset node, which does not survive replay on
+        # this stack: DESIGN.md section 6).  Since round 3 they are captured like every other step and it is the graph AUDIT
+        # (_StepGraph._capture: no memset node) plus the replay check that decide; opts.CAPTURE_LIBRARY_STEPS = False restores
+        # the eager rule.  Measured at batch 8, 128x384: 15.6 ms captured (932 kernel nodes, no memset) against 17.3 ms eager.
         weights = getattr(loss_object, "loss_weights", None) or {}
-        self.trains_flow_net = "flownet" in getattr(model, "models", {}) and any(k.startswith("flow") for k in weights)
+        self.trains_flow_net = ("flownet" in getattr(model, "models", {}) and any(k.startswith("flow") for k in weights)
+                                and getattr(opts, "CAPTURE_LIBRARY_STEPS", "audit") is False)
         self._graph = _StepGraph(self.train_a_step, state=self.optimizer_state, describe=self.describe_state,
                                  segments=self.state_segments, repair=self.repair_flagged,
                                  reference=self.augmenter is None)
