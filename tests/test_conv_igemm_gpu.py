@@ -53,9 +53,10 @@ def conv_plan():
 
 
 # 0: automatic choice; 901 / 902: the LDS-staged kernel (32 / 64 output channels per workgroup) forced on EVERY layer
-# shape (ragged tiles, residue classes, quad fold, 8-channel inputs); 110: the direct 32 x 32 kernel forced likewise
+# shape (ragged tiles, residue classes, quad fold, 8-channel inputs); 110: the direct 32 x 32 kernel forced likewise;
+# 911 / 912: the halo-tile kernel (32 / 64 output channels per workgroup) on every stride-1 layer, forward and data gradient
 @pytest.mark.parametrize("cin,cout,k,stride,H,W,ups", SHAPES)
-@pytest.mark.parametrize("plan", [0, 901, 902, 110])
+@pytest.mark.parametrize("plan", [0, 901, 902, 110, 911, 912])
 @pytest.mark.parametrize("batch", [2])
 def test_conv_fwd_bwd_matches_fp32_reference(gpu_device, conv_plan, cin, cout, k, stride, H, W, ups, batch, plan):
     from xpt_mde_2021_amd.hip import conv as xc

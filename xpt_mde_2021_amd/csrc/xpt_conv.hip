@@ -462,6 +462,181 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ halo-tile variant
+// Stride-1 layers on the large maps (the decoder from 32 x 104 up, forward and data gradient).  The im2col view of the two
+// kernels above fetches every input pixel once per tap (9 x for a 3 x 3 filter) and, in the LDS-staged kernel, pays one
+// memory round trip per 64 reduction elements with 4 RM MFMAs per wave behind it: those layers ran at one global-load
+// latency per chunk (22 - 33 us for 3 - 4 GFLOP and 20 MB).  Here a workgroup owns an 8 x 16 tile of output pixels and
+// TN = 32 RM output channels; per chunk of CC input channels it stages the tile's INPUT HALO ((8 + KH - 1) x (16 + KW - 1)
+// logical pixels, fewer physical ones when the input is up-sampled) and the weight slab [TN][taps][CC] in LDS -- every
+// input element is fetched once, in one burst of coalesced 16-byte loads -- and the taps are LDS address offsets:
+// taps x CC / 16 x RM MFMAs per wave and round trip (36 RM for a 3 x 3 filter on 64 channels).  Wave w owns rows 2w, 2w+1
+// of the tile; pixel decoding differs from the kernels above (tiles, not a flat pixel index), modes and epilogue are theirs.
+struct HaloPlan {
+  int CC;          // input channels per chunk (16 / 32 / 64)
+  int HR, WR;      // physical halo extent (upper bound used for the LDS layout)
+  int XP, WP;      // LDS pitches in bytes: per halo pixel, per weight row
+  int tiles_x, tiles_y;
+};
+
+template <int RM, bool K3>
+__global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs a, HaloPlan hp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char hl[];
+  constexpr int TN = 32 * RM;
+  const int XBYTES = hp.HR * hp.WR * hp.XP;
+  unsigned char* const lX = hl;
+  unsigned char* const lW = hl + XBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int T = a.KH * a.KW;
+
+  int tile = blockIdx.y;
+  const int txi = tile % hp.tiles_x; tile /= hp.tiles_x;
+  const int tyi = tile % hp.tiles_y;
+  const int b = tile / hp.tiles_y;
+  const int oh0 = tyi * 8, ow0 = txi * 16;
+  const int n0 = blockIdx.x * TN;
+
+  // logical input window of the tile and its physical footprint
+  const int lo_h = oh0 + a.off_h - (a.sgn > 0 ? 0 : a.KH - 1), lo_w = ow0 + a.off_w - (a.sgn > 0 ? 0 : a.KW - 1);
+  const int plo_h = lo_h >> a.shift, plo_w = lo_w >> a.shift;      // arithmetic shifts: floor for negative coordinates
+  const int WR = hp.WR, HPIX = hp.HR * WR;
+
+  // this lane's output pixel
+  int ty, tx;
+  if (a.quad) {
+    const int child = r & 3;
+    ty = 2 * wave + (child >> 1);
+    tx = 2 * (r >> 2) + (child & 1);
+  } else {
+    ty = 2 * wave + (r >> 4);
+    tx = r & 15;
+  }
+  const int oh = oh0 + ty, ow = ow0 + tx;
+  const bool pok = oh < a.OH && ow < a.OW;
+  const int base_h = (pok ? oh : oh0) + a.off_h, base_w = (pok ? ow : ow0) + a.off_w;
+
+  f32x16 acc[RM];
+#pragma unroll
+  for (int i = 0; i < RM; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+  // staging: vector v < xvecs of the halo = (pixel v >> lc, 8-channel group v & (cv8 - 1)); the vectors behind them are the
+  // weight slab, (row, tap, group).  cv8 is a power of two; the two divisions by small run-time numbers (halo width, taps)
+  // are exact float multiplications (an integer division costs ~40 instructions).  No register prefetch across chunks: it
+  // cost 200+ VGPRs (2 workgroups per CU); at ~90 VGPRs the other workgroups of the CU cover the round trip.  A thread
+  // issues SB loads before the first LDS store.  Rows of the slab past N are not staged (their accumulator rows are
+  // never stored).
+  const int CC = hp.CC, cv8 = CC >> 3, lc = cv8 == 8 ? 3 : (cv8 == 4 ? 2 : 1);
+  const int nrows = a.N - n0 < TN ? a.N - n0 : TN;
+  const int xvecs = HPIX * cv8, nvecs = xvecs + nrows * T * cv8;
+  const float inv_wr = 1.f / (float)WR, inv_t = 1.f / (float)T;
+  constexpr int SB = 8;
+  auto stage = [&](int c0) {
+    for (int v0 = tid; v0 < nvecs; v0 += 256 * SB) {
+      uint4 val[SB];
+      int lo[SB];
+#pragma unroll
+      for (int i = 0; i < SB; ++i) {
+        const int v = v0 + 256 * i;
+        const bool isx = v < xvecs;
+        const int u = isx ? v : v - xvecs;
+        const int cv = u & (cv8 - 1), rest = u >> lc;
+        const int c = c0 + cv * 8;
+        // halo vector: rest = pixel; slab vector: rest = row * T + tap
+        const int q = (int)(((float)rest + 0.5f) * (isx ? inv_wr : inv_t)), rem = rest - q * (isx ? WR : T);
+        const int pr = plo_h + q, pc = plo_w + rem;
+        const bool ok = v < nvecs && c < a.C && (!isx || (pr >= 0 && pr < a.PH && pc >= 0 && pc < a.PW));
+        const long long xoff = (((long long)b * a.PH + pr) * a.PW + pc) * a.xpitch + c;
+        const long long woff = ((long long)(n0 + q) * T + rem) * a.C + c;
+        const unsigned short* src = isx ? a.x + (ok ? xoff : 0) : a.w + (ok ? woff : 0);
+        const uint4 ld = *(const uint4*)src;
+        const unsigned keep = ok ? 0xffffffffu : 0u;
+        val[i] = make_uint4(ld.x & keep, ld.y & keep, ld.z & keep, ld.w & keep);
+        lo[i] = v >= nvecs ? -1 : (isx ? rest * hp.XP + cv * 16 : XBYTES + q * hp.WP + (rem * CC + cv * 8) * 2);
+      }
+#pragma unroll
+      for (int i = 0; i < SB; ++i)
+        if (lo[i] >= 0) *(uint4*)(hl + lo[i]) = val[i];
+    }
+  };
+
+  const int nchunks = (a.C + CC - 1) / CC;
+  for (int ck = 0; ck < nchunks; ++ck) {
+    if (ck > 0) __syncthreads();                     // the previous chunk's operand reads are done
+    stage(ck * CC);
+    __syncthreads();
+    const int c_left = a.C - ck * CC;
+    const int k16n = c_left >= CC ? CC >> 4 : (c_left + 15) >> 4;      // uniform: 16-channel steps of this chunk that hold data
+    // (a single 32-row tile with fewer than 32 output channels: rows past N are not in the slab -- any staged row will do)
+    const unsigned char* const wA = lW + ((RM == 1 && r >= nrows) ? 0 : r) * hp.WP + h * 16;
+    auto tap_mfma = [&](int kh, int kw) {
+      const int th = base_h + a.sgn * kh, tw = base_w + a.sgn * kw;
+      const int prow = (th >> a.shift) - plo_h, pcol = (tw >> a.shift) - plo_w;
+      const unsigned char* const xB = lX + (prow * WR + pcol) * hp.XP + h * 16;
+      const unsigned char* const wT = wA + (kh * a.KW + kw) * CC * 2;
+      for (int k16 = 0; k16 < k16n; ++k16) {
+        const uint4 fb = *(const uint4*)(xB + k16 * 32);
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+          const uint4 fa = *(const uint4*)(wT + 32 * i * hp.WP + k16 * 32);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
+                                                           acc[i], 0, 0, 0);
+        }
+      }
+    };
+    if constexpr (K3) {                                // 3 x 3 filters (the whole decoder): the taps unrolled
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) tap_mfma(kh, kw);
+    } else {
+      for (int kh = 0; kh < a.KH; ++kh)
+        for (int kw = 0; kw < a.KW; ++kw) tap_mfma(kh, kw);
+    }
+  }
+
+  // ---- epilogue (that of the kernels above): register q of tile i = channel n0 + 32 i + (q & 3) + 8 (q >> 2) + 4 h
+  const long long opix = a.quad ? ((long long)b * (a.OH >> 1) + (oh >> 1)) * (a.OW >> 1) + (ow >> 1)
+                                : ((long long)b * a.OH + oh) * a.OW + ow;
+  const bool vec_ok = (a.N % 4 == 0) && (a.ypitch % 4 == 0) && (((uintptr_t)a.y) % 8 == 0);
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+#pragma unroll
+    for (int qg = 0; qg < 4; ++qg) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * qg + e];
+      if (a.quad) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += __shfl_xor(v[e], 1, 64);
+          v[e] += __shfl_xor(v[e], 2, 64);
+        }
+      }
+      const int n = n0 + 32 * i + 8 * qg + 4 * h;
+      if (!pok || (a.quad && (r & 3) != 0) || n >= a.N) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (a.bias != nullptr && n + e < a.N) v[e] += a.bias[n + e];
+        v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+      }
+      unsigned short* dst = a.y + opix * a.ypitch + n;
+      if (vec_ok) {
+        uint2 pk;
+        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *(uint2*)dst = pk;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < a.N) dst[e] = f2bf(v[e]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight packer
 // One launch per step converts every dense convolution weight from its fp32 master copy (any strides; the flat parameter
 // buffer keeps them in channels_last order [N][KH][KW][C]) into the two bf16 operand layouts of the kernels above:
@@ -568,6 +743,44 @@ int launch_lds(const ConvArgs& a, long long Mmax, int classes, hipStream_t s) {
 
 int g_conv_plan = 0;   // 0 = automatic; otherwise RM*100 + RN*10 + log2(NKW), or 900 + RM for the LDS-staged kernel
 int g_conv_lds_min_blocks = 512;
+int g_conv_halo_min_tiles = 100;   // halo-tile kernel from this many 8 x 16 pixel tiles on (0 disables it)
+
+// the halo-tile kernel's plan for a layer; false when the layer is outside what it serves
+bool halo_plan(const ConvArgs& a, int rm, HaloPlan& hp, size_t& lds) {
+  if (a.so != 1 || a.xs != 1 || a.C % 8 != 0) return false;
+  if (a.quad && ((a.OH | a.OW) & 1)) return false;
+  const int T = a.KH * a.KW;
+  const int c16 = (a.C + 15) / 16 * 16;
+  hp.tiles_x = (a.OW + 15) / 16;
+  hp.tiles_y = (a.OH + 7) / 8;
+  const int rows = 8 + a.KH - 1, cols = 16 + a.KW - 1;
+  hp.HR = a.shift ? rows / 2 + 1 : rows;
+  hp.WR = a.shift ? cols / 2 + 1 : cols;
+  for (int cc = 64; cc >= 16; cc >>= 1) {
+    hp.CC = cc < c16 ? cc : c16;
+    hp.XP = hp.CC * 2 + 16;
+    hp.WP = T * hp.CC * 2 + 16;
+    const int xvecs = hp.HR * hp.WR * (hp.CC / 8), wvecs = 32 * rm * T * (hp.CC / 8);
+    const int wrows = (rm == 1 && a.N < 32) ? a.N : 32 * rm;      // rows past N are neither staged nor read
+    lds = (size_t)hp.HR * hp.WR * hp.XP + (size_t)wrows * hp.WP;
+    (void)xvecs; (void)wvecs;
+    if (lds <= 40 * 1024) return true;
+  }
+  return false;
+}
+
+template <int RM>
+int launch_halo(const ConvArgs& a, const HaloPlan& hp, size_t lds, hipStream_t s) {
+  const long long gy = (long long)a.B * hp.tiles_y * hp.tiles_x;
+  if (gy > 65535) return XPT_ERR_SHAPE;
+  const dim3 grid((a.N + 32 * RM - 1) / (32 * RM), (unsigned)gy);
+  XPT_BEGIN_LAUNCH();
+  if (a.KH == 3 && a.KW == 3)
+    hipLaunchKernelGGL((conv_halo_kernel<RM, true>), grid, dim3(256), lds, s, a, hp);
+  else
+    hipLaunchKernelGGL((conv_halo_kernel<RM, false>), grid, dim3(256), lds, s, a, hp);
+  return xpt_launch_status();
+}
 
 int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
   const int classes = a.xs * a.xs;
@@ -576,18 +789,35 @@ int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
   const long long ntile = (a.N + 31) / 32, mtile = (Mmax + 31) / 32;
   const long long waves11 = ntile * mtile * classes;
   int rm = 1, rn = 1, nkw = 1;
-  if (g_conv_plan == 901) return launch_lds<1>(a, Mmax, classes, s);
-  if (g_conv_plan == 902) return launch_lds<2>(a, Mmax, classes, s);
-  if (!g_conv_plan && g_conv_lds_min_blocks > 0) {
+  int plan = g_conv_plan;
+  if ((!plan && g_conv_halo_min_tiles > 0) || plan == 911 || plan == 912) {
+    // large stride-1 maps: the halo-tile kernel (every input element fetched once per workgroup, taps as LDS offsets)
+    const int hrm = plan == 912 ? 2 : 1;       // (automatic: 32 output channels per workgroup -- more, smaller workgroups won on every layer)
+    HaloPlan hp;
+    size_t lds = 0;
+    if (halo_plan(a, hrm, hp, lds) && (long long)a.B * hp.tiles_y * hp.tiles_x <= 65535) {
+      const long long tiles = (long long)a.B * hp.tiles_y * hp.tiles_x * ((a.N + 32 * hrm - 1) / (32 * hrm));
+      // measured hot (tools/hot_replay.py, batch 8, forward and data gradient of every decoder layer): faster than the two
+      // kernels above on every stride-1 layer with at least ~100 tiles and at most 256 reduction channels (13.9 - 30 us against
+      // 22 - 70 us); slower on the 432- / 1056-channel layers (17 - 33 chunks of one round trip each on 16 - 128 tiles) and
+      // on PoseNet's 2 x 7 maps
+      if (plan || (tiles >= g_conv_halo_min_tiles && a.C <= 256))
+        return hrm == 2 ? launch_halo<2>(a, hp, lds, s) : launch_halo<1>(a, hp, lds, s);
+    }
+    plan = 0;                      // (a forced halo plan on a layer it does not serve: the automatic choice)
+  }
+  if (plan == 901) return launch_lds<1>(a, Mmax, classes, s);
+  if (plan == 902) return launch_lds<2>(a, Mmax, classes, s);
+  if (!plan && g_conv_lds_min_blocks > 0) {
     // large maps: the LDS-staged kernel (coalesced staging instead of 32 cache lines per fragment load)
     const int lrm = a.N > 32 ? 2 : 1;
     const long long blocks = ((a.N + 32 * lrm - 1) / (32 * lrm)) * ((Mmax + 127) / 128) * classes;
     if (blocks >= g_conv_lds_min_blocks) return lrm == 2 ? launch_lds<2>(a, Mmax, classes, s) : launch_lds<1>(a, Mmax, classes, s);
   }
-  if (g_conv_plan) {
-    rm = g_conv_plan / 100;
-    rn = (g_conv_plan / 10) % 10;
-    nkw = 1 << (g_conv_plan % 10);
+  if (plan) {
+    rm = plan / 100;
+    rn = (plan / 10) % 10;
+    nkw = 1 << (plan % 10);
   } else {
     // measured per layer (tools/bench_conv.py, batch 8): 64 x 64 wave tiles pay when the output has at least two
     // 32-channel tiles AND the launch still fills the chip (4 MFMAs per 4 fragment loads); everything else runs best on
@@ -616,6 +846,10 @@ int dispatch_igemm(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" int xpt_conv2d_tune(int plan) {
+  if (plan <= -100000) {        // -100000 - n: minimum tiles for the halo-tile kernel (n = 0 disables it)
+    g_conv_halo_min_tiles = -plan - 100000;
+    return XPT_OK;
+  }
   if (plan <= -1000) {          // -1000 - n: minimum workgroups for the LDS-staged kernel (n = 0 disables it)
     g_conv_lds_min_blocks = -plan - 1000;
     return XPT_OK;
