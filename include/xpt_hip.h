@@ -406,13 +406,15 @@ int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* const* w, c
  *   y_j = bn_j(x_j w_j^T) + bf16(bn'_j(sib_x_j sib_w_j^T)) (+ residual_j)
  * in the same workgroups -- the sum never goes through memory -- and sib_ypre[j] receives the sibling's convolution output
  * (its BatchNorm backward needs it).  Bit for bit what two launches (siblings first, then the main layers with the sibling
- * outputs as residuals) produce.  The sib_* arrays hold n entries; entries of jobs without a sibling are NULL. */
+ * outputs as residuals) produce.  The sib_* arrays hold n entries (entries of jobs without a sibling are NULL) and may all
+ * be NULL.  pitch_y: row pitch of every y[j] in elements (0 = cout): the jobs of the "spatial" _adjust_block write the two
+ * halves of ONE [M, 2 cout] tensor (y[1] = y[0] + cout, pitch_y = 2 cout; no residuals then); ypre stays dense. */
 int xpt_pwconv_bn_multi_fwd_sib(int n, const void* const* x, const void* const* w, const float* const* gamma,
                                 const float* const* beta, const float* const* mean, const float* const* var, float eps,
                                 const void* const* residual, void* const* ypre, void* const* y, const void* const* sib_x,
                                 const void* const* sib_w, const float* const* sib_gamma, const float* const* sib_beta,
                                 const float* const* sib_mean, const float* const* sib_var, void* const* sib_ypre,
-                                long long M, int cin, int cout, long long pitch_x, void* stream);
+                                long long M, int cin, int cout, long long pitch_x, long long pitch_y, void* stream);
 
 /* ------------------------------------------------------------------ a2: gradient fan-in of a multiply used activation
  * out [rows, C] = sum_i inputs[i] [rows, C] (row pitch pitches[i] >= C elements; n = 2..8; dtype 0 float32 / 1 bfloat16,

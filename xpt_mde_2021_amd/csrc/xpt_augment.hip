@@ -84,11 +84,14 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
     float* __restrict__ dst = a.img_out[which];
     const long long total = (long long)a.n_img * H * W;
     const float sy = (d.y2 - d.y1) / (float)(H > 1 ? H - 1 : 1), sx = (d.x2 - d.x1) / (float)(W > 1 ? W - 1 : 1);
-    for (long long p = (long long)blk * 256 + threadIdx.x; p < total; p += (long long)a.img_blocks * 256) {
-      const int j = (int)(p % W);
-      const long long r = p / W;
-      const int i = (int)(r % H);
-      const long long n = r / H;
+    // (pixel index in 32 bits -- the launcher refuses 2^31 pixels or more --: the three 64-bit divisions of the decomposition
+    //  were two thirds of this kernel's instructions)
+    const unsigned total32 = (unsigned)total, step32 = a.img_blocks * 256u;
+    for (unsigned p = blk * 256u + threadIdx.x; p < total32; p += step32) {
+      const unsigned r = p / (unsigned)W;
+      const int j = (int)(p - r * (unsigned)W);
+      const unsigned n = r / (unsigned)H;
+      const int i = (int)(r - n * (unsigned)H);
       const int jj = d.flip ? W - 1 - j : j;
       // corner-aligned sample position (crop_and_resize): y = (y1 + (y2 - y1) i / (H - 1)) (H - 1)
       const float fy = (d.y1 + sy * (float)i) * (float)(H - 1), fx = (d.x1 + sx * (float)jj) * (float)(W - 1);
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
       const int y0 = (int)y0f, x0 = (int)x0f;
       const float wy = fy - y0f, wx = fx - x0f;
       float c[3] = {0.f, 0.f, 0.f};
-      const float* base = src + n * (long long)H * W * 3;
+      const float* base = src + (long long)n * H * W * 3;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int yy = y0 + (t >> 1), xx = x0 + (t & 1);
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
         c[0] += q[0] * w_; c[1] += q[1] * w_; c[2] += q[2] * w_;
       }
       if (d.jit) jitter(c, d.gamma, d.sat);
-      float* o = dst + p * 3;
+      float* o = dst + (long long)p * 3;
       o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
     }
     return;
@@ -116,15 +119,16 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
   if (blk < a.depth_blocks) {                       // ground-truth depth: nearest sample of the same box, never flipped
     const long long total = (long long)a.n_depth * H * W;
     const float sy = (d.y2 - d.y1) / (float)(H > 1 ? H - 1 : 1), sx = (d.x2 - d.x1) / (float)(W > 1 ? W - 1 : 1);
-    for (long long p = (long long)blk * 256 + threadIdx.x; p < total; p += (long long)a.depth_blocks * 256) {
-      const int j = (int)(p % W);
-      const long long r = p / W;
-      const int i = (int)(r % H);
-      const long long n = r / H;
+    const unsigned total32 = (unsigned)total, step32 = a.depth_blocks * 256u;
+    for (unsigned p = blk * 256u + threadIdx.x; p < total32; p += step32) {
+      const unsigned r = p / (unsigned)W;
+      const int j = (int)(p - r * (unsigned)W);
+      const unsigned n = r / (unsigned)H;
+      const int i = (int)(r - n * (unsigned)H);
       const float fy = (d.y1 + sy * (float)i) * (float)(H - 1), fx = (d.x1 + sx * (float)j) * (float)(W - 1);
       const int yy = (int)nearbyintf(fy), xx = (int)nearbyintf(fx);
       const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-      const float v = a.depth[n * (long long)H * W + (long long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+      const float v = a.depth[(long long)n * H * W + (long long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
       a.depth_out[p] = ok ? v : 0.f;
     }
     return;
@@ -240,7 +244,8 @@ extern "C" int xpt_augment(const float* u, float* params, const float* img0, flo
       (pose0 == nullptr) != (pose0_out == nullptr) || (pose1 == nullptr) != (pose1_out == nullptr) ||
       (stereo == nullptr) != (stereo_out == nullptr))
     return XPT_ERR_NULL;
-  if (!(p_crop > 0.f) || (long long)n_img * H * W >= (1LL << 40)) return XPT_ERR_ARG;
+  if (!(p_crop > 0.f) || (long long)n_img * H * W >= (1LL << 31) - (1LL << 24) || (long long)n_depth * H * W >= (1LL << 31) - (1LL << 24))
+    return XPT_ERR_ARG;
   AugArgs a{};
   a.u = u; a.params = params;
   a.img[0] = img0; a.img_out[0] = img0_out; a.img[1] = img1; a.img_out[1] = img1_out;

@@ -121,7 +121,8 @@ template <int V, int VO, int KW = 1>
 __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, const unsigned short* __restrict__ w,
                                           const PwBn& bn, const unsigned short* __restrict__ residual,
                                           unsigned short* __restrict__ ypre, unsigned short* __restrict__ y,
-                                          const PwSibling& sib, long long M, int cin, int cout, long long pitch_x) {
+                                          const PwSibling& sib, long long M, int cin, int cout, long long pitch_x,
+                                          long long pitch_y) {
   constexpr int NTH = KW == 1 ? 64 : 256;                // threads that share the store phase of one tile
   constexpr int CPR = 32 / VO, CHUNKS = 32 * CPR, ITER = (CHUNKS + NTH - 1) / NTH;
   constexpr int TILES = KW == 1 ? 4 : 1;
@@ -226,7 +227,7 @@ __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, 
     }
     const long long o = (m0 + row) * cout + n0 + col;
     *(ovec_t*)(ypre + o) = pre_v;
-    *(ovec_t*)(y + o) = y_v;
+    *(ovec_t*)(y + (m0 + row) * pitch_y + n0 + col) = y_v;       // (y may be a channel slice of a wider tensor)
     if (has_sib) *(ovec_t*)(sib.ypre + o) = pre2_v;
   }
 }
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void pwconv_bn_fwd_kernel(const unsigned short
                                                              unsigned short* __restrict__ y, long long M, int cin,
                                                              int cout, long long pitch_x) {
   const PwSibling none{};
-  pwconv_bn_fwd_body<V, VO, KW>(x, w, bn, residual, ypre, y, none, M, cin, cout, pitch_x);
+  pwconv_bn_fwd_body<V, VO, KW>(x, w, bn, residual, ypre, y, none, M, cin, cout, pitch_x, cout);
 }
 
 // up to 6 independent layers of one shape (the branch convolutions of a cell stage): job = blockIdx.z
@@ -256,9 +257,10 @@ struct PwMulti {
 
 template <int V, int VO>
 __global__ __launch_bounds__(256) void pwconv_bn_multi_fwd_kernel(PwMulti m, long long M, int cin, int cout,
-                                                                   long long pitch_x) {
+                                                                   long long pitch_x, long long pitch_y) {
   const int j = blockIdx.z;
-  pwconv_bn_fwd_body<V, VO>(m.x[j], m.w[j], m.bn[j], m.residual[j], m.ypre[j], m.y[j], m.sib[j], M, cin, cout, pitch_x);
+  pwconv_bn_fwd_body<V, VO>(m.x[j], m.w[j], m.bn[j], m.residual[j], m.ypre[j], m.y[j], m.sib[j], M, cin, cout, pitch_x,
+                            pitch_y);
 }
 
 // widest vector (elements) of the output-side tensors: cout and every base must allow it
@@ -299,9 +301,10 @@ static int pwconv_multi_launch(int n, const void* const* x, const void* const* w
                                const void* const* residual, void* const* ypre, void* const* y, const void* const* sib_x,
                                const void* const* sib_w, const float* const* sib_gamma, const float* const* sib_beta,
                                const float* const* sib_mean, const float* const* sib_var, void* const* sib_ypre,
-                               long long M, int cin, int cout, long long pitch_x, void* stream) {
+                               long long M, int cin, int cout, long long pitch_x, long long pitch_y, void* stream) {
   if (n < 1 || n > PW_MAX_JOBS) return XPT_ERR_ARG;
-  if (M <= 0 || cin <= 0 || cout <= 0 || pitch_x < cin) return XPT_ERR_SHAPE;
+  if (pitch_y == 0) pitch_y = cout;
+  if (M <= 0 || cin <= 0 || cout <= 0 || pitch_x < cin || pitch_y < cout) return XPT_ERR_SHAPE;
   int v = 8, vo = 8;
   PwMulti m{};
   for (int j = 0; j < n; ++j) {
@@ -314,7 +317,8 @@ static int pwconv_multi_launch(int n, const void* const* x, const void* const* w
                      ((uintptr_t)w[j]) % (2 * v) != 0 ||
                      (sib && (((uintptr_t)sib_x[j]) % (2 * v) != 0 || ((uintptr_t)sib_w[j]) % (2 * v) != 0))))
       v >>= 1;
-    const int o = out_width(cout, {residual[j], ypre[j], y[j], sib ? sib_ypre[j] : nullptr});
+    int o = out_width(cout, {residual[j], ypre[j], y[j], sib ? sib_ypre[j] : nullptr});
+    while (o > 1 && pitch_y % o != 0) o >>= 1;
     if (o < vo) vo = o;
     m.x[j] = (const unsigned short*)x[j];
     m.w[j] = (const unsigned short*)w[j];
@@ -330,11 +334,14 @@ static int pwconv_multi_launch(int n, const void* const* x, const void* const* w
   const long long mblocks = (M + 127) / 128;
   if (mblocks > 65535) return XPT_ERR_SHAPE;
   const dim3 grid((cout + 31) / 32, (unsigned)mblocks, n);
+  if (pitch_y != cout)                          // residuals are dense [M, cout] tensors; with a pitched y there are none
+    for (int j = 0; j < n; ++j)
+      if (residual[j]) return XPT_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
 #define XPT_PW_CASE(VV, VVO)                                                                                         \
   if (v == VV && vo == VVO)                                                                                          \
-    hipLaunchKernelGGL((pwconv_bn_multi_fwd_kernel<VV, VVO>), grid, dim3(256), 0, s, m, M, cin, cout, pitch_x);
+    hipLaunchKernelGGL((pwconv_bn_multi_fwd_kernel<VV, VVO>), grid, dim3(256), 0, s, m, M, cin, cout, pitch_x, pitch_y);
   XPT_PW_PAIRS(XPT_PW_CASE)
 #undef XPT_PW_CASE
   return xpt_launch_status();
@@ -347,7 +354,7 @@ extern "C" int xpt_pwconv_bn_multi_fwd(int n, const void* const* x, const void* 
   XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(gamma); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(mean);
   XPT_CHECK_PTR(var); XPT_CHECK_PTR(residual); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(y);
   return pwconv_multi_launch(n, x, w, gamma, beta, mean, var, eps, residual, ypre, y, nullptr, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, nullptr, M, cin, cout, pitch_x, stream);
+                             nullptr, nullptr, nullptr, M, cin, cout, pitch_x, 0, stream);
 }
 
 /* The same launch with SIBLING layers: where sib_x[j] is not NULL, job j computes
@@ -362,11 +369,11 @@ extern "C" int xpt_pwconv_bn_multi_fwd_sib(int n, const void* const* x, const vo
                                            const float* const* sib_gamma, const float* const* sib_beta,
                                            const float* const* sib_mean, const float* const* sib_var,
                                            void* const* sib_ypre, long long M, int cin, int cout, long long pitch_x,
-                                           void* stream) {
+                                           long long pitch_y, void* stream) {
   XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(gamma); XPT_CHECK_PTR(beta); XPT_CHECK_PTR(mean);
-  XPT_CHECK_PTR(var); XPT_CHECK_PTR(residual); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(y); XPT_CHECK_PTR(sib_x);
+  XPT_CHECK_PTR(var); XPT_CHECK_PTR(residual); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(y);
   return pwconv_multi_launch(n, x, w, gamma, beta, mean, var, eps, residual, ypre, y, sib_x, sib_w, sib_gamma, sib_beta,
-                             sib_mean, sib_var, sib_ypre, M, cin, cout, pitch_x, stream);
+                             sib_mean, sib_var, sib_ypre, M, cin, cout, pitch_x, pitch_y, stream);
 }
 
 extern "C" int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamma, const float* beta, const float* mean,

@@ -90,7 +90,7 @@ SIGNATURES = {
     "xpt_avgpool3_same": (_i, [_p, ctypes.c_longlong, _p, _i, _i, _i, _i, _f, _i, _i, _p]),
     "xpt_pwconv_bn_multi_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, ctypes.c_longlong, _i, _i, ctypes.c_longlong, _p]),
     "xpt_pwconv_bn_multi_fwd_sib": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                         ctypes.c_longlong, _i, _i, ctypes.c_longlong, _p]),
+                                         ctypes.c_longlong, _i, _i, ctypes.c_longlong, ctypes.c_longlong, _p]),
     "xpt_corr_cost_channels": (_i, [_i, _i]),
     "xpt_corr_cost_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "xpt_corr_cost_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -269,7 +269,7 @@ class _MultiConv1x1Bn(torch.autograd.Function):
                 pick = lambda ts: [ts[at[j]] if j in at else None for j in range(n)]         # noqa: E731
                 _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd_sib(
                     n, *main, ptr(pick(x2s)), ptr(pick(shadows)), ptr(det(pick(gs))), ptr(det(pick(bs))), ptr(pick(ms)),
-                    ptr(pick(vs)), ptr(pick(ypres)), M, cin, cout, pitch, _ops._stream()), "xpt_pwconv_bn_multi_fwd_sib")
+                    ptr(pick(vs)), ptr(pick(ypres)), M, cin, cout, pitch, 0, _ops._stream()), "xpt_pwconv_bn_multi_fwd_sib")
             else:
                 _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd(n, *main, M, cin, cout, pitch, _ops._stream()),
                                 "xpt_pwconv_bn_multi_fwd")
@@ -412,6 +412,82 @@ def multi_conv1x1_bn(xs, weights, bns, residuals=None, siblings=None):
         raise WrongInputException("multi_conv1x1_bn: a layer with a sibling cannot take a residual as well")
     return list(_MultiConv1x1Bn.apply(n, BN_EPS, sib_of, *all_x, *all_w, *[b.weight for b in all_bn], *[b.bias for b in all_bn],
                                       *[b.running_mean for b in all_bn], *[b.running_var for b in all_bn], *residuals))
+
+
+class _SpatialAdjustBn(torch.autograd.Function):
+    """bn(concat([conv1x1(p1, w1), conv1x1(p2, w2)])) of the "spatial" _adjust_block in ONE launch each way: the two
+    convolutions are two jobs of the multi-layer pointwise kernel that write the two channel halves of one tensor (their
+    BatchNorm parameters are the halves of the block's BatchNorm) -- instead of two GEMMs, a concat and a BatchNorm launch
+    forward, and a BatchNorm-backward launch plus two weight-gradient launches backward."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, w1, w2, gamma, beta, mean, var, eps, halves):
+        import ctypes
+        lib = _ops._lib.load()
+        B, cin, H, W = p1.shape
+        half = w1.shape[0]
+        x2s = [_ops.as_rows(p1), _ops.as_rows(p2)]
+        M = x2s[0].shape[0]
+        pitch = x2s[0].stride(0) if M > 1 else cin
+        shadows = [w.shadow_bf16.reshape(half, cin) for w in (w1, w2)]
+        y = torch.empty((B, 2 * half, H, W), dtype=torch.bfloat16, device=p1.device, memory_format=torch.channels_last)
+        ypres = [torch.empty((M, half), dtype=torch.bfloat16, device=p1.device) for _ in range(2)]
+        g_, b_ = gamma.detach(), beta.detach()
+        P = ctypes.c_void_p * 2
+        sl = lambda t: P(t[:half].data_ptr(), t[half:].data_ptr())       # noqa: E731
+        _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd_sib(
+            2, P(*[x.data_ptr() for x in x2s]), P(*[q.data_ptr() for q in shadows]), sl(g_), sl(b_), sl(mean), sl(var), float(eps),
+            P(None, None), P(*[q.data_ptr() for q in ypres]), P(y.data_ptr(), y.data_ptr() + 2 * half), None, None, None, None,
+            None, None, None, M, cin, half, pitch, 2 * half, _ops._stream()), "xpt_pwconv_bn_multi_fwd_sib")
+        ctx.save_for_backward(*x2s, *shadows, *ypres, g_, mean, var)
+        ctx.dims = (B, cin, H, W, half, float(eps))
+        ctx.dsts = [(w1.flat_grad,) + halves[0], (w2.flat_grad,) + halves[1]]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes
+        t = ctx.saved_tensors
+        x2s, shadows, ypres, gamma, mean, var = t[0:2], t[2:4], t[4:6], t[6], t[7], t[8]
+        B, cin, H, W, half, eps = ctx.dims
+        lib = _ops._lib.load()
+        sink = _ops.grad_sink
+        rows = _ops.as_rows(dy.to(torch.bfloat16))                        # [M, 2 half], unit channel stride
+        M = rows.shape[0]
+        pitch_dy = rows.stride(0) if M > 1 else 2 * half
+        nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, half, cin)
+        wparts = [sink.partials(d[0], "conv1x1", nsplit * half * cin) for d in ctx.dsts]
+        bparts = [sink.partials(d[2], "bnfuse", nsplit * 2 * half) for d in ctx.dsts]
+        P, LL = ctypes.c_void_p * 2, ctypes.c_longlong * 2
+        sl = lambda q: P(q[:half].data_ptr(), q[half:].data_ptr())       # noqa: E731
+        pitch_x = x2s[0].stride(0) if M > 1 else cin
+        dx_all = torch.empty((2, M, cin), dtype=torch.bfloat16, device=dy.device)
+        _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_fused(
+            2, P(rows.data_ptr(), rows.data_ptr() + 2 * half), LL(pitch_dy, pitch_dy), P(*[q.data_ptr() for q in ypres]),
+            P(*[q.data_ptr() for q in x2s]), P(*[q.data_ptr() for q in shadows]), sl(gamma), sl(var), sl(mean), eps,
+            P(dx_all[0].data_ptr(), dx_all[1].data_ptr()), P(*[q.data_ptr() for q in wparts]),
+            P(*[q.data_ptr() for q in bparts]), wparts[0].numel(), bparts[0].numel(), M, half, cin, pitch_x, _ops._stream()),
+            "xpt_conv1x1_bn_multi_bwd_fused")
+        for j, (w_dst, g_dst, b_dst) in enumerate(ctx.dsts):
+            sink.add(w_dst, wparts[j], 0, half * cin, nsplit, half * cin)
+            sink.add(b_dst, bparts[j], 0, half, nsplit, 2 * half)
+            sink.add(g_dst, bparts[j], half, half, nsplit, 2 * half)
+        dxs = [dx_all[j].view(B, H, W, cin).permute(0, 3, 1, 2) for j in range(2)]
+        return (dxs[0], dxs[1]) + (None,) * 8
+
+
+def _bn_grad_halves(bn, half):
+    """Persistent views of the two halves of a BatchNorm's deferred-gradient destinations (the gradient sink keys its
+    workspaces by the destination OBJECT: a fresh slice per step would look like a new parameter every time)."""
+    key = (bn.weight.flat_grad.data_ptr(), bn.bias.flat_grad.data_ptr(), half)
+    cached = getattr(bn, "_xpt_grad_halves", None)
+    if cached is None or cached[0] != key:
+        gw, gb = bn.weight.flat_grad, bn.bias.flat_grad
+        cached = bn._xpt_grad_halves = (key, ((gw[:half], gb[:half]), (gw[half:], gb[half:])))
+    return cached[1]
+
+
+_FUSED_SPATIAL_ADJUST = __import__("os").environ.get("XPT_DEBUG_UNFUSED_SPATIAL_ADJUST", "0") != "1"     # A/B: two GEMMs + concat + BatchNorm launches
 
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
@@ -557,7 +633,19 @@ class AdjustBlock(nn.Module):
             p = shared_relu(p)
             if p.is_cuda and _CELL_TAIL and p.dtype in (torch.float32, torch.bfloat16):
                 p1, p2 = _ops.adjust_gather(p)                  # both sub-sampled copies in one launch (one scatter backward)
-                p = self.bn(torch.cat([conv1x1(p1, self.conv1.weight), conv1x1(p2, self.conv2.weight)], dim=1))
+                w1, w2, bn = self.conv1.weight, self.conv2.weight, self.bn
+                half, cin = w1.shape[0], w1.shape[1]
+                sink = _ops.grad_sink
+                if (_FUSED_SPATIAL_ADJUST and _FUSE_CONV_BN and _FUSED_DGRAD and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD
+                        and p.dtype == torch.bfloat16 and torch.is_autocast_enabled() and torch.is_grad_enabled()
+                        and half % 2 == 0 and cin % 2 == 0 and cin <= _PWCONV_MAX_CIN
+                        and all(hasattr(w, "shadow_bf16") and sink.wants(w) and w.shadow_bf16.is_contiguous() for w in (w1, w2))
+                        and sink.wants(bn.weight) and sink.wants(bn.bias)):
+                    # both convolutions and the BatchNorm over their concatenation: one launch (and one backward launch)
+                    p = _SpatialAdjustBn.apply(p1, p2, w1, w2, bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS,
+                                               _bn_grad_halves(bn, half))
+                else:
+                    p = self.bn(torch.cat([conv1x1(p1, w1), conv1x1(p2, w2)], dim=1))
             else:
                 p1 = conv1x1(p[:, :, ::2, ::2], self.conv1.weight)                   # AveragePooling2D((1,1), strides 2)
                 p2 = F.pad(p, (0, 1, 0, 1))[:, :, 1:, 1:]            # ZeroPadding2D(((0,1),(0,1))) + Cropping2D(((1,0),(1,0)))
