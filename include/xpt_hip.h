@@ -554,6 +554,16 @@ int xpt_conv1x1_bn_multi_bwd_fused(int n, const void* const* dy, const long long
                                    float* const* w_partials, float* const* bn_partials, size_t w_partial_floats,
                                    size_t bn_partial_floats, long long M, int cout, int cin, long long pitch_x,
                                    void* stream);
+/* ... with gradient FAN-IN per layer: the output gradient of layer j is dy[j] + dy2[j] + dy3[j] (its output feeds up to three
+ * consumers of the cell: tape.gradient sums them, model/train_val.py:85; dy2[j] / dy3[j] and the arrays themselves may be
+ * NULL), added on load in fp32 and rounded to bf16 once -- what xpt_sum_rows in front of the launch would produce. */
+int xpt_conv1x1_bn_multi_bwd_fused_fan(int n, const void* const* dy, const long long* pitch_dy, const void* const* dy2,
+                                       const long long* pitch_dy2, const void* const* dy3, const long long* pitch_dy3,
+                                       const void* const* ypre, const void* const* x, const void* const* w,
+                                       const float* const* gamma, const float* const* var, const float* const* mean,
+                                       float eps, void* const* dx, float* const* w_partials, float* const* bn_partials,
+                                       size_t w_partial_floats, size_t bn_partial_floats, long long M, int cout, int cin,
+                                       long long pitch_x, void* stream);
 /* Several depthwise layers of one activation shape and stride in one launch (the mutually independent branch
  * convolutions of a NASNet cell stage): forward y[j] = dwconv(f(x[j]), w[j]) with kernel size k[j] in {3,5,7} and leading
  * padding (pad_t[j], pad_l[j]); backward: dxin[u] = gradient of the u-th DISTINCT input summed over the jobs reading it

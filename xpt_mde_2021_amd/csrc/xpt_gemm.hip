@@ -728,6 +728,10 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
                         width(mj.bn[j].ypre, cout, cout), width(mj.bn[j].g_out, cout, cout)};
       for (int q = 0; q < 4; ++q)
         if (c[q] < v) v = c[q];
+      for (int q = 0; q < mj.bn[j].n_extra; ++q) {
+        const int ve = width(mj.bn[j].dy_extra[q], mj.bn[j].pitch_extra[q], cout);
+        if (ve < v) v = ve;
+      }
     }
   }
   // scalar staging (odd channel counts): the 8-wave instantiation spills at its 128-register cap; 16 waves there
@@ -951,17 +955,12 @@ extern "C" int xpt_conv1x1_bn_multi_bwd_partials(int n, const void* const* dy, c
                       &m.bn[0], &m);
 }
 
-/* ... and with the data gradients dx[j] [M, cin] bf16 = (dy_j * s_j) W_j of the layers whose dx[j] is not NULL computed
- * by extra workgroups of the same launch (w[j]: bf16 weights [cout, cin], dense); g is not written. */
-extern "C" int xpt_conv1x1_bn_multi_bwd_fused(int n, const void* const* dy, const long long* pitch_dy,
-                                              const void* const* ypre, const void* const* x, const void* const* w,
-                                              const float* const* gamma, const float* const* var,
-                                              const float* const* mean, float eps, void* const* dx,
-                                              float* const* w_partials, float* const* bn_partials,
-                                              size_t w_partial_floats, size_t bn_partial_floats, long long M, int cout,
-                                              int cin, long long pitch_x, void* stream) {
-  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(pitch_dy); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(gamma);
-  XPT_CHECK_PTR(var); XPT_CHECK_PTR(mean); XPT_CHECK_PTR(dx); XPT_CHECK_PTR(w_partials); XPT_CHECK_PTR(bn_partials);
+static int multi_bwd_fused(int n, const void* const* dy, const long long* pitch_dy, const void* const* dy2,
+                           const long long* pitch_dy2, const void* const* dy3, const long long* pitch_dy3,
+                           const void* const* ypre, const void* const* x, const void* const* w, const float* const* gamma,
+                           const float* const* var, const float* const* mean, float eps, void* const* dx,
+                           float* const* w_partials, float* const* bn_partials, size_t w_partial_floats,
+                           size_t bn_partial_floats, long long M, int cout, int cin, long long pitch_x, void* stream) {
   if (n < 1 || n > WG_MAX_JOBS) return XPT_ERR_ARG;
   if (M <= 0 || cout <= 0 || cin <= 0 || pitch_x < cin) return XPT_ERR_SHAPE;
   const WgradPlan p = wgrad_plan(M, cout, cin, true);
@@ -976,11 +975,17 @@ extern "C" int xpt_conv1x1_bn_multi_bwd_fused(int n, const void* const* dy, cons
       return XPT_ERR_NULL;
     if (dx[j] && !w[j]) return XPT_ERR_NULL;
     if (pitch_dy[j] < cout) return XPT_ERR_SHAPE;
+    const void* e1 = dy2 ? dy2[j] : nullptr;
+    const void* e2 = dy3 ? dy3[j] : nullptr;
+    if (e2 && !e1) return XPT_ERR_NULL;
+    if ((e1 && (!pitch_dy2 || pitch_dy2[j] < cout)) || (e2 && (!pitch_dy3 || pitch_dy3[j] < cout))) return XPT_ERR_SHAPE;
     m.dy[j] = (const unsigned short*)dy[j];
     m.x[j] = (const unsigned short*)x[j];
     m.partial[j] = w_partials[j];
     m.pitch_dy[j] = pitch_dy[j];
-    m.bn[j] = BnFuse{gamma[j], var[j], mean[j], eps, (const unsigned short*)ypre[j], nullptr, bn_partials[j]};
+    m.bn[j] = BnFuse{gamma[j], var[j], mean[j], eps, (const unsigned short*)ypre[j], nullptr, bn_partials[j],
+                     {(const unsigned short*)e1, (const unsigned short*)e2},
+                     {e1 ? pitch_dy2[j] : 0, e2 ? pitch_dy3[j] : 0}, e2 ? 2 : (e1 ? 1 : 0)};
     if (dx[j]) {
       d.dx[d.n] = (unsigned short*)dx[j];
       d.w[d.n] = (const unsigned short*)w[j];
@@ -990,4 +995,37 @@ extern "C" int xpt_conv1x1_bn_multi_bwd_fused(int n, const void* const* dy, cons
   }
   return wgrad_launch(dy[0], x[0], nullptr, w_partials[0], nullptr, M, cout, cin, pitch_dy[0], pitch_x, p, 1, stream,
                       &m.bn[0], &m, &d);
+}
+
+/* ... and with the data gradients dx[j] [M, cin] bf16 = (dy_j * s_j) W_j of the layers whose dx[j] is not NULL computed
+ * by extra workgroups of the same launch (w[j]: bf16 weights [cout, cin], dense); g is not written. */
+extern "C" int xpt_conv1x1_bn_multi_bwd_fused(int n, const void* const* dy, const long long* pitch_dy,
+                                              const void* const* ypre, const void* const* x, const void* const* w,
+                                              const float* const* gamma, const float* const* var,
+                                              const float* const* mean, float eps, void* const* dx,
+                                              float* const* w_partials, float* const* bn_partials,
+                                              size_t w_partial_floats, size_t bn_partial_floats, long long M, int cout,
+                                              int cin, long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(pitch_dy); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(gamma);
+  XPT_CHECK_PTR(var); XPT_CHECK_PTR(mean); XPT_CHECK_PTR(dx); XPT_CHECK_PTR(w_partials); XPT_CHECK_PTR(bn_partials);
+  return multi_bwd_fused(n, dy, pitch_dy, nullptr, nullptr, nullptr, nullptr, ypre, x, w, gamma, var, mean, eps, dx,
+                         w_partials, bn_partials, w_partial_floats, bn_partial_floats, M, cout, cin, pitch_x, stream);
+}
+
+/* The same with gradient FAN-IN per layer: the output gradient of layer j is dy[j] + dy2[j] + dy3[j] (the layer's output
+ * feeds up to three consumers of the cell; dy2[j] / dy3[j] may be NULL, the arrays themselves too), added on load in fp32 and
+ * rounded to bf16 once -- what a separate xpt_sum_rows launch in front would produce. */
+extern "C" int xpt_conv1x1_bn_multi_bwd_fused_fan(int n, const void* const* dy, const long long* pitch_dy,
+                                                  const void* const* dy2, const long long* pitch_dy2,
+                                                  const void* const* dy3, const long long* pitch_dy3,
+                                                  const void* const* ypre, const void* const* x, const void* const* w,
+                                                  const float* const* gamma, const float* const* var,
+                                                  const float* const* mean, float eps, void* const* dx,
+                                                  float* const* w_partials, float* const* bn_partials,
+                                                  size_t w_partial_floats, size_t bn_partial_floats, long long M,
+                                                  int cout, int cin, long long pitch_x, void* stream) {
+  XPT_CHECK_PTR(dy); XPT_CHECK_PTR(pitch_dy); XPT_CHECK_PTR(ypre); XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(gamma);
+  XPT_CHECK_PTR(var); XPT_CHECK_PTR(mean); XPT_CHECK_PTR(dx); XPT_CHECK_PTR(w_partials); XPT_CHECK_PTR(bn_partials);
+  return multi_bwd_fused(n, dy, pitch_dy, dy2, pitch_dy2, dy3, pitch_dy3, ypre, x, w, gamma, var, mean, eps, dx, w_partials,
+                         bn_partials, w_partial_floats, bn_partial_floats, M, cout, cin, pitch_x, stream);
 }

@@ -82,6 +82,8 @@ SIGNATURES = {
                                       ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _p]),
     "xpt_conv1x1_bn_multi_bwd_fused": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _z, _z, ctypes.c_longlong,
                                             _i, _i, ctypes.c_longlong, _p]),
+    "xpt_conv1x1_bn_multi_bwd_fused_fan": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _z, _z,
+                                                ctypes.c_longlong, _i, _i, ctypes.c_longlong, _p]),
     "xpt_conv1x1_bn_multi_bwd_partials": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _z, _z, ctypes.c_longlong, _i, _i,
                                                ctypes.c_longlong, _p]),
     "xpt_conv1x1_bwd_weight_partials": (_i, [_p, _p, _p, _z, ctypes.c_longlong, _i, _i, ctypes.c_longlong,

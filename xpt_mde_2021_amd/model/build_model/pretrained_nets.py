@@ -414,6 +414,107 @@ def multi_conv1x1_bn(xs, weights, bns, residuals=None, siblings=None):
                                       *[b.running_mean for b in all_bn], *[b.running_var for b in all_bn], *residuals))
 
 
+class _PairConv1x1BnFan(torch.autograd.Function):
+    """The two 1x1 convolution + BatchNorm heads of a NASNet normal cell (the squeeze of the cell input and the projection
+    of the input of two cells ago: keras nasnet._normal_a_cell / _adjust_block) when both read tensors of one shape: ONE
+    forward launch for the two layers and ONE backward launch.  Each output goes to several branches of the cell: it is
+    handed out as aliases (one per consumer), and the consumers' gradients are added inside the backward launch
+    (xpt_conv1x1_bn_multi_bwd_fused_fan) -- no fan-in launch.  args = (n_alias_a, n_alias_b, eps, xa, xb, wa, wb, gammas,
+    betas, means, vars ...)."""
+
+    @staticmethod
+    def forward(ctx, na, nb, eps, xa, xb, wa, wb, ga, gb, ba, bb, ma, mb, va, vb):
+        import ctypes
+        lib = _ops._lib.load()
+        B, cin, H, W = xa.shape
+        cout = wa.shape[0]
+        x2s = [_ops.as_rows(xa), _ops.as_rows(xb)]
+        M = x2s[0].shape[0]
+        pitch = x2s[0].stride(0) if M > 1 else cin
+        shadows = [w.shadow_bf16.reshape(cout, cin) for w in (wa, wb)]
+        ypres = [torch.empty((M, cout), dtype=torch.bfloat16, device=xa.device) for _ in range(2)]
+        ys = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=xa.device, memory_format=torch.channels_last)
+              for _ in range(2)]
+        P = ctypes.c_void_p * 2
+        ptr = lambda ts: P(*[t.data_ptr() for t in ts])           # noqa: E731
+        gs, bs = [ga.detach(), gb.detach()], [ba.detach(), bb.detach()]
+        _ops._lib.check(lib.xpt_pwconv_bn_multi_fwd(2, ptr(x2s), ptr(shadows), ptr(gs), ptr(bs), ptr([ma, mb]), ptr([va, vb]),
+                                                    float(eps), P(None, None), ptr(ypres), ptr(ys), M, cin, cout, pitch,
+                                                    _ops._stream()), "xpt_pwconv_bn_multi_fwd")
+        ctx.save_for_backward(*x2s, *shadows, *ypres, *gs, ma, mb, va, vb)
+        ctx.na, ctx.nb = na, nb
+        ctx.dims = (B, cin, H, W, cout, float(eps))
+        ctx.dsts = [(wa.flat_grad, ga.flat_grad, ba.flat_grad), (wb.flat_grad, gb.flat_grad, bb.flat_grad)]
+        ctx.set_materialize_grads(False)
+        return tuple(ys[0].view_as(ys[0]) for _ in range(na)) + tuple(ys[1].view_as(ys[1]) for _ in range(nb))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        import ctypes
+        t = ctx.saved_tensors
+        x2s, shadows, ypres, gs, ms, vs = t[0:2], t[2:4], t[4:6], t[6:8], t[8:10], t[10:12]
+        B, cin, H, W, cout, eps = ctx.dims
+        pieces = [[d for d in dys[:ctx.na] if d is not None], [d for d in dys[ctx.na:] if d is not None]]
+        none = (None,) * 15
+        if not pieces[0] and not pieces[1]:
+            return none
+        need = [ctx.needs_input_grad[3], ctx.needs_input_grad[4]]
+        if not pieces[0] or not pieces[1]:                   # one head without gradient: the per-layer launch for the other
+            j = 0 if pieces[0] else 1
+            live = pieces[j] if len(pieces[j]) <= 3 else [_ops.sum_rows(pieces[j])]
+            dx = _conv_bn_backward(x2s[j], shadows[j], ypres[j], gs[j], ms[j], vs[j], ctx.dims, ctx.dsts[j], live[0], need[j],
+                                   extra=live[1:])
+            return (None, None, None) + ((dx, None) if j == 0 else (None, dx)) + (None,) * 10
+        lib = _ops._lib.load()
+        sink = _ops.grad_sink
+        rows = []
+        for j in range(2):
+            live = pieces[j] if len(pieces[j]) <= 3 else [_ops.sum_rows(pieces[j])]   # (the kernel adds up to three pieces)
+            rows.append([_ops.as_rows(d.to(torch.bfloat16)) for d in live])
+        M = rows[0][0].shape[0]
+        nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
+        wparts = [sink.partials(d[0], "conv1x1", nsplit * cout * cin) for d in ctx.dsts]
+        bparts = [sink.partials(d[2], "bnfuse", nsplit * 2 * cout) for d in ctx.dsts]
+        P, LL = ctypes.c_void_p * 2, ctypes.c_longlong * 2
+        pitch_of = lambda r: r.stride(0) if M > 1 else cout      # noqa: E731
+        piece = lambda k: (P(*[(r[k].data_ptr() if len(r) > k else None) for r in rows]),      # noqa: E731
+                           LL(*[(pitch_of(r[k]) if len(r) > k else 0) for r in rows]))
+        pitch_x = x2s[0].stride(0) if M > 1 else cin
+        dx_all = torch.empty((2, M, cin), dtype=torch.bfloat16, device=rows[0][0].device)
+        ptr = lambda ts: P(*[q.data_ptr() for q in ts])          # noqa: E731
+        _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_fused_fan(
+            2, *piece(0), *piece(1), *piece(2), ptr(ypres), ptr(x2s), ptr(shadows), ptr(gs), ptr(vs), ptr(ms), eps,
+            P(*[dx_all[j].data_ptr() if need[j] else None for j in range(2)]), ptr(wparts), ptr(bparts), wparts[0].numel(),
+            bparts[0].numel(), M, cout, cin, pitch_x, _ops._stream()), "xpt_conv1x1_bn_multi_bwd_fused_fan")
+        for j, (w_dst, g_dst, b_dst) in enumerate(ctx.dsts):
+            sink.add(w_dst, wparts[j], 0, cout * cin, nsplit, cout * cin)
+            sink.add(b_dst, bparts[j], 0, cout, nsplit, 2 * cout)
+            sink.add(g_dst, bparts[j], cout, cout, nsplit, 2 * cout)
+        dxs = [dx_all[j].view(B, H, W, cin).permute(0, 3, 1, 2) if need[j] else None for j in range(2)]
+        return (None, None, None, dxs[0], dxs[1]) + (None,) * 10
+
+
+_PAIR_HEADS = __import__("os").environ.get("XPT_DEBUG_SEPARATE_HEADS", "0") != "1"     # A/B: squeeze and projection as two launches
+
+
+def pair_conv1x1_bn_usable(xa, xb, wa, wb, bna, bnb):
+    sink = _ops.grad_sink
+    if not (_PAIR_HEADS and _FUSE_CONV_BN and _FUSED_DGRAD and _FUSE_FAN_IN and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD):
+        return False
+    if not (xa.is_cuda and xa.dtype == torch.bfloat16 and xb.dtype == torch.bfloat16 and xa.shape == xb.shape
+            and torch.is_autocast_enabled() and torch.is_grad_enabled() and wa.shape == wb.shape):
+        return False
+    cout, cin = wa.shape[0], wa.shape[1]
+    if cout % 2 or cin % 2 or cin > _PWCONV_MAX_CIN:
+        return False
+    if not all(hasattr(w, "shadow_bf16") and sink.wants(w) and w.shadow_bf16.is_contiguous() for w in (wa, wb)):
+        return False
+    if not all(sink.wants(b.weight) and sink.wants(b.bias) for b in (bna, bnb)):
+        return False
+    ra, rb = _ops.as_rows(xa), _ops.as_rows(xb)
+    return ra.stride(0) == rb.stride(0) and ra.stride(0) % 2 == 0 and ra.data_ptr() % 4 == 0 and rb.data_ptr() % 4 == 0
+
+
 class _SpatialAdjustBn(torch.autograd.Function):
     """bn(concat([conv1x1(p1, w1), conv1x1(p2, w2)])) of the "spatial" _adjust_block in ONE launch each way: the two
     convolutions are two jobs of the multi-layer pointwise kernel that write the two channel halves of one tensor (their
@@ -731,14 +832,14 @@ def fused_sep_stage(main, siblings=None, residuals=None):
     sib_out = {}
     if sib:
         _MultiConv1x1Bn.precomputed = ([ypre_b[j] for j in sib], [y_b[j] for j in sib])
-        outs = _MultiConv1x1Bn.apply(len(sib), BN_EPS, *ys_dw[n:], *[siblings[j][1].pointwise.weight for j in sib],
+        outs = _MultiConv1x1Bn.apply(len(sib), BN_EPS, (), *ys_dw[n:], *[siblings[j][1].pointwise.weight for j in sib],
                                      *[siblings[j][2].weight for j in sib], *[siblings[j][2].bias for j in sib],
                                      *[siblings[j][2].running_mean for j in sib], *[siblings[j][2].running_var for j in sib],
                                      *([None] * len(sib)))
         sib_out = dict(zip(sib, outs))
     adds = [sib_out.get(j, residuals[j]) for j in range(n)]
     _MultiConv1x1Bn.precomputed = (ypre_a, y_a)
-    outs = _MultiConv1x1Bn.apply(n, BN_EPS, *ys_dw[:n], *[e[1].pointwise.weight for e in main], *[e[2].weight for e in main],
+    outs = _MultiConv1x1Bn.apply(n, BN_EPS, (), *ys_dw[:n], *[e[1].pointwise.weight for e in main], *[e[2].weight for e in main],
                                  *[e[2].bias for e in main], *[e[2].running_mean for e in main],
                                  *[e[2].running_var for e in main], *adds)
     return list(outs), [sib_out.get(j) for j in range(n)]
@@ -776,10 +877,23 @@ class NormalCell(nn.Module):
         # h and p feed several branches each: one alias per consumer; where they come out of a fused pointwise + BatchNorm
         # layer their gradients are added inside that layer's weight-gradient launch, elsewhere by one fan-in kernel
         n_h, n_p = (3, 2 if _CELL_TAIL else 4) if wide else (4, 6)
-        ps = self.adjust(p, taps, fan_out=n_p)
         h = shared_relu(ip)
         taps.offer(self.act_id, h)
-        hs = conv1x1_bn(h, self.conv.weight, self.bn, fan_out=n_h)
+        ps = None
+        if wide and self.adjust.mode == "project":
+            pr = shared_relu(p)
+            if pair_conv1x1_bn_usable(h, pr, self.conv.weight, self.adjust.conv.weight, self.bn, self.adjust.bn):
+                # the squeeze of the cell input and the projection of p read tensors of one shape: one launch for both heads
+                # (and one backward launch, which also adds the gradients their consumers send back)
+                taps.offer(self.adjust.act_id, pr)
+                a, b = self.bn, self.adjust.bn
+                outs = _PairConv1x1BnFan.apply(n_h, n_p, BN_EPS, h, pr, self.conv.weight, self.adjust.conv.weight, a.weight,
+                                               b.weight, a.bias, b.bias, a.running_mean, b.running_mean, a.running_var,
+                                               b.running_var)
+                hs, ps = outs[:n_h], outs[n_h:]
+        if ps is None:
+            ps = self.adjust(p, taps, fan_out=n_p)
+            hs = conv1x1_bn(h, self.conv.weight, self.bn, fan_out=n_h)
         if wide:
             # The five separable-conv branches are mutually independent and of one shape: their depthwise halves run as
             # ONE launch per stage (and one backward launch each, which also sums the gradients of h and p over the
