@@ -52,21 +52,28 @@ __device__ inline bf16x8 tr_pair(const char* lds, unsigned off0, unsigned off1) 
 template <int MAXCH>
 __device__ __forceinline__ void wgrad_fetch(const WgradArgs a, int u, int tid, int n0, int c0, int TNB, int TCB, int Wt,
                                             int gchunks, int nchunks, uint4 (&stage)[MAXCH]) {
+  // (index arithmetic without integer divisions: the chunk -> (pixel, channel group) splits are shifts -- TNB / 8 and
+  //  TCB / 8 are 4 or 8 --, the pixel -> (row, column) splits exact float multiplications.  With six run-time divisions per
+  //  chunk, ~40 instructions each, this function was most of the kernel: 10 chunks per thread and unit.)
   const int seg = u % a.nseg, rb = (u / a.nseg) % a.nrb, b = u / (a.nseg * a.nrb);
   const int oh0 = rb * a.R, ow0 = seg * a.CB;
+  const int lg = __builtin_ctz((unsigned)(TNB >> 3)), lx = __builtin_ctz((unsigned)(TCB >> 3));      // TNB, TCB: 32 x {1, 2, 4}
+  const float inv_cb = 1.f / (float)a.CB, inv_wt = 1.f / (float)Wt;
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
     // ONE unconditional load per chunk from a clamped address, zeroed by select (a guarded load would get its own
     // branch and s_waitcnt: one memory round trip per chunk)
     const int ck = tid + 256 * i;
     const bool is_g = ck < gchunks;
-    const int gc8 = ck % (TNB / 8), gpix = ck / (TNB / 8);
-    const int oh = oh0 + gpix / a.CB, ow = ow0 + gpix % a.CB, n = n0 + 8 * gc8;
+    const int gc8 = ck & ((1 << lg) - 1), gpix = ck >> lg;
+    const int gr = (int)(((float)gpix + 0.5f) * inv_cb), gcol = gpix - gr * a.CB;
+    const int oh = oh0 + gr, ow = ow0 + gcol, n = n0 + 8 * gc8;
     const bool gok = is_g && oh < a.OH && ow < a.OW && n < a.N;
     const long long goff = (((long long)b * a.OH + oh) * a.OW + ow) * a.gpitch + n;
     const int cx = is_g ? 0 : ck - gchunks;
-    const int xc8 = cx % (TCB / 8), xpix = cx / (TCB / 8);
-    const int th = oh0 * a.stride - a.pad_t + xpix / Wt, tw = ow0 * a.stride - a.pad_l + xpix % Wt, c = c0 + 8 * xc8;
+    const int xc8 = cx & ((1 << lx) - 1), xpix = cx >> lx;
+    const int xr = (int)(((float)xpix + 0.5f) * inv_wt), xcol = xpix - xr * Wt;
+    const int th = oh0 * a.stride - a.pad_t + xr, tw = ow0 * a.stride - a.pad_l + xcol, c = c0 + 8 * xc8;
     const bool xok = !is_g && ck < nchunks && th >= 0 && th < a.Hlim && tw >= 0 && tw < a.Wlim && c < a.C;
     const long long xoff = (((long long)b * a.PH + (th >> a.shift)) * a.PW + (tw >> a.shift)) * a.xpitch + c;
     const unsigned short* src = is_g ? a.g + (gok ? goff : 0) : a.x + (xok ? xoff : 0);

@@ -1011,11 +1011,21 @@ class ReductionCell(nn.Module):
             z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
             y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
             ap = ap_h if ap_h is not None else F.avg_pool2d(h3, 3, 2)
-            outs = multi_conv1x1_bn(y2[1:], [b.conv2.pointwise.weight for b in blocks[1:]], [b.bn2 for b in blocks[1:]],
-                                    [None, mp1] + ([ap] if wide3 else []))
-            r1, x2 = outs[0], outs[1]
-            x3 = outs[2] if wide3 else self.right3(p_tap, taps, residual=ap, rectified=rectified)
-            x1 = conv1x1_bn(y2[0], self.left1.conv2.pointwise.weight, self.left1.bn2, residual=r1)
+            if _SIBLING_PW:
+                # x1 = left1 + right1 (right1 as the sibling of left1), x2 = right2 + max-pool, x3 = right3 + avg-pool: ONE launch
+                mains = [blocks[0], blocks[2]] + ([blocks[3]] if wide3 else [])
+                outs = multi_conv1x1_bn([y2[0], y2[2]] + ([y2[3]] if wide3 else []), [b.conv2.pointwise.weight for b in mains],
+                                        [b.bn2 for b in mains], [None, mp1] + ([ap] if wide3 else []),
+                                        siblings=[(y2[1], self.right1.conv2.pointwise.weight, self.right1.bn2), None]
+                                        + ([None] if wide3 else []))
+                x1, x2 = outs[0], outs[1]
+                x3 = outs[2] if wide3 else self.right3(p_tap, taps, residual=ap, rectified=rectified)
+            else:
+                outs = multi_conv1x1_bn(y2[1:], [b.conv2.pointwise.weight for b in blocks[1:]], [b.bn2 for b in blocks[1:]],
+                                        [None, mp1] + ([ap] if wide3 else []))
+                r1, x2 = outs[0], outs[1]
+                x3 = outs[2] if wide3 else self.right3(p_tap, taps, residual=ap, rectified=rectified)
+                x1 = conv1x1_bn(y2[0], self.left1.conv2.pointwise.weight, self.left1.bn2, residual=r1)
             x1a, x1b = _ops.fan_out(x1, 2)
             if _CELL_TAIL and x1.dtype == x2.dtype == x3.dtype:
                 # concat([x2, x3, x2 + avg(x1), x5]) and the consumers' relu: inputs (x2, x3, x1, x5)
