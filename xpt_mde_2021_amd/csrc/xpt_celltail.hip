@@ -78,12 +78,14 @@ __global__ __launch_bounds__(256) void cell_tail_fwd_kernel(TailFwd a, T* __rest
   const int nt = a.nterms[s];
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % groups) * V;
-    long long p = idx / groups;
+    unsigned c0_;
+    long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
+    const int c0 = (int)c0_ * V;
     const long long pix = p;
-    const int x = (int)(p % W); p /= W;
-    const int y = (int)(p % H);
-    const int b = (int)(p / H);
+    unsigned r1_, r2_;
+    const unsigned q1_ = xpt_divmod((unsigned)p, (unsigned)W, r1_);
+    const int b = (int)xpt_divmod(q1_, (unsigned)H, r2_);
+    const int x = (int)r1_, y = (int)r2_;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -177,8 +179,9 @@ __global__ __launch_bounds__(256) void cell_tail_bwd_kernel(TailBwd a, int B, in
   const long long gm_pitch = (long long)a.nslices * F;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % groups) * V;
-    long long p = idx / groups;
+    unsigned c0_;
+    long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
+    const int c0 = (int)c0_ * V;
     const long long pix = p;
     if (job < a.nslices) {                                             // uniform per workgroup
       float gmv[V];
@@ -188,9 +191,10 @@ __global__ __launch_bounds__(256) void cell_tail_bwd_kernel(TailBwd a, int B, in
       continue;
     }
     const BwdDense& d = a.d[job - a.nslices];
-    const int x = (int)(p % W); p /= W;
-    const int y = (int)(p % H);
-    const int b = (int)(p / H);
+    unsigned r1_, r2_;
+    const unsigned q1_ = xpt_divmod((unsigned)p, (unsigned)W, r1_);
+    const int b = (int)xpt_divmod(q1_, (unsigned)H, r2_);
+    const int x = (int)r1_, y = (int)r2_;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -240,13 +244,15 @@ __global__ __launch_bounds__(256) void adjust_gather_kernel(const T* __restrict_
   const long long total = (long long)B * H2 * W2 * 2 * groups;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % groups) * V;
-    long long p = idx / groups;
+    unsigned c0_;
+    long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
+    const int c0 = (int)c0_ * V;
     const int half = (int)(p & 1); p >>= 1;
     const long long opix = p;
-    const int j = (int)(p % W2); p /= W2;
-    const int i = (int)(p % H2);
-    const int b = (int)(p / H2);
+    unsigned r1_, r2_;
+    const unsigned q1_ = xpt_divmod((unsigned)p, (unsigned)W2, r1_);
+    const int b = (int)xpt_divmod(q1_, (unsigned)H2, r2_);
+    const int j = (int)r1_, i = (int)r2_;
     const int y = 2 * i + half, x = 2 * j + half;
     float v[V];
     const bool ok = y < H && x < W;
@@ -265,12 +271,14 @@ __global__ __launch_bounds__(256) void adjust_scatter_kernel(const T* __restrict
   const long long total = (long long)B * H * W * groups;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % groups) * V;
-    long long p = idx / groups;
+    unsigned c0_;
+    long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
+    const int c0 = (int)c0_ * V;
     const long long pix = p;
-    const int x = (int)(p % W); p /= W;
-    const int y = (int)(p % H);
-    const int b = (int)(p / H);
+    unsigned r1_, r2_;
+    const unsigned q1_ = xpt_divmod((unsigned)p, (unsigned)W, r1_);
+    const int b = (int)xpt_divmod(q1_, (unsigned)H, r2_);
+    const int x = (int)r1_, y = (int)r2_;
     float v[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) v[e] = 0.f;
@@ -297,12 +305,14 @@ __global__ __launch_bounds__(256) void pool_pair_fwd_kernel(const T* __restrict_
   const long long total = (long long)B * OH * OW * groups;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % groups) * V;
-    long long p = idx / groups;
+    unsigned c0_;
+    long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
+    const int c0 = (int)c0_ * V;
     const long long opix = p;
-    const int j = (int)(p % OW); p /= OW;
-    const int i = (int)(p % OH);
-    const int b = (int)(p / OH);
+    unsigned r1_, r2_;
+    const unsigned q1_ = xpt_divmod((unsigned)p, (unsigned)OW, r1_);
+    const int b = (int)xpt_divmod(q1_, (unsigned)OH, r2_);
+    const int j = (int)r1_, i = (int)r2_;
     float best[V], sum[V];
     int at[V];
 #pragma unroll
@@ -338,12 +348,14 @@ __global__ __launch_bounds__(256) void pool_pair_bwd_kernel(const T* __restrict_
   const long long total = (long long)B * H * W * groups;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % groups) * V;
-    long long p = idx / groups;
+    unsigned c0_;
+    long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
+    const int c0 = (int)c0_ * V;
     const long long pix = p;
-    const int x = (int)(p % W); p /= W;
-    const int y = (int)(p % H);
-    const int b = (int)(p / H);
+    unsigned r1_, r2_;
+    const unsigned q1_ = xpt_divmod((unsigned)p, (unsigned)W, r1_);
+    const int b = (int)xpt_divmod(q1_, (unsigned)H, r2_);
+    const int x = (int)r1_, y = (int)r2_;
     float acc[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) acc[e] = 0.f;
@@ -412,6 +424,7 @@ int xpt_cell_tail_fwd(int nslices, const int* nterms, const void* const* src, co
     }
   }
   const long long total = (long long)B * H * W * (F / v);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
   long long gx = (total + 255) / 256;
   if (gx > 4096) gx = 4096;
   const dim3 grid((unsigned)gx, nslices);
@@ -474,6 +487,7 @@ int xpt_cell_tail_bwd(int ngrads, const void* const* grads, const long long* gpi
     v >>= 1;
   }
   const long long total = (long long)B * H * W * (F / v);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
   long long gx = (total + 255) / 256;
   if (gx > 4096) gx = 4096;
   const dim3 grid((unsigned)gx, nslices + ndense);
@@ -503,6 +517,7 @@ int xpt_adjust_gather(const void* in, long long in_pitch, void* out, int B, int 
   int v = dtype == 0 ? 4 : 8;
   while (v > 1 && !(C % v == 0 && aligned_for(in, in_pitch, v, esz) && aligned_for(out, C, v, esz))) v >>= 1;
   const long long total = (long long)B * H2 * W2 * 2 * (C / v);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
   long long gx = (total + 255) / 256;
   if (gx > 8192) gx = 8192;
   hipStream_t st = (hipStream_t)stream;
@@ -528,6 +543,7 @@ int xpt_adjust_scatter(const void* d1, long long pitch1, const void* d2, long lo
                     (!d2 || aligned_for(d2, pitch2, v, esz))))
     v >>= 1;
   const long long total = (long long)B * H * W * (C / v);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
   long long gx = (total + 255) / 256;
   if (gx > 8192) gx = 8192;
   hipStream_t st = (hipStream_t)stream;
@@ -554,6 +570,7 @@ int xpt_pool_pair_fwd(const void* in, long long in_pitch, void* mp, void* ap, vo
   while (v > 1 && !(C % v == 0 && aligned_for(in, in_pitch, v, esz) && aligned_for(mp, C, v, esz) && aligned_for(ap, C, v, esz)))
     v >>= 1;
   const long long total = (long long)B * OH * OW * (C / v);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
   long long gx = (total + 255) / 256;
   if (gx > 8192) gx = 8192;
   hipStream_t st = (hipStream_t)stream;
@@ -581,6 +598,7 @@ int xpt_pool_pair_bwd(const void* gmp, long long pitch_m, const void* gap, long 
                     (!gap || aligned_for(gap, pitch_a, v, esz))))
     v >>= 1;
   const long long total = (long long)B * H * W * (C / v);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
   long long gx = (total + 255) / 256;
   if (gx > 8192) gx = 8192;
   hipStream_t st = (hipStream_t)stream;

@@ -17,6 +17,36 @@ static inline int xpt_launch_status() { return hipGetLastError() == hipSuccess ?
 // error of an earlier runtime call before launching so that the status we return is our own.
 #define XPT_BEGIN_LAUNCH() (void)hipGetLastError()
 
+// ---- index arithmetic without the integer divider this ISA does not have.
+// A 64-bit `%` or `/` by a run-time value expands to ~120 instructions, a 32-bit unsigned one to ~35; the element-wise and
+// stencil kernels split a flat index three times per thread, which at batch 8 was a third to a half of their instructions
+// (measured on the k x k weight gradient's staging: 5.81 -> 5.74 ms per step from that function alone).
+// xpt_divmod: q = n / d, rem = n % d for n < 2^31, 0 < d < 2^24, branch-free: a float estimate (v_rcp_f32, 1 ulp; off by up
+// to ~n 2^-22 / d + 2), one refinement on the small remainder it leaves (exact in float), and a +-1 fix-up.  (A variant
+// that fell back to the 32-bit division above 2^24 was if-converted by the compiler: both arms executed, slower than
+// before.)
+__device__ __forceinline__ unsigned xpt_divmod(unsigned n, unsigned d, unsigned& rem) {
+  const float inv = __builtin_amdgcn_rcpf((float)d);
+  unsigned q = (unsigned)((float)n * inv);
+  int r = (int)(n - q * d);
+  q += (unsigned)(int)((float)r * inv);
+  r = (int)(n - q * d);
+  if (r < 0) { --q; r += (int)d; }
+  if (r < 0) { --q; r += (int)d; }
+  if (r >= (int)d) { ++q; r -= (int)d; }
+  if (r >= (int)d) { ++q; r -= (int)d; }
+  rem = (unsigned)r;
+  return q;
+}
+// idx = ((i3 * n2 + i2) * n1 + i1) * n0 + i0  ->  (i0, i1, i2, i3)
+__device__ __forceinline__ void xpt_split4(unsigned idx, int n0, int n1, int n2, int& i0, int& i1, int& i2, int& i3) {
+  unsigned r0, r1, r2;
+  unsigned q = xpt_divmod(idx, (unsigned)n0, r0);
+  q = xpt_divmod(q, (unsigned)n1, r1);
+  q = xpt_divmod(q, (unsigned)n2, r2);
+  i0 = (int)r0; i1 = (int)r1; i2 = (int)r2; i3 = (int)q;
+}
+
 namespace xpt {
 
 // ---------------------------------------------------------------- camera (scaled intrinsic + inverse)

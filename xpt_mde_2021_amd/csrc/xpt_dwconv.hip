@@ -40,11 +40,8 @@ __device__ inline void dw_fwd_body(const T* __restrict__ x, const float* __restr
   const long long total = (long long)d.B * d.OH * OXG * d.C;
   constexpr int IN = (OXT - 1) * S + K;
   for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
-    const int c = (int)(idx % d.C);
-    long long r = idx / d.C;
-    const int oxg = (int)(r % OXG); r /= OXG;
-    const int oy = (int)(r % d.OH);
-    const int b = (int)(r / d.OH);
+    int c, oxg, oy, b;
+    xpt_split4((unsigned)idx, d.C, OXG, d.OH, c, oxg, oy, b);
     const int ox0 = oxg * OXT;
     const int ix0 = ox0 * S - d.pad_l;
     float acc[OXT];
@@ -162,11 +159,9 @@ __global__ __launch_bounds__(256) void dw_stencil_kernel(const T* __restrict__ x
   constexpr int IN = (OXT - 1) * S + K;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % CG) * V;
-    long long r = idx / CG;
-    const int oxg = (int)(r % OXG); r /= OXG;
-    const int oy = (int)(r % d.OH);
-    const int b = (int)(r / d.OH);
+    int c0, oxg, oy, b;
+    xpt_split4((unsigned)idx, CG, OXG, d.OH, c0, oxg, oy, b);
+    c0 *= V;
     const int ox0 = oxg * OXT;
     const int ix0 = ox0 * S - d.pad_l;
     float acc[OXT][V];
@@ -272,7 +267,8 @@ __device__ __forceinline__ void dw_vec_accumulate_k(int k, const T* __restrict__
 // sW[(flip ? kk - 1 - tap : tap) * C + c] = w[c][tap]
 __device__ inline void dw_stage_taps(float* sW, const float* __restrict__ w, int C, int kk, bool flip) {
   for (int i = threadIdx.x; i < C * kk; i += 256) {
-    const int c = i / kk, tap = i - c * kk;
+    unsigned tap_;
+    const int c = (int)xpt_divmod((unsigned)i, (unsigned)kk, tap_), tap = (int)tap_;
     sW[(flip ? kk - 1 - tap : tap) * C + c] = w[i];
   }
 }
@@ -289,11 +285,10 @@ __global__ __launch_bounds__(256) void dw_multi_fwd_vec_kernel(DwMultiFwd m, DwD
   const int CG = d.C / V, OXG = (d.OW + 1) / 2;
   const long long total = (long long)d.B * d.OH * OXG * CG;
   for (long long idx = blk * 256LL + threadIdx.x; idx < total; idx += 256LL * blocks_per_job) {
-    const int c0 = (int)(idx % CG) * V;
-    long long r = idx / CG;
-    const int ox0 = (int)(r % OXG) * 2; r /= OXG;
-    const int oy = (int)(r % d.OH);
-    const int b = (int)(r / d.OH);
+    int c0, ox0, oy, b;
+    xpt_split4((unsigned)idx, CG, OXG, d.OH, c0, ox0, oy, b);
+    c0 *= V;
+    ox0 *= 2;
     float acc[2][V];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -344,11 +339,8 @@ __device__ inline void dw_bwd_data_body(const T* __restrict__ x, const float* __
                                         long long nblocks) {
   const long long total = (long long)d.B * d.H * d.W * d.C;
   for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
-    const int c = (int)(idx % d.C);
-    long long r = idx / d.C;
-    const int ix = (int)(r % d.W); r /= d.W;
-    const int iy = (int)(r % d.H);
-    const int b = (int)(r / d.H);
+    int c, ix, iy, b;
+    xpt_split4((unsigned)idx, d.C, d.W, d.H, c, ix, iy, b);
     float acc = dw_bwd_data_value<T, K, S>(w, dy, d, c, iy, ix, b);
     if (relu_in && !(ldf<T>(x + idx) > 0.f)) acc = 0.f;
     stf<T>(dx + idx, acc);
@@ -375,11 +367,9 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_vec_kernel(const T* __rest
   const int CG = d.C / V;
   const long long total = (long long)d.B * d.H * d.W * CG;
   for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += 256LL * gridDim.x) {
-    const int c0 = (int)(idx % CG) * V;
-    long long r = idx / CG;
-    const int ix = (int)(r % d.W); r /= d.W;
-    const int iy = (int)(r % d.H);
-    const int b = (int)(r / d.H);
+    int c0, ix, iy, b;
+    xpt_split4((unsigned)idx, CG, d.W, d.H, c0, ix, iy, b);
+    c0 *= V;
     float acc[V];
 #pragma unroll
     for (int u = 0; u < V; ++u) acc[u] = 0.f;
@@ -566,11 +556,8 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims 
     T* dx = (T*)m.dxin[u];
     const long long total = (long long)d.B * d.H * d.W * d.C;
     for (long long idx = blk * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)data_blocks * blockDim.x) {
-      const int c = (int)(idx % d.C);
-      long long r = idx / d.C;
-      const int ix = (int)(r % d.W); r /= d.W;
-      const int iy = (int)(r % d.H);
-      const int b = (int)(r / d.H);
+      int c, ix, iy, b;
+      xpt_split4((unsigned)idx, d.C, d.W, d.H, c, ix, iy, b);
       float acc = 0.f;
       for (int j = 0; j < m.n; ++j) {
         if (m.input_of[j] != u) continue;
@@ -626,11 +613,10 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwD
     const int CG = d.C / V, IXG = (d.W + 1) / 2;
     const long long total = (long long)d.B * d.H * IXG * CG;
     for (long long idx = blk * 256LL + threadIdx.x; idx < total; idx += 256LL * data_blocks) {
-      const int c0 = (int)(idx % CG) * V;
-      long long r = idx / CG;
-      const int ix0 = (int)(r % IXG) * 2; r /= IXG;
-      const int iy = (int)(r % d.H);
-      const int b = (int)(r / d.H);
+      int c0, ix0, iy, b;
+      xpt_split4((unsigned)idx, CG, IXG, d.H, c0, ix0, iy, b);
+      c0 *= V;
+      ix0 *= 2;
       float acc[2][V];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -843,6 +829,8 @@ int launch_bwd_both(const void* x, const float* w, const void* dy, void* dx, flo
 int check_dims(int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW, int dtype) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || pad_t < 0 || pad_l < 0) return XPT_ERR_SHAPE;
   if ((k != 3 && k != 5 && k != 7) || (stride != 1 && stride != 2) || (dtype != 0 && dtype != 1)) return XPT_ERR_ARG;
+  // (the kernels split flat element indices in 32 bits)
+  if ((long long)B * H * W * C >= (1LL << 31) || (long long)B * OH * OW * C >= (1LL << 31)) return XPT_ERR_SHAPE;
   // every output window must start inside the padded input
   if ((OH - 1) * stride - pad_t >= H || (OW - 1) * stride - pad_l >= W) return XPT_ERR_SHAPE;
   return XPT_OK;

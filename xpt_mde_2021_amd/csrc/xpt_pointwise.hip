@@ -45,7 +45,9 @@ template <typename T>
 __global__ void affine_act_fwd_kernel(const T* __restrict__ x, Affine a, const T* __restrict__ residual,
                                       T* __restrict__ y, long long n, int C, float slope, int relu_in) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
+    unsigned c_;
+    (void)xpt_divmod((unsigned)i, (unsigned)C, c_);      // (n < 2^31: checked by the launcher)
+    const int c = (int)c_;
     float sc, sh, rstd, mu;
     affine_coeffs(a, c, sc, sh, rstd, mu);
     float v = ldf<T>(x + i);
@@ -190,8 +192,9 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(SumInputs in, T* __restri
   const long long total = rows * groups;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const long long r = idx / groups;
-    const int c0 = (int)(idx - r * groups) * V;
+    unsigned c0_;
+    const long long r = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
+    const int c0 = (int)c0_ * V;
     // all (up to 8) operand rows are requested before the first add: unused slots re-read operand 0 and add zero
     float acc[V], v[7][V];
     load_row<T, V>((const T*)in.ptr[0] + r * in.pitch[0] + c0, acc);
@@ -219,11 +222,13 @@ __global__ __launch_bounds__(256) void avgpool3_kernel(const T* __restrict__ in,
   const long long total = (long long)B * H * W * groups;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int c0 = (int)(idx % groups) * V;
-    long long p = idx / groups;
-    const int x = (int)(p % W); p /= W;
-    const int y = (int)(p % H);
-    const int b = (int)(p / H);
+    unsigned c0_;
+    long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
+    const int c0 = (int)c0_ * V;
+    unsigned r1_, r2_;
+    const unsigned q1_ = xpt_divmod((unsigned)p, (unsigned)W, r1_);
+    const int b = (int)xpt_divmod(q1_, (unsigned)H, r2_);
+    const int x = (int)r1_, y = (int)r2_;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -296,7 +301,9 @@ __global__ void gap_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, i
 template <typename T>
 __global__ void gap_bwd_kernel(const float* __restrict__ g, T* __restrict__ dx, long long total, int HW, int C) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
+    unsigned c_;
+    (void)xpt_divmod((unsigned)i, (unsigned)C, c_);      // (n < 2^31: checked by the launcher)
+    const int c = (int)c_;
     const long long b = i / ((long long)HW * C);
     stf<T>(dx + i, g[b * C + c] / (float)HW);
   }
@@ -524,6 +531,7 @@ int xpt_affine_act_fwd(const void* x, const float* gamma, const float* beta, con
   if (rows <= 0 || C <= 0) return XPT_ERR_SHAPE;
   if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
   const long long n = rows * C;
+  if (n >= (1LL << 31)) return XPT_ERR_SHAPE;            // (the kernel splits flat indices in 32 bits)
   const Affine a{gamma, beta, mean, var, eps};
   XPT_BEGIN_LAUNCH();
   if (dtype == 0)
@@ -626,6 +634,7 @@ int xpt_global_avgpool_bwd(const float* g, void* dx, int B, int HW, int C, int d
   if (B <= 0 || HW <= 0 || C <= 0) return XPT_ERR_SHAPE;
   if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
   const long long total = (long long)B * HW * C;
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;        // (the kernel splits flat indices in 32 bits)
   XPT_BEGIN_LAUNCH();
   if (dtype == 0)
     hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, (float*)dx,
@@ -717,6 +726,7 @@ int xpt_avgpool3_same(const void* in, long long in_pitch, void* out, int B, int 
                     ((uintptr_t)out) % (size_t)(v * esz) == 0))
     v >>= 1;
   const long long total = (long long)B * H * W * (C / v);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;        // (the kernel splits flat indices in 32 bits)
   const dim3 grid(grid_for(total));
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
@@ -761,6 +771,7 @@ int xpt_sum_rows(const void* const* inputs, const long long* pitches, int n, voi
     v >>= 1;
   }
   const long long total = rows * (C / v);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;        // (the kernel splits flat indices in 32 bits)
   const dim3 grid(grid_for(total));
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
