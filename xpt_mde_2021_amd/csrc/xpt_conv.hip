@@ -89,23 +89,20 @@ __global__ __launch_bounds__(NKW > 1 ? 64 * NKW : 256) void conv_igemm_kernel(Co
     pok[j] = m < Mc;
     if (!pok[j]) m = Mc - 1;
     int oh, ow, b;
+    // (pixel index below 2^31 -- the launcher checks --: split without the ~120-instruction 64-bit divisions)
     if (a.quad) {                                // m = parent * 4 + child over the (OH/2) x (OW/2) parent grid
       const int child = (int)(m & 3);
-      long long p = m >> 2;
-      const int pw_ = a.OW >> 1, ph_ = a.OH >> 1;
-      const int c = (int)(p % pw_);
-      p /= pw_;
-      const int rr = (int)(p % ph_);
-      b = (int)(p / ph_);
-      oh = 2 * rr + (child >> 1);
-      ow = 2 * c + (child & 1);
+      unsigned c_, rr_;
+      const unsigned q_ = xpt_divmod((unsigned)(m >> 2), (unsigned)(a.OW >> 1), c_);
+      b = (int)xpt_divmod(q_, (unsigned)(a.OH >> 1), rr_);
+      oh = 2 * (int)rr_ + (child >> 1);
+      ow = 2 * (int)c_ + (child & 1);
     } else {
-      const int c = (int)(m % cols_c);
-      long long p = m / cols_c;
-      const int rr = (int)(p % rows_c);
-      b = (int)(p / rows_c);
-      oh = rr * a.xs + ch;
-      ow = c * a.xs + cw;
+      unsigned c_, rr_;
+      const unsigned q_ = xpt_divmod((unsigned)m, (unsigned)cols_c, c_);
+      b = (int)xpt_divmod(q_, (unsigned)rows_c, rr_);
+      oh = (int)rr_ * a.xs + ch;
+      ow = (int)c_ * a.xs + cw;
     }
     pb[j] = b;
     poh[j] = oh;
@@ -311,17 +308,15 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(ConvArgs a) {
     const unsigned m = ok ? (unsigned)m64 : Mc32 - 1u;
     if (a.quad) {
       const unsigned child = m & 3u;
-      unsigned p = m >> 2;
-      const unsigned pw_ = (unsigned)a.OW >> 1, ph_ = (unsigned)a.OH >> 1;
-      const unsigned q1 = p / pw_, c = p - q1 * pw_;
-      const unsigned q2 = q1 / ph_, rr = q1 - q2 * ph_;
-      b = (int)q2;
+      unsigned c, rr;
+      const unsigned q1 = xpt_divmod(m >> 2, (unsigned)a.OW >> 1, c);
+      b = (int)xpt_divmod(q1, (unsigned)a.OH >> 1, rr);
       oh = (int)(2u * rr + (child >> 1));
       ow = (int)(2u * c + (child & 1u));
     } else {
-      const unsigned q1 = m / (unsigned)cols_c, c = m - q1 * (unsigned)cols_c;
-      const unsigned q2 = q1 / (unsigned)rows_c, rr = q1 - q2 * (unsigned)rows_c;
-      b = (int)q2;
+      unsigned c, rr;
+      const unsigned q1 = xpt_divmod(m, (unsigned)cols_c, c);
+      b = (int)xpt_divmod(q1, (unsigned)rows_c, rr);
       oh = (int)rr * a.xs + ch;
       ow = (int)c * a.xs + cw;
     }
@@ -724,7 +719,7 @@ template <int RM, int RN, int NKW>
 int launch_igemm(const ConvArgs& a, long long Mmax, int classes, hipStream_t s) {
   const long long mtiles = (Mmax + 32 * RN - 1) / (32 * RN);
   const long long gy = NKW > 1 ? mtiles : (mtiles + 3) / 4;
-  if (gy > 65535) return XPT_ERR_SHAPE;
+  if (gy > 65535 || Mmax >= 0x7fffffffLL) return XPT_ERR_SHAPE;
   const dim3 grid((a.N + 32 * RM - 1) / (32 * RM), (unsigned)gy, classes);
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL((conv_igemm_kernel<RM, RN, NKW>), grid, dim3(NKW > 1 ? 64 * NKW : 256), 0, s, a);
