@@ -416,6 +416,14 @@ int xpt_pwconv_bn_multi_fwd_sib(int n, const void* const* x, const void* const* 
                                 const float* const* sib_mean, const float* const* sib_var, void* const* sib_ypre,
                                 long long M, int cin, int cout, long long pitch_x, long long pitch_y, void* stream);
 
+/* ------------------------------------------------------------------ a2: the decoder's channel concatenation
+ * replaces tf.concat([upconv, skip, up-sampled prediction], axis=-1) of upconv_with_skip_connection
+ * (model/build_model/depth_net.py:104-107).  out [rows, Ct] bf16 (dense, Ct % 8 == 0, 16-byte aligned) = the n (1..4) bf16
+ * inputs [rows, channels[i]] (row pitches in elements) side by side and zeros in the remaining channels (the pad to the
+ * 8-channel groups xpt_conv2d_fwd reads). */
+int xpt_concat_channels(const void* const* inputs, const long long* pitches, const int* channels, int n, void* out,
+                        long long rows, int Ct, void* stream);
+
 /* ------------------------------------------------------------------ a2: gradient fan-in of a multiply used activation
  * out [rows, C] = sum_i inputs[i] [rows, C] (row pitch pitches[i] >= C elements; n = 2..8; dtype 0 float32 / 1 bfloat16,
  * fp32 accumulation in input order).  Replaces the chain of pairwise adds autograd (tape.gradient, train_val.py:85)

@@ -215,3 +215,36 @@ def test_deferred_weight_gradient_lands_unpermuted_whatever_the_weight_layout(gp
     got = flat.grad_views[0].detach().float().cpu()                 # the parameter-shaped view of the flat gradient buffer
     scale = wr.grad.abs().max().item()
     assert (got - wr.grad).abs().max().item() < 1.5e-2 * scale
+
+
+@pytest.mark.parametrize("chans", [(16, 1), (32, 32, 1), (64, 22, 1), (8,), (24, 8, 16, 3)])
+def test_concat_channels_matches_torch_cat_with_zero_pad(gpu_device, chans):
+    """xpt_concat_channels (the decoder's concat([upconv, skip, up-sampled prediction]) + the pad to 8-channel groups,
+    depth_net.py:104-107): values equal torch.cat + zeros bit for bit, gradients are the channel slices; inputs include a
+    channel slice of a wider tensor (row pitch) and a one-channel map in NCHW-contiguous layout."""
+    from xpt_mde_2021_amd.hip import ops
+    dev = gpu_device
+    g = torch.Generator().manual_seed(sum(chans))
+    B, H, W = 2, 6, 10
+    parts = []
+    for i, c in enumerate(chans):
+        if i == 1 and c > 1:         # a channel slice with a row pitch
+            wide = torch.randn(B, c + 8, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            t = wide[:, 8:]
+        elif c == 1:
+            t = torch.randn(B, 1, H, W, generator=g).to(dev, torch.bfloat16)
+        else:
+            t = torch.randn(B, c, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        parts.append(t.detach().requires_grad_(True))
+    out = ops.concat_channels(parts)
+    total = sum(chans)
+    ct = -(-total // 8) * 8
+    assert out.shape == (B, ct, H, W) and out.is_contiguous(memory_format=torch.channels_last)
+    ref = torch.cat([p.detach() for p in parts] + ([torch.zeros(B, ct - total, H, W, device=dev, dtype=torch.bfloat16)] if ct > total else []), dim=1)
+    assert torch.equal(out.detach(), ref)
+    gy = torch.randn(B, ct, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out.backward(gy)
+    off = 0
+    for p, c in zip(parts, chans):
+        assert torch.equal(p.grad, gy[:, off:off + c])
+        off += c

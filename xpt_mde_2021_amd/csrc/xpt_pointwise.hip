@@ -211,6 +211,55 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(SumInputs in, T* __restri
   }
 }
 
+// ---------------------------------------------------------------- channel concatenation (bf16)
+// out [rows, Ct] (dense, Ct a multiple of 8) = [in_0 | in_1 | ... | zeros]: the decoder's concat([up-convolution, skip,
+// up-sampled previous prediction]) (model/build_model/depth_net.py:104-107) with the zero channels that pad it to the
+// 8-channel groups the matrix-core convolution reads.  A thread moves one 16-byte group of the output: one 16-byte load
+// when the group lies inside one input on a 16-byte boundary, element-wise otherwise (the one-channel prediction, the
+// pad).  torch.cat's batched copy moved these 5 - 20 MB at 0.5 - 0.8 TB/s.
+struct CatInputs {
+  const unsigned short* ptr[4];
+  long long pitch[4];
+  int first[5];              // first[i] = output channel where input i starts; first[n] = total real channels
+  int n;
+};
+
+__global__ __launch_bounds__(256) void concat_channels_kernel(CatInputs in, unsigned short* __restrict__ out, unsigned total,
+                                                              int groups) {
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+    unsigned g_;
+    const long long row = (long long)xpt_divmod(idx, (unsigned)groups, g_);
+    const int c0 = (int)g_ * 8;
+    uint4 val = make_uint4(0u, 0u, 0u, 0u);
+    bool done = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < in.n && c0 >= in.first[i] && c0 + 8 <= in.first[i + 1]) {
+        const unsigned short* src = in.ptr[i] + row * in.pitch[i] + (c0 - in.first[i]);
+        if (((uintptr_t)src & 15) == 0) {
+          val = *(const uint4*)src;
+          done = true;
+        }
+      }
+    }
+    if (!done) {
+      unsigned short e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        unsigned short v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < in.n && c >= in.first[i] && c < in.first[i + 1]) v = in.ptr[i][row * in.pitch[i] + (c - in.first[i])];
+        e[k] = v;
+      }
+      val.x = e[0] | ((unsigned)e[1] << 16); val.y = e[2] | ((unsigned)e[3] << 16);
+      val.z = e[4] | ((unsigned)e[5] << 16); val.w = e[6] | ((unsigned)e[7] << 16);
+    }
+    *(uint4*)(out + (row * groups + (long long)g_) * 8) = val;
+  }
+}
+
 // 3x3 stride-1 SAME average pooling whose divisor excludes the padding (keras AveragePooling2D((3,3), strides 1,
 // padding='same') of the NASNet cells), times `scale`.  adjoint == 0: out = scale / cnt(out px) * sum of the valid
 // neighbours; adjoint == 1 (the backward): out = sum over the valid neighbours n of in[n] * scale / cnt(n).
@@ -787,6 +836,34 @@ int xpt_sum_rows(const void* const* inputs, const long long* pitches, int n, voi
     else XPT_SUM(__hip_bfloat16, 1);
   }
 #undef XPT_SUM
+  return xpt_launch_status();
+}
+
+/* out [rows, Ct] bf16 (dense, Ct % 8 == 0, 16-byte aligned) = the n (1..4) inputs [rows, channels[i]] (row pitches in
+ * elements) side by side, zeros in the remaining channels. */
+int xpt_concat_channels(const void* const* inputs, const long long* pitches, const int* channels, int n, void* out,
+                        long long rows, int Ct, void* stream) {
+  XPT_CHECK_PTR(inputs); XPT_CHECK_PTR(pitches); XPT_CHECK_PTR(channels); XPT_CHECK_PTR(out);
+  if (n < 1 || n > 4) return XPT_ERR_ARG;
+  if (rows <= 0 || Ct <= 0 || Ct % 8 != 0 || ((uintptr_t)out) % 16 != 0) return XPT_ERR_SHAPE;
+  CatInputs in{};
+  in.n = n;
+  int c = 0;
+  for (int i = 0; i < n; ++i) {
+    if (inputs[i] == nullptr) return XPT_ERR_NULL;
+    if (channels[i] <= 0 || pitches[i] < channels[i]) return XPT_ERR_SHAPE;
+    in.ptr[i] = (const unsigned short*)inputs[i];
+    in.pitch[i] = pitches[i];
+    in.first[i] = c;
+    c += channels[i];
+  }
+  for (int i = n; i <= 4; ++i) in.first[i] = c;
+  if (c > Ct) return XPT_ERR_SHAPE;
+  const long long total = rows * (Ct / 8);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(concat_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                     (unsigned short*)out, (unsigned)total, Ct / 8);
   return xpt_launch_status();
 }
 

@@ -1433,6 +1433,44 @@ def conv1x1_weight_grad_deferred(dy2, x2, dst, w=None):
     return dx
 
 
+class _ConcatChannels(torch.autograd.Function):
+    """concat(parts, channel axis) of bf16 NHWC activations plus the zero channels that pad the result to a multiple of 8:
+    one launch (xpt_concat_channels); the backward hands out channel slices of the incoming gradient (views, no launch)."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        import ctypes
+        lib = _lib.load()
+        B, _, H, W = parts[0].shape
+        rows = [as_rows(p) for p in parts]
+        chans = [p.shape[1] for p in parts]
+        total = sum(chans)
+        ct = -(-total // 8) * 8
+        out = torch.empty((B, ct, H, W), dtype=torch.bfloat16, device=parts[0].device, memory_format=torch.channels_last)
+        n = len(parts)
+        M = B * H * W
+        P, LL, I = ctypes.c_void_p * n, ctypes.c_longlong * n, ctypes.c_int * n
+        _lib.check(lib.xpt_concat_channels(P(*[r.data_ptr() for r in rows]), LL(*[(r.stride(0) if M > 1 else c) for r, c in zip(rows, chans)]),
+                                           I(*chans), n, _ptr(out), M, ct, _stream()), "xpt_concat_channels")
+        ctx.chans = chans
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for i, c in enumerate(ctx.chans):
+            outs.append(g[:, off:off + c] if ctx.needs_input_grad[i] else None)
+            off += c
+        return tuple(outs)
+
+
+def concat_channels(parts):
+    """torch.cat(parts, dim=1) for bf16 NCHW-indexed (channels_last) tensors, zero-padded to a multiple of 8 channels."""
+    if len(parts) > 4 or any((not p.is_cuda) or p.dtype != torch.bfloat16 for p in parts):
+        raise _lib.XptHipError("concat_channels: expected up to four bfloat16 CUDA/HIP tensors (no CPU fallback)")
+    return _ConcatChannels.apply(*parts)
+
+
 def vector_rows(t, channels):
     """Rows of a [M, channels] bf16 view start on 4-byte boundaries and hold an even number of channels (what the fused
     data gradient of the pointwise backward kernels needs: their scalar-staged instantiations carry no such code)."""

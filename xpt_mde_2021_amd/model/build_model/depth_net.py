@@ -27,6 +27,9 @@ class _ChannelsLastOne(torch.autograd.Function):
         return g
 
 
+_FUSED_CONCAT = __import__("os").environ.get("XPT_DEBUG_TORCH_CAT", "0") != "1"     # A/B: torch.cat + cached zero pad
+
+
 class UpconvWithSkip(nn.Module):
     """upconv_with_skip_connection of DepthNetNoResize (depth_net.py:101-109):
     nearest 2x -> conv3x3 -> concat([., skip][, up-sampled previous prediction]) -> conv3x3."""
@@ -43,6 +46,9 @@ class UpconvWithSkip(nn.Module):
         else:
             up = self.conv1(F.interpolate(bef_layer, scale_factor=2, mode="bilinear", align_corners=False))
         parts = [up] + [s.to(up.dtype) for s in skips]
+        if up.is_cuda and up.dtype == torch.bfloat16 and len(parts) <= 4 and _FUSED_CONCAT:
+            # the concatenation and its zero pad channels in one launch (torch.cat's batched copy ran at 0.5 - 0.8 TB/s here)
+            return self.conv2(_ops.concat_channels(parts))
         if up.is_cuda:
             # a one-channel map is "contiguous" in both layouts; give it channels_last strides explicitly, or torch.cat
             # sees mixed layouts, answers in NCHW and the convolution below pays a full re-layout copy of the concatenation
