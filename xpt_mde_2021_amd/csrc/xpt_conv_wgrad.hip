@@ -36,6 +36,7 @@ struct WgradArgs {
   int C, Cr, N, KH, KW, stride, pad_t, pad_l, OH, OW;
   int R, CB, nseg, nrb, units, nsplit;
   int WN, WC, WT;
+  int dbg;                   // lab knobs (xpt_conv2d_bwd_weight_tune(-bits, 0)): 1 no products, 2 no refetch, 4 no store
 };
 
 __device__ inline bf16x8 tr_pair(const char* lds, unsigned off0, unsigned off1) {
@@ -49,36 +50,69 @@ __device__ inline bf16x8 tr_pair(const char* lds, unsigned off0, unsigned off1) 
 }
 
 // the 16-byte chunks of one unit's g tile and x halo tile, chunk ck = tid + 256 i, into registers
+// Geometry of this thread's staging chunks, computed ONCE per workgroup: chunk ck = tid + 256 i is either 8 output channels
+// of one pixel of the g tile or 8 input channels of one pixel of the x halo tile; only the unit's origin changes from unit
+// to unit.  (The chunk -> (pixel, channel group) splits are shifts -- TNB / 8 and TCB / 8 are 4 or 8 --, the pixel ->
+// (row, column) splits exact float multiplications: with six run-time integer divisions per chunk, ~40 instructions
+// each, the staging function was most of the kernel; ablation with the lab knobs: products 7 us, refetch 6 us, store 4 us,
+// the rest 9 us of a 26 us launch.)
 template <int MAXCH>
-__device__ __forceinline__ void wgrad_fetch(const WgradArgs a, int u, int tid, int n0, int c0, int TNB, int TCB, int Wt,
-                                            int gchunks, int nchunks, uint4 (&stage)[MAXCH]) {
-  // (index arithmetic without integer divisions: the chunk -> (pixel, channel group) splits are shifts -- TNB / 8 and
-  //  TCB / 8 are 4 or 8 --, the pixel -> (row, column) splits exact float multiplications.  With six run-time divisions per
-  //  chunk, ~40 instructions each, this function was most of the kernel: 10 chunks per thread and unit.)
-  const int seg = u % a.nseg, rb = (u / a.nseg) % a.nrb, b = u / (a.nseg * a.nrb);
-  const int oh0 = rb * a.R, ow0 = seg * a.CB;
+struct WgradChunks {
+  int row[MAXCH], col[MAXCH];    // pixel of the chunk inside its tile (g: output pixel; x: logical halo pixel)
+  int ch[MAXCH];                 // first channel of the chunk (g: n0 + 8 gc8, x: c0 + 8 xc8); -1: no chunk
+  unsigned is_g;                 // bit i: chunk i belongs to the g tile
+};
+
+template <int MAXCH>
+__device__ __forceinline__ void wgrad_chunks(const WgradArgs& a, int tid, int n0, int c0, int TNB, int TCB, int Wt,
+                                             int gchunks, int nchunks, WgradChunks<MAXCH>& w) {
   const int lg = __builtin_ctz((unsigned)(TNB >> 3)), lx = __builtin_ctz((unsigned)(TCB >> 3));      // TNB, TCB: 32 x {1, 2, 4}
   const float inv_cb = 1.f / (float)a.CB, inv_wt = 1.f / (float)Wt;
+  w.is_g = 0u;
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int ck = tid + 256 * i;
+    const bool is_g = ck < gchunks;
+    if (is_g) {
+      const int gc8 = ck & ((1 << lg) - 1), gpix = ck >> lg;
+      const int gr = (int)(((float)gpix + 0.5f) * inv_cb);
+      w.row[i] = gr;
+      w.col[i] = gpix - gr * a.CB;
+      const int n = n0 + 8 * gc8;
+      w.ch[i] = n < a.N ? n : -1;
+      w.is_g |= 1u << i;
+    } else {
+      const int cx = ck - gchunks;
+      const int xc8 = cx & ((1 << lx) - 1), xpix = cx >> lx;
+      const int xr = (int)(((float)xpix + 0.5f) * inv_wt);
+      w.row[i] = xr;
+      w.col[i] = xpix - xr * Wt;
+      const int c = c0 + 8 * xc8;
+      w.ch[i] = (ck < nchunks && c < a.C) ? c : -1;
+    }
+  }
+}
+
+// the 16-byte chunks of one unit's g tile and x halo tile into registers
+template <int MAXCH>
+__device__ __forceinline__ void wgrad_fetch(const WgradArgs& a, int u, const WgradChunks<MAXCH>& w, uint4 (&stage)[MAXCH]) {
+  const int seg = u % a.nseg, rb = (u / a.nseg) % a.nrb, b = u / (a.nseg * a.nrb);      // (uniform)
+  const int oh0 = rb * a.R, ow0 = seg * a.CB;
+  const int th0 = oh0 * a.stride - a.pad_t, tw0 = ow0 * a.stride - a.pad_l;
+  const long long gimg = (long long)b * a.OH * a.OW, ximg = (long long)b * a.PH * a.PW;
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
     // ONE unconditional load per chunk from a clamped address, zeroed by select (a guarded load would get its own
     // branch and s_waitcnt: one memory round trip per chunk)
-    const int ck = tid + 256 * i;
-    const bool is_g = ck < gchunks;
-    const int gc8 = ck & ((1 << lg) - 1), gpix = ck >> lg;
-    const int gr = (int)(((float)gpix + 0.5f) * inv_cb), gcol = gpix - gr * a.CB;
-    const int oh = oh0 + gr, ow = ow0 + gcol, n = n0 + 8 * gc8;
-    const bool gok = is_g && oh < a.OH && ow < a.OW && n < a.N;
-    const long long goff = (((long long)b * a.OH + oh) * a.OW + ow) * a.gpitch + n;
-    const int cx = is_g ? 0 : ck - gchunks;
-    const int xc8 = cx & ((1 << lx) - 1), xpix = cx >> lx;
-    const int xr = (int)(((float)xpix + 0.5f) * inv_wt), xcol = xpix - xr * Wt;
-    const int th = oh0 * a.stride - a.pad_t + xr, tw = ow0 * a.stride - a.pad_l + xcol, c = c0 + 8 * xc8;
-    const bool xok = !is_g && ck < nchunks && th >= 0 && th < a.Hlim && tw >= 0 && tw < a.Wlim && c < a.C;
-    const long long xoff = (((long long)b * a.PH + (th >> a.shift)) * a.PW + (tw >> a.shift)) * a.xpitch + c;
-    const unsigned short* src = is_g ? a.g + (gok ? goff : 0) : a.x + (xok ? xoff : 0);
+    const bool is_g = (w.is_g >> i) & 1u;
+    const int r = (is_g ? oh0 : th0) + w.row[i], c = (is_g ? ow0 : tw0) + w.col[i];
+    const bool ok = w.ch[i] >= 0 && r >= 0 && c >= 0 && r < (is_g ? a.OH : a.Hlim) && c < (is_g ? a.OW : a.Wlim);
+    const int pr = is_g ? r : (r >> a.shift), pc = is_g ? c : (c >> a.shift);
+    const long long off = is_g ? (gimg + (long long)pr * a.OW + pc) * a.gpitch + w.ch[i]
+                               : (ximg + (long long)pr * a.PW + pc) * a.xpitch + w.ch[i];
+    const unsigned short* src = (is_g ? a.g : a.x) + (ok ? off : 0);
     uint4 ld = *(const uint4*)src;
-    const unsigned keep = (gok || xok) ? 0xffffffffu : 0u;     // (a uint4 select compiles to a scratch round trip)
+    const unsigned keep = ok ? 0xffffffffu : 0u;               // (a uint4 select compiles to a scratch round trip)
     ld.x &= keep; ld.y &= keep; ld.z &= keep; ld.w &= keep;
     stage[i] = ld;
   }
@@ -129,8 +163,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int gchunks = a.R * a.CB * (TNB / 8), xchunks = HR * Wt * (TCB / 8);
   const int nchunks = gchunks + xchunks;
   uint4 stage[MAXCH];
+  WgradChunks<MAXCH> chunks;
+  wgrad_chunks<MAXCH>(a, tid, n0, c0, TNB, TCB, Wt, gchunks, nchunks, chunks);
   int u = blockIdx.y;
-  if (u < a.units) wgrad_fetch<MAXCH>(a, u, tid, n0, c0, TNB, TCB, Wt, gchunks, nchunks, stage);
+  if (u < a.units) wgrad_fetch<MAXCH>(a, u, chunks, stage);
   for (; u < a.units; u += a.nsplit) {
     __syncthreads();                                           // the previous unit's LDS reads are done
 #pragma unroll
@@ -139,9 +175,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       if (ck < nchunks) *(uint4*)(smem + (size_t)ck * 16) = stage[i];     // gs and xs are contiguous: chunk order = LDS order
     }
     __syncthreads();
-    if (u + a.nsplit < a.units)                                // in flight during the products below
-      wgrad_fetch<MAXCH>(a, u + a.nsplit, tid, n0, c0, TNB, TCB, Wt, gchunks, nchunks, stage);
-    if (active) {
+    if (u + a.nsplit < a.units && !(a.dbg & 2))                // in flight during the products below
+      wgrad_fetch<MAXCH>(a, u + a.nsplit, chunks, stage);
+    if (active && !(a.dbg & 1)) {
       for (int rr = 0; rr < a.R; ++rr) {
         for (int c16 = 0; c16 < a.CB; c16 += 16) {
           const unsigned ga = (unsigned)((rr * a.CB + c16) * TNB * 2);
@@ -161,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   // partial of this split: register e of tap t -> output channel n0 + 32 wn + (e & 3) + 8 (e >> 2) + 4 h,
   // input channel c0 + 32 wc + (lane & 31)
-  if (!active) return;
+  if (!active || (a.dbg & 4)) return;
   const int c = c0 + wc * 32 + (lane & 31);
   float* dst = a.part + (long long)blockIdx.y * a.N * T * a.Cr;
 #pragma unroll
@@ -182,7 +218,7 @@ struct WgradPlan {
 };
 
 
-int g_wgrad_max_partial_mib = 12, g_wgrad_target_blocks = 512;
+int g_wgrad_max_partial_mib = 12, g_wgrad_target_blocks = 512, g_wgrad_dbg = 0;
 
 
 // one candidate decomposition: sub-tiles (WN x WC), taps split WT ways; pixel units bounded by the staging registers
@@ -246,6 +282,7 @@ bool make_plan(int B, int C, int N, int KH, int KW, int stride, int OH, int OW, 
 }  // namespace
 
 extern "C" int xpt_conv2d_bwd_weight_tune(int max_partial_mib, int target_blocks) {
+  if (max_partial_mib < 0) g_wgrad_dbg = -max_partial_mib;          // lab knobs, see WgradArgs::dbg
   if (max_partial_mib > 0) g_wgrad_max_partial_mib = max_partial_mib;
   if (target_blocks > 0) g_wgrad_target_blocks = target_blocks;
   return XPT_OK;
@@ -282,6 +319,7 @@ extern "C" int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, floa
   a.OH = OH; a.OW = OW;
   a.R = p.R; a.CB = p.CB; a.nseg = p.nseg; a.nrb = p.nrb; a.units = p.units; a.nsplit = p.nsplit;
   a.WN = p.WN; a.WC = p.WC; a.WT = p.WT;
+  a.dbg = g_wgrad_dbg;
   const int TNB = 32 * p.WN, TCB = 32 * p.WC;
   const dim3 grid(((N + TNB - 1) / TNB) * ((C + TCB - 1) / TCB), p.nsplit);
   hipStream_t s = (hipStream_t)stream;
