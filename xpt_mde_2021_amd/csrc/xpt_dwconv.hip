@@ -595,10 +595,12 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims 
 // The same launch with the data-gradient part vectorised (stride 1): dx_u = [x_u > 0] * sum over the jobs j reading input u
 // of conv(dy_j, w_j rotated by 180 degrees, pad' = k_j - 1 - pad_j); the rotated taps of those jobs sit in LDS.
 template <typename T, int V>
-__global__ __launch_bounds__(256) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwDims d, int relu_in, int RG, int GRP,
+__global__ __launch_bounds__(256) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwDims d, int relu_lab, int RG, int GRP,
                                                                int data_blocks, int cchunks, int wblocks_per_job) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
+  const int relu_in = relu_lab & 255, lab = relu_lab >> 8;      // lab knobs (xpt_dwconv_tune(-21 / -22)): 1 no data part, 2 no weight part
   const int ndata = m.n_inputs * data_blocks;
+  if (((int)blockIdx.x < ndata) ? (lab & 1) : (lab & 2)) return;
   if ((int)blockIdx.x < ndata) {
     const int u = blockIdx.x / data_blocks, blk = blockIdx.x - u * data_blocks;
     int off = 0;
@@ -680,6 +682,7 @@ inline unsigned grid_for(long long total) {
   return (unsigned)blocks;
 }
 
+int g_dw_lab = 0;           // lab knobs of the vectorised multi-layer backward (xpt_dwconv_tune(-20 - bits))
 int g_dw_multi_vec = 1;     // 0: the scalar multi-layer kernels (A/B, xpt_dwconv_tune(-1) / (-2))
 int g_dw_s2_vec = 1;        // 0: the scalar stride-2 data gradient (A/B, xpt_dwconv_tune(-3) / (-4))
 
@@ -887,6 +890,10 @@ int xpt_dwconv_tune(int wrw_groups) {
     g_dw_multi_vec = wrw_groups == -2;
     return XPT_OK;
   }
+  if (wrw_groups <= -20 && wrw_groups >= -23) {      // lab: -21 no data-gradient part, -22 no weight-gradient part, -20 off
+    g_dw_lab = -20 - wrw_groups;
+    return XPT_OK;
+  }
   if (wrw_groups == -3 || wrw_groups == -4) {        // -3: scalar stride-2 data gradient, -4: vectorised (default)
     g_dw_s2_vec = wrw_groups == -4;
     return XPT_OK;
@@ -1036,7 +1043,7 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
       const dim3 gridv(n_inputs * dbv + n * wbpj);
       XPT_BEGIN_LAUNCH();
 #define XPT_MV(T, V) \
-  hipLaunchKernelGGL((dw_multi_bwd_vec_kernel<T, V>), gridv, dim3(256), lds, s, m, d, relu_in, RG, GRP, dbv, cchunks, wbpj)
+  hipLaunchKernelGGL((dw_multi_bwd_vec_kernel<T, V>), gridv, dim3(256), lds, s, m, d, relu_in | (g_dw_lab << 8), RG, GRP, dbv, cchunks, wbpj)
       if (dtype == 0) { if (v == 4) XPT_MV(float, 4); else XPT_MV(float, 2); }
       else { if (v == 8) XPT_MV(__hip_bfloat16, 8); else if (v == 4) XPT_MV(__hip_bfloat16, 4); else XPT_MV(__hip_bfloat16, 2); }
 #undef XPT_MV

@@ -211,6 +211,35 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(SumInputs in, T* __restri
   }
 }
 
+// ---------------------------------------------------------------- several device-to-device copies in one launch
+// The captured training step reads its batch from static buffers (model/train_val.py: _StepGraph); a new batch is copied
+// into them in front of every replay: the snippet tensor (16 MB at batch 8) and half a dozen small ones.  One launch whose
+// workgroups walk the concatenation of all byte ranges in 16-byte vectors (every range 16-byte aligned and a multiple of
+// 16 bytes long, or copied byte-wise by its first workgroup otherwise); torch's multi-tensor copy took 25 us for them.
+struct CopyJobs {
+  const unsigned char* src[8];
+  unsigned char* dst[8];
+  long long first[9];        // first 16-byte vector of job i in the concatenated index space; first[n] = total
+  long long bytes[8];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void multi_copy_kernel(CopyJobs jobs) {
+  const long long total = jobs.first[jobs.n];
+  for (long long v = blockIdx.x * 256LL + threadIdx.x; v < total; v += gridDim.x * 256LL) {
+    int j = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+      if (i < jobs.n && v >= jobs.first[i]) j = i;
+    const long long off = (v - jobs.first[j]) * 16;
+    if (off + 16 <= jobs.bytes[j] && ((((uintptr_t)jobs.src[j]) | ((uintptr_t)jobs.dst[j])) & 15) == 0) {
+      *(uint4*)(jobs.dst[j] + off) = *(const uint4*)(jobs.src[j] + off);
+    } else {
+      for (long long b = off; b < off + 16 && b < jobs.bytes[j]; ++b) jobs.dst[j][b] = jobs.src[j][b];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- channel concatenation (bf16)
 // out [rows, Ct] (dense, Ct a multiple of 8) = [in_0 | in_1 | ... | zeros]: the decoder's concat([up-convolution, skip,
 // up-sampled previous prediction]) (model/build_model/depth_net.py:104-107) with the zero channels that pad it to the
@@ -836,6 +865,30 @@ int xpt_sum_rows(const void* const* inputs, const long long* pitches, int n, voi
     else XPT_SUM(__hip_bfloat16, 1);
   }
 #undef XPT_SUM
+  return xpt_launch_status();
+}
+
+/* dst[i][0 .. bytes[i]) = src[i][0 .. bytes[i]) for n (1..8) device buffers, one launch (no overlap between any src and dst) */
+int xpt_multi_copy(const void* const* src, void* const* dst, const long long* bytes, int n, void* stream) {
+  XPT_CHECK_PTR(src); XPT_CHECK_PTR(dst); XPT_CHECK_PTR(bytes);
+  if (n < 1 || n > 8) return XPT_ERR_ARG;
+  CopyJobs jobs{};
+  jobs.n = n;
+  long long vecs = 0;
+  for (int i = 0; i < n; ++i) {
+    if (src[i] == nullptr || dst[i] == nullptr) return XPT_ERR_NULL;
+    if (bytes[i] <= 0) return XPT_ERR_SHAPE;
+    jobs.src[i] = (const unsigned char*)src[i];
+    jobs.dst[i] = (unsigned char*)dst[i];
+    jobs.bytes[i] = bytes[i];
+    jobs.first[i] = vecs;
+    vecs += (bytes[i] + 15) / 16;
+  }
+  for (int i = n; i <= 8; ++i) jobs.first[i] = vecs;
+  long long blocks = (vecs + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, jobs);
   return xpt_launch_status();
 }
 

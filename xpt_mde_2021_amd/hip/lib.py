@@ -89,6 +89,7 @@ SIGNATURES = {
     "xpt_conv1x1_bwd_weight_partials": (_i, [_p, _p, _p, _z, ctypes.c_longlong, _i, _i, ctypes.c_longlong,
                                              ctypes.c_longlong, _p]),
     "xpt_pwconv_bn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _f, _p, _p, _p, ctypes.c_longlong, _i, _i, ctypes.c_longlong, _p]),
+    "xpt_multi_copy": (_i, [_p, _p, _p, _i, _p]),
     "xpt_concat_channels": (_i, [_p, _p, _p, _i, _p, ctypes.c_longlong, _i, _p]),
     "xpt_avgpool3_same": (_i, [_p, ctypes.c_longlong, _p, _i, _i, _i, _i, _f, _i, _i, _p]),
     "xpt_pwconv_bn_multi_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, ctypes.c_longlong, _i, _i, ctypes.c_longlong, _p]),

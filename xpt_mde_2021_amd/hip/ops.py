@@ -1433,6 +1433,22 @@ def conv1x1_weight_grad_deferred(dy2, x2, dst, w=None):
     return dx
 
 
+def multi_copy(dsts, srcs):
+    """dst_i.copy_(src_i) for up to 8 pairs of contiguous same-shape, same-dtype device tensors per launch."""
+    import ctypes
+    lib = _lib.load()
+    for d, s_ in zip(dsts, srcs):
+        if not (d.is_cuda and s_.is_cuda) or d.dtype != s_.dtype or d.shape != s_.shape \
+                or not d.is_contiguous() or not s_.is_contiguous():
+            raise _lib.XptHipError("multi_copy: pairs of contiguous device tensors of one shape and dtype expected")
+    for i in range(0, len(dsts), 8):
+        dd, ss = dsts[i:i + 8], srcs[i:i + 8]
+        n = len(dd)
+        P, LL = ctypes.c_void_p * n, ctypes.c_longlong * n
+        _lib.check(lib.xpt_multi_copy(P(*[t.data_ptr() for t in ss]), P(*[t.data_ptr() for t in dd]),
+                                      LL(*[t.numel() * t.element_size() for t in dd]), n, _stream()), "xpt_multi_copy")
+
+
 class _ConcatChannels(torch.autograd.Function):
     """concat(parts, channel axis) of bf16 NHWC activations plus the zero channels that pad the result to a multiple of 8:
     one launch (xpt_concat_channels); the backward hands out channel slices of the incoming gradient (views, no launch)."""

@@ -194,6 +194,7 @@ class ModelTrainer(TrainValBase):
 
 
 _DEBUG_REPLAY = __import__("os").environ.get("XPT_DEBUG_REPLAY", "0") == "1"
+_OWN_MULTI_COPY = __import__("os").environ.get("XPT_DEBUG_FOREACH_COPY", "0") != "1"     # A/B: torch._foreach_copy_ for the batch refresh
 
 
 class _GraphPair:
@@ -255,11 +256,15 @@ class _StepGraph:
             self.graph, self.static_in, self.static_out = entry
             self.signature = sig
             # the new batch into the graph's static inputs: ONE multi-tensor copy launch instead of one copy per feature
-            dst = [v for k, v in self.static_in.items() if features[k].is_cuda and features[k].dtype == v.dtype]
-            src = [features[k] for k, v in self.static_in.items() if features[k].is_cuda and features[k].dtype == v.dtype]
-            if len(dst) > 1:
+            fits = lambda k, v: (features[k].is_cuda and features[k].dtype == v.dtype and features[k].shape == v.shape      # noqa: E731
+                                 and features[k].is_contiguous() and v.is_contiguous() and v.numel() > 0)
+            dst = [v for k, v in self.static_in.items() if fits(k, v)]
+            src = [features[k] for k, v in self.static_in.items() if fits(k, v)]
+            if len(dst) > 1 and _OWN_MULTI_COPY:
+                _ops.multi_copy(dst, src)                       # (xpt_multi_copy: 16 MB + six small tensors in one launch)
+            elif len(dst) > 1:
                 torch._foreach_copy_(dst, src)
-            rest = [k for k, v in self.static_in.items() if not (features[k].is_cuda and features[k].dtype == v.dtype)]
+            rest = [k for k, v in self.static_in.items() if not fits(k, v)]
             for k in (rest if len(dst) > 1 else self.static_in):
                 self.static_in[k].copy_(features[k], non_blocking=True)
         if isinstance(self.graph, _GraphPair):
