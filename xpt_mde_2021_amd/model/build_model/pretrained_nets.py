@@ -881,10 +881,12 @@ class NormalCell(nn.Module):
         taps.offer(self.act_id, h)
         ps = None
         if wide and self.adjust.mode == "project":
-            pr = shared_relu(p)
-            if pair_conv1x1_bn_usable(h, pr, self.conv.weight, self.adjust.conv.weight, self.bn, self.adjust.bn):
+            # (usability is judged on p itself -- its rectified aliases share its shape, dtype and strides --: shared_relu
+            #  hands out one alias of the producing cell's output per CALL, so it must only be called by a real consumer)
+            if pair_conv1x1_bn_usable(h, p, self.conv.weight, self.adjust.conv.weight, self.bn, self.adjust.bn):
                 # the squeeze of the cell input and the projection of p read tensors of one shape: one launch for both heads
                 # (and one backward launch, which also adds the gradients their consumers send back)
+                pr = shared_relu(p)
                 taps.offer(self.adjust.act_id, pr)
                 a, b = self.bn, self.adjust.bn
                 outs = _PairConv1x1BnFan.apply(n_h, n_p, BN_EPS, h, pr, self.conv.weight, self.adjust.conv.weight, a.weight,
