@@ -265,31 +265,36 @@ __global__ void smooth_fwd_ms_kernel(SmoothMs a) {
   smooth_fwd_body(a.disp[s], a.image[s], a.part[s], a.h[s], a.w[s], a.gf, a.is_depth, a.nblk[s], red);
 }
 
-__global__ void smooth_reduce_kernel(const float* __restrict__ part, float* __restrict__ loss, int B, int nblk,
-                                     float inv_x, float inv_y) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// one wave per sample: lane l adds the partials l, l + 64, ... (all its loads independent), then a fixed shuffle tree --
+// deterministic, and the same order in the per-scale and the multi-scale launch
+__device__ __forceinline__ void smooth_reduce_body(const float* __restrict__ part, int nblk, float inv_x, float inv_y,
+                                                   float* __restrict__ out) {
   float sx = 0.f, sy = 0.f;
-  for (int k = 0; k < nblk; ++k) {
-    sx += part[((long long)b * nblk + k) * 2];
-    sy += part[((long long)b * nblk + k) * 2 + 1];
+  for (int k = threadIdx.x; k < nblk; k += 64) {
+    sx += part[2 * k];
+    sy += part[2 * k + 1];
   }
-  loss[b] = 0.5f * (sx * inv_x) + 0.5f * (sy * inv_y);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sx += __shfl_down(sx, off, 64);
+    sy += __shfl_down(sy, off, 64);
+  }
+  if (threadIdx.x == 0) *out = 0.5f * (sx * inv_x) + 0.5f * (sy * inv_y);
 }
 
-__global__ void smooth_reduce_ms_kernel(SmoothMs a) {
+__global__ __launch_bounds__(64) void smooth_reduce_kernel(const float* __restrict__ part, float* __restrict__ loss, int B,
+                                                          int nblk, float inv_x, float inv_y) {
+  const int b = blockIdx.x;
+  smooth_reduce_body(part + (long long)b * nblk * 2, nblk, inv_x, inv_y, loss + b);
+}
+
+// (the one-thread-per-sample loop this replaces walked up to 208 dependent iterations: 18 us)
+__global__ __launch_bounds__(64) void smooth_reduce_ms_kernel(SmoothMs a) {
   const int s = blockIdx.y;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+  const int b = blockIdx.x;
   const int nblk = a.nblk[s];
-  const float* part = a.part[s];
-  float sx = 0.f, sy = 0.f;
-  for (int k = 0; k < nblk; ++k) {
-    sx += part[((long long)b * nblk + k) * 2];
-    sy += part[((long long)b * nblk + k) * 2 + 1];
-  }
   const float inv_x = 1.0f / ((float)a.h[s] * (float)(a.w[s] - 1)), inv_y = 1.0f / ((float)(a.h[s] - 1) * (float)a.w[s]);
-  a.loss[s][b] = 0.5f * (sx * inv_x) + 0.5f * (sy * inv_y);
+  smooth_reduce_body(a.part[s] + (long long)b * nblk * 2, nblk, inv_x, inv_y, a.loss[s] + b);
 }
 
 __device__ inline float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
@@ -475,7 +480,7 @@ int xpt_smooth_fwd(const float* disp, const float* image, float* loss, float* wo
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nblk, B), dim3(256), 0, s, disp, image, workspace, h, w, grad_factor,
                      input_is_depth);
-  hipLaunchKernelGGL(smooth_reduce_kernel, dim3((B + 63) / 64), dim3(64), 0, s, workspace, loss, B, nblk,
+  hipLaunchKernelGGL(smooth_reduce_kernel, dim3(B), dim3(64), 0, s, workspace, loss, B, nblk,
                      1.0f / ((float)h * (float)(w - 1)), 1.0f / ((float)(h - 1) * (float)w));
   return xpt_launch_status();
 }
@@ -526,7 +531,7 @@ int xpt_smooth_ms_fwd(int nscales, const float* const* disp, const float* const*
   XPT_BEGIN_LAUNCH();
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(smooth_fwd_ms_kernel, dim3(max_blk, B, nscales), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(smooth_reduce_ms_kernel, dim3((B + 63) / 64, nscales), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(smooth_reduce_ms_kernel, dim3(B, nscales), dim3(64), 0, st, a);
   return xpt_launch_status();
 }
 
