@@ -484,6 +484,10 @@ int xpt_augment(const float* u, float* params, const float* img0, float* img0_ou
                 float* K1_out, int B, const float* pose0, float* pose0_out, const float* pose1, float* pose1_out, int n_pose,
                 const float* stereo, float* stereo_out, int H, int W, float p_crop, float p_flip, float p_jit,
                 float half_crop, void* stream);
+/* Pinned draws for the replay check of a captured step (xpt_mde_2021_amd/model/train_val.py): every later xpt_augment launch
+ * carries `pin` (device float[9], NULL to stop) and takes pin[1..8] as its uniforms while pin[0] > 0.5 -- decided on the
+ * device at run time, so replays of one captured graph can be made to repeat their draws and to draw freshly again. */
+int xpt_augment_pin(const float* pin);
 
 /* Encoder input as PretrainedModel prepares it (model/build_model/pretrained_nets.py:36-43): image / 127.5 - 1, bilinear resize
  * (TF2 half-pixel centres) to (H+2, W+2), written as the NHWC bf16 tensor [B, H+2, W+2, 8] (channels 3..7 zero) the stem

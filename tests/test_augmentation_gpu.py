@@ -131,3 +131,36 @@ def test_fused_augmentation_draws_like_the_chain(gpu_device):
     assert abs(cropped - 0.3) < 0.05, cropped
     assert abs(p[:, 4].mean().item() - 0.25) < 0.07 and abs(p[:, 5].mean().item() - 0.4) < 0.08
     assert (p[:, 6:8] >= 0.5).all() and (p[:, 6:8] < 1.5).all()
+
+
+def test_pinned_draws_repeat_inside_a_captured_graph_and_release(gpu_device):
+    """TotalAugment.pin_draws / unpin_draws (the replay check of a captured training step, train_val._StepGraph): while
+    pinned, every replay of ONE captured graph applies the same crop / flip / jitter; unpinned, the draws are fresh again --
+    without re-capturing (the kernel reads the pin flag on the device)."""
+    dev = gpu_device
+    torch.manual_seed(5)
+    g = torch.Generator().manual_seed(3)
+    feats = {"image5d": torch.rand(2, 5, 16, 24, 3, generator=g).to(dev) * 2 - 1,
+             "intrinsic": torch.tensor([[20., 0, 12], [0, 20., 8], [0, 0, 1]], device=dev).repeat(2, 1, 1)}
+    total = aug.augmentation_factory({"CropAndResize": 0.9, "HorizontalFlip": 0.5, "ColorJitter": 0.9})
+    assert total.can_pin()
+    total(feats)                                   # eager warm-up: allocates the pin buffer
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = total(feats)
+    params = total.params                          # the captured launch's parameter output (later calls rebind total.params)
+    def replay():
+        graph.replay()
+        torch.cuda.synchronize()
+        return out["image5d"].clone(), params.clone()
+    total.pin_draws()
+    a, pa = replay()
+    b, pb = replay()
+    eager = total(feats)                           # the eager path sees the pinned draws too
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(pa, pb) and torch.equal(eager["image5d"], a)
+    total.unpin_draws()
+    seen = {tuple(replay()[1].tolist()) for _ in range(6)}
+    assert len(seen) > 1                           # fresh draws again
+    assert tuple(pa.tolist()) not in seen

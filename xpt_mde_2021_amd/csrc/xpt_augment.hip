@@ -18,6 +18,7 @@ namespace {
 
 struct AugArgs {
   const float* u;              // [8] uniforms: crop y1, x1, y2, x2; flip; jitter; gamma; saturation
+  const float* pin;            // null, or [9]: pin[0] > 0.5 -> the draws are pin[1..8] instead of u (xpt_augment_pin)
   float* params;               // [8] out: box (y1, x1, y2, x2), flip (0/1), jitter (0/1), gamma, saturation
   const float* img[2];         // [n_img, H, W, 3] (image5d, image5d_R)
   float* img_out[2];
@@ -41,7 +42,9 @@ struct Draw {
 
 __device__ inline float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
-__device__ inline Draw decode(const AugArgs& a) {
+__device__ inline Draw decode(const AugArgs& a_) {
+  AugArgs a = a_;
+  if (a.pin != nullptr && a.pin[0] > 0.5f) a.u = a.pin + 1;       // pinned draws (the replay check of a captured step)
   Draw d;
   const float max1 = a.half_crop, min1 = -(1.f - a.p_crop) * a.half_crop / a.p_crop;
   const float min2 = 1.f - max1, max2 = 1.f - min1;
@@ -232,6 +235,17 @@ extern "C" int xpt_stem_input(const float* image, long long batch_stride, void* 
  * img / img_out: image5d (and image5d_R or NULL) as [n_img, H, W, 3] float32; depth / depth_out [n_depth, H, W] or NULL;
  * K / K_out [B, 3, 3] (second pair NULL without a right camera); pose / pose_out [n_pose, 4, 4] (NULL when the dataset has
  * no pose_gt); stereo / stereo_out [B, 4, 4] or NULL.  Outputs must not alias inputs. */
+static const float* g_aug_pin = nullptr;
+
+/* Pinned draws: every later xpt_augment launch carries `pin` (device float[9], or NULL to stop) and uses pin[1..8] as its
+ * uniforms WHILE pin[0] > 0.5 (decided on the device, at run time): a captured training step can then be replayed with the
+ * same draws -- its replay check compares replays with each other and with an eager step -- by flipping pin[0], without
+ * re-capturing.  The buffer must outlive the captured graphs. */
+extern "C" int xpt_augment_pin(const float* pin) {
+  g_aug_pin = pin;
+  return XPT_OK;
+}
+
 extern "C" int xpt_augment(const float* u, float* params, const float* img0, float* img0_out, const float* img1,
                            float* img1_out, int n_img, const float* depth, float* depth_out, int n_depth, const float* K0,
                            float* K0_out, const float* K1, float* K1_out, int B, const float* pose0, float* pose0_out,
@@ -247,6 +261,7 @@ extern "C" int xpt_augment(const float* u, float* params, const float* img0, flo
   if (!(p_crop > 0.f) || (long long)n_img * H * W >= (1LL << 31) - (1LL << 24) || (long long)n_depth * H * W >= (1LL << 31) - (1LL << 24))
     return XPT_ERR_ARG;
   AugArgs a{};
+  a.pin = g_aug_pin;
   a.u = u; a.params = params;
   a.img[0] = img0; a.img_out[0] = img0_out; a.img[1] = img1; a.img_out[1] = img1_out;
   a.depth = depth; a.depth_out = depth_out;

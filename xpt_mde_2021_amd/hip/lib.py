@@ -117,6 +117,7 @@ SIGNATURES = {
     "xpt_photo_march_ms_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),
     "xpt_photo_march_ms_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),
     "xpt_photo_march_ms_fwdbwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),
+    "xpt_augment_pin": (_i, [_p]),
     "xpt_augment": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _i, _i,
                          _f, _f, _f, _f, _p]),
     "xpt_stem_input": (_i, [_p, ctypes.c_longlong, _p, _i, _i, _i, _p]),

@@ -22,9 +22,41 @@ def augmentation_factory(augment_probs=None):
     return TotalAugment(augmenters)
 
 
+_PIN_BUFFERS = {}      # device -> float[9] (flag + eight pinned uniforms), see TotalAugment._pin_buffer
+
+
 class TotalAugment:
     def __init__(self, augment_objects=None):
         self.augment_objects = augment_objects or []
+        self._pin = None             # device float[9]: flag + eight pinned uniforms (fused path; see pin_draws)
+
+    # ---- pinned draws (the replay check of a captured step: replays and an eager run must see the SAME random draws)
+    def can_pin(self):
+        return ([type(a) for a in self.augment_objects] == [CropAndResize, HorizontalFlip, ColorJitter]
+                and all(a.aug_prob > 0 for a in self.augment_objects))
+
+    def _pin_buffer(self, device):
+        # ONE buffer per device for the life of the process: captured graphs keep its address (xpt_augment_pin hands it to
+        # every later launch), so it must never be freed or replaced
+        from ...hip import lib as _lib
+        buf = _PIN_BUFFERS.get(device)
+        if buf is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise WrongInputException("augmentation: run one eager step before capturing (the pin buffer is allocated on first use)")
+            buf = _PIN_BUFFERS[device] = torch.zeros(9, device=device)
+        _lib.check(_lib.load().xpt_augment_pin(buf.data_ptr()), "xpt_augment_pin")
+        self._pin = buf
+        return buf
+
+    def pin_draws(self):
+        """From now on the fused augmentation kernel repeats one set of draws (also inside already captured graphs)."""
+        if self._pin is not None:
+            self._pin[1:].uniform_()
+            self._pin[0] = 1.0
+
+    def unpin_draws(self):
+        if self._pin is not None:
+            self._pin[0] = 0.0
 
     def __call__(self, features):
         if self._fusable(features):
@@ -55,6 +87,7 @@ class TotalAugment:
         img = features["image5d"].contiguous()
         b, s, h, w, _ = img.shape
         dev = img.device
+        self._pin_buffer(dev)
         if u is None:
             u = torch.rand(8, device=dev)             # device generator: new draws on every replay of a captured step
         params = torch.empty(8, device=dev)

@@ -178,6 +178,13 @@ class ModelTrainer(TrainValBase):
                 return p.shape
         return ()
 
+    def _pin_hooks(self):
+        """(enter, leave) for _StepGraph's replay check when the augmenter can repeat its draws (the fused default chain)."""
+        aug = self.augmenter
+        if aug is not None and hasattr(aug, "can_pin") and aug.can_pin():
+            return (aug.pin_draws, aug.unpin_draws)
+        return None
+
     def optimizer_state(self):
         opt = self.optimizer
         state = [opt.flat.data, opt.flat.grad, opt.m, opt.v, opt.step_count]
@@ -214,7 +221,7 @@ class _StepGraph:
     """Captures fn(static_features) into a hipGraph; replays it after copying a new batch into the static buffers."""
 
     def __init__(self, fn, warmup=3, state=None, describe=None, segments=None, repair=None, reference=False,
-                 phases=None, between=None):
+                 phases=None, between=None, pin=None):
         self.fn = fn
         # phases = (first, second): the step is captured as TWO graphs sharing one memory pool, first(features) ->
         # (carry, outputs) and second(carry); `between` runs between their replays (the data-parallel trainer launches
@@ -228,6 +235,10 @@ class _StepGraph:
         self.repair = repair                   # callable -> number of layers switched to replay-safe gradients
         self.repairs = 0
         self.reference = reference             # the step draws no random numbers: compare the replays with an eager step
+        # pin = (enter, leave): make the step's random draws repeat / draw freshly again (the fused augmentation kernel reads
+        # pinned uniforms while a device flag is set): during the replay check an augmented step is then held to the same
+        # replay-vs-replay and replay-vs-eager comparisons as a step without random numbers
+        self.pin = pin
         self.graph = None
         self.static_in = None
         self.static_out = None
@@ -357,7 +368,18 @@ class _StepGraph:
             t.copy_(s)
         self.signature = sig
         check = state and __import__("os").environ.get("XPT_REPLAY_CHECK", "1") != "0"      # 0: diagnostics only
-        report = self._replay_report(state, saved) if check else None
+        report = None
+        if check:
+            was_reference = self.reference
+            if self.pin is not None:
+                self.pin[0]()
+                self.reference = True
+            try:
+                report = self._replay_report(state, saved)
+            finally:
+                if self.pin is not None:
+                    self.pin[1]()
+                self.reference = was_reference
         if report is not None:
             # Some library convolution solvers return garbage from the second replay of a captured graph on this stack
             # (DESIGN.md section 6); which solver MIOpen's find picks can vary from process to process.  Fall back to
@@ -533,7 +555,7 @@ class ModelTrainerGraph(ModelTrainer):
                                 and getattr(opts, "CAPTURE_LIBRARY_STEPS", "audit") is False)
         self._graph = _StepGraph(self.train_a_step, state=self.optimizer_state, describe=self.describe_state,
                                  segments=self.state_segments, repair=self.repair_flagged,
-                                 reference=self.augmenter is None)
+                                 reference=self.augmenter is None, pin=self._pin_hooks())
 
     def run_a_batch(self, features):
         if not features["image5d"].is_cuda or self.trains_flow_net:
@@ -571,7 +593,7 @@ class ModelTrainerDistrib(ModelTrainer):
         phases = (self.backward_first, self.backward_second) if self._early_start is not None else None
         self._graph = _StepGraph(self.forward_backward, state=self.optimizer_state, describe=self.describe_state,
                                  segments=self.state_segments, repair=self.repair_flagged,
-                                 reference=self.augmenter is None, phases=phases,
+                                 reference=self.augmenter is None, pin=self._pin_hooks(), phases=phases,
                                  between=self.reduce_early if phases else None) \
             if getattr(opts, "DISTRIB_GRAPH", True) else None
 
