@@ -49,14 +49,23 @@ class TotalAugment:
         return buf
 
     def pin_draws(self):
-        """From now on the fused augmentation kernel repeats one set of draws (also inside already captured graphs)."""
+        """From now on the fused augmentation kernel repeats one set of draws (also inside already captured graphs).
+        The parameter tensors the augmenters expose (`param`, `params`: outputs of the LAST call -- of the captured step,
+        when this is called right after a capture) are remembered: eager calls made while pinned rebind them."""
         if self._pin is not None:
             self._pin[1:].uniform_()
             self._pin[0] = 1.0
+            self._bound = (getattr(self, "params", None), [getattr(a, "param", None) for a in self.augment_objects])
 
     def unpin_draws(self):
         if self._pin is not None:
             self._pin[0] = 0.0
+            bound = getattr(self, "_bound", None)
+            if bound is not None:
+                self.params = bound[0]
+                for a, q in zip(self.augment_objects, bound[1]):
+                    a.param = q
+                self._bound = None
 
     def __call__(self, features):
         if self._fusable(features):
