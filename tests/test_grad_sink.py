@@ -500,3 +500,113 @@ def test_sibling_pointwise_layers_ride_in_the_main_launch(gpu_device, C, H, W, m
         assert torch.equal(a, b)
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
+
+
+def _pw_layer(pn, dev, cout, cin, seed):
+    gg = torch.Generator().manual_seed(seed)
+    w = torch.nn.Parameter((torch.randn(cout, cin, 1, 1, generator=gg) * 0.2).to(dev))
+    w.shadow_bf16 = w.detach().bfloat16()
+    w.flat_grad = torch.zeros_like(w)
+    bn = pn.FrozenBatchNorm(cout).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(cout, generator=gg) + 0.5); bn.bias.copy_(torch.randn(cout, generator=gg) * 0.3)
+        bn.running_mean.copy_(torch.randn(cout, generator=gg) * 0.2); bn.running_var.copy_(torch.rand(cout, generator=gg) + 0.3)
+    bn.weight.flat_grad = torch.zeros(cout, device=dev)
+    bn.bias.flat_grad = torch.zeros(cout, device=dev)
+    return w, bn
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(264, 44, 8, 13), (528, 88, 4, 7), (88, 44, 8, 13)])
+def test_paired_cell_heads_equal_two_separate_layers(gpu_device, cin, cout, H, W):
+    """_PairConv1x1BnFan (squeeze of the cell input + projection of p: one launch each way, 3 + 2 output aliases whose
+    gradients are added inside the backward launch, xpt_conv1x1_bn_multi_bwd_fused_fan) == two conv1x1_bn(fan_out=...)
+    calls (keras nasnet._normal_a_cell / _adjust_block): outputs bit for bit, input gradients bit for bit, parameter
+    gradients to the last ulps of their split-K sums."""
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
+    dev = gpu_device
+    g = torch.Generator().manual_seed(cin + W)
+    rnd = lambda c: torch.randn(2, c, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    xa0, xb0 = rnd(cin), rnd(cin)
+    gys = [rnd(cout) for _ in range(5)]
+
+    def run(paired):
+        (wa, bna), (wb, bnb) = _pw_layer(pn, dev, cout, cin, 3), _pw_layer(pn, dev, cout, cin, 4)
+        xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            if paired:
+                assert pn.pair_conv1x1_bn_usable(xa, xb, wa, wb, bna, bnb)
+                outs = pn._PairConv1x1BnFan.apply(3, 2, pn.BN_EPS, xa, xb, wa, wb, bna.weight, bnb.weight, bna.bias, bnb.bias,
+                                                  bna.running_mean, bnb.running_mean, bna.running_var, bnb.running_var)
+            else:
+                outs = tuple(pn.conv1x1_bn(xa, wa, bna, fan_out=3)) + tuple(pn.conv1x1_bn(xb, wb, bnb, fan_out=2))
+        torch.autograd.backward(outs, gys)
+        ops.grad_sink.flush()
+        torch.cuda.synchronize()
+        params = [t.flat_grad.clone() for w_, b_ in ((wa, bna), (wb, bnb)) for t in (w_, b_.weight, b_.bias)]
+        return [o.detach().float() for o in outs], [xa.grad.float(), xb.grad.float()], params
+
+    ya, ga, pa = run(True)
+    yb, gb, pb = run(False)
+    # (from 256 input channels on, the single-layer forward splits the k loop over the waves of a workgroup -- another
+    #  summation order than the two-job launch: bf16 results one rounding apart there, bit-equal below)
+    same = torch.equal if cin < 256 else (lambda a, b: torch.allclose(a, b, rtol=2 ** -7, atol=2 ** -7 * float(b.abs().max())))
+    for a, b in zip(ya, yb):
+        assert same(a, b)
+    for a, b in zip(ga, gb):
+        assert same(a, b)
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, atol=(1e-5 if cin < 256 else 2e-2) * max(1.0, float(b.abs().max())))
+
+
+@pytest.mark.parametrize("C,F_,H,W", [(44, 44, 16, 26), (264, 88, 8, 13), (528, 176, 5, 7)])
+def test_fused_spatial_adjust_block_equals_the_composed_ops(gpu_device, C, F_, H, W, monkeypatch):
+    """AdjustBlock in "spatial" mode (keras nasnet._adjust_block: two strided 1x1 convolutions, concat, BatchNorm): the
+    one-launch path (_SpatialAdjustBn: two jobs of the multi-layer pointwise kernel writing the halves of one tensor) against
+    the composed path (two GEMMs + cat + BatchNorm launch): output and all gradients to bf16 rounding (the composed path
+    rounds the GEMM outputs through rocBLAS, the fused one through the matrix-core kernel: same values up to summation order)."""
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
+    dev = gpu_device
+    g = torch.Generator().manual_seed(C + W)
+    x0 = torch.randn(2, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, F_, (H + 1) // 2, (W + 1) // 2, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    class _Net:
+        def __init__(self):
+            self.n = 0
+
+        def new_activation(self):
+            self.n += 1
+            return self.n
+
+    def run(fused):
+        monkeypatch.setattr(pn, "_FUSED_SPATIAL_ADJUST", fused)
+        torch.manual_seed(1)
+        block = pn.AdjustBlock(_Net(), C, 1, 2, F_).to(dev)
+        assert block.mode == "spatial"
+        with torch.no_grad():
+            block.bn.weight.copy_(torch.rand(F_) + 0.5); block.bn.bias.copy_(torch.randn(F_) * 0.3)
+            block.bn.running_mean.copy_(torch.randn(F_) * 0.2); block.bn.running_var.copy_(torch.rand(F_) + 0.3)
+        params = [block.conv1.weight, block.conv2.weight, block.bn.weight, block.bn.bias]
+        for q in params:
+            q.flat_grad = torch.zeros_like(q)
+        for q in params[:2]:
+            q.shadow_bf16 = q.detach().bfloat16()
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            y = block(x, pn._Taps(set()))
+            if fused:
+                assert "SpatialAdjustBn" in type(y.grad_fn).__name__
+        y.backward(gy)
+        ops.grad_sink.flush()
+        torch.cuda.synchronize()
+        grads = [q.flat_grad.clone() if float(q.flat_grad.abs().max()) > 0 else q.grad.float() for q in params]
+        return y.detach().float(), x.grad.float(), grads
+
+    ya, xa, pa = run(True)
+    yb, xb, pb = run(False)
+    assert torch.allclose(ya, yb, atol=2e-2 * float(yb.abs().max()))
+    assert torch.allclose(xa, xb, atol=3e-2 * float(xb.abs().max()))
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a.reshape(-1), b.reshape(-1), atol=2e-2 * max(1e-3, float(b.abs().max())))
