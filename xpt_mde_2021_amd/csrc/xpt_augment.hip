@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
     //  were two thirds of this kernel's instructions)
     const unsigned total32 = (unsigned)total, step32 = a.img_blocks * 256u;
     for (unsigned p = blk * 256u + threadIdx.x; p < total32; p += step32) {
-      const unsigned r = p / (unsigned)W;
-      const int j = (int)(p - r * (unsigned)W);
-      const unsigned n = r / (unsigned)H;
-      const int i = (int)(r - n * (unsigned)H);
+      unsigned j_, i_;
+      const unsigned r = xpt_divmod(p, (unsigned)W, j_);
+      const unsigned n = xpt_divmod(r, (unsigned)H, i_);
+      const int j = (int)j_, i = (int)i_;
       const int jj = d.flip ? W - 1 - j : j;
       // corner-aligned sample position (crop_and_resize): y = (y1 + (y2 - y1) i / (H - 1)) (H - 1)
       const float fy = (d.y1 + sy * (float)i) * (float)(H - 1), fx = (d.x1 + sx * (float)jj) * (float)(W - 1);
@@ -124,10 +124,10 @@ __global__ __launch_bounds__(256) void augment_kernel(AugArgs a) {
     const float sy = (d.y2 - d.y1) / (float)(H > 1 ? H - 1 : 1), sx = (d.x2 - d.x1) / (float)(W > 1 ? W - 1 : 1);
     const unsigned total32 = (unsigned)total, step32 = a.depth_blocks * 256u;
     for (unsigned p = blk * 256u + threadIdx.x; p < total32; p += step32) {
-      const unsigned r = p / (unsigned)W;
-      const int j = (int)(p - r * (unsigned)W);
-      const unsigned n = r / (unsigned)H;
-      const int i = (int)(r - n * (unsigned)H);
+      unsigned j_, i_;
+      const unsigned r = xpt_divmod(p, (unsigned)W, j_);
+      const unsigned n = xpt_divmod(r, (unsigned)H, i_);
+      const int j = (int)j_, i = (int)i_;
       const float fy = (d.y1 + sy * (float)i) * (float)(H - 1), fx = (d.x1 + sx * (float)j) * (float)(W - 1);
       const int yy = (int)nearbyintf(fy), xx = (int)nearbyintf(fx);
       const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
@@ -184,10 +184,10 @@ __global__ __launch_bounds__(256) void stem_input_kernel(const float* __restrict
   const long long total = (long long)B * OH * OW;
   const float ry = (float)H / (float)OH, rx = (float)W / (float)OW;
   for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
-    const int x = (int)(p % OW);
-    const long long r = p / OW;
-    const int y = (int)(r % OH);
-    const long long b = r / OH;
+    unsigned x_, y_;
+    const unsigned r = xpt_divmod((unsigned)p, (unsigned)OW, x_);      // (pixel count below 2^31: checked by the launcher)
+    const long long b = (long long)xpt_divmod(r, (unsigned)OH, y_);
+    const int x = (int)x_, y = (int)y_;
     const float fy = fmaxf(ry * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(rx * ((float)x + 0.5f) - 0.5f, 0.f);
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
@@ -222,6 +222,7 @@ extern "C" int xpt_stem_input(const float* image, long long batch_stride, void* 
   if (B <= 0 || H <= 0 || W <= 0 || batch_stride < (long long)H * W * 3) return XPT_ERR_SHAPE;
   if (((uintptr_t)out) % 16 != 0) return XPT_ERR_ARG;
   const long long total = (long long)B * (H + 2) * (W + 2);
+  if (total >= (1LL << 31)) return XPT_ERR_SHAPE;
   long long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   XPT_BEGIN_LAUNCH();
