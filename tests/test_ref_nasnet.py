@@ -145,7 +145,10 @@ def test_gfx950_encoder_equals_the_independent_restatement(gpu_device, weights):
     in fp32 (tools/lab/nasnet_grad_probe.py: the restatement in fp32, the product on the CPU and the product on the GPU
     disagree with the fp64 restatement in exactly that way, differently on an 8-thread and a 128-thread host).  Such an
     image says nothing about the kernels, so: every image must agree to the loose bar a mis-wired cell cannot meet (a swapped
-    branch moves ALL elements), and at least one of up to four images must agree to the tight one (1e-4 of the elements)."""
+    branch moves ALL elements), and at least one of up to four images must agree to the tight one: at most 0.2 % of the
+    gradient elements of any tap off by more than 2e-3 of the scale (single late switches still move ~0.1 % on some boxes --
+    the library GEMMs / the stem convolution of the fp32 path do not sum in the same order everywhere --, a wrong border or
+    pad rule moves the 4 % of the elements that sit on the perimeter)."""
     from tests.util import frac_close
     net = pn.NASNetMobileEncoder().float().eval()
     pn.load_keras_weights(net, {k: v.numpy() for k, v in weights.items()})
@@ -171,7 +174,7 @@ def test_gfx950_encoder_equals_the_independent_restatement(gpu_device, weights):
             shares.append(share)
             # loose bar, every image and tap: a few per cent of the elements behind one flipped switch, never more
             assert share <= 0.1 and float(err.max()) <= 0.2 * scale, (seed, k, share, float(err.max()) / scale)
-        if max(shares) <= 1e-4:
+        if max(shares) <= 2e-3:
             tight = True
             break
-    assert tight, f"no image of four agreed with the fp64 restatement to 1e-4 of the gradient elements (last: {shares})"
+    assert tight, f"no image of four agreed with the fp64 restatement to 0.2 % of the gradient elements (last: {shares})"
