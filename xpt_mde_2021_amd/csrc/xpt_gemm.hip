@@ -46,6 +46,10 @@ inline WgradPlan wgrad_plan(long long M, int cout, int cin, bool defer = false) 
   const int quadrants = (p.tco / 32) * (p.tci / 32);
   const int kslices = p.waves / quadrants;
   long long rows = 2LL * g_pairs_per_wave * kslices;
+  // larger weights: more rows per workgroup (fewer splits, so fewer partial tiles to write and to reduce; in-step sweep of
+  // the thresholds, round 3: 5.58 -> 5.53 ms).  The 44 x 44 layers of the first stack keep the short workgroups.
+  if ((long long)cout * cin >= 2048) rows *= 2;
+  if ((long long)cout * cin >= 30000) rows *= 2;
   // splits: bounded by what the finishing workgroup can add (in-kernel finish) or by 8 MiB of partials (deferred)
   long long smax = defer ? ((long long)g_defer_cap_mib << 20) / ((long long)cout * cin * 4)
                          : ((long long)g_max_partial_kib * 1024) / ((long long)p.tco * p.tci * 4);
