@@ -301,6 +301,85 @@ __global__ __launch_bounds__(256) void dw_multi_fwd_vec_kernel(DwMultiFwd m, DwD
   }
 }
 
+// ---------------------------------------------------------------- small maps: the whole map of an image in LDS (stride 1, bf16)
+// On the 8 x 26 and 4 x 13 maps of the deeper stacks a launch of the stencil kernels above is a few dozen workgroups whose
+// threads walk the filter rows one memory round trip at a time (k rows, and the backward the rows of up to three filters:
+// 11 dependent trips on 73 k elements).  Here a workgroup owns (job, image, chunk of CW channels): it stages the image's
+// whole map of those channels and the taps in LDS with ONE burst of loads and computes every output of the chunk from LDS,
+// in the same (ky, kx) order with the same fused multiply-adds as the stencil kernels: same bits.
+//   FLIP = 0: y = conv(f(x), w);   FLIP = 1: the data gradient dx_u = [x_u > 0] * sum over the jobs reading input u of
+//   conv(dy_j, w_j rotated by 180 degrees, pad' = k_j - 1 - pad_j).
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+
+template <int K>
+__device__ __forceinline__ void dw_small_accumulate(const unsigned short* __restrict__ xs, const float* __restrict__ ws, int H,
+                                                    int W, int cw, int oy, int ox, int c8, int pad_t, int pad_l, bool relu,
+                                                    float (&acc)[8]) {
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int sy = oy + ky - pad_t;
+    const bool row_ok = sy >= 0 && sy < H;
+    const int cy = min(max(sy, 0), H - 1);
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int sx = ox + kx - pad_l;
+      const bool ok = row_ok && sx >= 0 && sx < W;
+      const uint4 raw = *(const uint4*)(xs + (cy * W + min(max(sx, 0), W - 1)) * cw + c8);
+      const unsigned short* e = (const unsigned short*)&raw;
+      const float4 w0 = *(const float4*)(ws + (ky * K + kx) * cw + c8), w1 = *(const float4*)(ws + (ky * K + kx) * cw + c8 + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const float f = bf16_to_f32(e[v]);
+        const float in = ok ? (relu ? fmaxf(f, 0.f) : f) : 0.f;
+        acc[v] += in * wv[v];
+      }
+    }
+  }
+}
+
+// stage the map of `src` (image b, channels c_lo .. c_lo + cw) and the taps of `w` (rotated when flip) into LDS
+__device__ __forceinline__ void dw_small_stage(unsigned short* xs, float* ws, const unsigned short* __restrict__ src,
+                                               const float* __restrict__ w, int b, int HW, int C, int c_lo, int cw, int kk,
+                                               bool flip) {
+  const int g8 = cw >> 3, nvec = HW * g8;
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    unsigned g_;
+    const unsigned pix = xpt_divmod((unsigned)v, (unsigned)g8, g_);
+    *(uint4*)(xs + pix * cw + g_ * 8) = *(const uint4*)(src + ((long long)b * HW + pix) * C + c_lo + g_ * 8);
+  }
+  for (int i = threadIdx.x; i < cw * kk; i += 256) {
+    unsigned tap_;
+    const unsigned c = xpt_divmod((unsigned)i, (unsigned)kk, tap_);
+    ws[(flip ? kk - 1 - (int)tap_ : (int)tap_) * cw + c] = w[(long long)(c_lo + c) * kk + tap_];
+  }
+}
+
+__global__ __launch_bounds__(256) void dw_small_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, int CW) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const int job = blockIdx.x, b = blockIdx.y, c_lo = blockIdx.z * CW;
+  const int cw = d.C - c_lo < CW ? d.C - c_lo : CW;                     // multiple of 8
+  const int HW = d.H * d.W, k = m.k[job], kk = k * k;
+  unsigned short* xs = (unsigned short*)sm;                             // [HW][cw] bf16
+  float* ws = (float*)(sm + (size_t)HW * CW * 2);                       // [kk][cw]
+  dw_small_stage(xs, ws, (const unsigned short*)m.x[job], m.w[job], b, HW, d.C, c_lo, cw, kk, false);
+  __syncthreads();
+  unsigned short* y = (unsigned short*)m.y[job];
+  const int g8 = cw >> 3, items = HW * g8;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    unsigned g_, ox_;
+    const unsigned pix = xpt_divmod((unsigned)it, (unsigned)g8, g_);
+    const int oy = (int)xpt_divmod(pix, (unsigned)d.W, ox_), ox = (int)ox_, c8 = (int)g_ * 8;
+    float acc[8];
+#pragma unroll
+    for (int v = 0; v < 8; ++v) acc[v] = 0.f;
+    if (k == 3) dw_small_accumulate<3>(xs, ws, d.H, d.W, cw, oy, ox, c8, m.pad_t[job], m.pad_l[job], relu_in != 0, acc);
+    else if (k == 5) dw_small_accumulate<5>(xs, ws, d.H, d.W, cw, oy, ox, c8, m.pad_t[job], m.pad_l[job], relu_in != 0, acc);
+    else dw_small_accumulate<7>(xs, ws, d.H, d.W, cw, oy, ox, c8, m.pad_t[job], m.pad_l[job], relu_in != 0, acc);
+    store_chan<__hip_bfloat16, 8>((__hip_bfloat16*)y + ((long long)b * HW + pix) * d.C + c_lo + c8, acc);
+  }
+}
+
 // ---------------------------------------------------------------- data gradient
 // dx[b,iy,ix,c] = [x>0 if relu] * sum_{ky,kx : (iy+pad_t-ky) % S == 0, ...} dy[b,(iy+pad_t-ky)/S,(ix+pad_l-kx)/S,c] * w[c,ky,kx]
 // sum over the taps of one input element: dy[b, (iy+pad_t-ky)/S, (ix+pad_l-kx)/S, c] * w[c, ky, kx]
@@ -599,8 +678,59 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwD
                                                                int data_blocks, int cchunks, int wblocks_per_job) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
   const int relu_in = relu_lab & 255, lab = relu_lab >> 8;      // lab knobs (xpt_dwconv_tune(-21 / -22)): 1 no data part, 2 no weight part
+  // data_blocks < 0: the small-map data gradient (whole map of an image in LDS): -data_blocks = B * C / 8 workgroups per input
+  const bool small = data_blocks < 0;
+  if (small) data_blocks = -data_blocks;
   const int ndata = m.n_inputs * data_blocks;
   if (((int)blockIdx.x < ndata) ? (lab & 1) : (lab & 2)) return;
+  if constexpr (sizeof(T) == 2 && V == 8) {
+    if (small && (int)blockIdx.x < ndata) {
+      // workgroup = (input u, image b, 8-channel group): the maps dy_j of the jobs reading u and their rotated taps go to LDS
+      // in ONE burst; outputs are summed over those jobs in job order, tap by tap as the stencil path does: same bits
+      const int u = blockIdx.x / data_blocks, rest = blockIdx.x - u * data_blocks;
+      const int g8 = d.C >> 3, b = rest / g8, c_lo = (rest - b * g8) * 8;
+      const int HW = d.OH * d.OW;                                         // stride 1: output map = input map
+      unsigned char* sm = (unsigned char*)sW;
+      int nj = 0;
+      for (int j = 0; j < m.n; ++j) {
+        if (m.input_of[j] != u) continue;
+        const int kk = m.k[j] * m.k[j];
+        dw_small_stage((unsigned short*)(sm + (size_t)nj * HW * 16), (float*)(sm + (size_t)DW_MAX_JOBS * HW * 16) + nj * 49 * 8,
+                       (const unsigned short*)m.dy[j], m.w[j], b, HW, d.C, c_lo, 8, kk, true);
+        ++nj;
+      }
+      __syncthreads();
+      const unsigned short* x = (const unsigned short*)m.xin[u];
+      for (int pix = threadIdx.x; pix < HW; pix += 256) {
+        unsigned ix_;
+        const int iy = (int)xpt_divmod((unsigned)pix, (unsigned)d.W, ix_), ix = (int)ix_;
+        float acc[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) acc[v] = 0.f;
+        int q = 0;
+        for (int j = 0; j < m.n; ++j) {
+          if (m.input_of[j] != u) continue;
+          const int k = m.k[j];
+          const unsigned short* xs = (const unsigned short*)(sm + (size_t)q * HW * 16);
+          const float* ws = (const float*)(sm + (size_t)DW_MAX_JOBS * HW * 16) + q * 49 * 8;
+          if (k == 3) dw_small_accumulate<3>(xs, ws, d.OH, d.OW, 8, iy, ix, 0, k - 1 - m.pad_t[j], k - 1 - m.pad_l[j], false, acc);
+          else if (k == 5) dw_small_accumulate<5>(xs, ws, d.OH, d.OW, 8, iy, ix, 0, k - 1 - m.pad_t[j], k - 1 - m.pad_l[j], false, acc);
+          else dw_small_accumulate<7>(xs, ws, d.OH, d.OW, 8, iy, ix, 0, k - 1 - m.pad_t[j], k - 1 - m.pad_l[j], false, acc);
+          ++q;
+        }
+        const long long o = ((long long)b * HW + pix) * d.C + c_lo;
+        if (relu_in) {
+          const uint4 raw = *(const uint4*)(x + o);
+          const unsigned short* e = (const unsigned short*)&raw;
+#pragma unroll
+          for (int v = 0; v < 8; ++v)
+            if (!(bf16_to_f32(e[v]) > 0.f)) acc[v] = 0.f;
+        }
+        store_chan<T, 8>((T*)m.dxin[u] + o, acc);
+      }
+      return;
+    }
+  }
   if ((int)blockIdx.x < ndata) {
     const int u = blockIdx.x / data_blocks, blk = blockIdx.x - u * data_blocks;
     int off = 0;
@@ -682,6 +812,7 @@ inline unsigned grid_for(long long total) {
   return (unsigned)blocks;
 }
 
+int g_dw_small_cw = 8;      // channels per workgroup of the small-map forward (0: small-map kernels off; xpt_dwconv_tune(-100 - cw); in-step: 8 / 16 / 24 / 32 / 64 channels -> 5.46 / 5.50 / 5.52 / 5.55 / 5.72 ms, off 5.52)
 int g_dw_lab = 0;           // lab knobs of the vectorised multi-layer backward (xpt_dwconv_tune(-20 - bits))
 int g_dw_multi_vec = 1;     // 0: the scalar multi-layer kernels (A/B, xpt_dwconv_tune(-1) / (-2))
 int g_dw_s2_vec = 1;        // 0: the scalar stride-2 data gradient (A/B, xpt_dwconv_tune(-3) / (-4))
@@ -890,6 +1021,10 @@ int xpt_dwconv_tune(int wrw_groups) {
     g_dw_multi_vec = wrw_groups == -2;
     return XPT_OK;
   }
+  if (wrw_groups <= -100 && wrw_groups >= -356) {    // channels per workgroup of the small-map kernels: -100 off, -132 / -164 ...
+    g_dw_small_cw = (-100 - wrw_groups) / 8 * 8;
+    return XPT_OK;
+  }
   if (wrw_groups <= -20 && wrw_groups >= -23) {      // lab: -21 no data-gradient part, -22 no weight-gradient part, -20 off
     g_dw_lab = -20 - wrw_groups;
     return XPT_OK;
@@ -953,6 +1088,22 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
   }
   const DwDims d{B, H, W, C, OH, OW, 0, 0};
   hipStream_t s = (hipStream_t)stream;
+  if (stride == 1 && dtype == 1 && g_dw_small_cw > 0 && C % 8 == 0 && H * W <= 256 && OH == H && OW == W) {
+    // small maps (the 8 x 26 / 4 x 13 stacks): the whole map of an image in LDS, one round trip per workgroup
+    bool ok = true;
+    int kmax = 0;
+    for (int j = 0; j < n; ++j) {
+      ok = ok && ((uintptr_t)x[j]) % 16 == 0 && ((uintptr_t)y[j]) % 16 == 0;
+      kmax = k[j] > kmax ? k[j] : kmax;
+    }
+    const int cw = g_dw_small_cw < C ? g_dw_small_cw : C;
+    const size_t lds = (size_t)H * W * cw * 2 + (size_t)kmax * kmax * cw * 4;
+    if (ok && lds <= 64 * 1024) {
+      XPT_BEGIN_LAUNCH();
+      hipLaunchKernelGGL(dw_small_fwd_kernel, dim3(n, B, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw);
+      return xpt_launch_status();
+    }
+  }
   if (stride == 1 && g_dw_multi_vec) {      // vectorised path: V channels per thread, taps in LDS
     int kmax = 0;
     std::initializer_list<const void*> none{};
@@ -1039,8 +1190,17 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
       lds = fold > lds ? fold : lds;
     }
     if (v > 1 && lds <= 64 * 1024) {
-      const int dbv = (int)grid_for((long long)B * H * ((W + 1) / 2) * (C / v));
-      const dim3 gridv(n_inputs * dbv + n * wbpj);
+      int dbv = (int)grid_for((long long)B * H * ((W + 1) / 2) * (C / v));
+      // small maps (the 8 x 26 / 4 x 13 stacks), 16-byte channel groups: the data-gradient part stages whole maps in LDS
+      // (one round trip per workgroup instead of one per filter row of every job); dbv < 0 tells the kernel
+      if (g_dw_small_cw > 0 && dtype == 1 && v == 8 && H * W <= 256 && OH == H && OW == W) {
+        const size_t small_lds = (size_t)DW_MAX_JOBS * H * W * 16 + (size_t)DW_MAX_JOBS * 49 * 8 * sizeof(float);
+        if (small_lds <= 64 * 1024) {
+          lds = small_lds > lds ? small_lds : lds;
+          dbv = -(B * (C / 8));
+        }
+      }
+      const dim3 gridv(n_inputs * (dbv < 0 ? -dbv : dbv) + n * wbpj);
       XPT_BEGIN_LAUNCH();
 #define XPT_MV(T, V) \
   hipLaunchKernelGGL((dw_multi_bwd_vec_kernel<T, V>), gridv, dim3(256), lds, s, m, d, relu_in | (g_dw_lab << 8), RG, GRP, dbv, cchunks, wbpj)
