@@ -311,10 +311,16 @@ __global__ __launch_bounds__(256) void dw_multi_fwd_vec_kernel(DwMultiFwd m, DwD
 //   conv(dy_j, w_j rotated by 180 degrees, pad' = k_j - 1 - pad_j).
 __device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
 
-template <int K>
+template <int G> struct SmallVec;
+template <> struct SmallVec<8> { typedef uint4 type; };
+template <> struct SmallVec<4> { typedef uint2 type; };
+
+// G = channels of a group (8: 16-byte vectors; 4: 8-byte vectors, the 44-channel stack); the LDS map holds cw channels per pixel
+template <int K, int G>
 __device__ __forceinline__ void dw_small_accumulate(const unsigned short* __restrict__ xs, const float* __restrict__ ws, int H,
                                                     int W, int cw, int oy, int ox, int c8, int pad_t, int pad_l, bool relu,
-                                                    float (&acc)[8]) {
+                                                    float (&acc)[G]) {
+  typedef typename SmallVec<G>::type vec_t;
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
     const int sy = oy + ky - pad_t;
@@ -324,29 +330,39 @@ __device__ __forceinline__ void dw_small_accumulate(const unsigned short* __rest
     for (int kx = 0; kx < K; ++kx) {
       const int sx = ox + kx - pad_l;
       const bool ok = row_ok && sx >= 0 && sx < W;
-      const uint4 raw = *(const uint4*)(xs + (cy * W + min(max(sx, 0), W - 1)) * cw + c8);
+      const vec_t raw = *(const vec_t*)(xs + (cy * W + min(max(sx, 0), W - 1)) * cw + c8);
       const unsigned short* e = (const unsigned short*)&raw;
-      const float4 w0 = *(const float4*)(ws + (ky * K + kx) * cw + c8), w1 = *(const float4*)(ws + (ky * K + kx) * cw + c8 + 4);
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      const float* wp = ws + (ky * K + kx) * cw + c8;
 #pragma unroll
-      for (int v = 0; v < 8; ++v) {
+      for (int v = 0; v < G; ++v) {
         const float f = bf16_to_f32(e[v]);
         const float in = ok ? (relu ? fmaxf(f, 0.f) : f) : 0.f;
-        acc[v] += in * wv[v];
+        acc[v] += in * wp[v];
       }
     }
   }
 }
 
+template <int G>
+__device__ __forceinline__ void dw_small_accumulate_k(int k, const unsigned short* __restrict__ xs, const float* __restrict__ ws,
+                                                      int H, int W, int cw, int oy, int ox, int c8, int pad_t, int pad_l,
+                                                      bool relu, float (&acc)[G]) {
+  if (k == 3) dw_small_accumulate<3, G>(xs, ws, H, W, cw, oy, ox, c8, pad_t, pad_l, relu, acc);
+  else if (k == 5) dw_small_accumulate<5, G>(xs, ws, H, W, cw, oy, ox, c8, pad_t, pad_l, relu, acc);
+  else dw_small_accumulate<7, G>(xs, ws, H, W, cw, oy, ox, c8, pad_t, pad_l, relu, acc);
+}
+
 // stage the map of `src` (image b, channels c_lo .. c_lo + cw) and the taps of `w` (rotated when flip) into LDS
+template <int G>
 __device__ __forceinline__ void dw_small_stage(unsigned short* xs, float* ws, const unsigned short* __restrict__ src,
                                                const float* __restrict__ w, int b, int HW, int C, int c_lo, int cw, int kk,
                                                bool flip) {
-  const int g8 = cw >> 3, nvec = HW * g8;
+  typedef typename SmallVec<G>::type vec_t;
+  const int g8 = cw / G, nvec = HW * g8;
   for (int v = threadIdx.x; v < nvec; v += 256) {
     unsigned g_;
     const unsigned pix = xpt_divmod((unsigned)v, (unsigned)g8, g_);
-    *(uint4*)(xs + pix * cw + g_ * 8) = *(const uint4*)(src + ((long long)b * HW + pix) * C + c_lo + g_ * 8);
+    *(vec_t*)(xs + pix * cw + g_ * G) = *(const vec_t*)(src + ((long long)b * HW + pix) * C + c_lo + g_ * G);
   }
   for (int i = threadIdx.x; i < cw * kk; i += 256) {
     unsigned tap_;
@@ -355,28 +371,26 @@ __device__ __forceinline__ void dw_small_stage(unsigned short* xs, float* ws, co
   }
 }
 
+template <int G>
 __global__ __launch_bounds__(256) void dw_small_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, int CW) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int job = blockIdx.x, b = blockIdx.y, c_lo = blockIdx.z * CW;
-  const int cw = d.C - c_lo < CW ? d.C - c_lo : CW;                     // multiple of 8
+  const int cw = d.C - c_lo < CW ? d.C - c_lo : CW;                     // multiple of G
   const int HW = d.H * d.W, k = m.k[job], kk = k * k;
   unsigned short* xs = (unsigned short*)sm;                             // [HW][cw] bf16
-  float* ws = (float*)(sm + (size_t)HW * CW * 2);                       // [kk][cw]
-  dw_small_stage(xs, ws, (const unsigned short*)m.x[job], m.w[job], b, HW, d.C, c_lo, cw, kk, false);
+  float* ws = (float*)(sm + (((size_t)HW * CW * 2 + 15) & ~(size_t)15));      // [kk][cw]
+  dw_small_stage<G>(xs, ws, (const unsigned short*)m.x[job], m.w[job], b, HW, d.C, c_lo, cw, kk, false);
   __syncthreads();
-  unsigned short* y = (unsigned short*)m.y[job];
-  const int g8 = cw >> 3, items = HW * g8;
+  const int g8 = cw / G, items = HW * g8;
   for (int it = threadIdx.x; it < items; it += 256) {
     unsigned g_, ox_;
     const unsigned pix = xpt_divmod((unsigned)it, (unsigned)g8, g_);
-    const int oy = (int)xpt_divmod(pix, (unsigned)d.W, ox_), ox = (int)ox_, c8 = (int)g_ * 8;
-    float acc[8];
+    const int oy = (int)xpt_divmod(pix, (unsigned)d.W, ox_), ox = (int)ox_, c8 = (int)g_ * G;
+    float acc[G];
 #pragma unroll
-    for (int v = 0; v < 8; ++v) acc[v] = 0.f;
-    if (k == 3) dw_small_accumulate<3>(xs, ws, d.H, d.W, cw, oy, ox, c8, m.pad_t[job], m.pad_l[job], relu_in != 0, acc);
-    else if (k == 5) dw_small_accumulate<5>(xs, ws, d.H, d.W, cw, oy, ox, c8, m.pad_t[job], m.pad_l[job], relu_in != 0, acc);
-    else dw_small_accumulate<7>(xs, ws, d.H, d.W, cw, oy, ox, c8, m.pad_t[job], m.pad_l[job], relu_in != 0, acc);
-    store_chan<__hip_bfloat16, 8>((__hip_bfloat16*)y + ((long long)b * HW + pix) * d.C + c_lo + c8, acc);
+    for (int v = 0; v < G; ++v) acc[v] = 0.f;
+    dw_small_accumulate_k<G>(k, xs, ws, d.H, d.W, cw, oy, ox, c8, m.pad_t[job], m.pad_l[job], relu_in != 0, acc);
+    store_chan<__hip_bfloat16, G>((__hip_bfloat16*)m.y[job] + ((long long)b * HW + pix) * d.C + c_lo + c8, acc);
   }
 }
 
@@ -683,20 +697,21 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwD
   if (small) data_blocks = -data_blocks;
   const int ndata = m.n_inputs * data_blocks;
   if (((int)blockIdx.x < ndata) ? (lab & 1) : (lab & 2)) return;
-  if constexpr (sizeof(T) == 2 && V == 8) {
+  if constexpr (sizeof(T) == 2 && (V == 8 || V == 4)) {
     if (small && (int)blockIdx.x < ndata) {
-      // workgroup = (input u, image b, 8-channel group): the maps dy_j of the jobs reading u and their rotated taps go to LDS
+      // workgroup = (input u, image b, V-channel group): the maps dy_j of the jobs reading u and their rotated taps go to LDS
       // in ONE burst; outputs are summed over those jobs in job order, tap by tap as the stencil path does: same bits
       const int u = blockIdx.x / data_blocks, rest = blockIdx.x - u * data_blocks;
-      const int g8 = d.C >> 3, b = rest / g8, c_lo = (rest - b * g8) * 8;
+      const int g8 = d.C / V, b = rest / g8, c_lo = (rest - b * g8) * V;
       const int HW = d.OH * d.OW;                                         // stride 1: output map = input map
       unsigned char* sm = (unsigned char*)sW;
+      const size_t map_bytes = ((size_t)HW * V * 2 + 15) & ~(size_t)15, taps_at = (size_t)DW_MAX_JOBS * map_bytes;
       int nj = 0;
       for (int j = 0; j < m.n; ++j) {
         if (m.input_of[j] != u) continue;
         const int kk = m.k[j] * m.k[j];
-        dw_small_stage((unsigned short*)(sm + (size_t)nj * HW * 16), (float*)(sm + (size_t)DW_MAX_JOBS * HW * 16) + nj * 49 * 8,
-                       (const unsigned short*)m.dy[j], m.w[j], b, HW, d.C, c_lo, 8, kk, true);
+        dw_small_stage<V>((unsigned short*)(sm + nj * map_bytes), (float*)(sm + taps_at) + nj * 49 * V,
+                          (const unsigned short*)m.dy[j], m.w[j], b, HW, d.C, c_lo, V, kk, true);
         ++nj;
       }
       __syncthreads();
@@ -704,29 +719,26 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwD
       for (int pix = threadIdx.x; pix < HW; pix += 256) {
         unsigned ix_;
         const int iy = (int)xpt_divmod((unsigned)pix, (unsigned)d.W, ix_), ix = (int)ix_;
-        float acc[8];
+        float acc[V];
 #pragma unroll
-        for (int v = 0; v < 8; ++v) acc[v] = 0.f;
+        for (int v = 0; v < V; ++v) acc[v] = 0.f;
         int q = 0;
         for (int j = 0; j < m.n; ++j) {
           if (m.input_of[j] != u) continue;
           const int k = m.k[j];
-          const unsigned short* xs = (const unsigned short*)(sm + (size_t)q * HW * 16);
-          const float* ws = (const float*)(sm + (size_t)DW_MAX_JOBS * HW * 16) + q * 49 * 8;
-          if (k == 3) dw_small_accumulate<3>(xs, ws, d.OH, d.OW, 8, iy, ix, 0, k - 1 - m.pad_t[j], k - 1 - m.pad_l[j], false, acc);
-          else if (k == 5) dw_small_accumulate<5>(xs, ws, d.OH, d.OW, 8, iy, ix, 0, k - 1 - m.pad_t[j], k - 1 - m.pad_l[j], false, acc);
-          else dw_small_accumulate<7>(xs, ws, d.OH, d.OW, 8, iy, ix, 0, k - 1 - m.pad_t[j], k - 1 - m.pad_l[j], false, acc);
+          dw_small_accumulate_k<V>(k, (const unsigned short*)(sm + q * map_bytes), (const float*)(sm + taps_at) + q * 49 * V, d.OH,
+                                   d.OW, V, iy, ix, 0, k - 1 - m.pad_t[j], k - 1 - m.pad_l[j], false, acc);
           ++q;
         }
         const long long o = ((long long)b * HW + pix) * d.C + c_lo;
         if (relu_in) {
-          const uint4 raw = *(const uint4*)(x + o);
-          const unsigned short* e = (const unsigned short*)&raw;
+          float mk[V];
+          load_chan<T, V>((const T*)x + o, mk);
 #pragma unroll
-          for (int v = 0; v < 8; ++v)
-            if (!(bf16_to_f32(e[v]) > 0.f)) acc[v] = 0.f;
+          for (int v = 0; v < V; ++v)
+            if (!(mk[v] > 0.f)) acc[v] = 0.f;
         }
-        store_chan<T, 8>((T*)m.dxin[u] + o, acc);
+        store_chan<T, V>((T*)m.dxin[u] + o, acc);
       }
       return;
     }
@@ -813,6 +825,7 @@ inline unsigned grid_for(long long total) {
 }
 
 int g_dw_small_cw = 8;      // channels per workgroup of the small-map forward (0: small-map kernels off; xpt_dwconv_tune(-100 - cw); in-step: 8 / 16 / 24 / 32 / 64 channels -> 5.46 / 5.50 / 5.52 / 5.55 / 5.72 ms, off 5.52)
+int g_dw_small_max_px = 256;    // largest map (pixels) the small-map kernels take (xpt_dwconv_tune(-10000 - px)); 16x52 maps through them: 5.60 vs 5.41 ms/step
 int g_dw_lab = 0;           // lab knobs of the vectorised multi-layer backward (xpt_dwconv_tune(-20 - bits))
 int g_dw_multi_vec = 1;     // 0: the scalar multi-layer kernels (A/B, xpt_dwconv_tune(-1) / (-2))
 int g_dw_s2_vec = 1;        // 0: the scalar stride-2 data gradient (A/B, xpt_dwconv_tune(-3) / (-4))
@@ -1021,6 +1034,10 @@ int xpt_dwconv_tune(int wrw_groups) {
     g_dw_multi_vec = wrw_groups == -2;
     return XPT_OK;
   }
+  if (wrw_groups <= -10000) {                        // largest map (pixels) of the small-map kernels
+    g_dw_small_max_px = -10000 - wrw_groups;
+    return XPT_OK;
+  }
   if (wrw_groups <= -100 && wrw_groups >= -356) {    // channels per workgroup of the small-map kernels: -100 off, -132 / -164 ...
     g_dw_small_cw = (-100 - wrw_groups) / 8 * 8;
     return XPT_OK;
@@ -1088,19 +1105,26 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
   }
   const DwDims d{B, H, W, C, OH, OW, 0, 0};
   hipStream_t s = (hipStream_t)stream;
-  if (stride == 1 && dtype == 1 && g_dw_small_cw > 0 && C % 8 == 0 && H * W <= 256 && OH == H && OW == W) {
-    // small maps (the 8 x 26 / 4 x 13 stacks): the whole map of an image in LDS, one round trip per workgroup
+  if (stride == 1 && dtype == 1 && g_dw_small_cw > 0 && C % 4 == 0 && H * W <= g_dw_small_max_px && OH == H && OW == W) {
+    // small maps: the whole map of an image in LDS, one round trip per workgroup, G = 8 (or 4: the 44-channel stack)
+    // channels per workgroup
+    const int G = C % 8 == 0 ? 8 : 4;
     bool ok = true;
     int kmax = 0;
     for (int j = 0; j < n; ++j) {
-      ok = ok && ((uintptr_t)x[j]) % 16 == 0 && ((uintptr_t)y[j]) % 16 == 0;
+      ok = ok && ((uintptr_t)x[j]) % (2 * G) == 0 && ((uintptr_t)y[j]) % (2 * G) == 0;
       kmax = k[j] > kmax ? k[j] : kmax;
     }
-    const int cw = g_dw_small_cw < C ? g_dw_small_cw : C;
-    const size_t lds = (size_t)H * W * cw * 2 + (size_t)kmax * kmax * cw * 4;
+    int cw = g_dw_small_cw < C ? g_dw_small_cw : C;
+    cw = cw / G * G;
+    if (cw < G) cw = G;
+    const size_t lds = (((size_t)H * W * cw * 2 + 15) & ~(size_t)15) + (size_t)kmax * kmax * cw * 4;
     if (ok && lds <= 64 * 1024) {
       XPT_BEGIN_LAUNCH();
-      hipLaunchKernelGGL(dw_small_fwd_kernel, dim3(n, B, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw);
+      if (G == 8)
+        hipLaunchKernelGGL(dw_small_fwd_kernel<8>, dim3(n, B, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw);
+      else
+        hipLaunchKernelGGL(dw_small_fwd_kernel<4>, dim3(n, B, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw);
       return xpt_launch_status();
     }
   }
@@ -1193,11 +1217,12 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
       int dbv = (int)grid_for((long long)B * H * ((W + 1) / 2) * (C / v));
       // small maps (the 8 x 26 / 4 x 13 stacks), 16-byte channel groups: the data-gradient part stages whole maps in LDS
       // (one round trip per workgroup instead of one per filter row of every job); dbv < 0 tells the kernel
-      if (g_dw_small_cw > 0 && dtype == 1 && v == 8 && H * W <= 256 && OH == H && OW == W) {
-        const size_t small_lds = (size_t)DW_MAX_JOBS * H * W * 16 + (size_t)DW_MAX_JOBS * 49 * 8 * sizeof(float);
+      if (g_dw_small_cw > 0 && dtype == 1 && (v == 8 || v == 4) && H * W <= g_dw_small_max_px && OH == H && OW == W) {
+        const size_t map_bytes = ((size_t)H * W * v * 2 + 15) & ~(size_t)15;
+        const size_t small_lds = (size_t)DW_MAX_JOBS * map_bytes + (size_t)DW_MAX_JOBS * 49 * v * sizeof(float);
         if (small_lds <= 64 * 1024) {
           lds = small_lds > lds ? small_lds : lds;
-          dbv = -(B * (C / 8));
+          dbv = -(B * (C / v));
         }
       }
       const dim3 gridv(n_inputs * (dbv < 0 ? -dbv : dbv) + n * wbpj);
