@@ -384,6 +384,70 @@ def test_multi_depthwise_matches_single_layers(gpu_device, C, deferred, stride, 
         assert torch.allclose(a, b, atol=1e-4 * max(1.0, float(b.abs().max())))
 
 
+@pytest.mark.parametrize("C,ks,B,H,W", [(32, [7, 5, 7], 2, 24, 40), (22, [5, 7, 7, 5, 3], 2, 13, 27), (88, [5, 7, 7, 5, 3], 1, 16, 52),
+                                        (44, [5, 7, 7, 5, 3], 2, 10, 14), (8, [3, 5], 1, 5, 7), (12, [7], 3, 9, 9)])
+@pytest.mark.parametrize("multi", [True, False])
+def test_depthwise_stride2_tiles_match_the_kernels_they_replace(gpu_device, C, ks, B, H, W, multi):
+    """The stride-2 tile kernels (xpt_dwconv.hip: input region of a tile staged in LDS; forward, data gradient alone, with the
+    weight-gradient workgroups behind it, several layers per launch; 8- / 4- / 2-channel groups, ragged tiles) against the
+    stencil / scalar kernels (xpt_dwconv_tune(-20000) / (-30000) switch the tiles off): outputs bit for bit, input gradients
+    to one bf16 rounding, weight gradients exactly; and against fp32 autograd."""
+    import torch.nn.functional as F
+    from xpt_mde_2021_amd.hip import lib as _lib, ops
+    from xpt_mde_2021_amd.model.model_util.layer_ops import same_pad
+    lib = _lib.load()
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    pads = [same_pad(H, k, 2) + same_pad(W, k, 2) for k in ks]
+
+    def run(on, relu):
+        lib.xpt_dwconv_tune(-50000)                                  # forward tiles whatever the size
+        lib.xpt_dwconv_tune(-20000 - (1616 if on else 0))
+        lib.xpt_dwconv_tune(-30000 - (1 if on else 0))
+        g = torch.Generator().manual_seed(C * 7 + H)
+        mk = lambda *s: torch.randn(*s, generator=g).to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+        h, p = mk(B, C, H, W).requires_grad_(True), mk(B, C, H, W).requires_grad_(True)
+        params = [torch.nn.Parameter((torch.randn(C, 1, k, k, generator=g) * 0.2).to(gpu_device)) for k in ks]
+        for q in params:
+            q.flat_grad = torch.zeros_like(q)
+        gys = [mk(B, C, OH, OW) for _ in ks]
+        ins = [h, h, p, p, p][:len(ks)]
+        if multi:
+            ys = ops.multi_depthwise(ins, params, relu_in=relu, stride=2, pads=pads)
+        else:
+            ys = [ops.depthwise_conv2d(x, q, 2, pd, relu) for x, q, pd in zip(ins, params, pads)]
+        torch.autograd.backward(ys, gys)
+        ops.grad_sink.flush()
+        torch.cuda.synchronize()
+        grads = [h.grad.float()] + ([p.grad.float()] if len(ks) > 2 else [])
+        return [y.detach().float() for y in ys], grads, [q.flat_grad.clone() for q in params], (h, p, params, gys)
+
+    try:
+        for relu in (True, False):
+            ya, ga, wa, (h, p, params, gys) = run(True, relu)
+            yb, gb, wb, _ = run(False, relu)
+            for a, b in zip(ya, yb):
+                assert torch.equal(a, b)
+            for a, b in zip(ga, gb):
+                assert float((a - b).abs().max()) <= 2 ** -7 * max(1.0, float(b.abs().max()))
+            for a, b in zip(wa, wb):
+                assert torch.equal(a, b)
+            # fp32 autograd on the same bf16 inputs
+            hr, pr = h.detach().float().requires_grad_(True), p.detach().float().requires_grad_(True)
+            ins = [hr, hr, pr, pr, pr][:len(ks)]
+            yr = [F.conv2d(F.pad(F.relu(x) if relu else x, (pd[2], pd[3], pd[0], pd[1])), q.detach(), None, 2, 0, 1, C)
+                  for x, q, pd in zip(ins, params, pads)]
+            torch.autograd.backward(yr, [gy.float() for gy in gys])
+            for a, r in zip(ya, yr):
+                assert float((a - r).abs().max()) <= 2 ** -7 * max(1.0, float(r.abs().max()))
+            refs = [hr.grad] + ([pr.grad] if len(ks) > 2 else [])
+            for a, r in zip(ga, refs):
+                assert float((a - r).abs().max()) <= 2 ** -6 * max(1.0, float(r.abs().max()))
+    finally:
+        lib.xpt_dwconv_tune(-50021)
+        lib.xpt_dwconv_tune(-21616)
+        lib.xpt_dwconv_tune(-30001)
+
+
 def test_multi_conv1x1_bn_matches_single_layers(gpu_device):
     """multi_conv1x1_bn (one forward launch, one fused backward launch + n GEMMs) == n x conv1x1_bn, bit for bit in the
     forward and to rounding in the gradients; the incoming gradients are channel slices with different pitches."""

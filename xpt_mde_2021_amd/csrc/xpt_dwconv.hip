@@ -314,6 +314,7 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_a
 template <int G> struct SmallVec;
 template <> struct SmallVec<8> { typedef uint4 type; };
 template <> struct SmallVec<4> { typedef uint2 type; };
+template <> struct SmallVec<2> { typedef unsigned type; };
 
 // G = channels of a group (8: 16-byte vectors; 4: 8-byte vectors, the 44-channel stack); the LDS map holds cw channels per pixel
 template <int K, int G>
@@ -391,6 +392,104 @@ __global__ __launch_bounds__(256) void dw_small_fwd_kernel(DwMultiFwd m, DwDims 
     for (int v = 0; v < G; ++v) acc[v] = 0.f;
     dw_small_accumulate_k<G>(k, xs, ws, d.H, d.W, cw, oy, ox, c8, m.pad_t[job], m.pad_l[job], relu_in != 0, acc);
     store_chan<__hip_bfloat16, G>((__hip_bfloat16*)m.y[job] + ((long long)b * HW + pix) * d.C + c_lo + c8, acc);
+  }
+}
+
+// ---------------------------------------------------------------- tiles: the input region of an output tile in LDS (stride 2, bf16)
+// The stride-2 layers (the stem's 7x7 / 5x5 on the 64 x 208 map, the first layers of the reduction cells) ran on the stencil /
+// scalar kernels above, whose threads walk the filter rows one memory round trip at a time (k dependent trips: 17 us forward
+// and 30 us data gradient for 8.5 MB on the stem).  Here a workgroup owns (job, image, output tile, chunk of CW channels):
+// it stages the input region of the tile ((TH-1) S + k rows, zero outside the map) and the taps in LDS with ONE burst of
+// loads and computes the tile from LDS; (ky, kx) order and fused multiply-adds as everywhere else in this file: same bits
+// as the kernels it replaces in the forward.
+struct DwTile {
+  int TH, TW;           // tile (output pixels forward; input pixels in the data gradient)
+  int tiles_x, tiles;   // tiles along x, tiles per image
+  int CW, chunks;       // channels per workgroup, chunks per pixel
+  int map_bytes;        // LDS bytes of one staged region (largest kernel size of the launch), multiple of 16
+  int slot_bytes;       // data gradient: region + taps of one job
+};
+
+// rows [y0, y0 + RH) x columns [x0, x0 + RW) of image b of src (H x W x C), channels [c_lo, c_lo + cw), zero outside the map
+template <int G>
+__device__ __forceinline__ void dw_tile_stage(unsigned short* xs, const unsigned short* __restrict__ src, int b, int H, int W,
+                                              int C, int c_lo, int cw, int y0, int x0, int RH, int RW) {
+  typedef typename SmallVec<G>::type vec_t;
+  const int cg = cw / G, n = RH * RW * cg;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    unsigned g_, rx_;
+    const unsigned p = xpt_divmod((unsigned)i, (unsigned)cg, g_);
+    const int ry = (int)xpt_divmod(p, (unsigned)RW, rx_);
+    const int y = y0 + ry, x = x0 + (int)rx_;
+    const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+    vec_t v = *(const vec_t*)(src + (((long long)b * H + min(max(y, 0), H - 1)) * W + min(max(x, 0), W - 1)) * C + c_lo + g_ * G);
+    if (!ok) v = vec_t{};
+    *(vec_t*)(xs + p * cw + g_ * G) = v;
+  }
+}
+
+// taps of channels [c_lo, c_lo + cw) as ws[ky * KP + kx][cw], KP >= k (entries past k are zero: the parity classes of the
+// stride-2 data gradient visit them)
+__device__ __forceinline__ void dw_tile_stage_taps(float* ws, const float* __restrict__ w, int c_lo, int cw, int k, int KP) {
+  for (int i = threadIdx.x; i < cw * KP * KP; i += 256) {
+    unsigned c_, kx_;
+    const unsigned tap = xpt_divmod((unsigned)i, (unsigned)cw, c_);
+    const int ky = (int)xpt_divmod(tap, (unsigned)KP, kx_), kx = (int)kx_;
+    ws[i] = (ky < k && kx < k) ? w[(long long)(c_lo + (int)c_) * k * k + ky * k + kx] : 0.f;
+  }
+}
+
+template <int K, int S, int G>
+__device__ __forceinline__ void dw_tile_accumulate(const unsigned short* __restrict__ xs, const float* __restrict__ ws, int RW,
+                                                   int cw, int ly, int lx, int c8, bool relu, float (&acc)[G]) {
+  typedef typename SmallVec<G>::type vec_t;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const vec_t raw = *(const vec_t*)(xs + ((ly * S + ky) * RW + lx * S + kx) * cw + c8);
+      const unsigned short* e = (const unsigned short*)&raw;
+      const float* wp = ws + (ky * K + kx) * cw + c8;
+#pragma unroll
+      for (int v = 0; v < G; ++v) {
+        const float f = bf16_to_f32(e[v]);
+        const float in = relu ? fmaxf(f, 0.f) : f;
+        acc[v] += in * wp[v];
+      }
+    }
+  }
+}
+
+template <int S, int G>
+__global__ __launch_bounds__(256) void dw_tile_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, DwTile t) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  const int job = blockIdx.x / t.tiles, tile = blockIdx.x - job * t.tiles;
+  const int ty = tile / t.tiles_x, tx = tile - ty * t.tiles_x;
+  const int b = blockIdx.y, c_lo = blockIdx.z * t.CW;
+  const int cw = d.C - c_lo < t.CW ? d.C - c_lo : t.CW;                   // multiple of G
+  const int k = m.k[job];
+  const int oy0 = ty * t.TH, ox0 = tx * t.TW;
+  const int RH = (t.TH - 1) * S + k, RW = (t.TW - 1) * S + k;
+  unsigned short* xs = (unsigned short*)sm;                               // [RH][RW][cw] bf16
+  float* ws = (float*)(sm + t.map_bytes);                                 // [k*k][cw]
+  dw_tile_stage<G>(xs, (const unsigned short*)m.x[job], b, d.H, d.W, d.C, c_lo, cw, oy0 * S - m.pad_t[job],
+                   ox0 * S - m.pad_l[job], RH, RW);
+  dw_tile_stage_taps(ws, m.w[job], c_lo, cw, k, k);
+  __syncthreads();
+  const int cg = cw / G, items = t.TH * t.TW * cg;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    unsigned g_, lx_;
+    const unsigned px = xpt_divmod((unsigned)it, (unsigned)cg, g_);
+    const int ly = (int)xpt_divmod(px, (unsigned)t.TW, lx_), lx = (int)lx_, c8 = (int)g_ * G;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    if (oy >= d.OH || ox >= d.OW) continue;
+    float acc[G];
+#pragma unroll
+    for (int v = 0; v < G; ++v) acc[v] = 0.f;
+    if (k == 3) dw_tile_accumulate<3, S, G>(xs, ws, RW, cw, ly, lx, c8, relu_in != 0, acc);
+    else if (k == 5) dw_tile_accumulate<5, S, G>(xs, ws, RW, cw, ly, lx, c8, relu_in != 0, acc);
+    else dw_tile_accumulate<7, S, G>(xs, ws, RW, cw, ly, lx, c8, relu_in != 0, acc);
+    store_chan<__hip_bfloat16, G>((__hip_bfloat16*)m.y[job] + (((long long)b * d.OH + oy) * d.OW + ox) * d.C + c_lo + c8, acc);
   }
 }
 
@@ -685,6 +784,131 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims 
     dw_bwd_weight_body<T, 7, S, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, sFold);
 }
 
+// Stride-2 backward with the data-gradient part on tiles: a workgroup owns (input u, image, tile of dx, chunk of CW channels);
+// for every job reading u it stages the region of dy_j the tile's taps reach (zero outside the map) and the taps (as
+// [ky][kx] padded to even extents with zeros: a parity class visits ky = py, py + 2, ...) in LDS in one burst; each dx
+// element sums its (k+1)/2 x (k+1)/2 taps per job, jobs added in job order like the kernel above.
+template <int K, int G>
+__device__ __forceinline__ void dw_tile_bwd2_accumulate(const unsigned short* __restrict__ ds, const float* __restrict__ ws,
+                                                        int RW, int cw, int ty, int tx, int oy_min, int ox_min, int c8,
+                                                        float (&acc)[G]) {
+  typedef typename SmallVec<G>::type vec_t;
+  constexpr int KT = (K + 1) / 2, KP = 2 * KT;
+  const int py = ty & 1, px = tx & 1;                  // ty = iy + pad_t, tx = ix + pad_l
+  float a[G];
+#pragma unroll
+  for (int v = 0; v < G; ++v) a[v] = 0.f;
+#pragma unroll
+  for (int jy = 0; jy < KT; ++jy) {
+    const int ky = py + 2 * jy;
+    const int ry = ((ty - ky) >> 1) - oy_min;
+#pragma unroll
+    for (int jx = 0; jx < KT; ++jx) {
+      const int kx = px + 2 * jx;
+      const int rx = ((tx - kx) >> 1) - ox_min;
+      const vec_t raw = *(const vec_t*)(ds + (ry * RW + rx) * cw + c8);
+      const unsigned short* e = (const unsigned short*)&raw;
+      const float* wp = ws + (ky * KP + kx) * cw + c8;
+#pragma unroll
+      for (int v = 0; v < G; ++v) a[v] += bf16_to_f32(e[v]) * wp[v];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < G; ++v) acc[v] += a[v];
+}
+
+template <int G>
+__device__ __forceinline__ void dw_tile_bwd2_block(const DwMultiBwd& m, const DwDims& d, int relu_in, const DwTile& t, int blk,
+                                                   unsigned char* sm) {
+  // blk = ((u * B + b) * tiles + tile) * chunks + chunk
+  int r = blk;
+  const int chunk = r % t.chunks; r /= t.chunks;
+  const int tile = r % t.tiles; r /= t.tiles;
+  const int b = r % d.B, u = r / d.B;
+  const int tyi = tile / t.tiles_x, txi = tile - tyi * t.tiles_x;
+  const int c_lo = chunk * t.CW;
+  const int cw = d.C - c_lo < t.CW ? d.C - c_lo : t.CW;
+  const int iy0 = tyi * t.TH, ix0 = txi * t.TW;
+  int nj = 0;
+  for (int j = 0; j < m.n; ++j) {
+    if (m.input_of[j] != u) continue;
+    const int k = m.k[j], KP = k + 1;                                     // k odd: 2 * ((k + 1) / 2)
+    const int y_lo = (iy0 + m.pad_t[j] - (KP - 1)) >> 1, y_hi = (iy0 + t.TH - 1 + m.pad_t[j]) >> 1;
+    const int x_lo = (ix0 + m.pad_l[j] - (KP - 1)) >> 1, x_hi = (ix0 + t.TW - 1 + m.pad_l[j]) >> 1;
+    unsigned char* slot = sm + (size_t)nj * t.slot_bytes;
+    dw_tile_stage<G>((unsigned short*)slot, (const unsigned short*)m.dy[j], b, d.OH, d.OW, d.C, c_lo, cw, y_lo, x_lo,
+                     y_hi - y_lo + 1, x_hi - x_lo + 1);
+    dw_tile_stage_taps((float*)(slot + t.map_bytes), m.w[j], c_lo, cw, k, KP);
+    ++nj;
+  }
+  __syncthreads();
+  const unsigned short* x = (const unsigned short*)m.xin[u];
+  const int cg = cw / G, items = t.TH * t.TW * cg;
+  for (int it = threadIdx.x; it < items; it += 256) {
+    unsigned g_, lx_;
+    const unsigned px = xpt_divmod((unsigned)it, (unsigned)cg, g_);
+    const int ly = (int)xpt_divmod(px, (unsigned)t.TW, lx_), c8 = (int)g_ * G;
+    const int iy = iy0 + ly, ix = ix0 + (int)lx_;
+    if (iy >= d.H || ix >= d.W) continue;
+    const long long o = (((long long)b * d.H + iy) * d.W + ix) * d.C + c_lo + c8;
+    float mk[G], acc[G];
+#pragma unroll
+    for (int v = 0; v < G; ++v) {
+      mk[v] = 1.f;
+      acc[v] = 0.f;
+    }
+    if (relu_in) load_chan<__hip_bfloat16, G>((const __hip_bfloat16*)x + o, mk);
+    int q = 0;
+    for (int j = 0; j < m.n; ++j) {
+      if (m.input_of[j] != u) continue;
+      const unsigned char* slot = sm + (size_t)q * t.slot_bytes;
+      const unsigned short* ds = (const unsigned short*)slot;
+      const float* ws = (const float*)(slot + t.map_bytes);
+      const int k = m.k[j], tyy = iy + m.pad_t[j], txx = ix + m.pad_l[j];
+      const int y_lo = (iy0 + m.pad_t[j] - k) >> 1;                       // the region's origin and pitch, as staged above
+      const int x_lo = (ix0 + m.pad_l[j] - k) >> 1, rw = ((ix0 + t.TW - 1 + m.pad_l[j]) >> 1) - x_lo + 1;
+      if (k == 3) dw_tile_bwd2_accumulate<3, G>(ds, ws, rw, cw, tyy, txx, y_lo, x_lo, c8, acc);
+      else if (k == 5) dw_tile_bwd2_accumulate<5, G>(ds, ws, rw, cw, tyy, txx, y_lo, x_lo, c8, acc);
+      else dw_tile_bwd2_accumulate<7, G>(ds, ws, rw, cw, tyy, txx, y_lo, x_lo, c8, acc);
+      ++q;
+    }
+    if (relu_in) {
+#pragma unroll
+      for (int v = 0; v < G; ++v)
+        if (!(mk[v] > 0.f)) acc[v] = 0.f;
+    }
+    store_chan<__hip_bfloat16, G>((__hip_bfloat16*)m.dxin[u] + o, acc);
+  }
+}
+
+// wbpj == 0: data gradient only (the single-layer entry point)
+template <int G>
+__global__ __launch_bounds__(256) void dw_multi_bwd_tile_kernel(DwMultiBwd m, DwDims d, int relu_lab, int RG, int GRP,
+                                                                int ndata, int cchunks, int wblocks_per_job, DwTile t) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smt[];
+  const int relu_in = relu_lab & 255, lab = relu_lab >> 8;
+  if (((int)blockIdx.x < ndata) ? (lab & 1) : (lab & 2)) return;
+  if ((int)blockIdx.x < ndata) {
+    dw_tile_bwd2_block<G>(m, d, relu_in, t, blockIdx.x, smt);
+    return;
+  }
+  const int tt0 = (int)blockIdx.x - ndata;
+  const int job = tt0 / wblocks_per_job, tt = tt0 - job * wblocks_per_job;
+  DwDims dj = d;
+  dj.pad_t = m.pad_t[job];
+  dj.pad_l = m.pad_l[job];
+  typedef __hip_bfloat16 T;
+  const T* x = (const T*)m.xin[m.input_of[job]];
+  const T* dy = (const T*)m.dy[job];
+  float* fold = (float*)smt;
+  if (m.k[job] == 3)
+    dw_bwd_weight_body<T, 3, 2, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, fold);
+  else if (m.k[job] == 5)
+    dw_bwd_weight_body<T, 5, 2, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, fold);
+  else
+    dw_bwd_weight_body<T, 7, 2, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, fold);
+}
+
 // The same launch with the data-gradient part vectorised (stride 1): dx_u = [x_u > 0] * sum over the jobs j reading input u
 // of conv(dy_j, w_j rotated by 180 degrees, pad' = k_j - 1 - pad_j); the rotated taps of those jobs sit in LDS.
 template <typename T, int V>
@@ -873,9 +1097,17 @@ void launch_stencil(int v, const void* x, const float* w, const void* mask, void
 #undef XPT_STENCIL
 }
 
+bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, hipStream_t s);
+bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, int GRP, int cchunks, int wbpj, hipStream_t s);
+
 template <typename T, int K, int S>
 int launch_fwd(const void* x, const float* w, void* y, const DwDims& d, int relu_in, hipStream_t s) {
   constexpr int OXT = (S == 1) ? 4 : 2;
+  if (S == 2 && sizeof(T) == 2) {             // tiles in LDS
+    DwMultiFwd m{};
+    m.x[0] = x; m.w[0] = w; m.y[0] = y; m.k[0] = K; m.pad_t[0] = d.pad_t; m.pad_l[0] = d.pad_l;
+    if (tile_fwd_launch(m, 1, d, relu_in, s)) return xpt_launch_status();
+  }
   const int v = chan_vec<T>(d, K, {x, y});
   if (v > 1) {
     launch_stencil<T, K, S, OXT, 0>(v, x, w, nullptr, y, d, relu_in, s);
@@ -899,6 +1131,12 @@ int launch_bwd_data(const void* x, const float* w, const void* dy, void* dx, con
       launch_stencil<T, K, 1, 4, 1>(v, dy, w, x, dx, t, relu_in, s);
       return xpt_launch_status();
     }
+  }
+  if (S == 2 && sizeof(T) == 2) {             // tiles in LDS
+    DwMultiBwd m{};
+    m.n = 1; m.n_inputs = 1;
+    m.xin[0] = x; m.dxin[0] = dx; m.dy[0] = dy; m.w[0] = w; m.k[0] = K; m.pad_t[0] = d.pad_t; m.pad_l[0] = d.pad_l;
+    if (tile_bwd_launch(m, d, relu_in, 1, 1, 1, 0, s)) return xpt_launch_status();
   }
   if (S == 2 && g_dw_s2_vec) {
     const int v = chan_vec<T>(d, K, {dy, dx, relu_in ? x : nullptr});
@@ -947,10 +1185,114 @@ int launch_bwd_both(const void* x, const float* w, const void* dy, void* dx, flo
   const int nchunk = (int)((ngrp + GRP - 1) / GRP);
   const int RG = (d.C <= 32) ? (64 / d.C > GRP / 4 ? (GRP / 4 > 0 ? GRP / 4 : 1) : 64 / d.C) : 1;
   const int cchunks = (d.C + 63) / 64;
+  if (S == 2 && sizeof(T) == 2) {             // data gradient on tiles in LDS, weight-gradient workgroups behind them
+    DwMultiBwd m{};
+    m.n = 1; m.n_inputs = 1;
+    m.xin[0] = x; m.dxin[0] = dx; m.dy[0] = dy; m.w[0] = w; m.part[0] = ws; m.k[0] = K; m.pad_t[0] = d.pad_t; m.pad_l[0] = d.pad_l;
+    if (tile_bwd_launch(m, d, relu_in, RG, GRP, cchunks, cchunks * nchunk, s)) return xpt_launch_status();
+  }
   const int data_blocks = (int)grid_for((long long)d.B * d.H * d.W * d.C);
   hipLaunchKernelGGL((dw_bwd_both_kernel<T, K, S>), dim3(data_blocks + cchunks * nchunk), dim3(256), 0, s, (const T*)x, w,
                      (const T*)dy, (T*)dx, ws, d, relu_in, RG, GRP, data_blocks, cchunks);
   return xpt_launch_status();
+}
+
+// ---- tile kernels (stride 2, bf16): plan and launch; false = not served here (the caller falls through to the kernels above)
+// Measured hot at batch 8 (tools/lab/dw_tile_probe.py), kernels above -> tiles.  Backward (dx + weight-gradient partials in one
+// launch): stem 7x7 on 64x208x32 77 -> 29 us, 5x5 53 -> 21; the reduction cells' three layers 16x52x88 36 -> 15, 8x26x176
+// 20 -> 9.5, 32x104x22 (2-channel groups, 8 x 16 tiles) 36 -> 20.  Forward: only the stem gains (18.2 -> 13.5, 11.2 -> 9.1 us);
+// on the smaller maps the region of a stride-2 tile is four times its outputs and the old kernels win (7.9 vs 12.4 us).
+int g_dw_tile_fwd = 1616;   // TH * 100 + TW of the forward's output tiles, 0 = off (xpt_dwconv_tune(-20000 - code))
+int g_dw_tile_bwd = 1;      // TH * 100 + TW of the data gradient's dx tiles, 0 = off, 1 = 16 x 32 for 8-channel groups and
+                            // 8 x 16 for narrower ones (xpt_dwconv_tune(-30000 - code))
+long long g_dw_tile_fwd_min = 1LL << 21;   // forward: input elements from which the tiles are used
+int g_dw_tile_cw = 8;       // channels per workgroup when the channel count is a multiple of 8 (xpt_dwconv_tune(-40000 - cw))
+
+inline int tile_group(int C, std::initializer_list<const void*> ptrs) {
+  int g = C % 8 == 0 ? 8 : (C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 0));
+  for (const void* p : ptrs)
+    while (g > 1 && ((uintptr_t)p) % (2 * g)) g >>= 1;
+  return g >= 2 ? g : 0;
+}
+
+inline void tile_geometry(int code, int rows, int cols, int C, int G, DwTile& t) {
+  t.TH = code / 100 < rows ? code / 100 : rows;
+  t.TW = code % 100 < cols ? code % 100 : cols;
+  t.tiles_x = (cols + t.TW - 1) / t.TW;
+  t.tiles = t.tiles_x * ((rows + t.TH - 1) / t.TH);
+  int cw = C;
+  if (G == 8) {
+    cw = g_dw_tile_cw / 8 * 8;
+    if (cw < 8) cw = 8;
+    if (cw > C) cw = C;
+  }
+  t.CW = cw;
+  t.chunks = (C + cw - 1) / cw;
+}
+
+bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, hipStream_t s) {
+  if (g_dw_tile_fwd <= 0 || (long long)d.B * d.H * d.W * d.C < g_dw_tile_fwd_min) return false;
+  int G = tile_group(d.C, {});
+  int kmax = 0;
+  for (int j = 0; j < n && G; ++j) {
+    const int gj = tile_group(d.C, {m.x[j], m.y[j]});
+    G = gj < G ? gj : G;
+    kmax = m.k[j] > kmax ? m.k[j] : kmax;
+  }
+  if (!G) return false;
+  DwTile t{};
+  tile_geometry(g_dw_tile_fwd, d.OH, d.OW, d.C, G, t);
+  const size_t region = (size_t)((t.TH - 1) * 2 + kmax) * ((t.TW - 1) * 2 + kmax) * t.CW * 2;
+  t.map_bytes = (int)((region + 15) & ~(size_t)15);
+  const size_t lds = (size_t)t.map_bytes + (size_t)kmax * kmax * t.CW * sizeof(float);
+  if (lds > 64 * 1024 || (long long)n * t.tiles > 65535 * 32LL || d.B > 65535 || t.chunks > 65535) return false;
+  const dim3 grid(n * t.tiles, d.B, t.chunks);
+  XPT_BEGIN_LAUNCH();
+  if (G == 8) hipLaunchKernelGGL((dw_tile_fwd_kernel<2, 8>), grid, dim3(256), lds, s, m, d, relu_in, t);
+  else if (G == 4) hipLaunchKernelGGL((dw_tile_fwd_kernel<2, 4>), grid, dim3(256), lds, s, m, d, relu_in, t);
+  else hipLaunchKernelGGL((dw_tile_fwd_kernel<2, 2>), grid, dim3(256), lds, s, m, d, relu_in, t);
+  return true;
+}
+
+// wbpj = 0: the data gradient alone
+bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, int GRP, int cchunks, int wbpj, hipStream_t s) {
+  if (g_dw_tile_bwd <= 0) return false;
+  int G = tile_group(d.C, {});
+  for (int u = 0; u < m.n_inputs && G; ++u) {
+    const int gu = tile_group(d.C, {m.xin[u], m.dxin[u]});
+    G = gu < G ? gu : G;
+  }
+  int kmax = 0, slots = 0;
+  size_t fold = 0;
+  for (int j = 0; j < m.n && G; ++j) {
+    const int gj = tile_group(d.C, {m.dy[j]});
+    G = gj < G ? gj : G;
+    kmax = m.k[j] > kmax ? m.k[j] : kmax;
+    const size_t f = (size_t)3 * 64 * m.k[j] * m.k[j] * sizeof(float);
+    fold = f > fold ? f : fold;
+    int same = 0;
+    for (int i = 0; i < m.n; ++i) same += m.input_of[i] == m.input_of[j];
+    slots = same > slots ? same : slots;
+  }
+  if (!G) return false;
+  DwTile t{};
+  tile_geometry(g_dw_tile_bwd == 1 ? (G == 8 ? 1632 : 816) : g_dw_tile_bwd, d.H, d.W, d.C, G, t);
+  const int KP = kmax + 1;
+  const size_t region = (size_t)(t.TH / 2 + KP / 2 + 2) * (t.TW / 2 + KP / 2 + 2) * t.CW * 2;
+  t.map_bytes = (int)((region + 15) & ~(size_t)15);
+  t.slot_bytes = t.map_bytes + (int)(((size_t)KP * KP * t.CW * sizeof(float) + 15) & ~(size_t)15);
+  size_t lds = (size_t)slots * t.slot_bytes;
+  if (wbpj > 0 && fold > lds) lds = fold;
+  const long long ndata = (long long)m.n_inputs * d.B * t.tiles * t.chunks;
+  if (lds > 64 * 1024 || ndata + (long long)m.n * wbpj > 0x7fffffffLL) return false;
+  const dim3 grid((unsigned)(ndata + (long long)m.n * wbpj));
+  XPT_BEGIN_LAUNCH();
+#define XPT_TB(G_) \
+  hipLaunchKernelGGL((dw_multi_bwd_tile_kernel<G_>), grid, dim3(256), lds, s, m, d, relu_in | (g_dw_lab << 8), RG, GRP, (int)ndata, \
+                     cchunks, wbpj > 0 ? wbpj : 1, t)
+  if (G == 8) XPT_TB(8); else if (G == 4) XPT_TB(4); else XPT_TB(2);
+#undef XPT_TB
+  return true;
 }
 
 #define DW_DISPATCH(FN, ...)                                                   \
@@ -1032,6 +1374,22 @@ int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* works
 int xpt_dwconv_tune(int wrw_groups) {
   if (wrw_groups == -1 || wrw_groups == -2) {        // -1: scalar multi-layer kernels, -2: vectorised (default)
     g_dw_multi_vec = wrw_groups == -2;
+    return XPT_OK;
+  }
+  if (wrw_groups <= -50000) {                        // tile kernels: forward from 2^n input elements on
+    g_dw_tile_fwd_min = 1LL << (-50000 - wrw_groups);
+    return XPT_OK;
+  }
+  if (wrw_groups <= -40000) {                        // tile kernels: channels per workgroup
+    g_dw_tile_cw = -40000 - wrw_groups;
+    return XPT_OK;
+  }
+  if (wrw_groups <= -30000) {                        // tile kernels: TH * 100 + TW of the data gradient's tiles (0 = off)
+    g_dw_tile_bwd = -30000 - wrw_groups;
+    return XPT_OK;
+  }
+  if (wrw_groups <= -20000) {                        // tile kernels: TH * 100 + TW of the forward's tiles (0 = off)
+    g_dw_tile_fwd = -20000 - wrw_groups;
     return XPT_OK;
   }
   if (wrw_groups <= -10000) {                        // largest map (pixels) of the small-map kernels
@@ -1128,6 +1486,7 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
       return xpt_launch_status();
     }
   }
+  if (stride == 2 && dtype == 1 && tile_fwd_launch(m, n, d, relu_in, s)) return xpt_launch_status();      // tiles in LDS
   if (stride == 1 && g_dw_multi_vec) {      // vectorised path: V channels per thread, taps in LDS
     int kmax = 0;
     std::initializer_list<const void*> none{};
@@ -1195,6 +1554,7 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
   const int cchunks = (C + 63) / 64;
   const int wbpj = cchunks * nchunk;
   hipStream_t s = (hipStream_t)stream;
+  if (stride == 2 && dtype == 1 && tile_bwd_launch(m, d, relu_in, RG, GRP, cchunks, wbpj, s)) return xpt_launch_status();
   if (stride == 1 && g_dw_multi_vec) {
     std::initializer_list<const void*> none{};
     int v = multi_vec_width(dtype, C, none);
