@@ -1097,7 +1097,7 @@ void launch_stencil(int v, const void* x, const float* w, const void* mask, void
 #undef XPT_STENCIL
 }
 
-bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, hipStream_t s);
+bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, hipStream_t s, int stride = 2);
 bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, int GRP, int cchunks, int wbpj, hipStream_t s);
 
 template <typename T, int K, int S>
@@ -1206,7 +1206,9 @@ int g_dw_tile_fwd = 1616;   // TH * 100 + TW of the forward's output tiles, 0 = 
 int g_dw_tile_bwd = 1;      // TH * 100 + TW of the data gradient's dx tiles, 0 = off, 1 = 16 x 32 for 8-channel groups and
                             // 8 x 16 for narrower ones (xpt_dwconv_tune(-30000 - code))
 long long g_dw_tile_fwd_min = 1LL << 21;   // forward: input elements from which the tiles are used
-int g_dw_tile_cw = 8;       // channels per workgroup when the channel count is a multiple of 8 (xpt_dwconv_tune(-40000 - cw))
+int g_dw_tile_fwd1 = 0;     // stride-1 layers of one launch on maps above the small-map limit: tile code, 0 = off
+                            // (xpt_dwconv_tune(-60000 - code))
+int g_dw_tile_cw = 0;       // channels per workgroup; 0 = 8 for 8-channel groups, all channels for narrower ones (xpt_dwconv_tune(-40000 - cw))
 
 inline int tile_group(int C, std::initializer_list<const void*> ptrs) {
   int g = C % 8 == 0 ? 8 : (C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 0));
@@ -1220,18 +1222,18 @@ inline void tile_geometry(int code, int rows, int cols, int C, int G, DwTile& t)
   t.TW = code % 100 < cols ? code % 100 : cols;
   t.tiles_x = (cols + t.TW - 1) / t.TW;
   t.tiles = t.tiles_x * ((rows + t.TH - 1) / t.TH);
-  int cw = C;
-  if (G == 8) {
-    cw = g_dw_tile_cw / 8 * 8;
-    if (cw < 8) cw = 8;
-    if (cw > C) cw = C;
-  }
+  int cw = g_dw_tile_cw > 0 ? g_dw_tile_cw / G * G : (G == 8 ? 8 : C);      // 0: 8 channels, all of them for narrower groups
+  if (cw < G) cw = G;
+  if (cw > C) cw = C;
   t.CW = cw;
   t.chunks = (C + cw - 1) / cw;
 }
 
-bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, hipStream_t s) {
-  if (g_dw_tile_fwd <= 0 || (long long)d.B * d.H * d.W * d.C < g_dw_tile_fwd_min) return false;
+bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, hipStream_t s, int stride) {
+  const int code = stride == 2 ? g_dw_tile_fwd : g_dw_tile_fwd1;
+  if (code <= 0) return false;
+  const long long elems = (long long)d.B * d.H * d.W * d.C;
+  if (stride == 2 ? elems < g_dw_tile_fwd_min : (d.H * d.W <= g_dw_small_max_px)) return false;
   int G = tile_group(d.C, {});
   int kmax = 0;
   for (int j = 0; j < n && G; ++j) {
@@ -1241,16 +1243,20 @@ bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, h
   }
   if (!G) return false;
   DwTile t{};
-  tile_geometry(g_dw_tile_fwd, d.OH, d.OW, d.C, G, t);
-  const size_t region = (size_t)((t.TH - 1) * 2 + kmax) * ((t.TW - 1) * 2 + kmax) * t.CW * 2;
+  tile_geometry(code, d.OH, d.OW, d.C, G, t);
+  const size_t region = (size_t)((t.TH - 1) * stride + kmax) * ((t.TW - 1) * stride + kmax) * t.CW * 2;
   t.map_bytes = (int)((region + 15) & ~(size_t)15);
   const size_t lds = (size_t)t.map_bytes + (size_t)kmax * kmax * t.CW * sizeof(float);
   if (lds > 64 * 1024 || (long long)n * t.tiles > 65535 * 32LL || d.B > 65535 || t.chunks > 65535) return false;
   const dim3 grid(n * t.tiles, d.B, t.chunks);
   XPT_BEGIN_LAUNCH();
-  if (G == 8) hipLaunchKernelGGL((dw_tile_fwd_kernel<2, 8>), grid, dim3(256), lds, s, m, d, relu_in, t);
-  else if (G == 4) hipLaunchKernelGGL((dw_tile_fwd_kernel<2, 4>), grid, dim3(256), lds, s, m, d, relu_in, t);
-  else hipLaunchKernelGGL((dw_tile_fwd_kernel<2, 2>), grid, dim3(256), lds, s, m, d, relu_in, t);
+#define XPT_TF(S_, G_) hipLaunchKernelGGL((dw_tile_fwd_kernel<S_, G_>), grid, dim3(256), lds, s, m, d, relu_in, t)
+  if (stride == 2) {
+    if (G == 8) XPT_TF(2, 8); else if (G == 4) XPT_TF(2, 4); else XPT_TF(2, 2);
+  } else {
+    if (G == 8) XPT_TF(1, 8); else if (G == 4) XPT_TF(1, 4); else XPT_TF(1, 2);
+  }
+#undef XPT_TF
   return true;
 }
 
@@ -1376,6 +1382,10 @@ int xpt_dwconv_tune(int wrw_groups) {
     g_dw_multi_vec = wrw_groups == -2;
     return XPT_OK;
   }
+  if (wrw_groups <= -60000) {                        // tile kernels: tile code of the stride-1 multi-layer forward (0 = off)
+    g_dw_tile_fwd1 = -60000 - wrw_groups;
+    return XPT_OK;
+  }
   if (wrw_groups <= -50000) {                        // tile kernels: forward from 2^n input elements on
     g_dw_tile_fwd_min = 1LL << (-50000 - wrw_groups);
     return XPT_OK;
@@ -1486,7 +1496,7 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
       return xpt_launch_status();
     }
   }
-  if (stride == 2 && dtype == 1 && tile_fwd_launch(m, n, d, relu_in, s)) return xpt_launch_status();      // tiles in LDS
+  if (dtype == 1 && tile_fwd_launch(m, n, d, relu_in, s, stride)) return xpt_launch_status();      // tiles in LDS
   if (stride == 1 && g_dw_multi_vec) {      // vectorised path: V channels per thread, taps in LDS
     int kmax = 0;
     std::initializer_list<const void*> none{};

@@ -62,7 +62,9 @@ def shared_relu(x):
     cached = getattr(x, "_xpt_relu", None)
     if cached is None:
         cached = F.relu(x)
-        if x.is_cuda:
+        # (never on a leaf that requires grad: relu(x) -> ReluBackward -> AccumulateGrad -> x -> its attribute -> relu(x) is a
+        #  cycle through C++ that neither side's collector sees -- the graph of every step would stay alive)
+        if x.is_cuda and not (x.requires_grad and x.grad_fn is None):
             x._xpt_relu = cached
     return cached
 
