@@ -384,25 +384,32 @@ def test_multi_depthwise_matches_single_layers(gpu_device, C, deferred, stride, 
         assert torch.allclose(a, b, atol=1e-4 * max(1.0, float(b.abs().max())))
 
 
-@pytest.mark.parametrize("C,ks,B,H,W", [(32, [7, 5, 7], 2, 24, 40), (22, [5, 7, 7, 5, 3], 2, 13, 27), (88, [5, 7, 7, 5, 3], 1, 16, 52),
-                                        (44, [5, 7, 7, 5, 3], 2, 10, 14), (8, [3, 5], 1, 5, 7), (12, [7], 3, 9, 9)])
+@pytest.mark.parametrize("C,ks,B,H,W,stride", [(32, [7, 5, 7], 2, 24, 40, 2), (22, [5, 7, 7, 5, 3], 2, 13, 27, 2),
+                                               (88, [5, 7, 7, 5, 3], 1, 16, 52, 2), (44, [5, 7, 7, 5, 3], 2, 10, 14, 2),
+                                               (8, [3, 5], 1, 5, 7, 2), (12, [7], 3, 9, 9, 2), (11, [5, 7, 3], 2, 9, 15, 2),
+                                               (44, [5, 3, 3, 5, 3], 1, 16, 52, 1), (11, [5, 7, 3], 2, 18, 21, 1)])
 @pytest.mark.parametrize("multi", [True, False])
-def test_depthwise_stride2_tiles_match_the_kernels_they_replace(gpu_device, C, ks, B, H, W, multi):
-    """The stride-2 tile kernels (xpt_dwconv.hip: input region of a tile staged in LDS; forward, data gradient alone, with the
-    weight-gradient workgroups behind it, several layers per launch; 8- / 4- / 2-channel groups, ragged tiles) against the
-    stencil / scalar kernels (xpt_dwconv_tune(-20000) / (-30000) switch the tiles off): outputs bit for bit, input gradients
-    to one bf16 rounding, weight gradients exactly; and against fp32 autograd."""
+def test_depthwise_tiles_match_the_kernels_they_replace(gpu_device, C, ks, B, H, W, stride, multi):
+    """The tile kernels (xpt_dwconv.hip: input region of a tile staged in LDS; forward, data gradient alone, with the
+    weight-gradient workgroups behind it, several layers per launch; 8- / 4- / 2- / 1-channel groups, ragged tiles; stride 2 --
+    the default for even channel counts -- and stride 1 -- lab only --) against the stencil / scalar kernels
+    (xpt_dwconv_tune(-20000) / (-30000) / (-70000) switch the tiles off): outputs bit for bit, input gradients to one bf16
+    rounding, weight gradients exactly; and against fp32 autograd."""
     import torch.nn.functional as F
     from xpt_mde_2021_amd.hip import lib as _lib, ops
     from xpt_mde_2021_amd.model.model_util.layer_ops import same_pad
     lib = _lib.load()
-    OH, OW = (H + 1) // 2, (W + 1) // 2
-    pads = [same_pad(H, k, 2) + same_pad(W, k, 2) for k in ks]
+    OH, OW = ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W)
+    pads = [same_pad(H, k, 2) + same_pad(W, k, 2) if stride == 2 else (k // 2,) * 4 for k in ks]
 
     def run(on, relu):
         lib.xpt_dwconv_tune(-50000)                                  # forward tiles whatever the size
+        lib.xpt_dwconv_tune(-80001)                                  # and the channel count
+        lib.xpt_dwconv_tune(-10000)                                  # (stride 1: no small-map kernels in the way)
         lib.xpt_dwconv_tune(-20000 - (1616 if on else 0))
         lib.xpt_dwconv_tune(-30000 - (1 if on else 0))
+        lib.xpt_dwconv_tune(-60000 - (816 if on else 0))
+        lib.xpt_dwconv_tune(-70000 - (1 if on else 0))
         g = torch.Generator().manual_seed(C * 7 + H)
         mk = lambda *s: torch.randn(*s, generator=g).to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
         h, p = mk(B, C, H, W).requires_grad_(True), mk(B, C, H, W).requires_grad_(True)
@@ -412,9 +419,9 @@ def test_depthwise_stride2_tiles_match_the_kernels_they_replace(gpu_device, C, k
         gys = [mk(B, C, OH, OW) for _ in ks]
         ins = [h, h, p, p, p][:len(ks)]
         if multi:
-            ys = ops.multi_depthwise(ins, params, relu_in=relu, stride=2, pads=pads)
+            ys = ops.multi_depthwise(ins, params, relu_in=relu, stride=stride, pads=pads)
         else:
-            ys = [ops.depthwise_conv2d(x, q, 2, pd, relu) for x, q, pd in zip(ins, params, pads)]
+            ys = [ops.depthwise_conv2d(x, q, stride, pd, relu) for x, q, pd in zip(ins, params, pads)]
         torch.autograd.backward(ys, gys)
         ops.grad_sink.flush()
         torch.cuda.synchronize()
@@ -434,7 +441,7 @@ def test_depthwise_stride2_tiles_match_the_kernels_they_replace(gpu_device, C, k
             # fp32 autograd on the same bf16 inputs
             hr, pr = h.detach().float().requires_grad_(True), p.detach().float().requires_grad_(True)
             ins = [hr, hr, pr, pr, pr][:len(ks)]
-            yr = [F.conv2d(F.pad(F.relu(x) if relu else x, (pd[2], pd[3], pd[0], pd[1])), q.detach(), None, 2, 0, 1, C)
+            yr = [F.conv2d(F.pad(F.relu(x) if relu else x, (pd[2], pd[3], pd[0], pd[1])), q.detach(), None, stride, 0, 1, C)
                   for x, q, pd in zip(ins, params, pads)]
             torch.autograd.backward(yr, [gy.float() for gy in gys])
             for a, r in zip(ya, yr):
@@ -443,9 +450,8 @@ def test_depthwise_stride2_tiles_match_the_kernels_they_replace(gpu_device, C, k
             for a, r in zip(ga, refs):
                 assert float((a - r).abs().max()) <= 2 ** -6 * max(1.0, float(r.abs().max()))
     finally:
-        lib.xpt_dwconv_tune(-50021)
-        lib.xpt_dwconv_tune(-21616)
-        lib.xpt_dwconv_tune(-30001)
+        for code in (-50021, -80002, -10256, -21616, -30001, -60000, -70000):          # the defaults
+            lib.xpt_dwconv_tune(code)
 
 
 def test_multi_conv1x1_bn_matches_single_layers(gpu_device):

@@ -125,6 +125,7 @@ template <> struct ChanVec<float, 2> { typedef float2 type; };
 template <> struct ChanVec<__hip_bfloat16, 8> { typedef uint4 type; };
 template <> struct ChanVec<__hip_bfloat16, 4> { typedef uint2 type; };
 template <> struct ChanVec<__hip_bfloat16, 2> { typedef unsigned type; };
+template <> struct ChanVec<__hip_bfloat16, 1> { typedef unsigned short type; };
 
 template <typename T, int V>
 __device__ inline void load_chan(const T* p, float (&out)[V]) {
@@ -315,6 +316,7 @@ template <int G> struct SmallVec;
 template <> struct SmallVec<8> { typedef uint4 type; };
 template <> struct SmallVec<4> { typedef uint2 type; };
 template <> struct SmallVec<2> { typedef unsigned type; };
+template <> struct SmallVec<1> { typedef unsigned short type; };
 
 // G = channels of a group (8: 16-byte vectors; 4: 8-byte vectors, the 44-channel stack); the LDS map holds cw channels per pixel
 template <int K, int G>
@@ -788,24 +790,24 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims 
 // for every job reading u it stages the region of dy_j the tile's taps reach (zero outside the map) and the taps (as
 // [ky][kx] padded to even extents with zeros: a parity class visits ky = py, py + 2, ...) in LDS in one burst; each dx
 // element sums its (k+1)/2 x (k+1)/2 taps per job, jobs added in job order like the kernel above.
-template <int K, int G>
-__device__ __forceinline__ void dw_tile_bwd2_accumulate(const unsigned short* __restrict__ ds, const float* __restrict__ ws,
-                                                        int RW, int cw, int ty, int tx, int oy_min, int ox_min, int c8,
-                                                        float (&acc)[G]) {
+template <int K, int S, int G>
+__device__ __forceinline__ void dw_tile_bwd_accumulate(const unsigned short* __restrict__ ds, const float* __restrict__ ws,
+                                                       int RW, int cw, int ty, int tx, int oy_min, int ox_min, int c8,
+                                                       float (&acc)[G]) {
   typedef typename SmallVec<G>::type vec_t;
-  constexpr int KT = (K + 1) / 2, KP = 2 * KT;
-  const int py = ty & 1, px = tx & 1;                  // ty = iy + pad_t, tx = ix + pad_l
+  constexpr int KT = (S == 2) ? (K + 1) / 2 : K, KP = (S == 2) ? 2 * KT : K;
+  const int py = (S == 2) ? (ty & 1) : 0, px = (S == 2) ? (tx & 1) : 0;      // ty = iy + pad_t, tx = ix + pad_l
   float a[G];
 #pragma unroll
   for (int v = 0; v < G; ++v) a[v] = 0.f;
 #pragma unroll
   for (int jy = 0; jy < KT; ++jy) {
-    const int ky = py + 2 * jy;
-    const int ry = ((ty - ky) >> 1) - oy_min;
+    const int ky = py + S * jy;
+    const int ry = (S == 2 ? ((ty - ky) >> 1) : ty - ky) - oy_min;
 #pragma unroll
     for (int jx = 0; jx < KT; ++jx) {
-      const int kx = px + 2 * jx;
-      const int rx = ((tx - kx) >> 1) - ox_min;
+      const int kx = px + S * jx;
+      const int rx = (S == 2 ? ((tx - kx) >> 1) : tx - kx) - ox_min;
       const vec_t raw = *(const vec_t*)(ds + (ry * RW + rx) * cw + c8);
       const unsigned short* e = (const unsigned short*)&raw;
       const float* wp = ws + (ky * KP + kx) * cw + c8;
@@ -817,8 +819,8 @@ __device__ __forceinline__ void dw_tile_bwd2_accumulate(const unsigned short* __
   for (int v = 0; v < G; ++v) acc[v] += a[v];
 }
 
-template <int G>
-__device__ __forceinline__ void dw_tile_bwd2_block(const DwMultiBwd& m, const DwDims& d, int relu_in, const DwTile& t, int blk,
+template <int S, int G>
+__device__ __forceinline__ void dw_tile_bwd_block(const DwMultiBwd& m, const DwDims& d, int relu_in, const DwTile& t, int blk,
                                                    unsigned char* sm) {
   // blk = ((u * B + b) * tiles + tile) * chunks + chunk
   int r = blk;
@@ -832,9 +834,10 @@ __device__ __forceinline__ void dw_tile_bwd2_block(const DwMultiBwd& m, const Dw
   int nj = 0;
   for (int j = 0; j < m.n; ++j) {
     if (m.input_of[j] != u) continue;
-    const int k = m.k[j], KP = k + 1;                                     // k odd: 2 * ((k + 1) / 2)
-    const int y_lo = (iy0 + m.pad_t[j] - (KP - 1)) >> 1, y_hi = (iy0 + t.TH - 1 + m.pad_t[j]) >> 1;
-    const int x_lo = (ix0 + m.pad_l[j] - (KP - 1)) >> 1, x_hi = (ix0 + t.TW - 1 + m.pad_l[j]) >> 1;
+    const int k = m.k[j], KP = (S == 2) ? k + 1 : k;                      // stride 2, k odd: 2 * ((k + 1) / 2)
+    const int sh = S - 1;                                                 // (v >> 1 floors; stride 1: no shift)
+    const int y_lo = (iy0 + m.pad_t[j] - (KP - 1)) >> sh, y_hi = (iy0 + t.TH - 1 + m.pad_t[j]) >> sh;
+    const int x_lo = (ix0 + m.pad_l[j] - (KP - 1)) >> sh, x_hi = (ix0 + t.TW - 1 + m.pad_l[j]) >> sh;
     unsigned char* slot = sm + (size_t)nj * t.slot_bytes;
     dw_tile_stage<G>((unsigned short*)slot, (const unsigned short*)m.dy[j], b, d.OH, d.OW, d.C, c_lo, cw, y_lo, x_lo,
                      y_hi - y_lo + 1, x_hi - x_lo + 1);
@@ -865,11 +868,12 @@ __device__ __forceinline__ void dw_tile_bwd2_block(const DwMultiBwd& m, const Dw
       const unsigned short* ds = (const unsigned short*)slot;
       const float* ws = (const float*)(slot + t.map_bytes);
       const int k = m.k[j], tyy = iy + m.pad_t[j], txx = ix + m.pad_l[j];
-      const int y_lo = (iy0 + m.pad_t[j] - k) >> 1;                       // the region's origin and pitch, as staged above
-      const int x_lo = (ix0 + m.pad_l[j] - k) >> 1, rw = ((ix0 + t.TW - 1 + m.pad_l[j]) >> 1) - x_lo + 1;
-      if (k == 3) dw_tile_bwd2_accumulate<3, G>(ds, ws, rw, cw, tyy, txx, y_lo, x_lo, c8, acc);
-      else if (k == 5) dw_tile_bwd2_accumulate<5, G>(ds, ws, rw, cw, tyy, txx, y_lo, x_lo, c8, acc);
-      else dw_tile_bwd2_accumulate<7, G>(ds, ws, rw, cw, tyy, txx, y_lo, x_lo, c8, acc);
+      const int sh = S - 1, reach = (S == 2) ? k : k - 1;                 // the region's origin and pitch, as staged above
+      const int y_lo = (iy0 + m.pad_t[j] - reach) >> sh;
+      const int x_lo = (ix0 + m.pad_l[j] - reach) >> sh, rw = ((ix0 + t.TW - 1 + m.pad_l[j]) >> sh) - x_lo + 1;
+      if (k == 3) dw_tile_bwd_accumulate<3, S, G>(ds, ws, rw, cw, tyy, txx, y_lo, x_lo, c8, acc);
+      else if (k == 5) dw_tile_bwd_accumulate<5, S, G>(ds, ws, rw, cw, tyy, txx, y_lo, x_lo, c8, acc);
+      else dw_tile_bwd_accumulate<7, S, G>(ds, ws, rw, cw, tyy, txx, y_lo, x_lo, c8, acc);
       ++q;
     }
     if (relu_in) {
@@ -882,14 +886,14 @@ __device__ __forceinline__ void dw_tile_bwd2_block(const DwMultiBwd& m, const Dw
 }
 
 // wbpj == 0: data gradient only (the single-layer entry point)
-template <int G>
+template <int S, int G>
 __global__ __launch_bounds__(256) void dw_multi_bwd_tile_kernel(DwMultiBwd m, DwDims d, int relu_lab, int RG, int GRP,
                                                                 int ndata, int cchunks, int wblocks_per_job, DwTile t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smt[];
   const int relu_in = relu_lab & 255, lab = relu_lab >> 8;
   if (((int)blockIdx.x < ndata) ? (lab & 1) : (lab & 2)) return;
   if ((int)blockIdx.x < ndata) {
-    dw_tile_bwd2_block<G>(m, d, relu_in, t, blockIdx.x, smt);
+    dw_tile_bwd_block<S, G>(m, d, relu_in, t, blockIdx.x, smt);
     return;
   }
   const int tt0 = (int)blockIdx.x - ndata;
@@ -902,11 +906,11 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_tile_kernel(DwMultiBwd m, Dw
   const T* dy = (const T*)m.dy[job];
   float* fold = (float*)smt;
   if (m.k[job] == 3)
-    dw_bwd_weight_body<T, 3, 2, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, fold);
+    dw_bwd_weight_body<T, 3, S, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, fold);
   else if (m.k[job] == 5)
-    dw_bwd_weight_body<T, 5, 2, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, fold);
+    dw_bwd_weight_body<T, 5, S, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, fold);
   else
-    dw_bwd_weight_body<T, 7, 2, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, fold);
+    dw_bwd_weight_body<T, 7, S, true>(x, dy, m.part[job], dj, relu_in, RG, GRP, tt % cchunks, tt / cchunks, fold);
 }
 
 // The same launch with the data-gradient part vectorised (stride 1): dx_u = [x_u > 0] * sum over the jobs j reading input u
@@ -1098,7 +1102,8 @@ void launch_stencil(int v, const void* x, const float* w, const void* mask, void
 }
 
 bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, hipStream_t s, int stride = 2);
-bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, int GRP, int cchunks, int wbpj, hipStream_t s);
+bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, int GRP, int cchunks, int wbpj, hipStream_t s,
+                     int stride = 2);
 
 template <typename T, int K, int S>
 int launch_fwd(const void* x, const float* w, void* y, const DwDims& d, int relu_in, hipStream_t s) {
@@ -1185,11 +1190,11 @@ int launch_bwd_both(const void* x, const float* w, const void* dy, void* dx, flo
   const int nchunk = (int)((ngrp + GRP - 1) / GRP);
   const int RG = (d.C <= 32) ? (64 / d.C > GRP / 4 ? (GRP / 4 > 0 ? GRP / 4 : 1) : 64 / d.C) : 1;
   const int cchunks = (d.C + 63) / 64;
-  if (S == 2 && sizeof(T) == 2) {             // data gradient on tiles in LDS, weight-gradient workgroups behind them
+  if (sizeof(T) == 2) {                       // data gradient on tiles in LDS, weight-gradient workgroups behind them
     DwMultiBwd m{};
     m.n = 1; m.n_inputs = 1;
     m.xin[0] = x; m.dxin[0] = dx; m.dy[0] = dy; m.w[0] = w; m.part[0] = ws; m.k[0] = K; m.pad_t[0] = d.pad_t; m.pad_l[0] = d.pad_l;
-    if (tile_bwd_launch(m, d, relu_in, RG, GRP, cchunks, cchunks * nchunk, s)) return xpt_launch_status();
+    if (tile_bwd_launch(m, d, relu_in, RG, GRP, cchunks, cchunks * nchunk, s, S)) return xpt_launch_status();
   }
   const int data_blocks = (int)grid_for((long long)d.B * d.H * d.W * d.C);
   hipLaunchKernelGGL((dw_bwd_both_kernel<T, K, S>), dim3(data_blocks + cchunks * nchunk), dim3(256), 0, s, (const T*)x, w,
@@ -1206,15 +1211,20 @@ int g_dw_tile_fwd = 1616;   // TH * 100 + TW of the forward's output tiles, 0 = 
 int g_dw_tile_bwd = 1;      // TH * 100 + TW of the data gradient's dx tiles, 0 = off, 1 = 16 x 32 for 8-channel groups and
                             // 8 x 16 for narrower ones (xpt_dwconv_tune(-30000 - code))
 long long g_dw_tile_fwd_min = 1LL << 21;   // forward: input elements from which the tiles are used
+int g_dw_tile_min_group = 2; // narrowest channel group served (odd channel counts = 1: measured no gain, 23.2 -> 21.5 us on the
+                            // stem's 11-channel 5x5; xpt_dwconv_tune(-80000 - g))
+// Stride 1 on the 16 x 52 maps (above the small-map limit), measured: forward 7.1 -> 7.0 us, backward 12.0 -> 24.5: off.
+int g_dw_tile_bwd1 = 0;     // stride-1 backward on maps above the small-map limit: tile code (1 = as g_dw_tile_bwd), 0 = off
+                            // (xpt_dwconv_tune(-70000 - code))
 int g_dw_tile_fwd1 = 0;     // stride-1 layers of one launch on maps above the small-map limit: tile code, 0 = off
                             // (xpt_dwconv_tune(-60000 - code))
 int g_dw_tile_cw = 0;       // channels per workgroup; 0 = 8 for 8-channel groups, all channels for narrower ones (xpt_dwconv_tune(-40000 - cw))
 
 inline int tile_group(int C, std::initializer_list<const void*> ptrs) {
-  int g = C % 8 == 0 ? 8 : (C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 0));
+  int g = C % 8 == 0 ? 8 : (C % 4 == 0 ? 4 : (C % 2 == 0 ? 2 : 1));
   for (const void* p : ptrs)
     while (g > 1 && ((uintptr_t)p) % (2 * g)) g >>= 1;
-  return g >= 2 ? g : 0;
+  return g;
 }
 
 inline void tile_geometry(int code, int rows, int cols, int C, int G, DwTile& t) {
@@ -1241,7 +1251,7 @@ bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, h
     G = gj < G ? gj : G;
     kmax = m.k[j] > kmax ? m.k[j] : kmax;
   }
-  if (!G) return false;
+  if (G < g_dw_tile_min_group) return false;
   DwTile t{};
   tile_geometry(code, d.OH, d.OW, d.C, G, t);
   const size_t region = (size_t)((t.TH - 1) * stride + kmax) * ((t.TW - 1) * stride + kmax) * t.CW * 2;
@@ -1252,17 +1262,19 @@ bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, h
   XPT_BEGIN_LAUNCH();
 #define XPT_TF(S_, G_) hipLaunchKernelGGL((dw_tile_fwd_kernel<S_, G_>), grid, dim3(256), lds, s, m, d, relu_in, t)
   if (stride == 2) {
-    if (G == 8) XPT_TF(2, 8); else if (G == 4) XPT_TF(2, 4); else XPT_TF(2, 2);
+    if (G == 8) XPT_TF(2, 8); else if (G == 4) XPT_TF(2, 4); else if (G == 2) XPT_TF(2, 2); else XPT_TF(2, 1);
   } else {
-    if (G == 8) XPT_TF(1, 8); else if (G == 4) XPT_TF(1, 4); else XPT_TF(1, 2);
+    if (G == 8) XPT_TF(1, 8); else if (G == 4) XPT_TF(1, 4); else if (G == 2) XPT_TF(1, 2); else XPT_TF(1, 1);
   }
 #undef XPT_TF
   return true;
 }
 
 // wbpj = 0: the data gradient alone
-bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, int GRP, int cchunks, int wbpj, hipStream_t s) {
-  if (g_dw_tile_bwd <= 0) return false;
+bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, int GRP, int cchunks, int wbpj, hipStream_t s,
+                     int stride) {
+  const int code = stride == 2 ? g_dw_tile_bwd : g_dw_tile_bwd1;
+  if (code <= 0 || (stride == 1 && d.H * d.W <= g_dw_small_max_px)) return false;
   int G = tile_group(d.C, {});
   for (int u = 0; u < m.n_inputs && G; ++u) {
     const int gu = tile_group(d.C, {m.xin[u], m.dxin[u]});
@@ -1280,11 +1292,12 @@ bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, 
     for (int i = 0; i < m.n; ++i) same += m.input_of[i] == m.input_of[j];
     slots = same > slots ? same : slots;
   }
-  if (!G) return false;
+  if (G < g_dw_tile_min_group) return false;
   DwTile t{};
-  tile_geometry(g_dw_tile_bwd == 1 ? (G == 8 ? 1632 : 816) : g_dw_tile_bwd, d.H, d.W, d.C, G, t);
-  const int KP = kmax + 1;
-  const size_t region = (size_t)(t.TH / 2 + KP / 2 + 2) * (t.TW / 2 + KP / 2 + 2) * t.CW * 2;
+  tile_geometry(code == 1 ? (G == 8 ? 1632 : 816) : code, d.H, d.W, d.C, G, t);
+  const int KP = stride == 2 ? kmax + 1 : kmax;
+  const size_t region = stride == 2 ? (size_t)(t.TH / 2 + KP / 2 + 2) * (t.TW / 2 + KP / 2 + 2) * t.CW * 2
+                                    : (size_t)(t.TH + KP - 1) * (t.TW + KP - 1) * t.CW * 2;
   t.map_bytes = (int)((region + 15) & ~(size_t)15);
   t.slot_bytes = t.map_bytes + (int)(((size_t)KP * KP * t.CW * sizeof(float) + 15) & ~(size_t)15);
   size_t lds = (size_t)slots * t.slot_bytes;
@@ -1293,10 +1306,14 @@ bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, 
   if (lds > 64 * 1024 || ndata + (long long)m.n * wbpj > 0x7fffffffLL) return false;
   const dim3 grid((unsigned)(ndata + (long long)m.n * wbpj));
   XPT_BEGIN_LAUNCH();
-#define XPT_TB(G_) \
-  hipLaunchKernelGGL((dw_multi_bwd_tile_kernel<G_>), grid, dim3(256), lds, s, m, d, relu_in | (g_dw_lab << 8), RG, GRP, (int)ndata, \
+#define XPT_TB(S_, G_) \
+  hipLaunchKernelGGL((dw_multi_bwd_tile_kernel<S_, G_>), grid, dim3(256), lds, s, m, d, relu_in | (g_dw_lab << 8), RG, GRP, (int)ndata, \
                      cchunks, wbpj > 0 ? wbpj : 1, t)
-  if (G == 8) XPT_TB(8); else if (G == 4) XPT_TB(4); else XPT_TB(2);
+  if (stride == 2) {
+    if (G == 8) XPT_TB(2, 8); else if (G == 4) XPT_TB(2, 4); else if (G == 2) XPT_TB(2, 2); else XPT_TB(2, 1);
+  } else {
+    if (G == 8) XPT_TB(1, 8); else if (G == 4) XPT_TB(1, 4); else if (G == 2) XPT_TB(1, 2); else XPT_TB(1, 1);
+  }
 #undef XPT_TB
   return true;
 }
@@ -1380,6 +1397,14 @@ int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* works
 int xpt_dwconv_tune(int wrw_groups) {
   if (wrw_groups == -1 || wrw_groups == -2) {        // -1: scalar multi-layer kernels, -2: vectorised (default)
     g_dw_multi_vec = wrw_groups == -2;
+    return XPT_OK;
+  }
+  if (wrw_groups <= -80000) {                        // tile kernels: narrowest channel group served (1, 2, 4, 8)
+    g_dw_tile_min_group = -80000 - wrw_groups;
+    return XPT_OK;
+  }
+  if (wrw_groups <= -70000) {                        // tile kernels: tile code of the stride-1 backward (0 = off)
+    g_dw_tile_bwd1 = -70000 - wrw_groups;
     return XPT_OK;
   }
   if (wrw_groups <= -60000) {                        // tile kernels: tile code of the stride-1 multi-layer forward (0 = off)
@@ -1564,7 +1589,7 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
   const int cchunks = (C + 63) / 64;
   const int wbpj = cchunks * nchunk;
   hipStream_t s = (hipStream_t)stream;
-  if (stride == 2 && dtype == 1 && tile_bwd_launch(m, d, relu_in, RG, GRP, cchunks, wbpj, s)) return xpt_launch_status();
+  if (dtype == 1 && tile_bwd_launch(m, d, relu_in, RG, GRP, cchunks, wbpj, s, stride)) return xpt_launch_status();
   if (stride == 1 && g_dw_multi_vec) {
     std::initializer_list<const void*> none{};
     int v = multi_vec_width(dtype, C, none);
