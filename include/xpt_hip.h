@@ -228,7 +228,12 @@ int xpt_dwconv_fwd(const void* x, const float* w, void* y, int B, int H, int W, 
 int xpt_dwconv_bwd_data(const void* x, const float* w, const void* dy, void* dx, int B, int H, int W, int C, int k,
                         int stride, int pad_t, int pad_l, int OH, int OW, int relu_in, int dtype, void* stream);
 /* launch-plan knob (process-wide, for benchmarking): output groups per workgroup of the weight-gradient kernel (0, 4, 8,
- * 16, 32); -1 / -2: scalar / vectorised multi-layer kernels; -3 / -4: scalar / vectorised stride-2 data gradient */
+ * 16, 32); -1 / -2: scalar / vectorised multi-layer kernels; -3 / -4: scalar / vectorised stride-2 data gradient;
+ * -20 .. -23: lab (parts of the multi-layer backward off); -100 - cw: channels per workgroup of the small-map kernels
+ * (-100 = off); -10000 - px: largest map they take; tile kernels: -20000 - (TH * 100 + TW) forward tiles (0 = off),
+ * -30000 - code data-gradient tiles (1 = automatic, 0 = off), -40000 - cw channels per workgroup (0 = automatic),
+ * -50000 - n forward from 2^n input elements on, -60000 - code / -70000 - code the same tiles for stride-1 layers
+ * (0 = off, the default), -80000 - g narrowest channel group served (default 2) */
 int xpt_dwconv_tune(int wrw_groups);
 size_t xpt_dwconv_bwd_weight_workspace_floats(int B, int OH, int OW, int C, int k);
 int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_floats,
