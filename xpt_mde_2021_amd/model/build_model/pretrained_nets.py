@@ -595,6 +595,7 @@ _FUSED_SPATIAL_ADJUST = __import__("os").environ.get("XPT_DEBUG_UNFUSED_SPATIAL_
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
 _WIDE_CELL = __import__("os").environ.get("XPT_DEBUG_NARROW_CELL", "0") != "1"          # A/B: per-branch depthwise launches
+_WIDE_STEM = __import__("os").environ.get("XPT_DEBUG_NARROW_STEM", "0") != "1"          # A/B: the first reduction cell branch by branch
 _FUSE_FAN_IN = __import__("os").environ.get("XPT_DEBUG_SEPARATE_FAN_IN", "0") != "1"     # A/B: gradient fan-in as its own launch
 _FUSED_DGRAD = __import__("os").environ.get("XPT_DEBUG_GEMM_DGRAD", "0") != "1"     # A/B: data gradient of conv1x1+BN as a library GEMM launch
 _CELL_TAIL = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CELL_TAIL", "0") != "1"     # A/B: pools / add / concat / relu as separate launches
@@ -999,7 +1000,10 @@ class ReductionCell(nn.Module):
         def tapped(b):
             return taps.wants(b.act_id1) or taps.wants(b.act_id2)
 
-        if (h.is_cuda and not _DISABLE_HIP_DWCONV and _WIDE_CELL and h.shape == p.shape
+        # (the very first cell: h has `filters` channels, p the stem convolution's 32 -- its first stage runs the left branch
+        #  and the right branches as two groups, everything behind it is of one shape again)
+        mixed = _WIDE_STEM and h.shape[1] != p.shape[1] and h.shape[0] == p.shape[0] and h.shape[2:] == p.shape[2:]
+        if (h.is_cuda and not _DISABLE_HIP_DWCONV and _WIDE_CELL and (h.shape == p.shape or mixed)
                 and not any(tapped(b) for b in (self.left1, self.right1, self.right2, self.left4))):
             # the stride-2 separable-conv branches stage by stage, as in the normal cell (left4 follows on x1); right3
             # carries one of the decoder's skip taps in every reduction cell and then runs on its own
@@ -1010,9 +1014,15 @@ class ReductionCell(nn.Module):
             for b in blocks:
                 (pt, pb), (pl, pr) = correct_pad(H, W, b.conv1.k)
                 pads.append((pt, pb, pl, pr))
-            y1 = _ops.multi_depthwise([h] + [p] * (len(blocks) - 1), [b.conv1.depthwise.weight for b in blocks],
-                                      stride=2, pads=pads)
-            z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
+            if mixed:
+                rights = blocks[1:]
+                zl = self.left1.conv1(h, relu_in=True, bn=self.left1.bn1)
+                yr = _ops.multi_depthwise([p] * len(rights), [b.conv1.depthwise.weight for b in rights], stride=2, pads=pads[1:])
+                z1 = [zl] + list(multi_conv1x1_bn(yr, [b.conv1.pointwise.weight for b in rights], [b.bn1 for b in rights]))
+            else:
+                y1 = _ops.multi_depthwise([h] + [p] * (len(blocks) - 1), [b.conv1.depthwise.weight for b in blocks],
+                                          stride=2, pads=pads)
+                z1 = multi_conv1x1_bn(y1, [b.conv1.pointwise.weight for b in blocks], [b.bn1 for b in blocks])
             y2 = _ops.multi_depthwise(z1, [b.conv2.depthwise.weight for b in blocks])
             ap = ap_h if ap_h is not None else F.avg_pool2d(h3, 3, 2)
             if _SIBLING_PW:
