@@ -1008,10 +1008,10 @@ class ReductionCell(nn.Module):
             # the stride-2 separable-conv branches stage by stage, as in the normal cell (left4 follows on x1); right3
             # carries one of the decoder's skip taps in every reduction cell and then runs on its own
             wide3 = not tapped(self.right3)
-            if not wide3 and rectified and _WIDE_STEM and not taps.wants(self.right3.act_id2):
-                # the first cell: the tapped activation IS the (already rectified) input -- hand it out and let the block join
-                # the stage launches (the in-kernel ReLU of its depthwise layer is idempotent on it)
-                taps.offer(self.right3.act_id1, p_tap)
+            if not wide3 and _WIDE_STEM and not taps.wants(self.right3.act_id2):
+                # the tapped activation is relu(p) -- in the first cell the (already rectified) input itself --: hand it out and
+                # let the block join the stage launches on p (the in-kernel ReLU of its depthwise layer gives the same numbers)
+                taps.offer(self.right3.act_id1, p_tap if rectified else F.relu(p_tap))
                 wide3 = True
             blocks = (self.left1, self.right1, self.right2) + ((self.right3,) if wide3 else ())
             H, W = h.shape[2], h.shape[3]
