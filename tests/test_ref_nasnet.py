@@ -59,15 +59,65 @@ def test_every_manifest_variable_lands_on_exactly_one_tensor_of_the_encoder(mani
     table = pn.keras_variable_map(net)
     assert sorted(table) == sorted(n for n, _ in manifest["variables"])
     seen = set()
+    # (the first cell is built with 16 filters of which 5 are structurally zero: a variable addresses the LOGICAL entries of its
+    #  tensor -- pretrained_nets.NASNetMobileEncoder.structural_pads)
+    sel = pn.logical_entries(net)
     for name, shape in manifest["variables"]:
         tensor, kind = table[name]
-        assert list(pn._to_keras(kind, tensor).shape) == shape, name
+        assert list(pn._to_keras(kind, pn.logical_view(tensor, sel.get(id(tensor)))).shape) == shape, name
         assert tensor.data_ptr() not in seen, f"{name} shares storage with another variable"
         seen.add(tensor.data_ptr())
     # ... and nothing of the encoder is left unfilled (BatchNorm's num_batches_tracked does not exist: frozen statistics)
     own = {t.data_ptr() for t in list(net.parameters()) + list(net.buffers())}
     assert own == seen
-    assert sum(t.numel() for t in list(net.parameters()) + list(net.buffers())) == manifest["total_elements"]
+    tensors = list(net.parameters()) + list(net.buffers())
+    assert sum(pn.logical_view(t, sel.get(id(t))).numel() for t in tensors) == manifest["total_elements"]
+
+
+def test_structural_zeros_stay_zero_and_change_nothing(weights):
+    """The 16-filter first cell with 5 structurally-zero filters computes what the 11-filter cell computes: same taps (CPU,
+    fp32) from the same Keras variables; the zero entries are zero after loading, and the gradient of a loss reaches them as
+    exact zeros (so the optimiser leaves them there)."""
+    import importlib
+    x = torch.rand((1, 3, 64, 96), generator=torch.Generator().manual_seed(3)) * 255
+    arrays = {k: v.numpy() for k, v in weights.items()}
+    outs = {}
+    try:
+        for filters in (11, 16):
+            pn._STEM1_FILTERS = filters
+            net = pn.NASNetMobileEncoder().float().eval()
+            pn.load_keras_weights(net, arrays)
+            if filters == 16:
+                assert net.cells[0].conv.weight.shape[0] == 16 and len(net.structural_pads()) > 60
+                before = [(t.clone(), o, i) for t, o, i in net.structural_pads()]
+                net.apply_structural_zeros()
+                assert all(torch.equal(a, t) for (a, _, _), (t, _, _) in zip(before, net.structural_pads()))
+                for q in net.parameters():
+                    q.requires_grad_(True)
+                ys = net(x)
+                sum((y * y).mean() for y in ys).backward()
+                sel = pn.logical_entries(net)
+                for q in net.parameters():
+                    if id(q) in sel:
+                        o, i = sel[id(q)]
+                        keep = torch.zeros(q.shape[:2] if i is not None else q.shape[:1], dtype=torch.bool)
+                        oo = o if o is not None else torch.arange(q.shape[0])
+                        if i is not None:
+                            keep[oo[:, None], i[None, :]] = True
+                        else:
+                            keep[oo] = True
+                        pad_grad = q.grad[~keep]
+                        assert float(pad_grad.abs().max()) == 0.0 if pad_grad.numel() else True
+                outs[filters] = [y.detach() for y in ys]
+            else:
+                assert not net.structural_pads()
+                with torch.no_grad():
+                    outs[filters] = net(x)
+    finally:
+        pn._STEM1_FILTERS = 16
+    for a, b in zip(outs[11], outs[16]):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
 
 
 def test_loader_round_trips_and_is_strict(weights, tmp_path):

@@ -595,6 +595,7 @@ _FUSED_SPATIAL_ADJUST = __import__("os").environ.get("XPT_DEBUG_UNFUSED_SPATIAL_
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
 _WIDE_CELL = __import__("os").environ.get("XPT_DEBUG_NARROW_CELL", "0") != "1"          # A/B: per-branch depthwise launches
+_STEM1_FILTERS = int(__import__("os").environ.get("XPT_STEM1_FILTERS", "16"))     # physical filters of the first cell (11 logical; 11 = no padding)
 _WIDE_STEM = __import__("os").environ.get("XPT_DEBUG_NARROW_STEM", "0") != "1"          # A/B: the first reduction cell branch by branch
 _FUSE_FAN_IN = __import__("os").environ.get("XPT_DEBUG_SEPARATE_FAN_IN", "0") != "1"     # A/B: gradient fan-in as its own launch
 _FUSED_DGRAD = __import__("os").environ.get("XPT_DEBUG_GEMM_DGRAD", "0") != "1"     # A/B: data gradient of conv1x1+BN as a library GEMM launch
@@ -1102,18 +1103,33 @@ class NASNetMobileEncoder(nn.Module):
         x_ch, x_red = stem_block_filters, 1
         p_ch, p_red = None, None
 
-        def add(kind, f):
-            nonlocal x_ch, x_red, p_ch, p_red
+        # Physical channel indices of the logical channels of x / p (None: all of them).  The first cell has 11 filters: every
+        # tensor in it is 22 bytes per pixel, which no vector load, MFMA fragment or fused data gradient of the kernels takes
+        # (scalar paths, 13 library GEMMs, a third of the backward's tail).  It is built with 16 filters of which 5 are
+        # STRUCTURALLY ZERO: their weights, BatchNorm parameters and the columns its two consumers read them through are zero,
+        # so their activations and every gradient that reaches those entries are exactly zero, Adam leaves them at zero, and
+        # the other 11 channels compute what the 11-filter cell computes (structural_pads() lists the tensors; the Keras
+        # variable map addresses the logical entries only).
+        x_sel = p_sel = None
+
+        def add(kind, f, pad_to=None):
+            nonlocal x_ch, x_red, p_ch, p_red, x_sel, p_sel
             pc, pr = (x_ch, x_red) if p_ch is None else (p_ch, p_red)
             cls = ReductionCell if kind == "R" else NormalCell
-            cell = cls(self, x_ch, pc, x_red, pr, f, p_is_none=p_ch is None)
+            phys = pad_to if (pad_to is not None and pad_to > f) else f
+            cell = cls(self, x_ch, pc, x_red, pr, phys, p_is_none=p_ch is None)
+            cell.ip_sel, cell.p_sel = x_sel, (x_sel if p_ch is None else p_sel)
+            cell.f_sel = torch.arange(f) if phys != f else None
+            if cell.f_sel is not None and (kind != "R" or cell.adjust.mode != "none"):
+                raise WrongInputException("structurally padded filters: first cell only")
             cells.append(cell)
-            p_ch, p_red = x_ch, x_red                      # the cell returns (x, ip): p <- ip
+            p_ch, p_red, p_sel = x_ch, x_red, x_sel        # the cell returns (x, ip): p <- ip
             x_ch = cell.out_channels
+            x_sel = torch.cat([g * phys + torch.arange(f) for g in range(4)]) if phys != f else None
             if kind == "R":
                 x_red += 1
 
-        add("R", filters // (fm ** 2))                     # stem_1
+        add("R", filters // (fm ** 2), pad_to=_STEM1_FILTERS)    # stem_1
         add("R", filters // fm)                            # stem_2
         for _ in range(num_blocks):
             add("N", filters)
@@ -1127,6 +1143,57 @@ class NASNetMobileEncoder(nn.Module):
         self.final_act_id = self.new_activation()
         self.out_channels = x_ch
         self.num_activations = self._n_act
+        self.apply_structural_zeros(rescale=True)
+
+    def structural_pads(self):
+        """[(tensor, out_sel, in_sel)]: the tensors that carry structurally-zero entries and the indices of their LOGICAL
+        entries along the output (first) and input (second) axis (None: the whole axis)."""
+        out = []
+
+        def bn(m, sel):
+            out.extend((t, sel, None) for t in (m.weight, m.bias, m.running_mean, m.running_var))
+
+        def sep(block, in_sel, f):
+            out.append((block.conv1.depthwise.weight, in_sel, None))
+            out.append((block.conv1.pointwise.weight, f, in_sel))
+            bn(block.bn1, f)
+            out.append((block.conv2.depthwise.weight, f, None))
+            out.append((block.conv2.pointwise.weight, f, f))
+            bn(block.bn2, f)
+
+        for cell in self.cells:
+            f, ip, ps = cell.f_sel, cell.ip_sel, cell.p_sel
+            if f is None and ip is None and ps is None:
+                continue
+            adj = cell.adjust
+            if adj.mode == "spatial":
+                out.extend([(adj.conv1.weight, None, ps), (adj.conv2.weight, None, ps)])
+            elif adj.mode == "project":
+                out.append((adj.conv.weight, None, ps))
+            out.append((cell.conv.weight, f, ip))
+            if f is not None:
+                bn(cell.bn, f)
+                p_in = ps if adj.mode == "none" else f         # what the right branches read: raw p or the adjusted one
+                for name, in_sel in (("left1", f), ("right1", p_in), ("right2", p_in), ("right3", p_in), ("left4", f)):
+                    sep(getattr(cell, name), in_sel, f)
+        return [(t, o, i) for t, o, i in out if o is not None or i is not None]
+
+    def apply_structural_zeros(self, rescale=False):
+        """Zeroes the structural entries (running variances: 1).  rescale: once, right after the random initialisation --
+        the He scale of a weight follows its LOGICAL fan-in."""
+        with torch.no_grad():
+            for t, o, i in self.structural_pads():
+                keep = torch.zeros(t.shape[:2] if (t.dim() > 1 and i is not None) else t.shape[:1], dtype=torch.bool)
+                oo = o if o is not None else torch.arange(t.shape[0])
+                if keep.dim() == 2:
+                    keep[oo[:, None], i[None, :]] = True
+                else:
+                    keep[oo] = True
+                keep = keep.to(t.device).view(*keep.shape, *([1] * (t.dim() - keep.dim())))
+                is_var = any(t is m.running_var for m in self.modules() if isinstance(m, FrozenBatchNorm))
+                t.copy_(torch.where(keep, t, torch.ones_like(t) if is_var else torch.zeros_like(t)))
+                if rescale and t.dim() == 4 and i is not None:
+                    t.mul_((t.shape[1] / len(i)) ** 0.5)
 
     def new_activation(self):
         """Index this unnamed keras Activation layer would get ('activation', 'activation_1', ...)."""
@@ -1234,9 +1301,44 @@ def keras_variable_map(encoder):
     return out
 
 
+def logical_entries(encoder):
+    """{id(tensor): (out_sel, in_sel)} for the tensors of the encoder that carry structurally-zero entries
+    (NASNetMobileEncoder.structural_pads): the Keras variables address their logical entries only."""
+    return {id(t): (o, i) for t, o, i in encoder.structural_pads()}
+
+
+def logical_view(t, sel):
+    """The logical entries of t (a copy when t carries structural zeros, t itself otherwise)."""
+    if sel is None:
+        return t
+    o, i = sel
+    if o is not None:
+        t = t.index_select(0, o.to(t.device))
+    if i is not None:
+        t = t.index_select(1, i.to(t.device))
+    return t
+
+
+def _store_logical(t, sel, value, fill=0.0):
+    if sel is None:
+        t.copy_(value.to(device=t.device, dtype=t.dtype))
+        return
+    o, i = sel
+    full = torch.full_like(t, fill)
+    oo = (o if o is not None else torch.arange(t.shape[0])).to(t.device)
+    v = value.to(device=t.device, dtype=t.dtype)
+    if i is not None:
+        full[oo[:, None], i.to(t.device)[None, :]] = v
+    else:
+        full[oo] = v
+    t.copy_(full)
+
+
 def export_keras_weights(encoder):
     """{keras variable name: float32 array in the keras layout} of the encoder's current weights."""
-    return {name: _to_keras(kind, t.detach()).contiguous().float().cpu() for name, (t, kind) in keras_variable_map(encoder).items()}
+    sel = logical_entries(encoder)
+    return {name: _to_keras(kind, logical_view(t.detach(), sel.get(id(t)))).contiguous().float().cpu()
+            for name, (t, kind) in keras_variable_map(encoder).items()}
 
 
 def read_keras_weight_file(path):
@@ -1278,15 +1380,16 @@ def load_keras_weights(encoder, weights):
         raise WrongInputException(f"NASNet-Mobile weights: {len(missing)} variables missing (e.g. {missing[:3]}), "
                                   f"{len(unknown)} not part of the no-top model (e.g. {unknown[:3]})")
     staged = {}
+    sel = logical_entries(encoder)
     for name, (t, kind) in table.items():
         a = torch.as_tensor(weights[name])
-        if tuple(a.shape) != tuple(_to_keras(kind, t).shape):
-            raise WrongInputException(f"{name}: file has shape {tuple(a.shape)}, the model expects "
-                                      f"{tuple(_to_keras(kind, t).shape)}")
+        want = tuple(_to_keras(kind, logical_view(t, sel.get(id(t)))).shape)
+        if tuple(a.shape) != want:
+            raise WrongInputException(f"{name}: file has shape {tuple(a.shape)}, the model expects {want}")
         staged[name] = _from_keras(kind, a)
     with torch.no_grad():
         for name, (t, kind) in table.items():
-            t.copy_(staged[name].to(device=t.device, dtype=t.dtype))
+            _store_logical(t, sel.get(id(t)), staged[name], fill=1.0 if name.endswith("/moving_variance") else 0.0)
     return len(staged)
 
 
