@@ -19,8 +19,12 @@ def test_nasnet_mobile_structure():
     from xpt_mde_2021_amd.model.build_model.pretrained_nets import NASNetMobileEncoder
     torch.manual_seed(0)
     enc = NASNetMobileEncoder().eval()
-    trainable = sum(p.numel() for p in enc.parameters() if p.requires_grad)
-    stats = sum(b.numel() for n, b in enc.named_buffers() if n.endswith("running_mean") or n.endswith("running_var"))
+    # (logical entries: the first cell carries 5 structurally-zero filters, pretrained_nets.NASNetMobileEncoder.structural_pads)
+    from xpt_mde_2021_amd.model.build_model.pretrained_nets import logical_entries, logical_view
+    sel = logical_entries(enc)
+    count = lambda t: logical_view(t, sel.get(id(t))).numel()          # noqa: E731
+    trainable = sum(count(p) for p in enc.parameters() if p.requires_grad)
+    stats = sum(count(b) for n, b in enc.named_buffers() if n.endswith("running_mean") or n.endswith("running_var"))
     assert trainable == 4_232_978
     assert stats == 36_738
     assert trainable + stats == 4_269_716
