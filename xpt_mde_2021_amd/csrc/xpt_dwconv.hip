@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_tile_kernel(DwMultiBwd m, Dw
 // The same launch with the data-gradient part vectorised (stride 1): dx_u = [x_u > 0] * sum over the jobs j reading input u
 // of conv(dy_j, w_j rotated by 180 degrees, pad' = k_j - 1 - pad_j); the rotated taps of those jobs sit in LDS.
 template <typename T, int V>
-__global__ __launch_bounds__(256) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwDims d, int relu_lab, int RG, int GRP,
+__global__ __launch_bounds__(256, 4) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwDims d, int relu_lab, int RG, int GRP,
                                                                int data_blocks, int cchunks, int wblocks_per_job) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
   const int relu_in = relu_lab & 255, lab = relu_lab >> 8;      // lab knobs (xpt_dwconv_tune(-21 / -22)): 1 no data part, 2 no weight part
