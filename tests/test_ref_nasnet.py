@@ -84,11 +84,11 @@ def test_structural_zeros_stay_zero_and_change_nothing(weights):
     outs = {}
     try:
         for filters in (11, 16):
-            pn._STEM1_FILTERS = filters
+            pn._STEM1_FILTERS, pn._STEM2_FILTERS = filters, (22 if filters == 11 else 24)
             net = pn.NASNetMobileEncoder().float().eval()
             pn.load_keras_weights(net, arrays)
             if filters == 16:
-                assert net.cells[0].conv.weight.shape[0] == 16 and len(net.structural_pads()) > 60
+                assert net.cells[0].conv.weight.shape[0] == 16 and net.cells[1].conv.weight.shape[0] == 24 and len(net.structural_pads()) > 120
                 before = [(t.clone(), o, i) for t, o, i in net.structural_pads()]
                 net.apply_structural_zeros()
                 assert all(torch.equal(a, t) for (a, _, _), (t, _, _) in zip(before, net.structural_pads()))
@@ -114,7 +114,7 @@ def test_structural_zeros_stay_zero_and_change_nothing(weights):
                 with torch.no_grad():
                     outs[filters] = net(x)
     finally:
-        pn._STEM1_FILTERS = 16
+        pn._STEM1_FILTERS, pn._STEM2_FILTERS = 16, 24
     for a, b in zip(outs[11], outs[16]):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))

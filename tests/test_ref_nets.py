@@ -33,10 +33,18 @@ def pose_params(posenet):
 
 
 def decoder_params(depthnet):
+    """The decoder's weights as the restatement takes them.  The 1/4 tap reaches the decoder with the structurally-zero
+    channels of its encoder cell (depth_net.DepthNetPretrained): the convolution that reads it has two more input columns
+    than the reference's -- the restatement gets the logical ones."""
     P = {}
     for lvl in (4, 3, 2, 1, 0):
         up = getattr(depthnet, f"up{lvl}")
         P[f"dp_up{lvl}_conv1"], P[f"dp_up{lvl}_conv2"] = hwio(up.conv1.conv), hwio(up.conv2.conv)
+    if getattr(depthnet, "skip2_zero", None) is not None:
+        w, bias = P["dp_up2_conv2"]                             # [kh, kw, cin, cout]
+        keep = torch.ones(w.shape[2], dtype=torch.bool)
+        keep[depthnet.skip2_zero] = False
+        P["dp_up2_conv2"] = (w[:, :, keep].contiguous(), bias)
     for lvl in (3, 2, 1, 0):
         P[f"dp_depth{lvl}_conv"] = hwio(getattr(depthnet, f"depth{lvl}").conv.conv)
     return P
@@ -46,6 +54,19 @@ def random_taps(depthnet, batch, height, width, seed=3):
     g = torch.Generator().manual_seed(seed)
     return [torch.randn(batch, c, height >> (i + 1), width >> (i + 1), generator=g) * 0.5
             for i, c in enumerate(depthnet.encoder.TAP_CHANNELS)]
+
+
+def physical_taps(depthnet, taps):
+    """Logical taps -> what the encoder hands the decoder (zero channels where a cell carries structurally-zero filters)."""
+    out = []
+    for t, (ch, sel) in zip(taps, depthnet.encoder.tap_layout()):
+        if sel is None:
+            out.append(t)
+        else:
+            full = torch.zeros((t.shape[0], ch) + tuple(t.shape[2:]), dtype=t.dtype)
+            full[:, sel] = t
+            out.append(full)
+    return out
 
 
 def test_structural_pins():
@@ -69,7 +90,7 @@ def test_cpu_modules_match_restatement(high_res):
         assert pose.shape == ref.shape == (B, 4, 6)
         assert (pose - ref).abs().max().item() < 1e-5 * max(ref.abs().max().item(), 1e-3) + 1e-7
         taps = random_taps(depthnet, B, H, W)
-        out = depthnet.decode(*taps, H, W)
+        out = depthnet.decode(*physical_taps(depthnet, taps), H, W)
         ref = rn.depth_decoder([t.permute(0, 2, 3, 1) for t in taps], decoder_params(depthnet), H, W)
         for d, r in zip(out["depth_ms"], ref["depth_ms"]):
             assert d.shape == r.shape
@@ -99,7 +120,7 @@ def test_gpu_modules_match_restatement(gpu_device, height, width, batch, high_re
 
         def decode(*t):
             return depthnet.decode(*t, height, width)
-        dev_taps = [t.to(gpu_device).contiguous(memory_format=torch.channels_last) for t in taps]
+        dev_taps = [t.to(gpu_device).contiguous(memory_format=torch.channels_last) for t in physical_taps(depthnet, taps)]
         if dtype == "bf16":
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 out = decode(*[t.to(torch.bfloat16) for t in dev_taps])

@@ -8,6 +8,7 @@ import torch.nn.functional as F
 from ...hip import conv as _conv
 from ...hip import ops as _ops
 from ..model_util import layer_ops as lo
+from ...utils.util_class import WrongInputException
 from .pretrained_nets import PretrainedModel
 
 
@@ -113,7 +114,11 @@ class DepthNetPretrained(nn.Module):
         self.encoder = PretrainedModel(net_name, use_pt_weight).encoder()
         self.cut_backward = False      # see forward()
         self.cuts = []                 # [(encoder outputs, their detached stand-ins)] of the forward calls of this step
-        c1, c2, c3, c4, c5 = self.encoder.TAP_CHANNELS
+        # taps inside a cell with structurally-zero filters arrive WITH them (no gather launch): the convolution that reads
+        # such a skip has zero columns at those input channels -- zero by construction, like the encoder's (pretrained_nets)
+        layout = self.encoder.tap_layout() if hasattr(self.encoder, "tap_layout") else [(c, None) for c in self.encoder.TAP_CHANNELS]
+        self.physical_taps = any(sel is not None for _, sel in layout)
+        (c1, _), (c2, sel2), (c3, _), (c4, _), (c5, _) = layout
         self.up4 = UpconvWithSkip(conv2d, c5, c4, 256, upsample_iterp)            # 1/16
         self.up3 = UpconvWithSkip(conv2d, 256, c3, 128, upsample_iterp)           # 1/8
         self.depth3 = ScaledDepthHead(conv2d, 128, pred_depth)
@@ -123,11 +128,25 @@ class DepthNetPretrained(nn.Module):
         self.depth1 = ScaledDepthHead(conv2d, 32, pred_depth)
         self.up0 = UpconvWithSkip(conv2d, 32, 1, 16, upsample_iterp)              # 1/1: the only skip is p1 up-sampled
         self.depth0 = ScaledDepthHead(conv2d, 16, pred_depth)
+        if any(sel is not None for (_, sel) in (layout[0], layout[2], layout[3], layout[4])):
+            raise WrongInputException("structurally-zero channels are handled for the 1/4 tap only")
+        self.skip2_zero = None
+        if sel2 is not None:                                # input channels of up2.conv2: [64 upconv | c2 skip | 1 prediction]
+            keep = torch.zeros(c2, dtype=torch.bool)
+            keep[sel2] = True
+            self.skip2_zero = 64 + torch.nonzero(~keep).flatten()
+            self.apply_structural_zeros()
+
+    def apply_structural_zeros(self):
+        if self.skip2_zero is not None:
+            with torch.no_grad():
+                w = self.up2.conv2.conv.weight
+                w[:, self.skip2_zero.to(w.device)] = 0
 
     def forward(self, image5d):
         target = image5d[:, -1].permute(0, 3, 1, 2)                               # [B,3,H,W] view of the NHWC frame
         height, width = target.shape[2:]
-        taps = self.encoder(target)
+        taps = self.encoder(target, physical_taps=True) if self.physical_taps else self.encoder(target)
         if self.cut_backward and torch.is_grad_enabled() and all(t.requires_grad for t in taps):
             # the backward pass is cut between decoder and encoder (train_val.ModelTrainerDistrib: the gradients of
             # everything behind the encoder are all-reduced while the encoder's backward still runs): the decoder reads

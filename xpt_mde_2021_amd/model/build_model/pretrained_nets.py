@@ -595,6 +595,7 @@ _FUSED_SPATIAL_ADJUST = __import__("os").environ.get("XPT_DEBUG_UNFUSED_SPATIAL_
 
 _FUSE_CONV_BN = __import__("os").environ.get("XPT_DEBUG_UNFUSED_CONV_BN", "0") != "1"
 _WIDE_CELL = __import__("os").environ.get("XPT_DEBUG_NARROW_CELL", "0") != "1"          # A/B: per-branch depthwise launches
+_STEM2_FILTERS = int(__import__("os").environ.get("XPT_STEM2_FILTERS", "24"))     # physical filters of the second cell (22 logical; 22 = no padding)
 _STEM1_FILTERS = int(__import__("os").environ.get("XPT_STEM1_FILTERS", "16"))     # physical filters of the first cell (11 logical; 11 = no padding)
 _WIDE_STEM = __import__("os").environ.get("XPT_DEBUG_NARROW_STEM", "0") != "1"          # A/B: the first reduction cell branch by branch
 _FUSE_FAN_IN = __import__("os").environ.get("XPT_DEBUG_SEPARATE_FAN_IN", "0") != "1"     # A/B: gradient fan-in as its own launch
@@ -866,6 +867,7 @@ class NormalCell(nn.Module):
         self.right2 = SepConvBlock(net, p_ch, filters, 3)
         self.left5 = SepConvBlock(net, filters, filters, 3)
         self.out_channels = p_ch + 5 * filters
+        self.f_sel = self.ip_sel = self.p_sel = None
 
     def stack_groups(self):
         """Pointwise weights the wide cell consumes as one strided batch (order = the multi_conv1x1_bn calls below)."""
@@ -955,6 +957,21 @@ class NormalCell(nn.Module):
         return torch.cat([p, x1, x2, x3, x4, x5], dim=1), ip
 
 
+_SEL_ON_DEVICE = {}
+
+
+def _logical_channels(x, sel):
+    """The logical channels of a tensor that carries structurally-zero ones (sel None: x itself)."""
+    if sel is None:
+        return x
+    rows = _ops.as_rows(x) if x.is_cuda else x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+    key = (id(sel), x.device)
+    if key not in _SEL_ON_DEVICE:                # (uploaded by the eager warm-up steps, never inside a capture)
+        _SEL_ON_DEVICE[key] = (sel, sel.to(x.device))
+    picked = rows[:, _SEL_ON_DEVICE[key][1]]
+    return picked.view(x.shape[0], x.shape[2], x.shape[3], len(sel)).permute(0, 3, 1, 2)
+
+
 class ReductionCell(nn.Module):
     """_reduction_a_cell -> concat([x2, x3, x4, x5]) = 4 * filters channels at half the resolution."""
 
@@ -972,6 +989,7 @@ class ReductionCell(nn.Module):
         self.right3 = SepConvBlock(net, p_ch, filters, 5, 2)
         self.left4 = SepConvBlock(net, filters, filters, 3, 1)
         self.out_channels = 4 * filters
+        self.f_sel = self.ip_sel = self.p_sel = None       # logical channel indices (NASNetMobileEncoder: structural zeros)
 
     def stack_groups(self):
         return [[b.conv1.pointwise.weight for b in (self.left1, self.right1, self.right2)],
@@ -981,6 +999,7 @@ class ReductionCell(nn.Module):
         # h feeds the pooling pair and the left branch, p the stride-2 branches and the tapped right3 block: two aliases
         # each (their gradients are added inside the producing layer's weight-gradient launch where that layer is fused)
         rectified = self.adjust.mode == "none" and p is ip and ip.is_cuda
+        tap_sel = self.f_sel if self.adjust.mode != "none" else self.p_sel      # channel layout of what right3 reads (its tap)
         if rectified:
             # the very first cell: p IS ip and every branch starts with a ReLU, so one ReLU serves them all (the
             # in-kernel ReLU of the separable convolutions is idempotent on it) and the raw stem output has ONE consumer
@@ -1012,7 +1031,7 @@ class ReductionCell(nn.Module):
             if not wide3 and _WIDE_STEM and not taps.wants(self.right3.act_id2):
                 # the tapped activation is relu(p) -- in the first cell the (already rectified) input itself --: hand it out and
                 # let the block join the stage launches on p (the in-kernel ReLU of its depthwise layer gives the same numbers)
-                taps.offer(self.right3.act_id1, p_tap if rectified else F.relu(p_tap))
+                taps.offer(self.right3.act_id1, p_tap if rectified else F.relu(_logical_channels(p_tap, None if taps.physical else tap_sel)))
                 wide3 = True
             blocks = (self.left1, self.right1, self.right2) + ((self.right3,) if wide3 else ())
             H, W = h.shape[2], h.shape[3]
@@ -1063,6 +1082,8 @@ class ReductionCell(nn.Module):
         x2 = self.right2(p2, taps, residual=mp1)
         x2a, x2b = _ops.fan_out(x2, 2)
         x3 = self.right3(p3, taps, residual=ap_h if ap_h is not None else F.avg_pool2d(h3, 3, 2), rectified=rectified)
+        if tap_sel is not None and not taps.physical and self.right3.act_id1 in taps.found:
+            taps.found[self.right3.act_id1] = _logical_channels(taps.found[self.right3.act_id1], tap_sel)
         x4 = x2a + avg_pool_same(x1a)
         x5 = self.left4(x1b, taps, residual=mp2)
         x2 = x2b
@@ -1070,9 +1091,10 @@ class ReductionCell(nn.Module):
 
 
 class _Taps:
-    def __init__(self, wanted):
+    def __init__(self, wanted, physical=False):
         self.wanted = wanted
         self.found = {}
+        self.physical = physical       # hand out tapped tensors with their structurally-zero channels (no gather)
 
     def wants(self, act_id):
         return act_id in self.wanted
@@ -1080,6 +1102,14 @@ class _Taps:
     def offer(self, act_id, tensor):
         if act_id in self.wanted:
             self.found[act_id] = tensor
+
+
+def cell_phys(encoder, act_id):
+    """Physical channel count of the tensor tapped at act_id (a reduction cell's right3 input)."""
+    for cell in encoder.cells:
+        if isinstance(cell, ReductionCell) and cell.right3.act_id1 == act_id:
+            return cell.right3.conv1.depthwise.weight.shape[0]
+    raise WrongInputException(f"no tapped block at activation {act_id}")
 
 
 class NASNetMobileEncoder(nn.Module):
@@ -1119,18 +1149,23 @@ class NASNetMobileEncoder(nn.Module):
             phys = pad_to if (pad_to is not None and pad_to > f) else f
             cell = cls(self, x_ch, pc, x_red, pr, phys, p_is_none=p_ch is None)
             cell.ip_sel, cell.p_sel = x_sel, (x_sel if p_ch is None else p_sel)
-            cell.f_sel = torch.arange(f) if phys != f else None
-            if cell.f_sel is not None and (kind != "R" or cell.adjust.mode != "none"):
-                raise WrongInputException("structurally padded filters: first cell only")
+            cell.f_sel = None
+            if phys != f:
+                if kind != "R":
+                    raise WrongInputException("structurally padded filters: reduction cells only")
+                if cell.adjust.mode == "spatial":          # two halves of phys / 2 channels, f / 2 logical ones each
+                    cell.f_sel = torch.cat([torch.arange(f // 2), phys // 2 + torch.arange(f // 2)])
+                else:
+                    cell.f_sel = torch.arange(f)
             cells.append(cell)
             p_ch, p_red, p_sel = x_ch, x_red, x_sel        # the cell returns (x, ip): p <- ip
             x_ch = cell.out_channels
-            x_sel = torch.cat([g * phys + torch.arange(f) for g in range(4)]) if phys != f else None
+            x_sel = torch.cat([g * phys + cell.f_sel for g in range(4)]) if phys != f else None
             if kind == "R":
                 x_red += 1
 
         add("R", filters // (fm ** 2), pad_to=_STEM1_FILTERS)    # stem_1
-        add("R", filters // fm)                            # stem_2
+        add("R", filters // fm, pad_to=_STEM2_FILTERS)     # stem_2
         for _ in range(num_blocks):
             add("N", filters)
         add("R", filters * fm)                             # reduce_4  (skip_reduction=False: p <- p0 = its input)
@@ -1167,9 +1202,14 @@ class NASNetMobileEncoder(nn.Module):
                 continue
             adj = cell.adjust
             if adj.mode == "spatial":
-                out.extend([(adj.conv1.weight, None, ps), (adj.conv2.weight, None, ps)])
+                half = None if f is None else f[:len(f) // 2]          # the logical rows of each half
+                out.extend([(adj.conv1.weight, half, ps), (adj.conv2.weight, half, ps)])
+                if f is not None:
+                    bn(adj.bn, f)
             elif adj.mode == "project":
-                out.append((adj.conv.weight, None, ps))
+                out.append((adj.conv.weight, f, ps))
+                if f is not None:
+                    bn(adj.bn, f)
             out.append((cell.conv.weight, f, ip))
             if f is not None:
                 bn(cell.bn, f)
@@ -1207,8 +1247,21 @@ class NASNetMobileEncoder(nn.Module):
         h, w = image.shape[2:]
         return F.interpolate(x, size=(h + 2, w + 2), mode="bilinear", align_corners=False, antialias=False)
 
-    def forward(self, image):
-        taps = _Taps(self.TAP_ACTIVATIONS)
+    def tap_layout(self):
+        """[(physical channels, logical index set or None)] of the five taps as forward(image, physical_taps=True) returns them."""
+        out = []
+        for k, ch in zip(self.TAP_ACTIVATIONS, self.TAP_CHANNELS):
+            sel = None
+            for cell in self.cells:
+                if isinstance(cell, ReductionCell) and cell.right3.act_id1 == k:
+                    sel = cell.f_sel if cell.adjust.mode != "none" else cell.p_sel
+            out.append((ch if sel is None else (cell_phys(self, k)), sel))
+        return out
+
+    def forward(self, image, physical_taps=False):
+        """physical_taps: a tap that lies inside a cell with structurally-zero filters comes with them (tap_layout());
+        otherwise its logical channels are gathered (TAP_CHANNELS)."""
+        taps = _Taps(self.TAP_ACTIVATIONS, physical_taps)
         if _conv.stem_input_usable(image) and self.stem_conv.weight.dtype == torch.float32:
             # preprocessing, resize, cast and channel padding in one launch, then the matrix-core stem convolution
             x = _conv.conv2d_same(_conv.stem_input(image), self.stem_conv.weight, None, 2, 1.0, valid=True)
