@@ -7,11 +7,12 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from xpt_mde_2021_amd.hip import lib as _lib  # noqa: E402
+from xpt_mde_2021_amd.hip import conv as _conv, lib as _lib  # noqa: E402
 from xpt_mde_2021_amd.model.model_util.layer_ops import same_pad  # noqa: E402
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
+_conv._apply_env_tuning()          # XPT_DW_TUNE=<codes>
 
 
 def timeit(fn, n=20):
