@@ -235,6 +235,9 @@ int xpt_dwconv_bwd_data(const void* x, const float* w, const void* dy, void* dx,
  * -50000 - n forward from 2^n input elements on, -60000 - code / -70000 - code the same tiles for stride-1 layers
  * (0 = off, the default), -80000 - g narrowest channel group served (default 2) */
 int xpt_dwconv_tune(int wrw_groups);
+/* process-wide A/B switch (benchmarking): the kernels that number their workgroups image-major map image k of a batch of 8
+ * to XCD k (each XCD's L2 keeps what it wrote across kernel boundaries); pure renumbering, same results.  Default on. */
+int xpt_set_xcd_affinity(int on);
 size_t xpt_dwconv_bwd_weight_workspace_floats(int B, int OH, int OW, int C, int k);
 int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_floats,
                           int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW,

@@ -207,3 +207,22 @@ __device__ inline void block_sum_n(float (&v)[NV], float* red) {
 }
 
 }  // namespace xpt
+
+// ---- image-to-XCD affinity.  Workgroup i of a launch runs on XCD i % 8, and the L2 of an XCD keeps what its CUs wrote across
+// kernel boundaries (tools/lab/xcd_handoff.hip: a consumer kernel that reads on the XCD that wrote is up to 2x faster than one
+// that reads on another; the per-XCD L2s are not coherent with each other, so a remote reader goes to the Infinity Cache).
+// A kernel whose logical units are numbered image-major maps workgroup (bx, by) of a (gx, gy) grid to the unit
+//   u = (lin % 8) * (total / 8) + lin / 8,   lin = bx + gx * by,
+// so that units [k total / 8, (k + 1) total / 8) -- image k of a batch of 8 -- run on XCD k in EVERY kernel that follows
+// the convention.  Only when total % 8 == 0 (the launcher checks; otherwise the identity).  Pure renumbering: same results.
+extern int g_xpt_xcd_affinity;            // xpt_set_xcd_affinity(); defined in xpt_host.hip
+#ifdef __HIPCC__
+__device__ __forceinline__ void xpt_xcd_remap(bool on, unsigned& bx, unsigned& by, unsigned gx, unsigned gy) {
+  if (!on) return;
+  const unsigned lin = bx + gx * by, total = gx * gy;
+  const unsigned u = (lin & 7u) * (total >> 3) + (lin >> 3);
+  by = u / gx;
+  bx = u - by * gx;
+}
+#endif
+inline bool xpt_xcd_ok(unsigned long long total) { return g_xpt_xcd_affinity != 0 && total % 8 == 0 && total >= 64; }

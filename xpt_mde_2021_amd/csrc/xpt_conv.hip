@@ -52,6 +52,7 @@ struct ConvArgs {
   int xs;                    // residue classes per axis (transposed with forward stride 2: 2; else 1)
   int quad;                  // 1: pixels are enumerated as (parent, child) and the 4 children are summed into the parent
   float slope;               // LeakyReLU slope of the epilogue (1 = linear)
+  int xcd;                   // 1: workgroups renumbered image-major onto the XCDs (xpt_common.h)
 };
 
 template <int RM, int RN, int NKW>
@@ -75,9 +76,11 @@ __global__ __launch_bounds__(NKW > 1 ? 64 * NKW : 256) void conv_igemm_kernel(Co
   const int csteps = (a.C + 15) >> 4;
   const int nsteps = nkh * nkw * csteps;
 
-  const long long tile_m = (NKW > 1) ? (long long)blockIdx.y : (long long)blockIdx.y * 4 + wave;
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  xpt_xcd_remap(a.xcd != 0, bx, by, gridDim.x, gridDim.y);
+  const long long tile_m = (NKW > 1) ? (long long)by : (long long)by * 4 + wave;
   const long long m0 = tile_m * (32 * RN);
-  const int n0 = blockIdx.x * (32 * RM);
+  const int n0 = bx * (32 * RM);
   if (m0 >= Mc) return;                          // uniform per wave; with NKW > 1 uniform per workgroup
 
   // ---- per-lane pixel geometry (columns of the B operand)
@@ -296,8 +299,10 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(ConvArgs a) {
   const int nchunks = (npieces + 7) >> 3;
   const float inv_cp8 = 1.f / (float)cp8, inv_nkw = nkw > 0 ? 1.f / (float)nkw : 0.f;
 
-  const long long m0 = (long long)blockIdx.y * TP;
-  const int n0 = blockIdx.x * TN;
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  xpt_xcd_remap(a.xcd != 0, bx, by, gridDim.x, gridDim.y);
+  const long long m0 = (long long)by * TP;
+  const int n0 = bx * TN;
   if (m0 >= Mc) return;                                              // uniform per workgroup
 
   // (32-bit index arithmetic: the launcher refuses pixel grids of 2^31 or more; a 64-bit division costs ~10x a 32-bit one
@@ -485,12 +490,14 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs a, HaloPlan hp)
   const int r = lane & 31, h = lane >> 5;
   const int T = a.KH * a.KW;
 
-  int tile = blockIdx.y;
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  xpt_xcd_remap(a.xcd != 0, bx, by, gridDim.x, gridDim.y);
+  int tile = (int)by;
   const int txi = tile % hp.tiles_x; tile /= hp.tiles_x;
   const int tyi = tile % hp.tiles_y;
   const int b = tile / hp.tiles_y;
   const int oh0 = tyi * 8, ow0 = txi * 16;
-  const int n0 = blockIdx.x * TN;
+  const int n0 = bx * TN;
 
   // logical input window of the tile and its physical footprint
   const int lo_h = oh0 + a.off_h - (a.sgn > 0 ? 0 : a.KH - 1), lo_w = ow0 + a.off_w - (a.sgn > 0 ? 0 : a.KW - 1);
@@ -721,8 +728,10 @@ int launch_igemm(const ConvArgs& a, long long Mmax, int classes, hipStream_t s) 
   const long long gy = NKW > 1 ? mtiles : (mtiles + 3) / 4;
   if (gy > 65535 || Mmax >= 0x7fffffffLL) return XPT_ERR_SHAPE;
   const dim3 grid((a.N + 32 * RM - 1) / (32 * RM), (unsigned)gy, classes);
+  ConvArgs b = a;
+  b.xcd = xpt_xcd_ok((unsigned long long)grid.x * grid.y);
   XPT_BEGIN_LAUNCH();
-  hipLaunchKernelGGL((conv_igemm_kernel<RM, RN, NKW>), grid, dim3(NKW > 1 ? 64 * NKW : 256), 0, s, a);
+  hipLaunchKernelGGL((conv_igemm_kernel<RM, RN, NKW>), grid, dim3(NKW > 1 ? 64 * NKW : 256), 0, s, b);
   return xpt_launch_status();
 }
 
@@ -731,8 +740,10 @@ int launch_lds(const ConvArgs& a, long long Mmax, int classes, hipStream_t s) {
   const long long gy = (Mmax + 127) / 128;
   if (gy > 65535 || Mmax >= 0x7fffffffLL) return XPT_ERR_SHAPE;
   const dim3 grid((a.N + 32 * RM - 1) / (32 * RM), (unsigned)gy, classes);
+  ConvArgs b = a;
+  b.xcd = xpt_xcd_ok((unsigned long long)grid.x * grid.y);
   XPT_BEGIN_LAUNCH();
-  hipLaunchKernelGGL((conv_lds_kernel<RM>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((conv_lds_kernel<RM>), grid, dim3(256), 0, s, b);
   return xpt_launch_status();
 }
 
@@ -769,11 +780,13 @@ int launch_halo(const ConvArgs& a, const HaloPlan& hp, size_t lds, hipStream_t s
   const long long gy = (long long)a.B * hp.tiles_y * hp.tiles_x;
   if (gy > 65535) return XPT_ERR_SHAPE;
   const dim3 grid((a.N + 32 * RM - 1) / (32 * RM), (unsigned)gy);
+  ConvArgs b = a;
+  b.xcd = xpt_xcd_ok((unsigned long long)grid.x * grid.y);
   XPT_BEGIN_LAUNCH();
   if (a.KH == 3 && a.KW == 3)
-    hipLaunchKernelGGL((conv_halo_kernel<RM, true>), grid, dim3(256), lds, s, a, hp);
+    hipLaunchKernelGGL((conv_halo_kernel<RM, true>), grid, dim3(256), lds, s, b, hp);
   else
-    hipLaunchKernelGGL((conv_halo_kernel<RM, false>), grid, dim3(256), lds, s, a, hp);
+    hipLaunchKernelGGL((conv_halo_kernel<RM, false>), grid, dim3(256), lds, s, b, hp);
   return xpt_launch_status();
 }
 

@@ -96,3 +96,10 @@ extern "C" int xpt_graph_node_census(void* hip_graph, int* counts) {
   (void)hipGetLastError();
   return census_walk((hipGraph_t)hip_graph, counts, 0);
 }
+
+/* image-to-XCD affinity of the kernels that follow the convention of xpt_common.h (xpt_xcd_remap): 0 = off */
+int g_xpt_xcd_affinity = 1;
+extern "C" int xpt_set_xcd_affinity(int on) {
+  g_xpt_xcd_affinity = on ? 1 : 0;
+  return XPT_OK;
+}

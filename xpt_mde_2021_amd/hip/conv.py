@@ -126,6 +126,8 @@ def _apply_env_tuning():
     spec = os.environ.get("XPT_PW_WGRAD_TUNE")             # pointwise weight gradient: waves, row pairs per wave, max workgroups, KiB
     if spec:
         _lib.load().xpt_conv1x1_bwd_weight_tune(*[int(v) for v in spec.split(",")])
+    if os.environ.get("XPT_XCD_AFFINITY"):                 # 0: workgroups in launch order (A/B of the image-to-XCD numbering)
+        _lib.load().xpt_set_xcd_affinity(int(os.environ["XPT_XCD_AFFINITY"]))
     for code in os.environ.get("XPT_DW_TUNE", "").split(","):     # depthwise knobs (xpt_dwconv_tune codes, see xpt_hip.h)
         if code:
             _lib.load().xpt_dwconv_tune(int(code))

@@ -67,6 +67,7 @@ SIGNATURES = {
     "xpt_affine_act_bwd_partials": (_i, [_p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f, _p, _p, _z, ctypes.c_longlong,
                                          _i, _f, _i, _i, _p]),
     "xpt_dwconv_bwd_weight_chunks": (_i, [_i] * 6),
+    "xpt_set_xcd_affinity": (_i, [_i]),
     "xpt_dwconv_bwd_weight_partials": (_i, [_p, _p, _p, _z] + [_i] * 12 + [_p]),
     "xpt_dwconv_bwd_both": (_i, [_p, _p, _p, _p, _p, _z] + [_i] * 12 + [_p]),
     "xpt_dwconv_multi_fwd": (_i, [_p, _p, _p, _p, _p, _p] + [_i] * 10 + [_p]),
