@@ -156,7 +156,9 @@ def test_train_step_runs_and_learns(gpu_device):
         a, b = losses[("eager", "fp32")], losses[("graph", "fp32")]
         # fp32 = the library path (MIOpen solvers with atomics: runs are not repeatable bit for bit, and 8 Adam steps
         # amplify the rounding differences -- Adam moves every weight by ~lr whatever the gradient's size)
-        assert abs(a[0] - b[0]) < 1e-5 and abs(a[-1] - b[-1]) < 5e-3 * abs(a[-1]), (a, b)
+        # (first step: the same weights through whatever solver MIOpen's find picked in each trainer's warm-up -- seen 2e-6 to
+        #  2e-5 apart depending on the box)
+        assert abs(a[0] - b[0]) < 1e-4 * max(1.0, abs(a[0])) and abs(a[-1] - b[-1]) < 5e-3 * abs(a[-1]), (a, b)
         c = losses[("graph", "bf16")]
         assert abs(a[0] - c[0]) < 5e-2 * abs(a[0]), (a, c)
         # bf16 = own deterministic kernels end to end: the captured trainer IS the eager trainer, bit for bit
