@@ -477,6 +477,10 @@ int xpt_pool_pair_fwd(const void* in, long long in_pitch, void* mp, void* ap, vo
                       int OW, int pad_t, int pad_l, int dtype, void* stream);
 int xpt_pool_pair_bwd(const void* gmp, long long pitch_m, const void* gap, long long pitch_a, const void* arg, void* dh, int B,
                       int H, int W, int C, int OH, int OW, int pad_t, int pad_l, int dtype, void* stream);
+/* ... with a second gradient of the max-pooled tensor (two consumers of it: added on load, no fan-in launch); gmp2 may be NULL */
+int xpt_pool_pair_bwd2(const void* gmp, long long pitch_m, const void* gmp2, long long pitch_m2, const void* gap, long long pitch_a,
+                       const void* arg, void* dh, int B, int H, int W, int C, int OH, int OW, int pad_t, int pad_l, int dtype,
+                       void* stream);
 
 /* ------------------------------------------------------------------ f-2: the in-step augmentation
  * TotalAugment over [CropAndResize(p_crop), HorizontalFlip(p_flip), ColorJitter(p_jit)] (model/model_util/augmentation.py:

@@ -131,3 +131,31 @@ def test_pool_pair_matches_padded_library_pools(gpu_device, dtype, C, H, W):
     ((md.float() * wm.to(gpu_device).float()).sum() + (ad.float() * wa.to(gpu_device).float()).sum()).backward()
     scale = xr.grad.abs().max().item()
     assert (xd.grad.float().cpu() - xr.grad).abs().max().item() <= (1e-5 if dtype == torch.float32 else 1e-2) * scale
+
+
+@pytest.mark.parametrize("dtype,C,H,W", [(torch.float32, 6, 8, 12), (torch.bfloat16, 24, 9, 13), (torch.bfloat16, 88, 8, 26)])
+def test_pool_pair_with_two_consumers_of_the_maximum(gpu_device, dtype, C, H, W):
+    """pool_pair(split_mp=True): the max-pooled tensor as two aliases whose gradients the backward adds on load
+    (xpt_pool_pair_bwd2) == one tensor with both gradients added beforehand; one consumer silent: the other alone."""
+    from xpt_mde_2021_amd.hip import ops
+    from xpt_mde_2021_amd.model.build_model.pretrained_nets import correct_pad
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(2, C, H, W, generator=g).to(dtype)
+    pads = correct_pad(H, W, 3)
+    xa = x.to(gpu_device).contiguous(memory_format=torch.channels_last).detach().requires_grad_(True)
+    xb = xa.detach().clone().requires_grad_(True)
+    m1, m2, ap = ops.pool_pair(xa, pads, split_mp=True)
+    mr, ar = ops.pool_pair(xb, pads)
+    assert torch.equal(m1, mr) and torch.equal(m2, mr) and torch.equal(ap, ar)
+    w1, w2, wa = (torch.randn(mr.shape, generator=g).to(gpu_device, dtype) for _ in range(3))
+    torch.autograd.backward([m1, m2, ap], [w1, w2, wa])
+    torch.autograd.backward([mr, ar], [(w1.float() + w2.float()).to(dtype), wa])
+    scale = float(xb.grad.abs().max())
+    assert float((xa.grad.float() - xb.grad.float()).abs().max()) <= (1e-6 if dtype == torch.float32 else 2 ** -7) * scale
+    xc = xa.detach().clone().requires_grad_(True)
+    xd = xa.detach().clone().requires_grad_(True)
+    n1, n2, _ = ops.pool_pair(xc, pads, split_mp=True)
+    n2.backward(w2)                                          # only the second alias receives a gradient
+    q, _ = ops.pool_pair(xd, pads)
+    q.backward(w2)
+    assert torch.equal(xc.grad, xd.grad)

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void pool_pair_fwd_kernel(const T* __restrict_
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void pool_pair_bwd_kernel(const T* __restrict__ gmp, long long pitch_m,
+                                                            const T* __restrict__ gmp2, long long pitch_m2,
                                                             const T* __restrict__ gap, long long pitch_a,
                                                             const unsigned char* __restrict__ arg, T* __restrict__ dh, int B,
                                                             int H, int W, int C, int OH, int OW, int pad_t, int pad_l) {
@@ -373,6 +374,12 @@ __global__ __launch_bounds__(256) void pool_pair_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < V; ++e) { gm[e] = 0.f; ga[e] = 0.f; }
         if (gmp != nullptr) load_row<T, V>(gmp + o * pitch_m + c0, gm);
+        if (gmp2 != nullptr) {                         // the max-pooled tensor had two consumers: their gradients added here
+          float g2[V];
+          load_row<T, V>(gmp2 + o * pitch_m2 + c0, g2);
+#pragma unroll
+          for (int e = 0; e < V; ++e) gm[e] += g2[e];
+        }
         if (gap != nullptr) load_row<T, V>(gap + o * pitch_a + c0, ga);
         const int tap = ty * 3 + tx;
 #pragma unroll
@@ -588,14 +595,21 @@ int xpt_pool_pair_fwd(const void* in, long long in_pitch, void* mp, void* ap, vo
  * be NULL and may have a row pitch */
 int xpt_pool_pair_bwd(const void* gmp, long long pitch_m, const void* gap, long long pitch_a, const void* arg, void* dh, int B,
                       int H, int W, int C, int OH, int OW, int pad_t, int pad_l, int dtype, void* stream) {
+  return xpt_pool_pair_bwd2(gmp, pitch_m, nullptr, 0, gap, pitch_a, arg, dh, B, H, W, C, OH, OW, pad_t, pad_l, dtype, stream);
+}
+
+int xpt_pool_pair_bwd2(const void* gmp, long long pitch_m, const void* gmp2, long long pitch_m2, const void* gap, long long pitch_a,
+                       const void* arg, void* dh, int B, int H, int W, int C, int OH, int OW, int pad_t, int pad_l, int dtype,
+                       void* stream) {
   XPT_CHECK_PTR(arg); XPT_CHECK_PTR(dh);
-  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || (gmp && pitch_m < C) || (gap && pitch_a < C))
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0 || (gmp && pitch_m < C) || (gap && pitch_a < C) ||
+      (gmp2 && (pitch_m2 < C || !gmp)))
     return XPT_ERR_SHAPE;
   if ((dtype != 0 && dtype != 1) || pad_t < 0 || pad_l < 0 || pad_t > 2 || pad_l > 2) return XPT_ERR_ARG;
   const int esz = dtype == 0 ? 4 : 2;
   int v = dtype == 0 ? 4 : 8;
   while (v > 1 && !(C % v == 0 && aligned_for(dh, C, v, esz) && (!gmp || aligned_for(gmp, pitch_m, v, esz)) &&
-                    (!gap || aligned_for(gap, pitch_a, v, esz))))
+                    (!gmp2 || aligned_for(gmp2, pitch_m2, v, esz)) && (!gap || aligned_for(gap, pitch_a, v, esz))))
     v >>= 1;
   const long long total = (long long)B * H * W * (C / v);
   if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
@@ -604,8 +618,8 @@ int xpt_pool_pair_bwd(const void* gmp, long long pitch_m, const void* gap, long 
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
 #define XPT_K(T, V)                                                                                                    \
-  hipLaunchKernelGGL((pool_pair_bwd_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)gmp, pitch_m, (const T*)gap, \
-                     pitch_a, (const unsigned char*)arg, (T*)dh, B, H, W, C, OH, OW, pad_t, pad_l)
+  hipLaunchKernelGGL((pool_pair_bwd_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)gmp, pitch_m, (const T*)gmp2, \
+                     pitch_m2, (const T*)gap, pitch_a, (const unsigned char*)arg, (T*)dh, B, H, W, C, OH, OW, pad_t, pad_l)
   if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
   else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
 #undef XPT_K

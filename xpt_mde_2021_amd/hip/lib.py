@@ -128,6 +128,8 @@ SIGNATURES = {
     "xpt_adjust_scatter": (_i, [_p, ctypes.c_longlong, _p, ctypes.c_longlong, _p, _i, _i, _i, _i, _i, _p]),
     "xpt_pool_pair_fwd": (_i, [_p, ctypes.c_longlong, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "xpt_pool_pair_bwd": (_i, [_p, ctypes.c_longlong, _p, ctypes.c_longlong, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "xpt_pool_pair_bwd2": (_i, [_p, ctypes.c_longlong, _p, ctypes.c_longlong, _p, ctypes.c_longlong, _p, _p, _i, _i, _i, _i, _i, _i,
+                                _i, _i, _i, _p]),
     "xpt_cell_tail_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _i, _i, _i, _i, _i, _p]),
     "xpt_cell_tail_bwd": (_i, [_i, _p, _p, _p, ctypes.c_longlong, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "xpt_crc32c": (ctypes.c_uint32, [_p, _z]),

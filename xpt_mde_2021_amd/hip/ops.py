@@ -1269,7 +1269,8 @@ class _PoolPair(torch.autograd.Function):
     """(max_pool2d, avg_pool2d)(zero_pad(h), 3, stride 2) in one launch; the backward routes both gradients in one."""
 
     @staticmethod
-    def forward(ctx, h, pad_t, pad_b, pad_l, pad_r):
+    def forward(ctx, h, pad_t, pad_b, pad_l, pad_r, split_mp=False):
+        """split_mp: (mp, mp', ap) with mp' an alias of mp for a second consumer -- the backward adds their gradients on load."""
         lib = _lib.load()
         hr, pitch = _rows_with_pitch(_nhwc_any(h))
         B, C, H, W = h.shape
@@ -1282,28 +1283,34 @@ class _PoolPair(torch.autograd.Function):
                                          _stream()), "xpt_pool_pair_fwd")
         ctx.save_for_backward(arg)
         ctx.cfg = (B, C, H, W, OH, OW, pad_t, pad_l, dt, h.dtype)
+        ctx.split = bool(split_mp)
         ctx.set_materialize_grads(False)
-        return mp, ap
+        return (mp, mp.view_as(mp), ap) if split_mp else (mp, ap)
 
     @staticmethod
-    def backward(ctx, gm, ga):
+    def backward(ctx, *grads):
+        gm, gm2, ga = grads if ctx.split else (grads[0], None, grads[1])
+        if gm is None and gm2 is not None:
+            gm, gm2 = gm2, None
         if gm is None and ga is None:
-            return None, None, None, None, None
+            return (None,) * 6
         lib = _lib.load()
         arg, = ctx.saved_tensors
         B, C, H, W, OH, OW, pad_t, pad_l, dt, dtype = ctx.cfg
         (rm, pm) = _rows_with_pitch(gm.to(dtype)) if gm is not None else (None, 0)
+        (rm2, pm2) = _rows_with_pitch(gm2.to(dtype)) if gm2 is not None else (None, 0)
         (ra, pa) = _rows_with_pitch(ga.to(dtype)) if ga is not None else (None, 0)
         dh = torch.empty((B, C, H, W), dtype=dtype, device=arg.device, memory_format=torch.channels_last)
-        _lib.check(lib.xpt_pool_pair_bwd(_ptr(rm), pm, _ptr(ra), pa, _ptr(arg), _ptr(dh), B, H, W, C, OH, OW, pad_t, pad_l, dt,
-                                         _stream()), "xpt_pool_pair_bwd")
-        return dh, None, None, None, None
+        _lib.check(lib.xpt_pool_pair_bwd2(_ptr(rm), pm, _ptr(rm2), pm2, _ptr(ra), pa, _ptr(arg), _ptr(dh), B, H, W, C, OH, OW, pad_t,
+                                          pad_l, dt, _stream()), "xpt_pool_pair_bwd2")
+        return (dh,) + (None,) * 5
 
 
-def pool_pair(h, pads):
-    """pads = ((top, bottom), (left, right)) of the zero padding -> (max pooled, average pooled), 3x3 windows, stride 2."""
+def pool_pair(h, pads, split_mp=False):
+    """pads = ((top, bottom), (left, right)) of the zero padding -> (max pooled, average pooled), 3x3 windows, stride 2.
+    split_mp: (max pooled, an alias of it for a second consumer, average pooled): no gradient fan-in launch."""
     (pt, pb), (pl, pr) = pads
-    return _PoolPair.apply(h, pt, pb, pl, pr)
+    return _PoolPair.apply(h, pt, pb, pl, pr, bool(split_mp))
 
 
 # ------------------------------------------------------------------------------- gradient fan-in

@@ -1011,12 +1011,13 @@ class ReductionCell(nn.Module):
         h, h_pool = conv1x1_bn(h, self.conv.weight, self.bn, fan_out=2)
         if h.is_cuda and _CELL_TAIL and h.dtype in (torch.float32, torch.bfloat16):
             # both poolings of the zero-padded h in one launch (and one backward launch)
-            mp, ap_h = _ops.pool_pair(h_pool, correct_pad(h.shape[2], h.shape[3], 3))
+            # (the max-pooled tensor feeds x2 and x5: two aliases, their gradients added inside the pooling backward)
+            mp1, mp2, ap_h = _ops.pool_pair(h_pool, correct_pad(h.shape[2], h.shape[3], 3), split_mp=True)
         else:
             h3 = zero_pad(h_pool, correct_pad(h.shape[2], h.shape[3], 3))
             mp = F.max_pool2d(h3, 3, 2)                      # MaxPooling2D of h feeds x2 and x5: pooled once
             ap_h = None
-        mp1, mp2 = _ops.fan_out(mp, 2)
+            mp1, mp2 = _ops.fan_out(mp, 2)
         def tapped(b):
             return taps.wants(b.act_id1) or taps.wants(b.act_id2)
 
