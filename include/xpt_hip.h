@@ -156,6 +156,10 @@ int xpt_photo_fused_ms_bwd(int nscales, const float* const* src, const float* co
  * Replaces the same reference callables (synthesize_base.py:13-20, 88-178; bilinear_interp.py:7-147;
  * loss_util.py:6-25, 52-96; losses.py:179-195).  xpt_photo_march_tune: launch-plan knobs as xpt_photo_fused_tune. */
 int xpt_photo_march_tune(int fwd_min_waves, int bwd_min_waves, int min_rows);
+/* xpt_photo_march_plan: bwd_variant 1 = the pipelined row step of round 4 (the next row's tap gathers in flight behind the
+ * SSIM-coefficient and gradient stages of the current one), 0 = the round-3 row step; rows_s*: rows per chunk of the
+ * backward launch for pyramid scale s (0 = the automatic, occupancy-balanced choice). */
+int xpt_photo_march_plan(int bwd_variant, int rows_s0, int rows_s1, int rows_s2, int rows_s3);
 int xpt_photo_march_ms_fwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
                            const float* const* target, float* losses, float* workspace, size_t workspace_floats,
                            int B, int N, const int* h, const int* w, const float* scale, void* stream);

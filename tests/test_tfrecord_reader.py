@@ -155,3 +155,18 @@ def test_prefetching_reader_propagates_errors_and_stops_early(tmp_path):
     import time
     time.sleep(0.5)
     assert not [t for t in threading.enumerate() if t.name == "xpt-tfrecord-prefetch" and t.is_alive()]
+
+
+def test_prefetching_reader_keeps_its_descriptor_count_over_epochs(tmp_path):
+    """train() iterates ONE dataset object every epoch: the shard mappings must be reused, not re-created (a mapping per
+    shard and epoch ran a long training into EMFILE)."""
+    _write(tmp_path, 16, shard_size=4)
+    ds = tr.TfrecordReader(str(tmp_path), batch_size=2, prefetch=2, workers=2).get_dataset()
+    counts = []
+    for _ in range(5):
+        assert len(list(ds)) == 8
+        counts.append(len(os.listdir("/proc/self/fd")))
+    assert len(set(counts)) == 1, counts
+    assert len(ds._maps) == 4
+    ds.close()
+    assert not ds._maps

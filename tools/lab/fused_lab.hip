@@ -193,6 +193,17 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     printf("calibration: calib_copy16 reads %lld B and writes %lld B; calib_read12 reads %lld B\n", n * 16, n * 16, (n * 4 / 3) * 12);
   }
+  if (const char* plan = getenv("LAB_PLAN")) {             // "variant,rows0,rows1,rows2,rows3" -> xpt_photo_march_plan
+    int v = 1, r[4] = {0, 0, 0, 0};
+    sscanf(plan, "%d,%d,%d,%d,%d", &v, &r[0], &r[1], &r[2], &r[3]);
+    const int rc = xpt_photo_march_plan(v, r[0], r[1], r[2], r[3]);
+    printf("plan %s -> rc %d\n", plan, rc);
+  }
+  if (const char* tune = getenv("LAB_TUNE")) {             // "fwd_min_waves,bwd_min_waves,min_rows" -> xpt_photo_march_tune
+    int f = 4096, bw = 1536, mr = 8;
+    sscanf(tune, "%d,%d,%d", &f, &bw, &mr);
+    printf("tune %s -> rc %d\n", tune, xpt_photo_march_tune(f, bw, mr));
+  }
   Run a, b;
   const bool do_old = strcmp(mode, "new") != 0, do_new = strcmp(mode, "old") != 0;
   if (do_old) a = run(false);

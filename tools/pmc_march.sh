@@ -17,7 +17,7 @@ import csv, sys, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
-    m = re.search(r"(march_fwd_ms_kernel|march_bwd_ms_kernel<\d>|march_bwd_finish_kernel|calib_copy16|calib_read12)", k)
+    m = re.search(r"(march_fwd_ms_kernel|march_bwd_ms_kernel<\d>|march_bwd_ms_p_kernel<\d>|march_bwd_finish_kernel|calib_copy16|calib_read12)", k)
     if m:
         agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for key, cs in sorted(agg.items()):

@@ -606,6 +606,258 @@ __device__ __forceinline__ void march_bwd_body(const float* __restrict__ src, co
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward, pipelined
+// Round 4.  At batch 8 the one-pass launch is ~3,100 waves on 3,072 wave slots (3 per SIMD): ONE round of waves whose row
+// step is a dependent chain  depth -> projection -> tap gathers -> (wait) -> 280 vector instructions;  with three waves per
+// SIMD the gather latency of every row was exposed (PMC: 36 % of the wave-cycles parked on s_waitcnt, the launch at 2.4 x
+// its vector-issue time).  Here the gathers of row r+1 are issued right after stage A has consumed the taps of row r --
+// into the same registers -- and fly during stages B and C (two thirds of the row step); the target pixel of row r+1 rides
+// with them and the depth is fetched two rows ahead.  The loads are plain C++ loads: the compiler tracks them across the
+// loop edges and places the s_waitcnt in front of the first use (top of the next row step).  Same arithmetic as
+// march_bwd_body, except that the pose-gradient accumulator drops its column terms: G(., d col) = col * G(., d) per lane.
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int MODE>
+__device__ __forceinline__ void march_bwd_body_p(const float* __restrict__ src, const float* __restrict__ depth,
+                                                 const float* __restrict__ T, const float* __restrict__ K,
+                                                 const float* __restrict__ target, const float* __restrict__ g_l1,
+                                                 const float* __restrict__ g_ssim, float* __restrict__ ddepth,
+                                                 float* __restrict__ part, const MDims& d, float inv_count, unsigned block,
+                                                 float* __restrict__ lds) {
+  const WaveJob job = wave_job(d, block);
+  if (!job.valid) return;                   // MODE 0: nwaves % 4 == 0, whole workgroups leave together
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int W = __builtin_amdgcn_readfirstlane(d.w), H = __builtin_amdgcn_readfirstlane(d.h);
+  float* ring = lds + wid * RING_FLOATS + lane;           // ring[(slot * 16 + k) * 64]
+  float* lds_dd = lds + 4 * RING_FLOATS;
+  const int P = H * W;
+  const int col = job.s * MSTRIP_B - 2 + lane;
+  const bool col_in = (col >= 0) && (col < W);
+  const bool out_lane = (lane >= 2) && (lane < 2 + MSTRIP_B) && col_in;
+  const int col_c = min(max(col, 0), W - 1);
+  const int r0 = job.ck * d.R, r1 = min(r0 + d.R, H);
+  const Cam cam = load_cam(K + 9 * job.b, d.scale);
+  const Fold f = fold_camera(cam, load_pose(T + 16 * (job.b * d.N + job.n)));
+  const char* simg = (const char*)(src + (long long)(job.b * d.N + job.n) * P * 3);
+  const float* dimg = depth + (long long)job.b * P;
+  const char* timg = (const char*)(target + (long long)job.b * P * 3);
+  float* gimg = ddepth + (long long)job.b * P;
+  const float colf = (float)col;
+  float m_c[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) m_c[i] = f.M[3 * i] * colf + f.M[3 * i + 2];
+  const float colm = col_in ? 1.f : 0.f;
+  const float outm = out_lane ? 1.f : 0.f;
+  const float cnt_c = (float)((col > 0 ? 1 : 0) + 1 + (col < W - 1 ? 1 : 0));
+  const float u_hi = (float)(W - 1), v_hi = (float)(H - 1);
+  const unsigned row_b = 12u * (unsigned)W;
+  const float gl1 = g_l1[job.b] * inv_count;
+  const float gss_h = g_ssim[job.b] * inv_count * (-0.5f);
+
+  float G[9];                               // sum of dq (x) (d row, d, 1); the (d col) column is col * the (d) column
+#pragma unroll
+  for (int i = 0; i < 9; ++i) G[i] = 0.f;
+  float acc_l1 = 0.f, acc_ss = 0.f;
+  float hA[NW], hB[NW], hC[NW], hpair[NW], cA[NC], cB[NC], cC[NC], cpair[NC];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) { hA[i] = 0.f; hB[i] = 0.f; hC[i] = 0.f; hpair[i] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < NC; ++i) { cA[i] = 0.f; cB[i] = 0.f; cC[i] = 0.f; cpair[i] = 0.f; }
+  float nb1 = 0.f, nb2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) ring[k * 64] = 0.f;
+
+  // in flight between two row steps: the taps and the target pixel of the next row, the depth of the row after it
+  f32x4 a0, a1;
+  f32x2 b0, b1;
+  f32x3 tx;
+  float nd2;
+  float c_d, c_zinv, c_us, c_vs, c_okf;     // the next row's projection (invalid pixels: coordinates 0, everything else times 0)
+  auto issue = [&](int rn, float dd) {
+    const bool row_in = (rn >= 0) && (rn < H);                           // wave-uniform
+    const float fr = (float)rn;
+    const float q0 = (f.M[1] * fr + m_c[0]) * dd + f.kt[0];
+    const float q1 = (f.M[4] * fr + m_c[1]) * dd + f.kt[1];
+    const float q2 = (f.M[7] * fr + m_c[2]) * dd + f.kt[2];
+    const float zinv = rcpf(q2 + 1e-10f);
+    const float up = q0 * zinv, vp = q1 * zinv;
+    const bool ok = row_in && col_in && (up >= 0.f) && (up < u_hi) && (vp >= 0.f) && (vp < v_hi) && (dd != 0.f);
+    c_okf = ok ? 1.f : 0.f;
+    c_us = ok ? up : 0.f; c_vs = ok ? vp : 0.f;
+    c_d = dd; c_zinv = ok ? zinv : 0.f;
+    const int iu = cvt_floor(c_us), iv = cvt_floor(c_vs);
+    const unsigned off0 = (unsigned)iv * row_b + (unsigned)iu * 12u;
+    const unsigned off1 = off0 + row_b;
+    a0 = *(const f32x4u*)(simg + off0);
+    b0 = *(const f32x2u*)(simg + off0 + 16u);
+    a1 = *(const f32x4u*)(simg + off1);
+    b1 = *(const f32x2u*)(simg + off1 + 16u);
+    const unsigned pt = (unsigned)(min(max(rn, 0), H - 1) * W + col_c);
+    tx = *(const f32x3u*)(timg + pt * 12u);
+    const unsigned pd = (unsigned)(min(max(rn + 1, 0), H - 1) * W + col_c);
+    nd2 = *(const float*)((const char*)dimg + pd * 4u);
+  };
+
+  auto flush_dd = [&](int first_row, int nrows) {
+    __syncthreads();
+    for (int row = wid; row < nrows; row += 4) {
+      const float* v = lds_dd + row * 64 + lane;
+      const float sum = ((v[0] + v[DD_ROWS * 64]) + v[2 * DD_ROWS * 64]) + v[3 * DD_ROWS * 64];
+      if (out_lane) gimg[(first_row + row) * W + col] = sum;
+    }
+    __syncthreads();
+  };
+
+  auto body = [&](int r, float (&hcur)[NW], const float (&hm1)[NW], float (&ccur)[NC], const float (&cm1)[NC]) {
+    float* slot = ring + (r & 1) * (16 * 64);                              // holds row r-2 now, row r at the end of the step
+    RowSt scur;
+    // ---- stage A: row r from its taps (issued one row step ago)
+    {
+      const bool row_in = (r >= 0) && (r < H);                           // wave-uniform
+      const float rm = row_in ? colm : 0.f;
+      scur.x[0] = tx.x * rm; scur.x[1] = tx.y * rm; scur.x[2] = tx.z * rm;
+      scur.d = c_d; scur.zinv = c_zinv; scur.up = c_us; scur.vp = c_vs;
+      const float okf = c_okf;
+      const float wuc = __builtin_amdgcn_fractf(c_us), wvc = __builtin_amdgcn_fractf(c_vs);
+      const float ff[3] = {a0.x, a0.y, a0.z}, cf[3] = {a0.w, b0.x, b0.y};
+      const float fc[3] = {a1.x, a1.y, a1.z}, cc[3] = {a1.w, b1.x, b1.y};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float ca = cf[c] - ff[c], eb = cc[c] - fc[c];
+        const float top = ff[c] + ca * wuc, bot = fc[c] + eb * wuc;
+        const float gv = bot - top;
+        scur.y[c] = (top + gv * wvc) * okf;
+        scur.gv[c] = gv * okf;
+        scur.gu[c] = (ca + (eb - ca) * wvc) * okf;
+      }
+      scur.nb = (((scur.y[0] + scur.y[1]) + scur.y[2]) == 0.f) ? 0.f : 1.f;
+    }
+    // ---- the next row's gathers leave now (into the registers stage A has just read)
+    issue(r + 1, nd2);
+    {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        hcur[c] = hsum3(scur.x[c]);
+        hcur[3 + c] = hsum3(scur.y[c]);
+        hcur[6 + c] = hsum3(scur.x[c] * scur.x[c] + scur.y[c] * scur.y[c]);
+        hcur[9 + c] = hsum3(scur.x[c] * scur.y[c]);
+      }
+    }
+    // ---- stage B: SSIM coefficients of centre row p = r-1, then their horizontal sums
+    {
+      const int p = r - 1;
+      if (p >= 0 && p < H && p >= r0 - 1 && p <= r1) {                   // wave-uniform
+        const SsimK k = ssim_consts(cnt_c, window_rows(p, H));
+        const float gg = gss_h * nb1;
+        float co[NC], lsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          lsum += ssim_coeffs_sums(hpair[c] + hcur[c], hpair[3 + c] + hcur[3 + c], hpair[6 + c] + hcur[6 + c],
+                                   hpair[9 + c] + hcur[9 + c], k, gg, co[c], co[3 + c], co[6 + c]);
+        if (p >= r0 && p < r1) acc_ss += lsum * (outm * nb1);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) ccur[i] = hsum3(co[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) ccur[i] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < NW; ++i) hpair[i] = hm1[i] + hcur[i];
+    }
+    // ---- stage C: gradient of pixel (q = r-2, col) (its state comes back from the ring); window rows q-1, q, q+1
+    const int q = r - 2;
+    if (q >= r0 && q < r1) {                                               // wave-uniform
+      const float gl1n = gl1 * nb2;
+      float du = 0.f, dv = 0.f, l1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float x = slot[c * 64], y = slot[(3 + c) * 64], gu = slot[(6 + c) * 64], gv = slot[(9 + c) * 64];
+        const float SA = cpair[c] + ccur[c];
+        const float SB = cpair[3 + c] + ccur[3 + c];
+        const float SC = cpair[6 + c] + ccur[6 + c];
+        const float df = y - x;
+        const float sg = __builtin_amdgcn_fmed3f(df * 1e30f, -1.f, 1.f);
+        l1 += fabsf(df);
+        const float g = ((gl1n * sg + SA) + SB * y) + SC * x;
+        du += g * gu;
+        dv += g * gv;
+      }
+      const float dq_d = slot[12 * 64], zinv = slot[13 * 64], up = slot[14 * 64], vp = slot[15 * 64];
+      acc_l1 += l1 * (outm * nb2);
+      du *= outm; dv *= outm;
+      const float dq0 = du * zinv, dq1 = dv * zinv;
+      const float dq2 = -(du * up + dv * vp) * zinv;
+      const float fq = (float)q;
+      const float ddv = (dq0 * (f.M[1] * fq + m_c[0]) + dq1 * (f.M[4] * fq + m_c[1])) + dq2 * (f.M[7] * fq + m_c[2]);
+      const float P1 = dq_d * fq, P2 = dq_d;
+      G[0] += dq0 * P1; G[1] += dq0 * P2; G[2] += dq0;
+      G[3] += dq1 * P1; G[4] += dq1 * P2; G[5] += dq1;
+      G[6] += dq2 * P1; G[7] += dq2 * P2; G[8] += dq2;
+      if (MODE == 0) {
+        lds_dd[(wid * DD_ROWS + ((q - r0) & (DD_ROWS - 1))) * 64 + lane] = ddv;
+        if (((q - r0) & (DD_ROWS - 1)) == DD_ROWS - 1 && q != r1 - 1) flush_dd(q - (DD_ROWS - 1), DD_ROWS);
+      } else if (out_lane) {
+        gimg[q * W + col] = ddv;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) cpair[i] = cm1[i] + ccur[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      slot[c * 64] = scur.x[c]; slot[(3 + c) * 64] = scur.y[c]; slot[(6 + c) * 64] = scur.gu[c]; slot[(9 + c) * 64] = scur.gv[c];
+    }
+    slot[12 * 64] = scur.d; slot[13 * 64] = scur.zinv; slot[14 * 64] = scur.up; slot[15 * 64] = scur.vp;
+    nb2 = nb1; nb1 = scur.nb;
+  };
+
+  int r = r0 - 2;
+  const int rend = r1 + 1;      // inclusive
+  issue(r, *(const float*)((const char*)dimg + (unsigned)(min(max(r, 0), H - 1) * W + col_c) * 4u));
+  while (r <= rend) {
+    body(r, hA, hC, cA, cC); ++r;
+    if (r > rend) break;
+    body(r, hB, hA, cB, cA); ++r;
+    if (r > rend) break;
+    body(r, hC, hB, cC, cB); ++r;
+  }
+  if (MODE == 0) {
+    const int done = (r1 - r0 - 1) & ~(DD_ROWS - 1);
+    flush_dd(r0 + done, r1 - r0 - done);
+  }
+  float Gs[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    Gs[4 * i] = wave_sum_all(G[3 * i + 1] * colf);
+    Gs[4 * i + 1] = wave_sum_all(G[3 * i]);
+    Gs[4 * i + 2] = wave_sum_all(G[3 * i + 1]);
+    Gs[4 * i + 3] = wave_sum_all(G[3 * i + 2]);
+  }
+  acc_l1 = wave_sum_all(acc_l1);
+  acc_ss = wave_sum_all(acc_ss);
+  if (lane == 0) {
+    const long long gw = ((long long)(job.b * d.S + job.s) * d.CH + job.ck) * d.N + job.n;
+    float KtG[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int bcol = 0; bcol < 4; ++bcol)
+        KtG[4 * i + bcol] = (cam.k[i] * Gs[bcol] + cam.k[3 + i] * Gs[4 + bcol]) + cam.k[6 + i] * Gs[8 + bcol];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        part[16 * gw + 4 * i + j] = (KtG[4 * i] * cam.ki[3 * j] + KtG[4 * i + 1] * cam.ki[3 * j + 1]) + KtG[4 * i + 2] * cam.ki[3 * j + 2];
+      part[16 * gw + 4 * i + 3] = KtG[4 * i + 3];
+    }
+    part[16 * gw + 12] = acc_l1;
+    part[16 * gw + 13] = acc_ss;
+  }
+}
+
 #ifndef MARCH_BWD_WAVES
 #define MARCH_BWD_WAVES 3     // waves per SIMD the register allocation is asked to allow
 #endif
@@ -617,6 +869,16 @@ __global__ __launch_bounds__(256, MARCH_BWD_WAVES) void march_bwd_ms_kernel(MArg
   const unsigned local = blockIdx.x - m.block_off[s], n = m.block_off[s + 1] - m.block_off[s];
   march_bwd_body<MODE>(m.src[s], m.depth[s], T, K, m.target[s], m.g_l1[s], m.g_ss[s], m.ddepth[s], part + m.part_off[s],
                        m.d[s], m.inv_count[s], xcd_contiguous(local, n), lds_dyn);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, MARCH_BWD_WAVES) void march_bwd_ms_p_kernel(MArgs m, const float* __restrict__ T, const float* __restrict__ K,
+                                                                               float* __restrict__ part) {
+  extern __shared__ float lds_dyn[];
+  const int s = scale_of(m, blockIdx.x);
+  const unsigned local = blockIdx.x - m.block_off[s], n = m.block_off[s + 1] - m.block_off[s];
+  march_bwd_body_p<MODE>(m.src[s], m.depth[s], T, K, m.target[s], m.g_l1[s], m.g_ss[s], m.ddepth[s], part + m.part_off[s],
+                         m.d[s], m.inv_count[s], xcd_contiguous(local, n), lds_dyn);
 }
 
 // One finishing launch: workgroups [0, nb_dT) add the pose-gradient partials over the waves and the scales (in scale
@@ -669,6 +931,8 @@ inline MDims make_dims(int B, int N, int h, int w, float scale, int rows_per_chu
 
 int g_fwd_min_waves = 4096, g_bwd_min_waves = 1536, g_min_rows = 8;
 int g_bwd_max_rows = 32;
+int g_bwd_variant = 1;                   // 1: pipelined row step (march_bwd_body_p); 0: the round-3 body
+int g_bwd_rows[4] = {0, 0, 0, 0};        // rows per chunk of the backward launch per scale (0 = automatic)
 
 // Rows per chunk: enough waves to cover 256 CUs x 4 SIMDs a few times over, as few halo rows as possible.
 inline int pick_rows(int B, int N, int h, int w, long long min_waves, int max_rows = 32) {
@@ -688,6 +952,16 @@ int xpt_photo_march_tune(int fwd_min_waves, int bwd_min_waves, int min_rows) {
   g_fwd_min_waves = fwd_min_waves;
   g_bwd_min_waves = bwd_min_waves;
   g_min_rows = min_rows;
+  return XPT_OK;
+}
+
+int xpt_photo_march_plan(int bwd_variant, int rows_s0, int rows_s1, int rows_s2, int rows_s3) {
+  const int rows[4] = {rows_s0, rows_s1, rows_s2, rows_s3};
+  if (bwd_variant != 0 && bwd_variant != 1) return XPT_ERR_ARG;
+  for (int s = 0; s < 4; ++s)
+    if (rows[s] < 0 || rows[s] > 4096) return XPT_ERR_ARG;
+  g_bwd_variant = bwd_variant;
+  for (int s = 0; s < 4; ++s) g_bwd_rows[s] = rows[s];
   return XPT_OK;
 }
 
@@ -740,7 +1014,8 @@ int xpt_photo_march_ms_fwdbwd(int nscales, const float* const* src, const float*
   for (int s = 0; s < nscales; ++s) {
     if (!src[s] || !depth[s] || !target[s] || !g_l1[s] || !g_ssim[s] || !ddepth[s]) return XPT_ERR_NULL;
     if (h[s] <= 0 || w[s] <= 0 || !(scale[s] > 0.f) || (long long)h[s] * w[s] * 12 >= (1LL << 31)) return XPT_ERR_SHAPE;
-    MDims d = make_dims(B, N, h[s], w[s], scale[s], pick_rows(B, N, h[s], w[s], g_bwd_min_waves, g_bwd_max_rows), MSTRIP_B);
+    const int rows = g_bwd_rows[s] > 0 ? g_bwd_rows[s] : pick_rows(B, N, h[s], w[s], g_bwd_min_waves, g_bwd_max_rows);
+    MDims d = make_dims(B, N, h[s], w[s], scale[s], rows, MSTRIP_B);
     const long long nwaves = (long long)d.B * d.S * d.CH * d.N;
     m.src[s] = src[s]; m.depth[s] = depth[s]; m.target[s] = target[s];
     m.g_l1[s] = g_l1[s]; m.g_ss[s] = g_ssim[s]; m.ddepth[s] = ddepth[s];
@@ -758,8 +1033,13 @@ int xpt_photo_march_ms_fwdbwd(int nscales, const float* const* src, const float*
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
   const size_t ring_bytes = 4 * RING_FLOATS * sizeof(float);          // row-state rings of the four waves
-  if (N == 4) hipLaunchKernelGGL(march_bwd_ms_kernel<0>, dim3(blocks), dim3(256), ring_bytes + (size_t)DD_ROWS * 1024, st, m, T, K, workspace);
-  else hipLaunchKernelGGL(march_bwd_ms_kernel<1>, dim3(blocks), dim3(256), ring_bytes, st, m, T, K, workspace);
+  if (g_bwd_variant == 1) {
+    if (N == 4) hipLaunchKernelGGL(march_bwd_ms_p_kernel<0>, dim3(blocks), dim3(256), ring_bytes + (size_t)DD_ROWS * 1024, st, m, T, K, workspace);
+    else hipLaunchKernelGGL(march_bwd_ms_p_kernel<1>, dim3(blocks), dim3(256), ring_bytes, st, m, T, K, workspace);
+  } else {
+    if (N == 4) hipLaunchKernelGGL(march_bwd_ms_kernel<0>, dim3(blocks), dim3(256), ring_bytes + (size_t)DD_ROWS * 1024, st, m, T, K, workspace);
+    else hipLaunchKernelGGL(march_bwd_ms_kernel<1>, dim3(blocks), dim3(256), ring_bytes, st, m, T, K, workspace);
+  }
   const unsigned nb_dT = (unsigned)((B * N * 16 + 15) / 16);
   hipLaunchKernelGGL(march_bwd_finish_kernel, dim3(nb_dT + (losses ? (unsigned)(B * nscales) : 0u)), dim3(256), 0, st, m, nscales,
                      workspace, dT, losses, B, N, nb_dT);

@@ -115,6 +115,7 @@ SIGNATURES = {
     "xpt_graph_node_census": (_i, [_p, _p]),
     "xpt_sepconv_bn_multi_fwd": (_i, [_i] + [_p] * 23 + [_f, _i, _i, _i, _i, _i, _p]),
     "xpt_photo_march_tune": (_i, [_i, _i, _i]),
+    "xpt_photo_march_plan": (_i, [_i, _i, _i, _i, _i]),
     "xpt_photo_march_ms_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),
     "xpt_photo_march_ms_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),
     "xpt_photo_march_ms_fwdbwd": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _p, _p, _p, _p]),

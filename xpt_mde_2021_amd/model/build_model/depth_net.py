@@ -137,6 +137,16 @@ class DepthNetPretrained(nn.Module):
             self.skip2_zero = 64 + torch.nonzero(~keep).flatten()
             self.apply_structural_zeros()
 
+    def structural_pads(self):
+        """[(tensor, out_sel, in_sel)] of the DECODER's own tensors with structurally-zero entries (the encoder lists its own):
+        up2.conv2 reads the 1/4 tap with its zero channels, so its logical input channels are all but `skip2_zero`."""
+        if self.skip2_zero is None:
+            return []
+        w = self.up2.conv2.conv.weight
+        keep = torch.ones(w.shape[1], dtype=torch.bool)
+        keep[self.skip2_zero] = False
+        return [(w, None, torch.nonzero(keep).flatten())]
+
     def apply_structural_zeros(self):
         if self.skip2_zero is not None:
             with torch.no_grad():

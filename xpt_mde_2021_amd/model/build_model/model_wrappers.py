@@ -9,6 +9,52 @@ from ...config import opts
 from ...utils import util_funcs as uf
 
 
+def _structural_pads(model):
+    """{id(tensor): (out_sel, in_sel)} over every sub-module that declares structurally-zero entries."""
+    pads = {}
+    for m in model.modules():
+        fn = getattr(m, "structural_pads", None)
+        if callable(fn):
+            for t, o, i in fn():
+                pads[id(t)] = (o, i)
+    return pads
+
+
+def logical_state_dict(model):
+    """state_dict() with every structurally padded tensor cut down to its logical entries: the on-disk shapes are the
+    reference's and do not depend on XPT_STEM1_FILTERS / XPT_STEM2_FILTERS."""
+    from .pretrained_nets import logical_view
+    pads = _structural_pads(model)
+    return {k: logical_view(v.detach(), pads.get(id(v))).clone() for k, v in model.state_dict(keep_vars=True).items()}
+
+
+def load_logical_state_dict(model, state):
+    """Strict load of a logical_state_dict() file into a model of ANY physical padding; files of earlier rounds that hold
+    the physical (padded) shapes are accepted too.  The structural zeros are re-applied afterwards, so a file with non-zero
+    padded entries cannot break the 'same function' invariant."""
+    from .pretrained_nets import _store_logical, logical_view
+    pads = _structural_pads(model)
+    own = model.state_dict(keep_vars=True)
+    missing, unexpected = sorted(set(own) - set(state)), sorted(set(state) - set(own))
+    if missing or unexpected:
+        raise RuntimeError(f"checkpoint does not match the model: missing {missing[:4]} ({len(missing)}), "
+                           f"unexpected {unexpected[:4]} ({len(unexpected)})")
+    with torch.no_grad():
+        for k, t in own.items():
+            v, sel = state[k], pads.get(id(t))
+            if sel is not None and tuple(v.shape) == tuple(logical_view(t, sel).shape) and tuple(v.shape) != tuple(t.shape):
+                _store_logical(t, sel, v, fill=1.0 if k.endswith("running_var") else 0.0)
+            elif tuple(v.shape) == tuple(t.shape):
+                t.copy_(v.to(device=t.device, dtype=t.dtype))
+            else:
+                raise RuntimeError(f"checkpoint tensor {k}: shape {tuple(v.shape)}, the model expects {tuple(t.shape)}"
+                                   + (f" or its logical {tuple(logical_view(t, sel).shape)}" if sel is not None else ""))
+        for m in model.modules():
+            fn = getattr(m, "apply_structural_zeros", None)
+            if callable(fn):
+                fn()
+
+
 class ModelWrapper:
     def __init__(self, models):
         self.models = models                      # {"depthnet": nn.Module, "posenet": nn.Module}
@@ -153,10 +199,12 @@ class ModelWrapper:
         return None
 
     def save_weights(self, ckpt_dir_path, suffix):
-        """model_wrappers.py:101-105 ({netname}_{suffix}; torch state_dict instead of Keras H5)."""
+        """model_wrappers.py:101-105 ({netname}_{suffix}; torch state_dict instead of Keras H5).  The file holds the
+        LOGICAL tensors -- the reference's shapes (11 / 22-filter stem cells, 87 input channels of up2.conv2) -- whatever
+        physical padding this build runs with (logical_state_dict)."""
         for netname, model in self.models.items():
             save_path = op.join(ckpt_dir_path, f"{netname}_{suffix}.pt")
-            torch.save(model.state_dict(), save_path)
+            torch.save(logical_state_dict(model), save_path)
             print(f"===== {netname} weights are saved to", save_path)
 
     def load_weights(self, ckpt_dir_path, suffix):
@@ -164,7 +212,7 @@ class ModelWrapper:
         for netname, model in self.models.items():
             ckpt_file = op.join(ckpt_dir_path, f"{netname}_{suffix}.pt")
             if op.isfile(ckpt_file):
-                model.load_state_dict(torch.load(ckpt_file, map_location="cpu"))
+                load_logical_state_dict(model, torch.load(ckpt_file, map_location="cpu"))
                 print(f"===== {netname} weights loaded from", ckpt_file)
                 print(f"      {netname} num params:", sum(p.numel() for p in model.parameters()))
             else:

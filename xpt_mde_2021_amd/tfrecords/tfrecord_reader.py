@@ -348,22 +348,46 @@ class _PrefetchedDataset:
     def __init__(self, reader):
         self.reader = reader
         self.reader_seconds = 0.0             # time the consumer spent waiting for a batch (diagnostics)
-        self._maps = []
+        self._maps = {}                       # filename -> (mmap, size): every shard is mapped ONCE per dataset object
+
+    def _map(self, filename):
+        """The read-only mapping of a shard, created on first use and reused by every later epoch / iteration (a mapping
+        per epoch leaked one mmap and one descriptor per shard and epoch: EMFILE after a few dozen epochs)."""
+        import mmap
+        hit = self._maps.get(filename)
+        if hit is None:
+            with open(filename, "rb") as f:
+                size = f.seek(0, 2)
+                mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if size else None
+            hit = self._maps[filename] = (mm, size)
+        return hit
+
+    def close(self):
+        """Releases the shard mappings (payload views handed out earlier must be gone: call between iterations only)."""
+        maps, self._maps = self._maps, {}
+        for mm, _ in maps.values():
+            if mm is not None:
+                try:
+                    mm.close()
+                except BufferError:           # a view is still exported: the mapping dies with its last view
+                    pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                     # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def _refs(self):
         """(payload view, record name) of this rank's records in file order; nothing is copied."""
-        import mmap
         rd = self.reader
         filenames = sorted(glob.glob(op.join(rd.tfrpath, "*.tfrecord")))
         index = 0
         for _ in range(rd.epochs):
             for filename in filenames:
-                with open(filename, "rb") as f:
-                    size = f.seek(0, 2)
-                    if size == 0:
-                        continue
-                    mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
-                self._maps.append(mm)
+                mm, size = self._map(filename)
+                if size == 0:
+                    continue
                 view = memoryview(mm)
                 pos = 0
                 while pos + 12 <= size:
@@ -438,6 +462,7 @@ class _PrefetchedDataset:
         stream = torch.cuda.Stream(device=rd.device) if on_gpu else None
         nslots = rd.prefetch + 3                                    # a slot is reused only after its batch was consumed
         staging = [None] * nslots
+        uploaded = [None] * nslots                                  # event behind the last asynchronous upload out of a slot
         inflight = []                                               # (futures, slot) of batches being decoded
 
         def finish(futures, slot):
@@ -449,6 +474,7 @@ class _PrefetchedDataset:
                     feats = rd.finish_images({k: v.to(rd.device, non_blocking=True) for k, v in host.items()})
                     ready = torch.cuda.Event()
                     ready.record(stream)
+                uploaded[slot] = ready
                 item = (feats, ready)
             else:
                 item = (rd.finish_images({k: v.clone() for k, v in host.items()}), None)
@@ -467,6 +493,9 @@ class _PrefetchedDataset:
                         return
                     if staging[slot] is None:
                         staging[slot] = self._staging(on_gpu)
+                    if uploaded[slot] is not None:                  # the DMA out of these pinned rows must be over before
+                        uploaded[slot].synchronize()                # a decode worker writes them again
+                        uploaded[slot] = None
                     inflight.append(([pool.submit(self._decode_into, ref, staging[slot], i) for i, ref in enumerate(refs)], slot))
                     slot = (slot + 1) % nslots
                     if len(inflight) > 1:                           # the next batch decodes while this one is uploaded
