@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--data", default="resident", choices=["resident", "tfrecord"],
                     help="tfrecord: ALSO write a synthetic shard set with the repo's TFRecord writer and train from it through the "
                          "prefetching reader (`host_fed`: reader alone, and the step fed from the host; never `value`)")
+    ap.add_argument("--no-host-fed", action="store_true",
+                    help="skip the `host_fed` leg (TFRecord shards written, read back through the prefetching reader, trained on)")
     ap.add_argument("--sustained-seconds", type=float, default=6.0,
                     help="back-to-back steps after the timed region, reported separately (`sustained`); 0 disables")
     args = ap.parse_args()
@@ -175,7 +177,8 @@ def host_fed_leg(args, trainer, dataset, note):
         writer.close([feats["image5d"].shape[1], args.height, args.width, 3])
         nbytes = sum(os.path.getsize(os.path.join(root, f)) for f in os.listdir(root))
         note(f"host-fed leg: {n} snippets, {nbytes / 1e6:.0f} MB of TFRecord shards in {root}")
-        workers = min(8, max(2, (os.cpu_count() or 4) // 2))
+        from xpt_mde_2021_amd.tfrecords.tfrecord_reader import default_workers
+        workers = default_workers()
         kw = dict(shuffle=True, batch_size=args.batch, device="cuda", prefetch=3, workers=workers)
         # (a) the reader alone
         torch.cuda.synchronize()
@@ -428,7 +431,8 @@ def run(args):
                                 "ms_per_step": round(1000.0 * loop / args.steps, 4),
                                 "what": "run_an_epoch over the same batches: training step + per-step metrics (merge_results)"}
         note(f"epoch loop done: {loop:.3f} s")
-    if rank == 0 and world == 1 and args.data == "tfrecord" and args.config != "c5" and args.nets == "rigid" and not args.stereo:
+    if (rank == 0 and world == 1 and (args.data == "tfrecord" or not args.no_host_fed) and args.config != "c5"
+            and args.nets == "rigid" and not args.stereo and mode.startswith("graph")):
         result["host_fed"] = host_fed_leg(args, trainer, dataset, note)
         result["host_fed"]["vs_resident"] = round(result["host_fed"]["value_host_fed"] / result["value"], 4)
         note("host-fed leg done")

@@ -157,7 +157,8 @@ int xpt_photo_fused_ms_bwd(int nscales, const float* const* src, const float* co
  * loss_util.py:6-25, 52-96; losses.py:179-195).  xpt_photo_march_tune: launch-plan knobs as xpt_photo_fused_tune. */
 int xpt_photo_march_tune(int fwd_min_waves, int bwd_min_waves, int min_rows);
 /* xpt_photo_march_plan: bwd_variant 1 = the pipelined row step of round 4 (the next row's tap gathers in flight behind the
- * SSIM-coefficient and gradient stages of the current one), 0 = the round-3 row step; rows_s*: rows per chunk of the
+ * SSIM-coefficient and gradient stages of the current one; the waves with the most row steps get the higher issue priority),
+ * 2 = the same without wave priorities, 0 = the round-3 row step; rows_s*: rows per chunk of the
  * backward launch for pyramid scale s (0 = the automatic, occupancy-balanced choice). */
 int xpt_photo_march_plan(int bwd_variant, int rows_s0, int rows_s1, int rows_s2, int rows_s3);
 int xpt_photo_march_ms_fwd(int nscales, const float* const* src, const float* const* depth, const float* T, const float* K,
@@ -216,6 +217,10 @@ int xpt_merge_total_bwd(int n, const float* c, const float* g_total, float* grad
 int xpt_adam_step(float* param, float* grad, float* m, float* v, long long n, const float* step, float lr,
                   float beta1, float beta2, float eps, float grad_scale, int zero_grad, void* shadow_bf16,
                   void* stream);
+/* tf.optimizers.SGD(learning_rate) of optimizer_factory's "sgd_constant" (model/model_util/optimizers.py:10-11; momentum 0):
+ * p -= lr * grad_scale * g over the same flat buffers; zero_grad / shadow_bf16 as xpt_adam_step. */
+int xpt_sgd_step(float* param, float* grad, long long n, float lr, float grad_scale, int zero_grad, void* shadow_bf16,
+                 void* stream);
 
 /* ------------------------------------------------------------------ a2: depthwise convolution (NASNet separable convs)
  * replaces the depthwise half of every keras SeparableConv2D(use_bias=False) inside
@@ -344,6 +349,22 @@ int xpt_conv2d_fwd(const void* x, const void* w, const float* bias, void* y, int
 int xpt_conv2d_bwd_data(const void* g, const void* wb, void* dx, int B, int OH, int OW, int Np, long long gpitch,
                         int C, int KH, int KW, int stride, int pad_t, int pad_l, int IH, int IW, long long dxpitch,
                         int fold2x2, void* stream);
+/* Split-K variants for the deep decoder layers (csrc/xpt_conv_splitk.hip; depth_net.py:101-109 dp_up4 / dp_up3: 1,056 ... 216
+ * reduction channels on the 8 x 26 / 16 x 52 maps): 128-pixel x 128 (64)-channel LDS tiles, the reduction axis cut into
+ * 1 ... 16 slices whose fp32 partial tiles [slice][pixel][channel] go to `workspace`, a finishing launch adds the slices in
+ * order (+ bias + LeakyReLU, + the 2 x 2 fold of a nearest-2x input) -- deterministic, no atomics.  Stride 1 only.
+ * xpt_conv2d_splitk_workspace_floats: floats of workspace the launch needs, 0 = this layer is not served (use
+ *   xpt_conv2d_fwd / xpt_conv2d_bwd_data); pixels = B x OH x OW of the grid the launch enumerates (data gradient with
+ *   fold2x2: B x 2 IH x 2 IW), out_channels / red_channels of THAT launch (data gradient: out = C, red = Np).
+ * xpt_conv2d_splitk_tune: enable, forced slice count (0 = automatic), minimum reduction length, maximum pixels served. */
+int xpt_conv2d_splitk_tune(int enable, int force_split, int min_k, int max_pixels);
+size_t xpt_conv2d_splitk_workspace_floats(long long pixels, int out_channels, int red_channels, int taps, int stride);
+int xpt_conv2d_fwd_splitk(const void* x, const void* w, const float* bias, void* y, int B, int PH, int PW, int C,
+                          long long xpitch, int N, int KH, int KW, int pad_t, int pad_l, int OH, int OW, long long ypitch,
+                          int upsample, float slope, float* workspace, size_t workspace_floats, void* stream);
+int xpt_conv2d_bwd_data_splitk(const void* g, const void* wb, void* dx, int B, int OH, int OW, int Np, long long gpitch,
+                               int C, int KH, int KW, int pad_t, int pad_l, int IH, int IW, long long dxpitch, int fold2x2,
+                               float* workspace, size_t workspace_floats, void* stream);
 int xpt_conv2d_bwd_weight_tune(int max_partial_mib, int target_blocks);
 int xpt_conv2d_bwd_weight_splits(int B, int C, int N, int KH, int KW, int stride, int OH, int OW);
 int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, float* partials, size_t partial_floats, int B, int PH,
@@ -635,6 +656,17 @@ int xpt_conv1x1_bwd_weight_partials(const void* dy, const void* x, float* partia
  * CRC-32C of a host buffer: the checksum of the TFRecord framing read by tfrecords/tfrecord_reader.py:61-75
  * (tf.data.TFRecordDataset); masked value = ((crc >> 15) | (crc << 17)) + 0xa282ead8. */
 uint32_t xpt_crc32c(const void* data, size_t nbytes);
+/* The reader's per-record work, natively (round 4; tfrecords/tfrecord_reader.py:61-108, tfr_util.py:8-77 of the reference):
+ * xpt_tfrecord_index frames a shard held in memory (payload offset / length / stored masked CRC per record; header CRCs
+ *   checked when verify_crc); returns the record count, max_records when the arrays were too small, -(k + 1) when record k is
+ *   truncated or corrupt.
+ * xpt_tfrecord_decode checks one payload's masked CRC-32C, walks the serialized tf.train.Example and copies, for every listed
+ *   key, the first bytes_list value (exactly dst_bytes[i] bytes) / int64_list value (8) / float_list value (4) into dst[i].
+ *   0 ok, -10 CRC mismatch, -11 malformed, -(100 + i) key i missing, -(1000 + i) key i has another size.  Thread-safe. */
+long long xpt_tfrecord_index(const void* shard, size_t nbytes, int verify_crc, unsigned long long* payload_off,
+                             unsigned long long* payload_len, unsigned int* payload_crc, long long max_records);
+int xpt_tfrecord_decode(const void* payload, size_t nbytes, unsigned int stored_crc, int verify_crc, int nkeys,
+                        const char* const* keys, void* const* dst, const size_t* dst_bytes);
 
 /* ------------------------------------------------------------------ NASNet branch stage in one launch (xpt_sepconv.hip)
  * keras nasnet._separable_conv_block halves (Activation('relu') -> SeparableConv2D(k, stride 1, 'same') ->

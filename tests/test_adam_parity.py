@@ -75,3 +75,41 @@ def test_adam_kernel_matches_keras_adam(gpu_device, n, grad_scale):
         assert np.allclose(v.double().cpu().numpy(), ref.v, rtol=4e-6, atol=1e-30)
         assert float(gbuf.abs().max()) == 0.0                   # zero_grad happened in the same pass
         assert torch.equal(shadow, p.to(torch.bfloat16))        # bf16 shadow = round-to-nearest-even of the updated weight
+
+
+def test_sgd_constant_host_branch():
+    """optimizer_factory("sgd_constant") = tf.optimizers.SGD(lr) (reference optimizers.py:10-11): w <- w - lr g, momentum 0."""
+    from xpt_mde_2021_amd.model.model_util.optimizers import KerasSGD, optimizer_factory
+    w0, grads = make_problem(1000, seed=3)
+    p = torch.nn.Parameter(w0.clone())
+    opt = optimizer_factory("sgd_constant", 1e-2)
+    assert isinstance(opt, KerasSGD)
+    flat = opt.bind([p])
+    w = w0.double()
+    for g in grads:
+        flat.grad[:p.numel()].copy_(g)
+        opt.apply_gradients()
+        w = w - 1e-2 * g.double()
+        assert torch.allclose(flat.data[:p.numel()].double(), w, rtol=0, atol=3e-7 * float(w.abs().max()))
+        assert float(flat.grad.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grad_scale", [1.0, 0.125])
+def test_sgd_kernel(gpu_device, grad_scale):
+    from xpt_mde_2021_amd.hip import lib as _lib
+    lib = _lib.load()
+    n = 4096 + 3
+    w0, grads = make_problem(n, seed=9)
+    p, gbuf = w0.clone().to(gpu_device), torch.zeros(n, device=gpu_device)
+    shadow = torch.zeros(n, dtype=torch.bfloat16, device=gpu_device)
+    w = w0.clone()
+    for g in grads:
+        gbuf.copy_(g.to(gpu_device) / grad_scale)
+        _lib.check(lib.xpt_sgd_step(p.data_ptr(), gbuf.data_ptr(), n, 1e-2, grad_scale, 1, shadow.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream), "xpt_sgd_step")
+        torch.cuda.synchronize()
+        w = w - 1e-2 * ((g / grad_scale) * grad_scale)
+        assert torch.allclose(p.cpu(), w, rtol=0, atol=3e-7 * float(w.abs().max()))
+        assert float(gbuf.abs().max()) == 0.0
+        assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))

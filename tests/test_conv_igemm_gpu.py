@@ -48,15 +48,26 @@ def conv_plan():
     """Forces one kernel instantiation for forward + data gradient (xpt_conv2d_tune), restores the automatic choice."""
     from xpt_mde_2021_amd.hip import lib as _lib
     lib = _lib.load()
-    yield lambda plan: _lib.check(lib.xpt_conv2d_tune(plan), "tune")
+
+    def set_plan(plan):
+        if plan >= 5000:          # 5000 + n: the split-K kernels (csrc/xpt_conv_splitk.hip) with n slices on EVERY stride-1 layer
+            _lib.check(lib.xpt_conv2d_tune(0), "tune")
+            _lib.check(lib.xpt_conv2d_splitk_tune(1, plan - 5000, 1, 1 << 30), "splitk tune")
+        else:
+            _lib.check(lib.xpt_conv2d_splitk_tune(0, 0, 0, 0), "splitk tune")
+            _lib.check(lib.xpt_conv2d_tune(plan), "tune")
+
+    yield set_plan
     lib.xpt_conv2d_tune(0)
+    lib.xpt_conv2d_splitk_tune(1, 0, 1024, 8192)
 
 
 # 0: automatic choice; 901 / 902: the LDS-staged kernel (32 / 64 output channels per workgroup) forced on EVERY layer
 # shape (ragged tiles, residue classes, quad fold, 8-channel inputs); 110: the direct 32 x 32 kernel forced likewise;
 # 911 / 912: the halo-tile kernel (32 / 64 output channels per workgroup) on every stride-1 layer, forward and data gradient
 @pytest.mark.parametrize("cin,cout,k,stride,H,W,ups", SHAPES)
-@pytest.mark.parametrize("plan", [0, 901, 902, 110, 911, 912])
+# 5001 / 5002 / 5008 / 5016: the split-K tile kernels (1 / 2 / 8 / 16 slices of the reduction axis) on every stride-1 layer
+@pytest.mark.parametrize("plan", [0, 901, 902, 110, 911, 912, 5001, 5002, 5008, 5016])
 @pytest.mark.parametrize("batch", [2])
 def test_conv_fwd_bwd_matches_fp32_reference(gpu_device, conv_plan, cin, cout, k, stride, H, W, ups, batch, plan):
     from xpt_mde_2021_amd.hip import conv as xc

@@ -68,11 +68,16 @@ def device_run(ops, dev, srcs, depths, tgts, scales, K, T, weights, grad_hint=No
     return [(a.detach(), b.detach()) for a, b in pairs], [d.grad for d in ds], Td.grad
 
 
-@pytest.mark.parametrize("B,N,H,W,nscales,pose_scale", [(4, 4, 128, 416, 4, 1.0), (4, 4, 256, 832, 4, 1.0), (3, 1, 128, 416, 4, 0.5),
-                                                        (1, 4, 24, 70, 2, 0.3), (2, 4, 37, 130, 1, 0.3)])
-def test_march_matches_fp64_oracle_with_tight_flip_aware_bars(ops, gpu_device, B, N, H, W, nscales, pose_scale):
+# share_cap: the largest share of target pixels the flip mask may take out at any scale.  Measured (fp64 oracle, these seeds):
+# 0.96 - 1.8 % at the BASELINE sizes, 0.35 - 0.64 % with one source view; only the 24 x 70 / 12 x 35 toy pyramid reaches
+# 8.5 / 13.3 % (1e-3-px bands around the integer rows of a 12-row image are a large part of it).
+@pytest.mark.parametrize("B,N,H,W,nscales,pose_scale,share_cap", [(4, 4, 128, 416, 4, 1.0, 0.02), (4, 4, 256, 832, 4, 1.0, 0.02),
+                                                                  (3, 1, 128, 416, 4, 0.5, 0.01), (1, 4, 24, 70, 2, 0.3, 0.15),
+                                                                  (2, 4, 37, 130, 1, 0.3, 0.02)])
+def test_march_matches_fp64_oracle_with_tight_flip_aware_bars(ops, gpu_device, B, N, H, W, nscales, pose_scale, share_cap):
     srcs, depths, tgts, scales, K, T, weights, shares = pyramid_case(B, N, H, W, nscales, 4000 + H + N, pose_scale)
-    assert max(shares) < 0.3, shares                       # the mask removes some pixels (most where the motion is small), not the test
+    print(f"flip-mask share per scale at {B}x{N}x{H}x{W}: " + ", ".join(f"{100 * s:.2f} %" for s in shares))
+    assert max(shares) <= share_cap, shares                # the mask removes a known, small share of the pixels, not the test
     values_ref, dd_ref, dT_ref = oracle_run(srcs, depths, tgts, scales, K, T, weights)
     values, dd, dT = device_run(ops, gpu_device, srcs, depths, tgts, scales, K, T, weights)
     for k in range(nscales):

@@ -155,7 +155,7 @@ class VodeOptions(LossOptions):
     ENABLE_SHAPE_DECOR = False
     LOG_LOSS = True
     READER_PREFETCH = 2      # batches the TFRecord reader keeps ready ahead of the step (0: synchronous generator)
-    READER_WORKERS = 4       # decode threads of the prefetching reader
+    READER_WORKERS = 0       # decode threads of the prefetching reader (0: from os.sched_getaffinity, tfrecord_reader.default_workers)
     TRAIN_MODE = "graph"                      # "eager" | "graph" (hipGraph replay) | "distributed" (RCCL DP)
     # steps with library (MIOpen) convolutions on the path -- fp32 mode, PWC-Net: "audit" = captured when the node audit of
     # the captured graph finds no memset node (memset nodes replay wrongly on this runtime), True = captured regardless,

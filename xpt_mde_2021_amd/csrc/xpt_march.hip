@@ -69,6 +69,7 @@ struct MArgs {
   float inv_count[4];
   unsigned block_off[5];       // first workgroup of every scale; unused scales = the total
   int waves_per_b[4];
+  int prio[4];                 // s_setprio level of the scale's waves (backward launch: longest waves first)
 };
 
 __device__ inline int scale_of(const MArgs& m, unsigned b) {
@@ -877,6 +878,11 @@ __global__ __launch_bounds__(256, MARCH_BWD_WAVES) void march_bwd_ms_p_kernel(MA
   extern __shared__ float lds_dyn[];
   const int s = scale_of(m, blockIdx.x);
   const unsigned local = blockIdx.x - m.block_off[s], n = m.block_off[s + 1] - m.block_off[s];
+  // the launch is ONE round of waves whose length is set by its longest waves (the chunks of the finest scale run more row
+  // steps than those of the coarse scales): they win the issue arbitration of their SIMD, the short waves fill the gaps
+  if (m.prio[s] >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (m.prio[s] == 2) __builtin_amdgcn_s_setprio(2);
+  else if (m.prio[s] == 1) __builtin_amdgcn_s_setprio(1);
   march_bwd_body_p<MODE>(m.src[s], m.depth[s], T, K, m.target[s], m.g_l1[s], m.g_ss[s], m.ddepth[s], part + m.part_off[s],
                          m.d[s], m.inv_count[s], xcd_contiguous(local, n), lds_dyn);
 }
@@ -931,6 +937,7 @@ inline MDims make_dims(int B, int N, int h, int w, float scale, int rows_per_chu
 
 int g_fwd_min_waves = 4096, g_bwd_min_waves = 1536, g_min_rows = 8;
 int g_bwd_max_rows = 32;
+int g_bwd_prio = 1;                      // 1: wave priorities by chunk length in the backward launch
 int g_bwd_variant = 1;                   // 1: pipelined row step (march_bwd_body_p); 0: the round-3 body
 int g_bwd_rows[4] = {0, 0, 0, 0};        // rows per chunk of the backward launch per scale (0 = automatic)
 
@@ -957,7 +964,9 @@ int xpt_photo_march_tune(int fwd_min_waves, int bwd_min_waves, int min_rows) {
 
 int xpt_photo_march_plan(int bwd_variant, int rows_s0, int rows_s1, int rows_s2, int rows_s3) {
   const int rows[4] = {rows_s0, rows_s1, rows_s2, rows_s3};
-  if (bwd_variant != 0 && bwd_variant != 1) return XPT_ERR_ARG;
+  if (bwd_variant < 0 || bwd_variant > 2) return XPT_ERR_ARG;      // 2: the pipelined row step without wave priorities (lab)
+  g_bwd_prio = bwd_variant != 2;
+  if (bwd_variant == 2) bwd_variant = 1;
   for (int s = 0; s < 4; ++s)
     if (rows[s] < 0 || rows[s] > 4096) return XPT_ERR_ARG;
   g_bwd_variant = bwd_variant;
@@ -1030,6 +1039,13 @@ int xpt_photo_march_ms_fwdbwd(int nscales, const float* const* src, const float*
   }
   for (int s = nscales; s <= 4; ++s) m.block_off[s] = blocks;
   if (workspace_floats < need) return XPT_ERR_WORKSPACE;
+  if (g_bwd_prio) {             // priority 3 for the scales with the most row steps per wave, one level less per shorter class
+    for (int s = 0; s < nscales; ++s) {
+      int longer = 0;
+      for (int t = 0; t < nscales; ++t) longer += (m.d[t].R > m.d[s].R && (t == 0 || m.d[t].R != m.d[t - 1].R)) ? 1 : 0;
+      m.prio[s] = 3 - longer < 0 ? 0 : 3 - longer;
+    }
+  }
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
   const size_t ring_bytes = 4 * RING_FLOATS * sizeof(float);          // row-state rings of the four waves

@@ -63,3 +63,27 @@ extern "C" int xpt_adam_step(float* param, float* grad, float* m, float* v, long
                      step, lr, beta1, beta2, eps, grad_scale, zero_grad, (__hip_bfloat16*)shadow_bf16);
   return xpt_launch_status();
 }
+
+// tf.optimizers.SGD(learning_rate) (momentum 0, optimizers.py:10-11): p -= lr * g; same buffers, same bf16 shadow refresh.
+__global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, long long n, float lr, float grad_scale, int zero_grad,
+                           __hip_bfloat16* __restrict__ shadow) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float pk = p[i] - lr * (g[i] * grad_scale);
+    p[i] = pk;
+    if (zero_grad) g[i] = 0.f;
+    if (shadow) shadow[i] = __float2bfloat16(pk);
+  }
+}
+
+extern "C" int xpt_sgd_step(float* param, float* grad, long long n, float lr, float grad_scale, int zero_grad, void* shadow_bf16,
+                            void* stream) {
+  XPT_CHECK_PTR(param); XPT_CHECK_PTR(grad);
+  if (n <= 0) return XPT_ERR_SHAPE;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  XPT_BEGIN_LAUNCH();
+  hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, n, lr, grad_scale,
+                     zero_grad, (__hip_bfloat16*)shadow_bf16);
+  return xpt_launch_status();
+}

@@ -135,6 +135,9 @@ def _apply_env_tuning():
     if plan:
         for code in plan.split(","):
             _lib.load().xpt_conv2d_tune(int(code))
+    spec = os.environ.get("XPT_SPLITK_TUNE")               # deep-layer split-K path: enable, forced slices, min K, max pixels
+    if spec:
+        _lib.load().xpt_conv2d_splitk_tune(*[int(v) for v in spec.split(",")])
     spec = os.environ.get("XPT_PWCONV_TUNE")               # fused pointwise forward: k split from this cin on, up to this many tiles
     if spec:
         _lib.load().xpt_pwconv_tune(*[int(v) for v in spec.split(",")])
@@ -196,9 +199,18 @@ class _Conv2dSame(torch.autograd.Function):
         b_ = None if bias is None else bias.detach()
         if b_ is not None and (b_.dtype != torch.float32 or not b_.is_contiguous()):
             raise _lib.XptHipError("conv: bias must be a contiguous float32 vector")
-        _lib.check(lib.xpt_conv2d_fwd(x.data_ptr(), e["fwd"].data_ptr(), None if b_ is None else b_.data_ptr(),
-                                      y.data_ptr(), B, PH, PW, Cp, xpitch, N, KH, KW, stride, pt, pl, OH, OW, N,
-                                      int(upsample), float(slope), _stream()), "xpt_conv2d_fwd")
+        wsf = 0 if valid else lib.xpt_conv2d_splitk_workspace_floats(B * OH * OW, N, Cp, KH * KW, stride)
+        if wsf:
+            # deep layers on the small maps: LDS-tiled implicit GEMM with a deterministic split of the reduction axis
+            ws = torch.empty(wsf, dtype=torch.float32, device=x.device)
+            _lib.check(lib.xpt_conv2d_fwd_splitk(x.data_ptr(), e["fwd"].data_ptr(), None if b_ is None else b_.data_ptr(),
+                                                 y.data_ptr(), B, PH, PW, Cp, xpitch, N, KH, KW, pt, pl, OH, OW, N,
+                                                 int(upsample), float(slope), ws.data_ptr(), wsf, _stream()),
+                       "xpt_conv2d_fwd_splitk")
+        else:
+            _lib.check(lib.xpt_conv2d_fwd(x.data_ptr(), e["fwd"].data_ptr(), None if b_ is None else b_.data_ptr(),
+                                          y.data_ptr(), B, PH, PW, Cp, xpitch, N, KH, KW, stride, pt, pl, OH, OW, N,
+                                          int(upsample), float(slope), _stream()), "xpt_conv2d_fwd")
         ctx.save_for_backward(x, y if slope != 1.0 else None, b_)
         ctx.geom = (B, PH, PW, Cp, C, xpitch, N, KH, KW, stride, pt, pl, OH, OW, int(upsample), float(slope))
         ctx.weight = weight
@@ -258,8 +270,15 @@ class _Conv2dSame(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             e = packer.get(weight, need_bwd=True)
             dx = torch.empty((B, Cp, PH, PW), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
-            _lib.check(lib.xpt_conv2d_bwd_data(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"], gpitch,
-                                               Cp, KH, KW, stride, pt, pl, PH, PW, Cp, ups, _stream()), "xpt_conv2d_bwd_data")
+            wsf = lib.xpt_conv2d_splitk_workspace_floats(B * (PH << ups) * (PW << ups), Cp, e["Np"], KH * KW, stride)
+            if wsf:
+                ws = torch.empty(wsf, dtype=torch.float32, device=g.device)
+                _lib.check(lib.xpt_conv2d_bwd_data_splitk(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"],
+                                                          gpitch, Cp, KH, KW, pt, pl, PH, PW, Cp, ups, ws.data_ptr(), wsf,
+                                                          _stream()), "xpt_conv2d_bwd_data_splitk")
+            else:
+                _lib.check(lib.xpt_conv2d_bwd_data(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"], gpitch,
+                                                   Cp, KH, KW, stride, pt, pl, PH, PW, Cp, ups, _stream()), "xpt_conv2d_bwd_data")
         return dx, dw, dbias, None, None, None, None
 
 

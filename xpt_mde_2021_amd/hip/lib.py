@@ -51,6 +51,7 @@ SIGNATURES = {
     "xpt_smooth_ms_fwd": (_i, [_i, _p, _p, _p, _p, _z, _i, _p, _p, _f, _i, _p]),
     "xpt_smooth_ms_bwd": (_i, [_i, _p, _p, _p, _p, _i, _p, _p, _f, _i, _p]),
     "xpt_adam_step": (_i, [_p, _p, _p, _p, ctypes.c_longlong, _p, _f, _f, _f, _f, _f, _i, _p, _p]),
+    "xpt_sgd_step": (_i, [_p, _p, ctypes.c_longlong, _f, _f, _i, _p, _p]),
     "xpt_dwconv_fwd": (_i, [_p, _p, _p] + [_i] * 12 + [_p]),
     "xpt_dwconv_bwd_data": (_i, [_p, _p, _p, _p] + [_i] * 12 + [_p]),
     "xpt_dwconv_tune": (_i, [_i]),
@@ -134,6 +135,8 @@ SIGNATURES = {
     "xpt_cell_tail_fwd": (_i, [_i, _p, _p, _p, _p, _p, _p, ctypes.c_longlong, _i, _i, _i, _i, _i, _p]),
     "xpt_cell_tail_bwd": (_i, [_i, _p, _p, _p, ctypes.c_longlong, _p, _i, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "xpt_crc32c": (ctypes.c_uint32, [_p, _z]),
+    "xpt_tfrecord_index": (ctypes.c_longlong, [_p, _z, _i, _p, _p, _p, ctypes.c_longlong]),
+    "xpt_tfrecord_decode": (_i, [_p, _z, ctypes.c_uint32, _i, _i, _p, _p, _p]),
     "xpt_conv_pack_job_bytes": (_i, []),
     "xpt_conv_pack_weights": (_i, [_p, _i, ctypes.c_longlong, _p]),
     "xpt_conv2d_tune": (_i, [_i]),
@@ -141,6 +144,12 @@ SIGNATURES = {
                             ctypes.c_longlong, _i, _f, _p]),
     "xpt_conv2d_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _i, _i,
                                  ctypes.c_longlong, _i, _p]),
+    "xpt_conv2d_splitk_tune": (_i, [_i, _i, _i, _i]),
+    "xpt_conv2d_splitk_workspace_floats": (_z, [ctypes.c_longlong, _i, _i, _i, _i]),
+    "xpt_conv2d_fwd_splitk": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _i,
+                                   ctypes.c_longlong, _i, _f, _p, _z, _p]),
+    "xpt_conv2d_bwd_data_splitk": (_i, [_p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _i,
+                                        ctypes.c_longlong, _i, _p, _z, _p]),
     "xpt_conv2d_bwd_weight_tune": (_i, [_i, _i]),
     "xpt_conv2d_bwd_weight_splits": (_i, [_i] * 8),
     "xpt_conv2d_bwd_weight_partials": (_i, [_p, _p, _p, _z, _i, _i, _i, _i, _i, ctypes.c_longlong, _i, ctypes.c_longlong,

@@ -130,6 +130,19 @@ def measure_fused_ms(ops, feats, repeats, batch=None, nscales=4, generation=2):
             {"B": B, "N": N, "h": H, "w": W, "scales": nscales})
 
 
+def _pmc_entry(kernel, shape):
+    """The committed PMC record (bytes, vector-instruction count) of a kernel at a shape, or None."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "profiles",
+                        "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel]["{B}x{N}x{h}x{w}".format(**shape)]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def _pmc_traffic(kernel, shape):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json: separate
     FETCH_SIZE / WRITE_SIZE runs with the gfx950 x2 FETCH_SIZE correction); None when no pass exists for this shape."""
@@ -183,17 +196,37 @@ def measure(ops, feats, repeats, hbm_peak_gbs, large_batch=128):
     def gbs(ms_, nbytes):
         return round(nbytes / (ms_ * 1e-3) / 1e9, 2)
 
-    return {"bound": "hbm", "kernel": "march_fwd_ms_kernel (warp + L1 + SSIM, the 4 pyramid scales in one launch; csrc/xpt_march.hip)",
-            "achieved": round(achieved, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(achieved / hbm_peak_gbs, 4),
-            "traffic": traffic, "launch_us": round(f_ms * 1e3, 3), "algorithmic_bytes_per_launch": int(f_bytes),
-            "bytes_per_warped_pixel": round((16 + 12 * N) / N, 3), "shape": shape,
-            "fwd": {"launch_us": round(f_ms * 1e3, 3), "GBps": round(achieved, 2), "frac": round(achieved / hbm_peak_gbs, 4)},
-            "bwd": {"kernel": "march_bwd_ms_kernel<0> + its finisher: losses AND gradients in one pass (the training step's march launch)",
+    # TOP LEVEL = the launch the training step actually runs: the one-pass march (losses AND gradients of the four scales)
+    # with its finisher; the forward-only launch (evaluation / the two-pass path) is reported beside it under "fwd"
+    step_kernel = "march_bwd_ms_p_kernel<0>" if N == 4 else "march_bwd_ms_p_kernel<1>"
+    pmc = _pmc_entry(step_kernel, shape)
+    valu = None
+    if pmc is not None and pmc.get("valu_wave_instructions"):
+        # vector-pipe ceiling of the launch: PMC instruction count over the chip's SIMDs at the measured class mix
+        # (tools/lab/valu_rates.hip: 1.95 cycles full-rate, 3.2 DPP / select / convert, 6.2 reciprocal; ~2.5 on this mix)
+        issue_us = pmc["valu_wave_instructions"] / 1024.0 * 2.5 / 2.4e3
+        valu = {"wave_instructions_per_launch": int(pmc["valu_wave_instructions"]), "per_wave": round(pmc["valu_wave_instructions"] / pmc["waves"], 1),
+                "issue_time_us": round(issue_us, 2), "frac_of_issue_ceiling": round(issue_us / (b_ms * 1e3), 4),
+                "how": "SQ_INSTS_VALU of the committed PMC pass (profiles/pmc_traffic.json) / 1,024 SIMDs x 2.5 cycles / 2.4 GHz "
+                       "against the launch time measured here"}
+    return {"bound": "hbm",
+            "kernel": step_kernel + " + finisher: view synthesis + L1 + SSIM of the 4 pyramid scales, losses AND gradients in one "
+                      "pass -- the training step's only march launch (csrc/xpt_march.hip)",
+            "achieved": round(achieved_b, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(achieved_b / hbm_peak_gbs, 4),
+            "traffic": None if pmc is None else pmc["bytes"], "launch_us": round(b_ms * 1e3, 3),
+            "algorithmic_bytes_per_launch": int(b_bytes), "bytes_per_warped_pixel": round((20 + 12 * N) / N, 3), "shape": shape,
+            "valu": valu,
+            "fwd": {"kernel": "march_fwd_ms_kernel (forward only: evaluation and the two-pass path; not launched by the training step)",
+                    "launch_us": round(f_ms * 1e3, 3), "GBps": round(achieved, 2), "frac": round(achieved / hbm_peak_gbs, 4),
+                    "algorithmic_bytes_per_launch": int(f_bytes), "bytes_per_warped_pixel": round((16 + 12 * N) / N, 3),
+                    "traffic": traffic},
+            "bwd": {"kernel": step_kernel + " + its finisher (= the top-level entry)",
                     "launch_us": round(b_ms * 1e3, 3), "GBps": round(achieved_b, 2), "frac": round(achieved_b / hbm_peak_gbs, 4),
                     "algorithmic_bytes_per_launch": int(b_bytes), "bytes_per_warped_pixel": round((20 + 12 * N) / N, 3),
-                    "traffic": _pmc_traffic("march_bwd_ms_kernel<0>", shape)},
-            "valu_note": "both launches are bound by vector-instruction issue, not by bytes: ~172 (forward) / ~336 (one-pass) "
-                         "instructions per warped pixel row of a wave at 3.4-6 cycles each (DESIGN.md section 5, profiles/r03_lab_*)",
+                    "traffic": None if pmc is None else pmc["bytes"]},
+            "valu_note": "the one-pass launch is bound by vector-instruction issue, not by bytes: PMC counts ~5,500 vector "
+                         "instructions per wave (~290 per pixel row of a wave) issued at ~2.5 cycles each on the measured class mix; "
+                         "see `valu` and DESIGN.md section 5",
             "all": {k: {"launch_us": round(v[0] * 1e3, 3), "GBps": gbs(*v)} for k, v in extra.items()},
             "hires": point(hfeats, repeats),
             "hires_large_batch": point(hfeats, max(repeats // 5, 5), batch=32),

@@ -139,7 +139,7 @@ def get_dataset(dataset_name, split, shuffle, batch_size=None):
         steps = int(os.environ.get("XPT_SYNTHETIC_STEPS", 20 if split == "train" else 4))
         ds = SyntheticDataset(per_replica, steps, h, w, dataset_name.endswith("stereo"), device())
         return ds, ds.config, steps
-    from ..tfrecords.tfrecord_reader import TfrecordReader
+    from ..tfrecords.tfrecord_reader import TfrecordReader, default_workers
     tfr_path = op.join(opts.DATAPATH_TFR, f"{dataset_name}_{split}")
     print("tfr path : ", tfr_path)
     assert op.isdir(tfr_path), tfr_path
@@ -147,7 +147,7 @@ def get_dataset(dataset_name, split, shuffle, batch_size=None):
     # background read / decode / pinned staging / side-stream upload (tf.data's role, tfrecord_reader.py:61-108)
     reader = TfrecordReader(tfr_path, shuffle=shuffle, batch_size=per_replica, rank=rank, world_size=world,
                             device=device(), prefetch=int(getattr(opts, "READER_PREFETCH", 2)),
-                            workers=int(getattr(opts, "READER_WORKERS", 4)))
+                            workers=int(getattr(opts, "READER_WORKERS", 0)) or default_workers())
     return reader.get_dataset(), reader.get_tfr_config(), reader.get_total_steps()
 
 

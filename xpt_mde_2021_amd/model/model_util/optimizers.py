@@ -175,7 +175,40 @@ class KerasAdam:
                 f.grad.zero_()
 
 
+class KerasSGD(KerasAdam):
+    """tf.optimizers.SGD(learning_rate) (optimizers.py:10-11: momentum 0, constant rate) over the same flat buffers; the
+    trainers see the KerasAdam interface (bind / add_l2 / apply_gradients; `m` and `v` are empty)."""
+
+    def __init__(self, learning_rate):
+        super().__init__(learning_rate)
+
+    def bind(self, params, groups=None):
+        self.flat = params if isinstance(params, FlatParameters) else FlatParameters(list(params), groups=groups)
+        self.m = torch.zeros(0, dtype=torch.float32, device=self.flat.data.device)
+        self.v = torch.zeros(0, dtype=torch.float32, device=self.flat.data.device)
+        self.step_count = torch.zeros(1, dtype=torch.float32, device=self.flat.data.device)
+        return self.flat
+
+    def apply_gradients(self, grad_scale=1.0, zero_grad=True):
+        f = self.flat
+        self.step_count += 1
+        for a, b, coef in self._ranges():
+            f.grad[a:b].add_(f.data[a:b], alpha=coef / float(grad_scale))
+        if f.data.is_cuda:
+            lib = _lib.load()
+            _lib.check(lib.xpt_sgd_step(f.data.data_ptr(), f.grad.data_ptr(), f.numel, self.lr, float(grad_scale), int(zero_grad),
+                                        None if f.shadow is None else f.shadow.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "xpt_sgd_step")
+            return
+        with torch.no_grad():
+            f.data.sub_(f.grad, alpha=self.lr * float(grad_scale))
+            if zero_grad:
+                f.grad.zero_()
+
+
 def optimizer_factory(opt_name, basic_lr, epoch=0):
     if opt_name == "adam_constant":
         return KerasAdam(learning_rate=basic_lr)
+    if opt_name == "sgd_constant":
+        return KerasSGD(learning_rate=basic_lr)
     raise WrongInputException(f"{opt_name} is NOT an available optimizer name")

@@ -39,6 +39,18 @@ from ..hip import lib as _lib
 _MASK_DELTA = 0xA282EAD8
 
 
+def default_workers():
+    """Decode threads of the prefetching reader: the cores this process may run on (os.sched_getaffinity), shared among the
+    ranks of the node, minus one for the training thread; at least 2, at most 16."""
+    import os
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 4
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    return max(2, min(16, cores // ranks - 1))
+
+
 def masked_crc32c(data):
     if isinstance(data, memoryview):             # zero-copy: the address of the (memory-mapped) bytes
         arr = np.frombuffer(data, dtype=np.uint8)
@@ -348,24 +360,48 @@ class _PrefetchedDataset:
     def __init__(self, reader):
         self.reader = reader
         self.reader_seconds = 0.0             # time the consumer spent waiting for a batch (diagnostics)
-        self._maps = {}                       # filename -> (mmap, size): every shard is mapped ONCE per dataset object
+        self._maps = {}                       # filename -> (mmap, size, ..., frame index): every shard is mapped ONCE per dataset object
+        self._row_tables = {}                 # id(staging buffers) -> per-row (pointer, size) tables
+        self._key_table = None
 
     def _map(self, filename):
-        """The read-only mapping of a shard, created on first use and reused by every later epoch / iteration (a mapping
-        per epoch leaked one mmap and one descriptor per shard and epoch: EMFILE after a few dozen epochs)."""
+        """(mapping, size, base address, payload offsets, lengths, stored CRCs) of a shard: mapped and framed ONCE per dataset
+        object (xpt_tfrecord_index: header CRCs checked there) and reused by every later epoch / iteration (a mapping per
+        epoch leaked one mmap and one descriptor per shard and epoch: EMFILE after a few dozen epochs)."""
         import mmap
         hit = self._maps.get(filename)
         if hit is None:
+            rd = self.reader
             with open(filename, "rb") as f:
                 size = f.seek(0, 2)
                 mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if size else None
-            hit = self._maps[filename] = (mm, size)
+            if mm is None:
+                hit = (None, 0, 0, None, None, None)
+            else:
+                lib = _lib.load()
+                base = np.frombuffer(mm, dtype=np.uint8)            # (keeps the mapping exported: released in close())
+                cap = max(16, size // 64)
+                while True:
+                    off = np.empty(cap, dtype=np.uint64)
+                    ln = np.empty(cap, dtype=np.uint64)
+                    crc = np.empty(cap, dtype=np.uint32)
+                    n = lib.xpt_tfrecord_index(ctypes.c_void_p(base.ctypes.data), size, int(rd.verify_crc),
+                                               ctypes.c_void_p(off.ctypes.data), ctypes.c_void_p(ln.ctypes.data),
+                                               ctypes.c_void_p(crc.ctypes.data), cap)
+                    if n < 0:
+                        raise IOError(f"corrupted or truncated TFRecord in {filename} (record {-n - 1})")
+                    if n < cap:
+                        break
+                    cap *= 2
+                hit = (mm, size, base, off[:n].tolist(), ln[:n].tolist(), crc[:n].tolist())
+            self._maps[filename] = hit
         return hit
 
     def close(self):
-        """Releases the shard mappings (payload views handed out earlier must be gone: call between iterations only)."""
+        """Releases the shard mappings (call between iterations only: decode jobs address the mapped bytes)."""
         maps, self._maps = self._maps, {}
-        for mm, _ in maps.values():
+        for key in list(maps):
+            mm = maps.pop(key)[0]             # (the popped tuple held the numpy view that exported the mapping)
             if mm is not None:
                 try:
                     mm.close()
@@ -379,30 +415,20 @@ class _PrefetchedDataset:
             pass
 
     def _refs(self):
-        """(payload view, record name) of this rank's records in file order; nothing is copied."""
+        """(payload address, length, stored CRC, file name) of this rank's records in file order; nothing is copied."""
         rd = self.reader
         filenames = sorted(glob.glob(op.join(rd.tfrpath, "*.tfrecord")))
         index = 0
         for _ in range(rd.epochs):
             for filename in filenames:
-                mm, size = self._map(filename)
+                mm, size, base, offs, lens, crcs = self._map(filename)
                 if size == 0:
                     continue
-                view = memoryview(mm)
-                pos = 0
-                while pos + 12 <= size:
-                    header = view[pos:pos + 8]
-                    (length,) = struct.unpack("<Q", header)
-                    (hcrc,) = struct.unpack("<I", view[pos + 8:pos + 12])
-                    if rd.verify_crc and hcrc != masked_crc32c(header):
-                        raise IOError(f"corrupted TFRecord in {filename} (CRC32C mismatch)")
-                    end = pos + 12 + length
-                    if end + 4 > size:
-                        raise IOError(f"truncated TFRecord in {filename}")
+                addr = base.ctypes.data
+                for k in range(len(offs)):
                     if index % rd.world_size == rd.rank:
-                        yield view[pos + 12:end], struct.unpack("<I", view[end:end + 4])[0], filename
+                        yield addr + offs[k], lens[k], crcs[k], filename
                     index += 1
-                    pos = end + 4
 
     def _batched_refs(self):
         rd = self.reader
@@ -423,38 +449,53 @@ class _PrefetchedDataset:
                 yield batch
                 batch = []                                          # a trailing partial batch is dropped
 
-    def _staging(self, pinned):
-        """Host buffers of one batch: [batch, *shape] per feature of the side-car config (uint8 images stay uint8)."""
+    def _keys(self):
         rd = self.reader
+        if getattr(self, "_key_table", None) is None:
+            names = [k for k, conf in rd.config.items() if isinstance(conf, dict)]
+            self._key_names = names
+            self._key_table = (ctypes.c_char_p * len(names))(*[k.encode("utf-8") for k in names])
+        return self._key_names, self._key_table
+
+    def _staging(self, pinned):
+        """Host buffers of one batch: [batch, *shape] per feature of the side-car config (uint8 images stay uint8), and per
+        batch row the destination-pointer / size tables xpt_tfrecord_decode fills them through."""
+        rd = self.reader
+        names, _ = self._keys()
         bufs = {}
-        for key, conf in rd.config.items():
-            if not isinstance(conf, dict):
-                continue
+        for key in names:
+            conf = rd.config[key]
             if conf["parse_type"] == "tf.int64":
                 t = torch.empty((rd.batch_size,), dtype=torch.int64)
             else:
                 dtype = torch.uint8 if conf["decode_type"] == "tf.uint8" else torch.float32
                 t = torch.empty((rd.batch_size,) + tuple(conf["shape"] or ()), dtype=dtype)
             bufs[key] = t.pin_memory() if pinned else t
+        rows = []
+        for row in range(rd.batch_size):
+            ptrs = (ctypes.c_void_p * len(names))(*[bufs[k][row].data_ptr() for k in names])
+            sizes = (ctypes.c_size_t * len(names))(*[bufs[k][row].numel() * bufs[k].element_size() for k in names])
+            rows.append((ptrs, sizes))
+        self._row_tables[id(bufs)] = rows
         return bufs
 
     def _decode_into(self, ref, bufs, row):
+        """CRC check, tf.train.Example walk and the one host copy of the record's bytes, in C (ctypes drops the GIL)."""
         rd = self.reader
-        payload, pcrc, filename = ref
-        if rd.verify_crc and pcrc != masked_crc32c(payload):
+        addr, length, pcrc, filename = ref
+        names, table = self._keys()
+        ptrs, sizes = self._row_tables[id(bufs)][row]
+        rc = _lib.load().xpt_tfrecord_decode(ctypes.c_void_p(addr), length, pcrc, int(rd.verify_crc), len(names), table, ptrs,
+                                             sizes)
+        if rc == 0:
+            return
+        if rc == -10:
             raise IOError(f"corrupted TFRecord in {filename} (CRC32C mismatch)")
-        parsed = parse_example(payload)
-        for key, conf in rd.config.items():
-            if not isinstance(conf, dict):
-                continue
-            if key not in parsed:
-                raise IOError(f"record without feature '{key}' in {filename}")
-            if conf["parse_type"] == "tf.int64":
-                bufs[key][row] = int(parsed[key])
-                continue
-            dst = bufs[key][row].numpy()
-            src = np.frombuffer(parsed[key], dtype=dst.dtype)
-            np.copyto(dst, src.reshape(dst.shape))                  # the one host copy of the record's bytes
+        if -164 <= rc <= -100:
+            raise IOError(f"record without feature '{names[-rc - 100]}' in {filename}")
+        if -1064 <= rc <= -1000:
+            raise IOError(f"feature '{names[-rc - 1000]}' of a record in {filename} does not have the size of its side-car shape")
+        raise IOError(f"malformed tf.train.Example in {filename} (code {rc})")
 
     def _produce(self, out, stop):
         rd = self.reader
