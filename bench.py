@@ -92,6 +92,8 @@ def launch_children(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # the pool's host driver supports dmabuf IPC only: with the legacy IPC mode RCCL's peer buffer exchange fails with
+    # `hipIpcGetMemHandle: invalid argument` (the image exports this value; a launcher-less start keeps it for its ranks)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     print(f"[bench] starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
@@ -229,8 +231,9 @@ def main():
         result, world = run(args)
     if result is not None:
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_available() and dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 
@@ -274,6 +277,18 @@ def run(args):
         raise SystemExit(f"bench.py: {world} RCCL ranks but {ndev} GPUs on this node (one card per rank; "
                          "XPT_DIST_BACKEND=gloo rehearses several ranks on one card)")
     torch.cuda.set_device(local_rank % ndev if backend == "gloo" else local_rank)
+    if args.mode == "distributed" and world == 1:
+        # one GPU, "distributed" asked for: a real one-rank process group (nccl = RCCL) whose collectives ARE issued (the
+        # identity), with the two-graph step and its overlapped bucket -- so that the line measures the data-parallel
+        # step's structure including its communication launches, not a communication-free copy of the graph mode
+        os.environ["XPT_DP_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("XPT_DP_OVERLAP", "1")
+        if "RANK" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1 or (args.mode == "distributed" and "RANK" in os.environ):
         dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
@@ -395,7 +410,38 @@ def run(args):
             result["config"]["grad_exchange"] = {
                 "buckets": 2 if early is not None else 1, "bytes": int(flat.numel) * 4,
                 "overlapped_bytes": (int(flat.numel) - int(early)) * 4 if early is not None else 0,
-                "how": "two-graph step, backward cut between decoder and encoder" if early is not None else "after the step"}
+                "how": "two-graph step, backward cut between decoder and encoder" if early is not None else "after the step",
+                "collectives_issued": bool(world > 1 or os.environ.get("XPT_DP_FORCE_COLLECTIVES") == "1")}
+        if dist.is_available() and dist.is_initialized() and rank == 0 and "grad_exchange" in (result or {}).get("config", {}):
+            result["config"]["grad_exchange"]["measure_all_reduce"] = True
+    if dist.is_available() and dist.is_initialized():
+        # the all-reduce of the two buckets by itself (every rank takes part): HIP events around 10 back-to-back collectives
+        flat = trainer.optimizer.flat
+        early = getattr(trainer, "_early_start", None)
+        cut = int(early) if early is not None else 0
+        scratch = torch.zeros_like(flat.grad)
+
+        def timed_all_reduce(lo, hi):
+            if hi <= lo:
+                return None
+            for _ in range(2):
+                dist.all_reduce(scratch[lo:hi])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dist.all_reduce(scratch[lo:hi])
+            e1.record()
+            torch.cuda.synchronize()
+            return round(e0.elapsed_time(e1) * 100.0, 2)          # us per collective
+
+        late_us, early_us = timed_all_reduce(0, cut), timed_all_reduce(cut, int(flat.numel))
+        if rank == 0 and "grad_exchange" in result["config"]:
+            result["config"]["grad_exchange"].pop("measure_all_reduce", None)
+            result["config"]["grad_exchange"]["all_reduce_us"] = {
+                "overlapped_bucket": early_us, "trailing_bucket": late_us, "ranks": world,
+                "how": "10 back-to-back dist.all_reduce(SUM) of the bucket's fp32 range on this process group, HIP events "
+                       "(one rank: RCCL's identity collective -- its launch and copy cost, no link traffic)"}
     note(f"timed region done: {elapsed:.3f} s")
     if args.sustained_seconds > 0 and world == 1 and args.config != "c5":
         # a longer stretch of the same steps (outside `value`): long enough for an outside observer's GPU-busy sampling

@@ -365,6 +365,21 @@ int xpt_conv2d_fwd_splitk(const void* x, const void* w, const float* bias, void*
 int xpt_conv2d_bwd_data_splitk(const void* g, const void* wb, void* dx, int B, int OH, int OW, int Np, long long gpitch,
                                int C, int KH, int KW, int pad_t, int pad_l, int IH, int IW, long long dxpitch, int fold2x2,
                                float* workspace, size_t workspace_floats, void* stream);
+/* Persistent, weight-stationary variants for the 3 x 3 stride-1 layers of the decoder's half- / full-resolution levels
+ * (csrc/xpt_conv_stream.hip; depth_net.py:101-109 dp_up1 / dp_up0: <= 96 output channels, weight slab + input halo <= 80 KB of
+ * LDS): a workgroup stages the layer's weights once and walks over 8 x 16-pixel tiles, the next tile's halo in flight while
+ * the current one is multiplied and stored; zeros of the padding come from the buffer loads' range check.
+ * xpt_conv2d_stream_serves: 1 when these entry points serve the layer (else use xpt_conv2d_fwd / xpt_conv2d_bwd_data);
+ *   arguments as for xpt_conv2d_splitk_workspace_floats, upsample_or_fold = the forward's upsample / the gradient's fold2x2.
+ * xpt_conv2d_stream_tune: enable, minimum tile count served, workgroups per CU, LDS budget (KiB); 0 keeps a value. */
+int xpt_conv2d_stream_tune(int enable, int min_tiles, int wgs_per_cu, int max_lds_kib);
+int xpt_conv2d_stream_serves(int B, int OH, int OW, int out_channels, int red_channels, int KH, int KW, int stride,
+                             int upsample_or_fold);
+int xpt_conv2d_fwd_stream(const void* x, const void* w, const float* bias, void* y, int B, int PH, int PW, int C,
+                          long long xpitch, int N, int pad_t, int pad_l, int OH, int OW, long long ypitch, int upsample,
+                          float slope, void* stream);
+int xpt_conv2d_bwd_data_stream(const void* g, const void* wb, void* dx, int B, int OH, int OW, int Np, long long gpitch, int C,
+                               int pad_t, int pad_l, int IH, int IW, long long dxpitch, int fold2x2, void* stream);
 int xpt_conv2d_bwd_weight_tune(int max_partial_mib, int target_blocks);
 int xpt_conv2d_bwd_weight_splits(int B, int C, int N, int KH, int KW, int stride, int OH, int OW);
 int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, float* partials, size_t partial_floats, int B, int PH,

@@ -50,16 +50,28 @@ def conv_plan():
     lib = _lib.load()
 
     def set_plan(plan):
-        if plan >= 5000:          # 5000 + n: the split-K kernels (csrc/xpt_conv_splitk.hip) with n slices on EVERY stride-1 layer
+        if plan == 0:             # the product's automatic choice among ALL kernel families
             _lib.check(lib.xpt_conv2d_tune(0), "tune")
-            _lib.check(lib.xpt_conv2d_splitk_tune(1, plan - 5000, 1, 1 << 30), "splitk tune")
-        else:
+            _lib.check(lib.xpt_conv2d_splitk_tune(1, 0, 1024, 8192), "splitk tune")
+            _lib.check(lib.xpt_conv2d_stream_tune(1, 512, 3, 80), "stream tune")
+        elif plan >= 6000:        # 6000 + w: the persistent weight-stationary kernels (csrc/xpt_conv_stream.hip), w workgroups per CU,
+            _lib.check(lib.xpt_conv2d_tune(0), "tune")                      # on EVERY 3 x 3 stride-1 layer they can hold
             _lib.check(lib.xpt_conv2d_splitk_tune(0, 0, 0, 0), "splitk tune")
+            # (6100 + w: the generic kernel for every shape; 6000 + w: the specialised instantiations where they exist)
+            _lib.check(lib.xpt_conv2d_stream_tune(2 if plan >= 6100 else 1, 1, plan % 100, 150), "stream tune")
+        elif plan >= 5000:        # 5000 + n: the split-K kernels (csrc/xpt_conv_splitk.hip) with n slices on EVERY stride-1 layer
+            _lib.check(lib.xpt_conv2d_tune(0), "tune")
+            _lib.check(lib.xpt_conv2d_stream_tune(0, 0, 0, 0), "stream tune")
+            _lib.check(lib.xpt_conv2d_splitk_tune(1, plan - 5000, 1, 1 << 30), "splitk tune")
+        else:                     # the kernels of csrc/xpt_conv.hip, one instantiation forced
+            _lib.check(lib.xpt_conv2d_splitk_tune(0, 0, 0, 0), "splitk tune")
+            _lib.check(lib.xpt_conv2d_stream_tune(0, 0, 0, 0), "stream tune")
             _lib.check(lib.xpt_conv2d_tune(plan), "tune")
 
     yield set_plan
     lib.xpt_conv2d_tune(0)
     lib.xpt_conv2d_splitk_tune(1, 0, 1024, 8192)
+    lib.xpt_conv2d_stream_tune(1, 512, 3, 80)
 
 
 # 0: automatic choice; 901 / 902: the LDS-staged kernel (32 / 64 output channels per workgroup) forced on EVERY layer
@@ -67,7 +79,9 @@ def conv_plan():
 # 911 / 912: the halo-tile kernel (32 / 64 output channels per workgroup) on every stride-1 layer, forward and data gradient
 @pytest.mark.parametrize("cin,cout,k,stride,H,W,ups", SHAPES)
 # 5001 / 5002 / 5008 / 5016: the split-K tile kernels (1 / 2 / 8 / 16 slices of the reduction axis) on every stride-1 layer
-@pytest.mark.parametrize("plan", [0, 901, 902, 110, 911, 912, 5001, 5002, 5008, 5016])
+# 6001 / 6003 / 6102: the persistent weight-stationary kernels, 1 / 3 workgroups per CU (6102: generic kernel only, 2 per CU), on
+# every 3 x 3 stride-1 layer that fits
+@pytest.mark.parametrize("plan", [0, 901, 902, 110, 911, 912, 5001, 5002, 5008, 5016, 6001, 6003, 6102])
 @pytest.mark.parametrize("batch", [2])
 def test_conv_fwd_bwd_matches_fp32_reference(gpu_device, conv_plan, cin, cout, k, stride, H, W, ups, batch, plan):
     from xpt_mde_2021_amd.hip import conv as xc

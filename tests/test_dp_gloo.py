@@ -212,3 +212,24 @@ def test_bench_launcher_starts_two_ranks():
     assert len(lines) == 1, run.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["ranks"] == 2 and out["value"] == 2.0 and out["config"]["backend"] == "gloo"
+
+
+def test_bench_launcher_starts_eight_ranks():
+    """The driver's 8-GPU run starts `bench.py --gpus 8` (or torch.distributed.run with 8 ranks): the launcher path -- child
+    process, rendezvous on 127.0.0.1, RANK / LOCAL_RANK / WORLD_SIZE, one all-reduce, rank 0's single JSON line -- with eight
+    gloo ranks on the CPU, so that the first 8-GPU run cannot fail on plumbing."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""
+    env["OMP_NUM_THREADS"] = "1"
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--selftest-launch"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["ranks"] == 8 and out["value"] == 8.0 and out["config"]["backend"] == "gloo"

@@ -103,3 +103,23 @@ def test_fp32_library_step_is_captured_when_its_graph_has_no_memset_node_and_tra
     for a, b in zip(eager, graph):
         assert abs(a - b) <= 1e-3 * abs(a) + 1e-5, (eager, graph)
     assert graph[-1] < graph[0]
+
+
+def test_structural_zeros_survive_captured_training_and_checkpoints_keep_the_reference_layout(gpu_device):
+    """The first two NASNet cells run 16 / 24 filters wide with 5 / 2 structurally-zero filters and dp_up2_conv2 reads two zero
+    columns.  After 20 CAPTURED bf16 training steps WITH augmentation every such entry must still be
+    exactly 0.0 in the fp32 master weights, the bf16 shadow, both Adam moments and the last gradient (the bf16 HIP backward,
+    the deferred-gradient sink and xpt_adam_step all have to keep them there), and the checkpoint written afterwards holds
+    the reference's logical shapes (11 / 22 filters, 87 input channels; 4,269,716 Keras elements: model_wrappers.py:101-117)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", "determinism_train.py"), "graph", "aug", "20"],
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ, XPT_DET_CHECKPOINT="1"))
+    assert run.returncode == 0, (run.stdout + run.stderr)[-2000:]
+    line = [l for l in run.stdout.splitlines() if l.startswith("STRUCTZERO")]
+    assert len(line) == 1, run.stdout[-1500:]
+    words = line[0].split()
+    assert int(words[2]) > 120 and int(words[4]) > 30000 and int(words[6]) == 0, line[0]
+    assert "CAPTURED True own-kernels" in run.stdout, run.stdout[-1500:]
+    ck = [l for l in run.stdout.splitlines() if l.startswith("CHECKPOINT")]
+    assert len(ck) == 1 and "stem1 (11," in ck[0] and "stem2 (22," in ck[0] and "up2.conv2 (64, 87, 3, 3)" in ck[0] \
+        and "keras_elements 4269716" in ck[0], ck

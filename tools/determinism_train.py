@@ -55,3 +55,57 @@ if mode == "distributed":
     print("TWO_PHASE", trainer._early_start is not None, type(trainer._graph.graph).__name__)
 print("LOSSES", mode, "aug" if use_aug else "noaug", " ".join(f"{v:.9f}" for v in losses))
 print("PARAMSUM", f"{float(flat.data.double().abs().sum()):.9f}" if hasattr(flat, "data") else "")
+
+# ---- structurally-zero entries (pretrained_nets.NASNetMobileEncoder.structural_pads, depth_net.DepthNetPretrained): after K
+# captured bf16 steps every padded entry must still be EXACTLY 0.0 in the fp32 master weights, their bf16 shadow and both Adam
+# moments (running variances: 1.0) -- the "same function as the 11 / 22-filter cells" invariant on the GPU path
+def _pad_mask(t, o, i):
+    keep = torch.zeros(t.shape[:2] if (t.dim() > 1 and i is not None) else t.shape[:1], dtype=torch.bool)
+    oo = o if o is not None else torch.arange(t.shape[0])
+    if keep.dim() == 2:
+        keep[oo[:, None], i[None, :]] = True
+    else:
+        keep[oo] = True
+    return (~keep).to(t.device).view(*keep.shape, *([1] * (t.dim() - keep.dim()))).expand_as(t)
+
+
+pads, bad, entries = [], [], 0
+for net in model.models.values():
+    for m in net.modules():
+        fn = getattr(m, "structural_pads", None)
+        if callable(fn):
+            pads.extend(fn())
+index = {id(p): k for k, p in enumerate(flat.params)} if hasattr(flat, "params") else {}
+for t, o, i in pads:
+    mask = _pad_mask(t, o, i)
+    if not bool(mask.any()):
+        continue
+    is_var = t.dim() == 1 and float(t.detach()[mask].float().min()) == 1.0 and float(t.detach()[mask].float().max()) == 1.0
+    views = {"master": t.detach()}
+    if id(t) in index:
+        k = index[id(t)]
+        off = flat.offsets[k]
+        views["adam_m"] = flat._view(optimizer.m, t, off)
+        views["adam_v"] = flat._view(optimizer.v, t, off)
+        if getattr(t, "shadow_bf16", None) is not None:
+            views["shadow_bf16"] = t.shadow_bf16
+        if t.grad is not None:
+            views["grad"] = t.grad
+    for what, v in views.items():
+        vals = v[mask].float()
+        entries += vals.numel()
+        if what == "master" and is_var:
+            continue
+        if float(vals.abs().max()) != 0.0:
+            bad.append((what, tuple(t.shape), float(vals.abs().max())))
+print("STRUCTZERO", f"tensors {len(pads)} entries {entries} nonzero {len(bad)}", bad[:4])
+if os.environ.get("XPT_DET_CHECKPOINT"):
+    import tempfile
+    from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
+    with tempfile.TemporaryDirectory() as tmp:
+        model.save_weights(tmp, "det")
+        disk = torch.load(os.path.join(tmp, "depthnet_det.pt"))
+        enc = model.models["depthnet"].encoder
+        exported = pn.export_keras_weights(enc)
+        print("CHECKPOINT", "stem1", tuple(disk["encoder.cells.0.conv.weight"].shape), "stem2", tuple(disk["encoder.cells.1.conv.weight"].shape),
+              "up2.conv2", tuple(disk["up2.conv2.conv.weight"].shape), "keras_elements", sum(v.numel() for v in exported.values()))

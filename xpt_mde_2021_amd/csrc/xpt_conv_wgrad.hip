@@ -24,6 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WGRAD_MAXCH = 12;     // 16-byte chunks a thread stages per pixel unit (48 KiB of LDS tiles at most)
 
@@ -31,7 +32,7 @@ struct WgradArgs {
   const unsigned short* g;   // [B,OH,OW,N] bf16, pixel pitch gpitch
   const unsigned short* x;   // [B,PH,PW,C] bf16, pixel pitch xpitch (C = channels readable per pixel, multiple of 8)
   float* part;               // [nsplit][N][T][Cr] fp32
-  long long gpitch, xpitch;
+  long long gpitch, xpitch, gbytes, xbytes;
   int B, PH, PW, shift, Hlim, Wlim;
   int C, Cr, N, KH, KW, stride, pad_t, pad_l, OH, OW;
   int R, CB, nseg, nrb, units, nsplit;
@@ -59,62 +60,66 @@ __device__ inline bf16x8 tr_pair(const char* lds, unsigned off0, unsigned off1) 
 template <int MAXCH>
 struct WgradChunks {
   int row[MAXCH], col[MAXCH];    // pixel of the chunk inside its tile (g: output pixel; x: logical halo pixel)
-  int ch[MAXCH];                 // first channel of the chunk (g: n0 + 8 gc8, x: c0 + 8 xc8); -1: no chunk
-  unsigned is_g;                 // bit i: chunk i belongs to the g tile
+  unsigned chb[MAXCH];           // byte offset of the chunk's first channel (g: n0 + 8 gc8, x: c0 + 8 xc8); WG_OOB: no chunk
 };
+
+// Round 4: staging slot i of every thread is a g chunk for i < gi and an x chunk behind that (the g chunks are padded to whole
+// passes of 256), so that each slot reads ONE operand through ONE buffer descriptor: the range check of the buffer load
+// supplies the zeros of the padding, of the ragged tiles and of the dead chunks (no masks on the loaded vectors, 32-bit
+// offsets instead of 64-bit address arithmetic).
+constexpr unsigned WG_OOB = 0x40000000u;
 
 template <int MAXCH>
 __device__ __forceinline__ void wgrad_chunks(const WgradArgs& a, int tid, int n0, int c0, int TNB, int TCB, int Wt,
-                                             int gchunks, int nchunks, WgradChunks<MAXCH>& w) {
+                                             int gi, int gchunks, int xchunks, WgradChunks<MAXCH>& w) {
   const int lg = __builtin_ctz((unsigned)(TNB >> 3)), lx = __builtin_ctz((unsigned)(TCB >> 3));      // TNB, TCB: 32 x {1, 2, 4}
   const float inv_cb = 1.f / (float)a.CB, inv_wt = 1.f / (float)Wt;
-  w.is_g = 0u;
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
-    const int ck = tid + 256 * i;
-    const bool is_g = ck < gchunks;
-    if (is_g) {
+    if (i < gi) {                                              // (uniform)
+      const int ck = tid + 256 * i;
       const int gc8 = ck & ((1 << lg) - 1), gpix = ck >> lg;
       const int gr = (int)(((float)gpix + 0.5f) * inv_cb);
       w.row[i] = gr;
       w.col[i] = gpix - gr * a.CB;
       const int n = n0 + 8 * gc8;
-      w.ch[i] = n < a.N ? n : -1;
-      w.is_g |= 1u << i;
+      w.chb[i] = (ck < gchunks && n < a.N) ? (unsigned)n * 2u : WG_OOB;
     } else {
-      const int cx = ck - gchunks;
+      const int cx = tid + 256 * (i - gi);
       const int xc8 = cx & ((1 << lx) - 1), xpix = cx >> lx;
       const int xr = (int)(((float)xpix + 0.5f) * inv_wt);
       w.row[i] = xr;
       w.col[i] = xpix - xr * Wt;
       const int c = c0 + 8 * xc8;
-      w.ch[i] = (ck < nchunks && c < a.C) ? c : -1;
+      w.chb[i] = (cx < xchunks && c < a.C) ? (unsigned)c * 2u : WG_OOB;
     }
   }
 }
 
 // the 16-byte chunks of one unit's g tile and x halo tile into registers
 template <int MAXCH>
-__device__ __forceinline__ void wgrad_fetch(const WgradArgs& a, int u, const WgradChunks<MAXCH>& w, uint4 (&stage)[MAXCH]) {
-  const int seg = u % a.nseg, rb = (u / a.nseg) % a.nrb, b = u / (a.nseg * a.nrb);      // (uniform)
-  const int oh0 = rb * a.R, ow0 = seg * a.CB;
+__device__ __forceinline__ void wgrad_fetch(const WgradArgs& a, int u, int gi, const WgradChunks<MAXCH>& w,
+                                            const __amdgpu_buffer_rsrc_t& rg, const __amdgpu_buffer_rsrc_t& rx, u32x4 (&stage)[MAXCH]) {
+  unsigned seg, rb;
+  const unsigned q1 = xpt_divmod((unsigned)u, (unsigned)a.nseg, seg);
+  const unsigned b = xpt_divmod(q1, (unsigned)a.nrb, rb);      // (uniform)
+  const int oh0 = (int)rb * a.R, ow0 = (int)seg * a.CB;
   const int th0 = oh0 * a.stride - a.pad_t, tw0 = ow0 * a.stride - a.pad_l;
-  const long long gimg = (long long)b * a.OH * a.OW, ximg = (long long)b * a.PH * a.PW;
+  const unsigned gimg = b * (unsigned)(a.OH * a.OW), ximg = b * (unsigned)(a.PH * a.PW);
+  const unsigned gp2 = (unsigned)(a.gpitch * 2), xp2 = (unsigned)(a.xpitch * 2);
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
-    // ONE unconditional load per chunk from a clamped address, zeroed by select (a guarded load would get its own
-    // branch and s_waitcnt: one memory round trip per chunk)
-    const bool is_g = (w.is_g >> i) & 1u;
-    const int r = (is_g ? oh0 : th0) + w.row[i], c = (is_g ? ow0 : tw0) + w.col[i];
-    const bool ok = w.ch[i] >= 0 && r >= 0 && c >= 0 && r < (is_g ? a.OH : a.Hlim) && c < (is_g ? a.OW : a.Wlim);
-    const int pr = is_g ? r : (r >> a.shift), pc = is_g ? c : (c >> a.shift);
-    const long long off = is_g ? (gimg + (long long)pr * a.OW + pc) * a.gpitch + w.ch[i]
-                               : (ximg + (long long)pr * a.PW + pc) * a.xpitch + w.ch[i];
-    const unsigned short* src = (is_g ? a.g : a.x) + (ok ? off : 0);
-    uint4 ld = *(const uint4*)src;
-    const unsigned keep = ok ? 0xffffffffu : 0u;               // (a uint4 select compiles to a scratch round trip)
-    ld.x &= keep; ld.y &= keep; ld.z &= keep; ld.w &= keep;
-    stage[i] = ld;
+    if (i < gi) {                                              // (uniform)
+      const int r = oh0 + w.row[i], c = ow0 + w.col[i];
+      const bool ok = r < a.OH && c < a.OW;
+      const unsigned off = ok ? (gimg + (unsigned)(r * a.OW + c)) * gp2 + w.chb[i] : WG_OOB;
+      stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
+    } else {
+      const int r = th0 + w.row[i], c = tw0 + w.col[i];
+      const bool ok = r >= 0 && c >= 0 && r < a.Hlim && c < a.Wlim;
+      const unsigned off = ok ? (ximg + (unsigned)((r >> a.shift) * a.PW + (c >> a.shift))) * xp2 + w.chb[i] : WG_OOB;
+      stage[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+    }
   }
 }
 
@@ -127,8 +132,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int ntc = (a.C + TCB - 1) / TCB;
   const int n0 = (blockIdx.x / ntc) * TNB, c0 = (blockIdx.x % ntc) * TCB;
   const int HR = (a.R - 1) * a.stride + a.KH, Wt = (a.CB - 1) * a.stride + a.KW;
+  const int gchunks = a.R * a.CB * (TNB / 8), xchunks = HR * Wt * (TCB / 8);
+  const int gi = (gchunks + 255) >> 8;                         // staging slots that hold g chunks (whole passes of 256)
   char* gs = smem;                                             // [R][CB][TNB] bf16
-  char* xs = smem + (size_t)a.R * a.CB * TNB * 2;              // [HR][Wt][TCB] bf16
+  char* xs = smem + (size_t)gi * 256 * 16;                     // [HR][Wt][TCB] bf16, behind the padded g passes
 
   // this wave's sub-tile and taps
   const int wt = wave % a.WT, wc = (wave / a.WT) % a.WC, wn = wave / (a.WT * a.WC);
@@ -160,23 +167,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   // multiplied (the loads stay in flight across the MFMA loop), then written to LDS behind the barrier that retires
   // unit u's reads.  MAXCH chunks per thread bound the tile (the plan keeps gchunks + xchunks <= 256 * MAXCH).
   constexpr int MAXCH = WGRAD_MAXCH;
-  const int gchunks = a.R * a.CB * (TNB / 8), xchunks = HR * Wt * (TCB / 8);
-  const int nchunks = gchunks + xchunks;
-  uint4 stage[MAXCH];
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, (int)a.gbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.xbytes, 0x00020000);
+  u32x4 stage[MAXCH];
   WgradChunks<MAXCH> chunks;
-  wgrad_chunks<MAXCH>(a, tid, n0, c0, TNB, TCB, Wt, gchunks, nchunks, chunks);
+  wgrad_chunks<MAXCH>(a, tid, n0, c0, TNB, TCB, Wt, gi, gchunks, xchunks, chunks);
   int u = blockIdx.y;
-  if (u < a.units) wgrad_fetch<MAXCH>(a, u, chunks, stage);
+  if (u < a.units) wgrad_fetch<MAXCH>(a, u, gi, chunks, rg, rx, stage);
   for (; u < a.units; u += a.nsplit) {
     __syncthreads();                                           // the previous unit's LDS reads are done
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
-      const int ck = tid + 256 * i;
-      if (ck < nchunks) *(uint4*)(smem + (size_t)ck * 16) = stage[i];     // gs and xs are contiguous: chunk order = LDS order
+      const int ck = tid + 256 * i;                            // slot order = LDS order (g passes padded to 256 chunks)
+      if (i < gi ? ck < gchunks : ck - gi * 256 < xchunks) *(u32x4*)(smem + (size_t)ck * 16) = stage[i];
     }
     __syncthreads();
     if (u + a.nsplit < a.units && !(a.dbg & 2))                // in flight during the products below
-      wgrad_fetch<MAXCH>(a, u + a.nsplit, chunks, stage);
+      wgrad_fetch<MAXCH>(a, u + a.nsplit, gi, chunks, rg, rx, stage);
     if (active && !(a.dbg & 1)) {
       for (int rr = 0; rr < a.R; ++rr) {
         for (int c16 = 0; c16 < a.CB; c16 += 16) {
@@ -242,8 +249,10 @@ bool plan_for(int wn, int wc, int B, int C, int N, int KH, int KW, int stride, i
   if (p.R > OH) p.R = OH;
   for (;;) {
     const int HR = (p.R - 1) * stride + KH, Wt = (p.CB - 1) * stride + KW;
-    p.lds = ((size_t)p.R * p.CB * TNB + (size_t)HR * Wt * TCB) * 2;
-    if (p.lds <= max_lds) break;
+    const size_t gch = (size_t)p.R * p.CB * (TNB / 8), xch = (size_t)HR * Wt * (TCB / 8);
+    const size_t slots = (gch + 255) / 256 + (xch + 255) / 256;          // staging slots per thread: g passes, then x passes
+    p.lds = ((gch + 255) / 256 * 256 + xch) * 16;
+    if (slots <= (size_t)WGRAD_MAXCH && p.lds <= max_lds) break;
     if (p.R > 1) p.R -= 1;
     else if (p.CB > 16) { p.CB -= 16; p.nseg = (OW + p.CB - 1) / p.CB; }
     else return false;
@@ -314,6 +323,9 @@ extern "C" int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, floa
   WgradArgs a{};
   a.g = (const unsigned short*)g; a.x = (const unsigned short*)x; a.part = partials;
   a.gpitch = gpitch; a.xpitch = xpitch;
+  a.gbytes = ((long long)B * OH * OW - 1) * gpitch * 2 + (long long)N * 2;
+  a.xbytes = ((long long)B * PH * PW - 1) * xpitch * 2 + (long long)C * 2;
+  if (a.gbytes >= (1LL << 30) || a.xbytes >= (1LL << 30)) return XPT_ERR_SHAPE;      // 32-bit offsets + the 1 GiB out-of-range marker
   a.B = B; a.PH = PH; a.PW = PW; a.shift = upsample; a.Hlim = PH << upsample; a.Wlim = PW << upsample;
   a.C = C; a.Cr = Cr; a.N = N; a.KH = KH; a.KW = KW; a.stride = stride; a.pad_t = pad_t; a.pad_l = pad_l;
   a.OH = OH; a.OW = OW;

@@ -138,6 +138,9 @@ def _apply_env_tuning():
     spec = os.environ.get("XPT_SPLITK_TUNE")               # deep-layer split-K path: enable, forced slices, min K, max pixels
     if spec:
         _lib.load().xpt_conv2d_splitk_tune(*[int(v) for v in spec.split(",")])
+    spec = os.environ.get("XPT_STREAM_TUNE")               # persistent 3 x 3 path: enable, min tiles, workgroups per CU, LDS KiB
+    if spec:
+        _lib.load().xpt_conv2d_stream_tune(*[int(v) for v in spec.split(",")])
     spec = os.environ.get("XPT_PWCONV_TUNE")               # fused pointwise forward: k split from this cin on, up to this many tiles
     if spec:
         _lib.load().xpt_pwconv_tune(*[int(v) for v in spec.split(",")])
@@ -207,6 +210,11 @@ class _Conv2dSame(torch.autograd.Function):
                                                  y.data_ptr(), B, PH, PW, Cp, xpitch, N, KH, KW, pt, pl, OH, OW, N,
                                                  int(upsample), float(slope), ws.data_ptr(), wsf, _stream()),
                        "xpt_conv2d_fwd_splitk")
+        elif not valid and lib.xpt_conv2d_stream_serves(B, OH, OW, N, Cp, KH, KW, stride, int(upsample)):
+            # 3 x 3 layers of the half- / full-resolution levels: persistent workgroups, weights staged once
+            _lib.check(lib.xpt_conv2d_fwd_stream(x.data_ptr(), e["fwd"].data_ptr(), None if b_ is None else b_.data_ptr(),
+                                                 y.data_ptr(), B, PH, PW, Cp, xpitch, N, pt, pl, OH, OW, N, int(upsample),
+                                                 float(slope), _stream()), "xpt_conv2d_fwd_stream")
         else:
             _lib.check(lib.xpt_conv2d_fwd(x.data_ptr(), e["fwd"].data_ptr(), None if b_ is None else b_.data_ptr(),
                                           y.data_ptr(), B, PH, PW, Cp, xpitch, N, KH, KW, stride, pt, pl, OH, OW, N,
@@ -276,6 +284,10 @@ class _Conv2dSame(torch.autograd.Function):
                 _lib.check(lib.xpt_conv2d_bwd_data_splitk(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"],
                                                           gpitch, Cp, KH, KW, pt, pl, PH, PW, Cp, ups, ws.data_ptr(), wsf,
                                                           _stream()), "xpt_conv2d_bwd_data_splitk")
+            elif lib.xpt_conv2d_stream_serves(B, PH << ups, PW << ups, Cp, e["Np"], KH, KW, stride, ups):
+                _lib.check(lib.xpt_conv2d_bwd_data_stream(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"],
+                                                          gpitch, Cp, pt, pl, PH, PW, Cp, ups, _stream()),
+                           "xpt_conv2d_bwd_data_stream")
             else:
                 _lib.check(lib.xpt_conv2d_bwd_data(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"], gpitch,
                                                    Cp, KH, KW, stride, pt, pl, PH, PW, Cp, ups, _stream()), "xpt_conv2d_bwd_data")

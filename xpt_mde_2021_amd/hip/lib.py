@@ -150,6 +150,12 @@ SIGNATURES = {
                                    ctypes.c_longlong, _i, _f, _p, _z, _p]),
     "xpt_conv2d_bwd_data_splitk": (_i, [_p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _i,
                                         ctypes.c_longlong, _i, _p, _z, _p]),
+    "xpt_conv2d_stream_tune": (_i, [_i, _i, _i, _i]),
+    "xpt_conv2d_stream_serves": (_i, [_i] * 9),
+    "xpt_conv2d_fwd_stream": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, ctypes.c_longlong,
+                                   _i, _f, _p]),
+    "xpt_conv2d_bwd_data_stream": (_i, [_p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, ctypes.c_longlong,
+                                        _i, _p]),
     "xpt_conv2d_bwd_weight_tune": (_i, [_i, _i]),
     "xpt_conv2d_bwd_weight_splits": (_i, [_i] * 8),
     "xpt_conv2d_bwd_weight_partials": (_i, [_p, _p, _p, _z, _i, _i, _i, _i, _i, ctypes.c_longlong, _i, ctypes.c_longlong,
