@@ -398,6 +398,11 @@ int xpt_headconv_fwd(const void* x, long long xpitch, const float* w, const floa
                      int C, void* stream);
 int xpt_headconv_bwd(const void* x, long long xpitch, const float* w, const float* g, void* dx, float* partials,
                      size_t partial_floats, int B, int H, int W, int C, void* stream);
+/* the same with the gradient the feature map received from its OTHER consumer (the next decoder level's first convolution,
+ * depth_net.py:137-167) added in: dx = addend + head data gradient; addend bf16 [B,H,W,C] with pixel pitch addend_pitch, or NULL. */
+int xpt_headconv_bwd_add(const void* x, long long xpitch, const float* w, const float* g, const void* addend,
+                         long long addend_pitch, void* dx, float* partials, size_t partial_floats, int B, int H, int W, int C,
+                         void* stream);
 
 /* ------------------------------------------------------------------ a2/a4: depth head activation
  * InverseSigmoid (model/build_model/model_factory.py:134-138) and safe_reciprocal_number (utils/util_funcs.py:157-160):
@@ -423,6 +428,10 @@ int xpt_global_avgpool_bwd(const float* g, void* dx, int B, int HW, int C, int d
  * channel slice of the NHWC concatenation's gradient, in place) -> dsrc float32 [M,h,w] (gather form: no zero fill). */
 int xpt_upsample2x_fwd(const float* src, void* out, long long M, int h, int w, int dtype, void* stream);
 int xpt_upsample2x_bwd(const void* g, long long g_pitch, float* dsrc, long long M, int h, int w, int dtype, void* stream);
+/* the same with the gradient src received from its OTHER consumer (the depth activation of the same raw prediction,
+ * depth_net.py:87-92) added in: dsrc = addend + adjoint(g); addend float32 [M,h,w] or NULL. */
+int xpt_upsample2x_bwd_add(const void* g, long long g_pitch, const float* addend, float* dsrc, long long M, int h, int w, int dtype,
+                           void* stream);
 
 /* ------------------------------------------------------------------ f-4: PWC-Net correlation cost volume
  * tfa.layers.CorrelationCost(kernel_size=1, max_displacement=md, stride_1=1, stride_2=s2, pad=md, channels_last)

@@ -707,10 +707,11 @@ __global__ __launch_bounds__(256) void restack_kernel(const float* __restrict__ 
   const int slots = S + ((Cp - 3 * S + 2) / 3);
   const long long total = (long long)B * HW * slots;
   if (i >= total) return;
-  const int sl = (int)(i % slots);
-  const long long bp = i / slots;
-  const long long p = bp % HW;
-  const long long b = bp / HW;
+  unsigned slu, pu;                                   // (total < 2^31: the launcher checks)
+  const unsigned bpu = xpt_divmod((unsigned)i, (unsigned)slots, slu);
+  const long long b = (long long)xpt_divmod(bpu, (unsigned)HW, pu);
+  const int sl = (int)slu;
+  const long long bp = (long long)bpu, p = (long long)pu;
   unsigned short* o = out + bp * Cp + 3 * sl;
   if (sl < S) {
     const float* src = img + ((b * S + sl) * HW + p) * 3;
@@ -927,7 +928,7 @@ extern "C" int xpt_restack_bf16(const float* image5d, void* out, int B, int S, i
   const int slots = S + ((Cp - 3 * S + 2) / 3);
   const long long total = (long long)B * HW * slots;
   const long long blocks = (total + 255) / 256;
-  if (blocks > 0x7fffffffLL) return XPT_ERR_SHAPE;
+  if (total >= 0x7fffffffLL || HW >= (1LL << 24)) return XPT_ERR_SHAPE;
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(restack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, image5d,
                      (unsigned short*)out, B, S, HW, Cp);

@@ -45,8 +45,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned short* __r
     const long long p = p0 + pl;
     const bool live = p < P;
     const long long pc = live ? p : P - 1;
-    const int col = (int)(pc % W);
-    const int row = (int)((pc / W) % H);
+    unsigned colu, rowu;                          // (P < 2^31: the launcher checks; a 64-bit % is ~120 instructions on this ISA)
+    xpt_divmod(xpt_divmod((unsigned)pc, (unsigned)W, colu), (unsigned)H, rowu);
+    const int col = (int)colu, row = (int)rowu;
     float acc = 0.f;
     uint4 v[9];
 #pragma unroll
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const unsigned short* __r
 template <int LPP>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned short* __restrict__ x, long long xpitch,
                                                         const float* __restrict__ w, const float* __restrict__ g,
+                                                        const unsigned short* __restrict__ addend, long long apitch,
                                                         unsigned short* __restrict__ dx, float* __restrict__ partials,
                                                         int B, int H, int W) {
   constexpr int C = 8 * LPP, PPW = 64 / LPP;
@@ -93,39 +95,44 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const unsigned short* __r
     const long long p = p0 + pl;
     const bool live = p < P;
     const long long pc = live ? p : P - 1;
-    const int col = (int)(pc % W);
-    const int row = (int)((pc / W) % H);
+    unsigned colu, rowu;                          // (P < 2^31: the launcher checks; a 64-bit % is ~120 instructions on this ISA)
+    xpt_divmod(xpt_divmod((unsigned)pc, (unsigned)W, colu), (unsigned)H, rowu);
+    const int col = (int)colu, row = (int)rowu;
     const float gp = live ? g[pc] : 0.f;
     if (sub == 0) db += gp;
-    uint4 v[9];
+    // Both gradients from the MIRRORED neighbours of g (one channel: 4-byte loads that hit the cache) and ONE 16-byte load
+    // of this pixel's features:  dx[p][c] = sum_tap g[p - off(tap)] w[tap][c]  and, re-indexed over the input pixel,
+    // dW[tap][c] = sum_q g[q - off(tap)] x[q][c]  (round 4; the first version read x[p + off(tap)] for all nine taps:
+    // nine 16-byte loads per lane and pixel, 24 us at full resolution).
     float gn[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       const int dr = t / 3 - 1, dc = t % 3 - 1;
-      const bool ok = row + dr >= 0 && row + dr < H && col + dc >= 0 && col + dc < W;
-      const long long q = ok ? pc + (long long)dr * W + dc : pc;
-      const uint4 ld = *(const uint4*)(x + q * xpitch + 8 * sub);
-      v[t] = ok ? ld : make_uint4(0u, 0u, 0u, 0u);
-      // data gradient: pixel p receives g of the output pixel p - off(tap) = the mirrored neighbour
-      const bool ok2 = row - dr >= 0 && row - dr < H && col - dc >= 0 && col - dc < W;
+      const bool ok2 = live && row - dr >= 0 && row - dr < H && col - dc >= 0 && col - dc < W;
       const long long q2 = ok2 ? pc - (long long)dr * W - dc : pc;
       const float gl = g[q2];
       gn[t] = ok2 ? gl : 0.f;
     }
+    float fc[8];
+    unpack8(*(const uint4*)(x + pc * xpitch + 8 * sub), fc);
     float d[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) d[e] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      float f[8];
-      unpack8(v[t], f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        dw[t][e] = fmaf(gp, f[e], dw[t][e]);
+        dw[t][e] = fmaf(gn[t], fc[e], dw[t][e]);
         d[e] = fmaf(gn[t], wt[t][e], d[e]);
       }
     }
     if (live) {
+      if (addend != nullptr) {                     // the gradient the feature map's other consumer left (fan-in folded in)
+        float fa[8];
+        unpack8(*(const uint4*)(addend + p * apitch + 8 * sub), fa);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] += fa[e];
+      }
       uint4 o;
       o.x = pack_bf2(d[0], d[1]); o.y = pack_bf2(d[2], d[3]); o.z = pack_bf2(d[4], d[5]); o.w = pack_bf2(d[6], d[7]);
       *(uint4*)(dx + p * C + 8 * sub) = o;
@@ -180,7 +187,7 @@ extern "C" int xpt_headconv_bwd_blocks(int B, int H, int W, int C) {
 extern "C" int xpt_headconv_fwd(const void* x, long long xpitch, const float* w, const float* bias, float* pre, int B, int H,
                                 int W, int C, void* stream) {
   XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(pre);
-  if (B <= 0 || H <= 0 || W <= 0) return XPT_ERR_SHAPE;
+  if (B <= 0 || H <= 0 || W <= 0 || (long long)B * H * W >= 0x7fffffffLL) return XPT_ERR_SHAPE;
   if ((C != 16 && C != 32 && C != 64 && C != 128) || xpitch < C || xpitch % 8 != 0 || ((uintptr_t)x) % 16 != 0) return XPT_ERR_ARG;
   const long long P = (long long)B * H * W;
   const long long ppb = 4 * (64 / (C / 8));
@@ -198,26 +205,34 @@ extern "C" int xpt_headconv_fwd(const void* x, long long xpitch, const float* w,
   return xpt_launch_status();
 }
 
-/* g [B,H,W] fp32 -> dx [B,H,W,C] bf16 dense, partials [xpt_headconv_bwd_blocks()][9 C + 1] fp32
- * (row = dW [3][3][C] followed by dbias) */
-extern "C" int xpt_headconv_bwd(const void* x, long long xpitch, const float* w, const float* g, void* dx, float* partials,
-                                size_t partial_floats, int B, int H, int W, int C, void* stream) {
+extern "C" int xpt_headconv_bwd_add(const void* x, long long xpitch, const float* w, const float* g, const void* addend,
+                                    long long addend_pitch, void* dx, float* partials, size_t partial_floats, int B, int H, int W,
+                                    int C, void* stream) {
   XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(g); XPT_CHECK_PTR(dx); XPT_CHECK_PTR(partials);
-  if (B <= 0 || H <= 0 || W <= 0) return XPT_ERR_SHAPE;
+  if (B <= 0 || H <= 0 || W <= 0 || (long long)B * H * W >= 0x7fffffffLL) return XPT_ERR_SHAPE;
   if ((C != 16 && C != 32 && C != 64 && C != 128) || xpitch < C || xpitch % 8 != 0 || ((uintptr_t)x) % 16 != 0 ||
       ((uintptr_t)dx) % 16 != 0)
     return XPT_ERR_ARG;
+  if (addend != nullptr && (addend_pitch < C || addend_pitch % 8 != 0 || ((uintptr_t)addend) % 16 != 0)) return XPT_ERR_ARG;
   const int blocks = head_blocks((long long)B * H * W, C);
   if (partial_floats < (size_t)blocks * (9 * C + 1)) return XPT_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const unsigned short* xp = (const unsigned short*)x;
+  const unsigned short* ap = (const unsigned short*)addend;
   unsigned short* dxp = (unsigned short*)dx;
   XPT_BEGIN_LAUNCH();
   switch (C / 8) {
-    case 2: hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, xp, xpitch, w, g, dxp, partials, B, H, W); break;
-    case 4: hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, xp, xpitch, w, g, dxp, partials, B, H, W); break;
-    case 8: hipLaunchKernelGGL(head_bwd_kernel<8>, dim3(blocks), dim3(256), 0, s, xp, xpitch, w, g, dxp, partials, B, H, W); break;
-    default: hipLaunchKernelGGL(head_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, xp, xpitch, w, g, dxp, partials, B, H, W); break;
+    case 2: hipLaunchKernelGGL(head_bwd_kernel<2>, dim3(blocks), dim3(256), 0, s, xp, xpitch, w, g, ap, addend_pitch, dxp, partials, B, H, W); break;
+    case 4: hipLaunchKernelGGL(head_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, xp, xpitch, w, g, ap, addend_pitch, dxp, partials, B, H, W); break;
+    case 8: hipLaunchKernelGGL(head_bwd_kernel<8>, dim3(blocks), dim3(256), 0, s, xp, xpitch, w, g, ap, addend_pitch, dxp, partials, B, H, W); break;
+    default: hipLaunchKernelGGL(head_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, xp, xpitch, w, g, ap, addend_pitch, dxp, partials, B, H, W); break;
   }
   return xpt_launch_status();
+}
+
+/* g [B,H,W] fp32 -> dx [B,H,W,C] bf16 dense, partials [xpt_headconv_bwd_blocks()][9 C + 1] fp32
+ * (row = dW [3][3][C] followed by dbias) */
+extern "C" int xpt_headconv_bwd(const void* x, long long xpitch, const float* w, const float* g, void* dx, float* partials,
+                                size_t partial_floats, int B, int H, int W, int C, void* stream) {
+  return xpt_headconv_bwd_add(x, xpitch, w, g, nullptr, 0, dx, partials, partial_floats, B, H, W, C, stream);
 }

@@ -401,10 +401,9 @@ template <typename T>
 __global__ void upsample2x_fwd_kernel(const float* __restrict__ src, T* __restrict__ out, long long total, int h, int w) {
   const int H = 2 * h, W = 2 * w;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int x = (int)(i % W);
-    long long r = i / W;
-    const int y = (int)(r % H);
-    const long long m = r / H;
+    unsigned xu, yu;                                // (total < 2^31: the launcher checks; 64-bit divisions are ~120 instructions each)
+    const long long m = (long long)xpt_divmod(xpt_divmod((unsigned)i, (unsigned)W, xu), (unsigned)H, yu);
+    const int x = (int)xu, y = (int)yu;
     int y0, y1, x0, x1;
     float ly, lx;
     up2_taps(y, h, y0, y1, ly);
@@ -428,15 +427,14 @@ __device__ inline float up2_weight(int y, int i, int h) {
 // gather form of the backward: input (i, j) collects its (at most) 4 x 4 outputs; g has a pixel pitch (a channel slice
 // of an NHWC concatenation gradient is read in place)
 template <typename T>
-__global__ void upsample2x_bwd_kernel(const T* __restrict__ g, long long g_pitch, float* __restrict__ dsrc,
-                                      long long total, int h, int w) {
+__global__ void upsample2x_bwd_kernel(const T* __restrict__ g, long long g_pitch, const float* __restrict__ addend,
+                                      float* __restrict__ dsrc, long long total, int h, int w) {
   const int W = 2 * w, H = 2 * h;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int j = (int)(idx % w);
-    long long r = idx / w;
-    const int i = (int)(r % h);
-    const long long m = r / h;
+    unsigned ju, iu;
+    const long long m = (long long)xpt_divmod(xpt_divmod((unsigned)idx, (unsigned)w, ju), (unsigned)h, iu);
+    const int j = (int)ju, i = (int)iu;
     const T* gm = g + m * H * W * g_pitch;
     float acc = 0.f;
 #pragma unroll
@@ -453,7 +451,7 @@ __global__ void upsample2x_bwd_kernel(const T* __restrict__ g, long long g_pitch
       }
       acc += wy * row;
     }
-    dsrc[idx] = acc;
+    dsrc[idx] = addend != nullptr ? addend[idx] + acc : acc;      // (the gradient the other consumer of src left: one fan-in launch less)
   }
 }
 
@@ -731,6 +729,7 @@ int xpt_upsample2x_fwd(const float* src, void* out, long long M, int h, int w, i
   if (M <= 0 || h <= 0 || w <= 0) return XPT_ERR_SHAPE;
   if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
   const long long total = M * 4 * h * w;
+  if (total >= 0x7fffffffLL) return XPT_ERR_SHAPE;          // (32-bit index splits in the kernel)
   XPT_BEGIN_LAUNCH();
   if (dtype == 0)
     hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
@@ -741,19 +740,25 @@ int xpt_upsample2x_fwd(const float* src, void* out, long long M, int h, int w, i
   return xpt_launch_status();
 }
 
-int xpt_upsample2x_bwd(const void* g, long long g_pitch, float* dsrc, long long M, int h, int w, int dtype, void* stream) {
+int xpt_upsample2x_bwd_add(const void* g, long long g_pitch, const float* addend, float* dsrc, long long M, int h, int w, int dtype,
+                           void* stream) {
   XPT_CHECK_PTR(g); XPT_CHECK_PTR(dsrc);
   if (M <= 0 || h <= 0 || w <= 0 || g_pitch < 1) return XPT_ERR_SHAPE;
   if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
   const long long total = M * h * w;
+  if (total >= 0x7fffffffLL) return XPT_ERR_SHAPE;
   XPT_BEGIN_LAUNCH();
   if (dtype == 0)
     hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)g, g_pitch, dsrc, total, h, w);
+                       (const float*)g, g_pitch, addend, dsrc, total, h, w);
   else
     hipLaunchKernelGGL(upsample2x_bwd_kernel<__hip_bfloat16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16*)g, g_pitch, dsrc, total, h, w);
+                       (const __hip_bfloat16*)g, g_pitch, addend, dsrc, total, h, w);
   return xpt_launch_status();
+}
+
+int xpt_upsample2x_bwd(const void* g, long long g_pitch, float* dsrc, long long M, int h, int w, int dtype, void* stream) {
+  return xpt_upsample2x_bwd_add(g, g_pitch, nullptr, dsrc, M, h, w, dtype, stream);
 }
 
 /* The same for nscales (1..4) prediction maps in one launch; a scale whose g_depth[s] and g_disp[s] are both NULL gets gx = 0. */

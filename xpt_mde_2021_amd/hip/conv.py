@@ -431,6 +431,52 @@ class _HeadConv(torch.autograd.Function):
         return dx, dw, (tot[9 * C:].clone() if ctx.has_bias else None)
 
 
+class _HeadConvSplit(_HeadConv):
+    """(pre, x itself): the decoder's feature map feeds its prediction head AND the next decoder level (depth_net.py:137-167);
+    as one autograd node the next level's gradient is added inside the head's backward launch (xpt_headconv_bwd_add)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        pre = _HeadConv.forward(ctx, x, weight, bias)
+        ctx.set_materialize_grads(False)
+        return pre, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, g_x):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        B, C, H, W, xpitch = ctx.geom
+        if g is None:
+            return g_x, None, None
+        g = g.contiguous().float()
+        add, apitch = (None, 0)
+        if g_x is not None:
+            add, apitch = nhwc_view(g_x.to(torch.bfloat16))
+        dx = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+        nblk = lib.xpt_headconv_bwd_blocks(B, H, W, C)
+        row = 9 * C + 1
+        if ctx.sink is not None:
+            ws = _ops.grad_sink.partials(ctx.sink[0], "head", nblk * row)
+        else:
+            ws = torch.empty(nblk * row, dtype=torch.float32, device=g.device)
+        _lib.check(lib.xpt_headconv_bwd_add(x.data_ptr(), xpitch, w.data_ptr(), g.data_ptr(), None if add is None else add.data_ptr(),
+                                            apitch, dx.data_ptr(), ws.data_ptr(), ws.numel(), B, H, W, C, _stream()),
+                   "xpt_headconv_bwd_add")
+        if ctx.sink is not None:
+            _ops.grad_sink.add(ctx.sink[0], ws, 0, 9 * C, nblk, row)
+            if ctx.sink[1] is not None:
+                _ops.grad_sink.add(ctx.sink[1], ws, 9 * C, 1, nblk, row)
+            return dx, None, None
+        tot = ws[:nblk * row].view(nblk, row).sum(0)
+        dw = tot[:9 * C].view(1, 3, 3, C).permute(0, 3, 1, 2)
+        return dx, dw, (tot[9 * C:].clone() if ctx.has_bias else None)
+
+
+def head_conv_split(x, weight, bias):
+    """(head_conv(x, weight, bias), x as an alias for the feature map's other consumer); see _HeadConvSplit."""
+    return _HeadConvSplit.apply(x, weight, bias)
+
+
 def head_conv(x, weight, bias):
     """Conv2D(1, 3, padding="same", linear) of get_scaled_depth (depth_net.py:87-92): x [B,C,H,W] bf16 (NHWC storage,
     C in 16/32/64/128) -> [B,1,H,W] float32."""

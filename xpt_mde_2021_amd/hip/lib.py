@@ -108,6 +108,7 @@ SIGNATURES = {
     "xpt_global_avgpool_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "xpt_upsample2x_fwd": (_i, [_p, _p, ctypes.c_longlong, _i, _i, _i, _p]),
     "xpt_upsample2x_bwd": (_i, [_p, ctypes.c_longlong, _p, ctypes.c_longlong, _i, _i, _i, _p]),
+    "xpt_upsample2x_bwd_add": (_i, [_p, ctypes.c_longlong, _p, _p, ctypes.c_longlong, _i, _i, _i, _p]),
     "xpt_depth_head_ms_fwd": (_i, [_i, _p, _p, _p, _p, _p]),
     "xpt_depth_head_ms_bwd": (_i, [_i, _p, _p, _p, _p, _p, _p]),
     "xpt_sum_rows": (_i, [_p, _p, _i, _p, ctypes.c_longlong, _i, _i, _p]),
@@ -163,6 +164,7 @@ SIGNATURES = {
     "xpt_headconv_bwd_blocks": (_i, [_i, _i, _i, _i]),
     "xpt_headconv_fwd": (_i, [_p, ctypes.c_longlong, _p, _p, _p, _i, _i, _i, _i, _p]),
     "xpt_headconv_bwd": (_i, [_p, ctypes.c_longlong, _p, _p, _p, _p, _z, _i, _i, _i, _i, _p]),
+    "xpt_headconv_bwd_add": (_i, [_p, ctypes.c_longlong, _p, _p, _p, ctypes.c_longlong, _p, _p, _z, _i, _i, _i, _i, _p]),
     "xpt_restack_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "xpt_affine_act_fwd": (_i, [_p, _p, _p, _p, _p, _f, _p, _p, ctypes.c_longlong, _i, _f, _i, _i, _p]),
     "xpt_affine_act_bwd_workspace_floats": (_z, [ctypes.c_longlong, _i]),

@@ -1039,6 +1039,49 @@ class _Upsample2x(torch.autograd.Function):
         return dx, None
 
 
+class _Upsample2xSplit(torch.autograd.Function):
+    """(x itself, its exact 2x bilinear up-sampling): the two consumers of a raw prediction (depth_net.py:87-92: the depth
+    activation and the next decoder level) as ONE autograd node, so that their gradients meet inside the up-sampling's backward
+    launch (xpt_upsample2x_bwd_add) instead of in a separate fan-in launch."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        lib = _lib.load()
+        x = _dev(x, "x")
+        B, C, h, w = x.shape
+        out = torch.empty((B, C, 2 * h, 2 * w), dtype=dtype, device=x.device)
+        _lib.check(lib.xpt_upsample2x_fwd(_ptr(x), _ptr(out), B * C, h, w, 0 if dtype == torch.float32 else 1, _stream()),
+                   "xpt_upsample2x_fwd")
+        ctx.shape = (B, C, h, w)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), out
+
+    @staticmethod
+    def backward(ctx, g_self, g):
+        lib = _lib.load()
+        if g is None:
+            return g_self, None
+        B, C, h, w = ctx.shape
+        if g.dtype not in (torch.float32, torch.bfloat16):
+            g = g.float()
+        H, W = 2 * h, 2 * w
+        pitch = g.stride(3)
+        if not (C == 1 and pitch >= 1 and g.stride(2) == pitch * W and g.stride(0) == pitch * W * H):
+            g, pitch = g.contiguous(), 1
+        add = None
+        if g_self is not None:
+            add = g_self.contiguous().float()
+        dx = torch.empty((B, C, h, w), dtype=torch.float32, device=g.device)
+        _lib.check(lib.xpt_upsample2x_bwd_add(_ptr(g), pitch, None if add is None else _ptr(add), _ptr(dx), B * C, h, w,
+                                              0 if g.dtype == torch.float32 else 1, _stream()), "xpt_upsample2x_bwd_add")
+        return dx, None
+
+
+def upsample2x_split(x, dtype=torch.float32):
+    """(x as an alias for its other consumer, upsample2x(x, dtype)); see _Upsample2xSplit."""
+    return _Upsample2xSplit.apply(x, dtype)
+
+
 def upsample2x(x, dtype=torch.float32):
     """Bilinear (half-pixel centres) 2x up-sampling of float32 [B,C,h,w] -> [B,C,2h,2w] of `dtype` (float32 / bfloat16)
     in one launch; the backward gathers (one launch, no zero fill, reads a strided one-channel gradient in place)."""

@@ -29,6 +29,7 @@ class _ChannelsLastOne(torch.autograd.Function):
 
 
 _FUSED_CONCAT = __import__("os").environ.get("XPT_DEBUG_TORCH_CAT", "0") != "1"     # A/B: torch.cat + cached zero pad
+_FUSED_FAN_IN = __import__("os").environ.get("XPT_DEBUG_ATEN_FAN_IN", "0") != "1"    # A/B: autograd's add launches for the decoder's fan-ins
 
 
 class UpconvWithSkip(nn.Module):
@@ -79,12 +80,20 @@ class ScaledDepthHead(nn.Module):
         self.conv = conv2d(cin, 1, 3, activation="linear")
         self.predict_depth = pred_depth
 
-    def forward(self, src, dst_height, dst_width, activate=True):
+    def forward(self, src, dst_height, dst_width, activate=True, split=False):
         """activate=False: depth is None -- the caller applies the activation to all scales at once
-        (predict_depth.with_disparity_multi), the decoder itself only consuming the raw prediction."""
+        (predict_depth.with_disparity_multi), the decoder itself only consuming the raw prediction.
+        split=True (a feature map that ALSO feeds the next decoder level): a fourth result, `src` as an alias for that other
+        consumer -- head and next level become one autograd node and their gradients are added inside the head's backward
+        launch; likewise the raw prediction's two consumers (activation, up-sampling) below."""
+        src_alias = src
         with torch.autocast(device_type=src.device.type, enabled=False):
+            fused_fan_in = _FUSED_FAN_IN and split and torch.is_grad_enabled() and src.requires_grad
             if _conv.head_usable(src, self.conv.conv) and self.conv.slope == 1.0:
-                conv = _conv.head_conv(src, self.conv.conv.weight, self.conv.conv.bias)     # bf16 features in, fp32 prediction out
+                if fused_fan_in:
+                    conv, src_alias = _conv.head_conv_split(src, self.conv.conv.weight, self.conv.conv.bias)
+                else:
+                    conv = _conv.head_conv(src, self.conv.conv.weight, self.conv.conv.bias)     # bf16 features in, fp32 prediction out
             else:
                 conv = self.conv(src.float())
             if not activate:
@@ -96,9 +105,14 @@ class ScaledDepthHead(nn.Module):
             if (_BATCHED_HEADS and conv.is_cuda and conv.dtype == torch.float32 and conv.is_contiguous()
                     and src.dtype == torch.bfloat16 and (dst_height, dst_width) == (2 * conv.shape[2], 2 * conv.shape[3])):
                 # the exact 2x resize and the cast to the decoder's dtype in one launch (one more for the backward)
-                conv_up = _ops.upsample2x(conv, torch.bfloat16)
+                if _FUSED_FAN_IN and not activate and torch.is_grad_enabled() and conv.requires_grad:
+                    conv, conv_up = _ops.upsample2x_split(conv, torch.bfloat16)
+                else:
+                    conv_up = _ops.upsample2x(conv, torch.bfloat16)
             else:
                 conv_up = lo.resize_image(conv, dst_height, dst_width)
+        if split:
+            return depth, conv_up, conv, src_alias
         return depth, conv_up, conv
 
 
@@ -175,11 +189,13 @@ class DepthNetPretrained(nn.Module):
         batched = _BATCHED_HEADS and conv5.is_cuda and hasattr(self.depth0.predict_depth, "with_disparity_multi")
         upconv4 = self.up4(conv5, [conv4])
         upconv3 = self.up3(upconv4, [conv3])
-        depth3, dpconv2_up, dpconv3 = self.depth3(upconv3, height // 4, width // 4, not batched)
+        # (split=True: the level's feature map comes back as an alias for the next level -- its two gradients meet inside the
+        #  prediction head's backward launch instead of in an aten add)
+        depth3, dpconv2_up, dpconv3, upconv3 = self.depth3(upconv3, height // 4, width // 4, not batched, split=True)
         upconv2 = self.up2(upconv3, [conv2, dpconv2_up])
-        depth2, dpconv1_up, dpconv2 = self.depth2(upconv2, height // 2, width // 2, not batched)
+        depth2, dpconv1_up, dpconv2, upconv2 = self.depth2(upconv2, height // 2, width // 2, not batched, split=True)
         upconv1 = self.up1(upconv2, [conv1, dpconv1_up])
-        depth1, dpconv0_up, dpconv1 = self.depth1(upconv1, height, width, not batched)
+        depth1, dpconv0_up, dpconv1, upconv1 = self.depth1(upconv1, height, width, not batched, split=True)
         upconv0 = self.up0(upconv1, [dpconv0_up])
         depth0, _, dpconv0 = self.depth0(upconv0, height, width, not batched)
         if batched:
