@@ -50,6 +50,11 @@ def conv_plan():
     lib = _lib.load()
 
     def set_plan(plan):
+        # 7002: as plan 0, with the specialised persistent weight-gradient kernel (conv_wgrad_fast_kernel) on EVERY 3 x 3 stride-1
+        # layer of at most 32 output channels (the product uses it from 512 tiles on); every other plan: from 512 tiles (none here)
+        _lib.check(lib.xpt_conv2d_bwd_weight_tune(-1000, 2 if plan == 7002 else 1), "wgrad tune")
+        if plan == 7002:
+            plan = 0
         if plan == 0:             # the product's automatic choice among ALL kernel families
             _lib.check(lib.xpt_conv2d_tune(0), "tune")
             _lib.check(lib.xpt_conv2d_splitk_tune(1, 0, 1024, 8192), "splitk tune")
@@ -69,6 +74,7 @@ def conv_plan():
             _lib.check(lib.xpt_conv2d_tune(plan), "tune")
 
     yield set_plan
+    lib.xpt_conv2d_bwd_weight_tune(-1000, 1)
     lib.xpt_conv2d_tune(0)
     lib.xpt_conv2d_splitk_tune(1, 0, 1024, 8192)
     lib.xpt_conv2d_stream_tune(1, 512, 3, 80)
@@ -81,7 +87,7 @@ def conv_plan():
 # 5001 / 5002 / 5008 / 5016: the split-K tile kernels (1 / 2 / 8 / 16 slices of the reduction axis) on every stride-1 layer
 # 6001 / 6003 / 6102: the persistent weight-stationary kernels, 1 / 3 workgroups per CU (6102: generic kernel only, 2 per CU), on
 # every 3 x 3 stride-1 layer that fits
-@pytest.mark.parametrize("plan", [0, 901, 902, 110, 911, 912, 5001, 5002, 5008, 5016, 6001, 6003, 6102])
+@pytest.mark.parametrize("plan", [0, 901, 902, 110, 911, 912, 5001, 5002, 5008, 5016, 6001, 6003, 6102, 7002])
 @pytest.mark.parametrize("batch", [2])
 def test_conv_fwd_bwd_matches_fp32_reference(gpu_device, conv_plan, cin, cout, k, stride, H, W, ups, batch, plan):
     from xpt_mde_2021_amd.hip import conv as xc

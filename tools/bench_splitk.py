@@ -19,6 +19,7 @@ LAYERS = [
     ("up4a", 1056, 256, 4, 13, True), ("up4b", 432, 256, 8, 26, False),
     ("up3a", 256, 128, 8, 26, True), ("up3b", 216, 128, 16, 52, False),
     ("up2a", 128, 64, 16, 52, True), ("up2b", 96, 64, 32, 104, False),
+    ("pose6", 256, 256, 2, 7, False), ("up3bd", 128, 216, 16, 52, False),
 ]
 
 
@@ -88,10 +89,18 @@ for name, cin, cout, H, W, ups in LAYERS:
 
     t_of, t_od = timeit(old_f), timeit(old_d)
     cells = []
+    ef = ed = float('nan')
     for force in ((0,) if ONE else (0, 1, 2, 4, 8, 16)):
         lib.xpt_conv2d_splitk_tune(1, force, 1, 1 << 30)
-        t_f, t_d = timeit(new_f), timeit(new_d)
-        if force == 0:
+        try:
+            t_f = timeit(new_f)
+        except _lib.XptHipError:
+            t_f = float("nan")
+        try:
+            t_d = timeit(new_d)
+        except _lib.XptHipError:
+            t_d = float("nan")
+        if force == 0 and t_f == t_f and t_d == t_d:
             torch.cuda.synchronize()
             ef = (y2.float() - y.float()).abs().max().item() / (y.float().abs().max().item() + 1e-9)
             ed = (dx2.float() - dx.float()).abs().max().item() / (dx.float().abs().max().item() + 1e-9)
@@ -105,4 +114,4 @@ for name, cin, cout, H, W, ups in LAYERS:
     if ONE:
         break
     print(f"{name:5s} {cin:4d}->{cout:3d} {OH:3d}x{OW:3d} | old {t_of:5.1f}/{t_od:5.1f} | " + " | ".join(cells) +
-          f" | rel diff {ef:.1e}/{ed:.1e} | auto fwd {flops / float(cells[0].split('/')[0]) * 1e-6:6.1f} TF/s", flush=True)
+          f" | rel diff {ef:.1e}/{ed:.1e}", flush=True)

@@ -218,6 +218,197 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ specialised: 3 x 3, stride 1
+// The weight gradients of the half- / full-resolution decoder layers (dp_up1 / dp_up0: <= 32 output channels on the 64 x 208
+// and 128 x 416 maps) were 26 - 30 us each for 20 - 34 MB: PMC counts 2,339 vector + 1,096 scalar instructions per wave of
+// conv_wgrad_kernel<3> -- the generic staging (12 unrolled slots with run-time geometry) and the run-time strides of the
+// product loop, again the instruction stream.  Here, as in xpt_conv_stream.hip: persistent workgroups over 8 x 16-pixel
+// tiles, ONE 32-channel column block of dW per workgroup (acc = 3 taps x 16 registers per wave: wave w owns taps w, w + 4,
+// w + 8), the geometry of a thread's staged vectors computed once, interior tiles addressed as lane constant + scalar tile
+// offset through buffer loads whose range check supplies the zeros, and a fully unrolled product loop whose LDS addresses are
+// lane constants + instruction immediates (tiles start at even rows / columns, so the nearest-2x source row of an output row
+// is a compile-time number as well).
+struct WfArgs {
+  const unsigned short* g;   // [B,OH,OW,N] bf16, pixel pitch gpitch
+  const unsigned short* x;   // [B,PH,PW,C] bf16, pixel pitch xpitch
+  float* part;               // [nsplit][N][9][Cr] fp32
+  long long gpitch, xpitch, gbytes, xbytes;
+  int B, PH, PW, OH, OW, C, Cr, N;
+  int pad_t, pad_l, taps;
+  int tiles_x, tiles_y, ntiles, nsplit, ct, nb; // ct / nb = 32-channel column / row blocks of dW (grid = ct x nb x nsplit)
+  int xcd;
+};
+
+// K x K filter, stride S (TF SAME: the pads are arguments), UPS: nearest-2x input (3 x 3, stride 1 only)
+template <int K, int S, bool UPS>
+__global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WfArgs a) {
+  constexpr int HR = UPS ? 6 : 7 * S + K, WR = UPS ? 10 : 15 * S + K, HPIX = HR * WR;
+  constexpr int T = K * K, TPW = (T + 3) / 4;                  // taps; taps per wave (wave w owns taps w, w + 4, ...)
+  __shared__ __attribute__((aligned(16))) char smem[8192 + HPIX * 64];
+  constexpr int NG = 2, NX = (HPIX * 4 + 255) / 256;          // staged 16-byte vectors per thread: g tile, x halo block
+  char* const gs = smem;                                       // [8 x 16 px][32 ch] bf16
+  char* const xs = smem + 8192;                                // [HR x WR px][32 ch] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int cblk = (int)blockIdx.x % a.ct, nblk = ((int)blockIdx.x / a.ct) % a.nb, split = (int)blockIdx.x / (a.ct * a.nb);
+  const int c0 = cblk * 32, n0 = nblk * 32;
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, (int)a.gbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.xbytes, 0x00020000);
+  const unsigned gp2 = (unsigned)(a.gpitch * 2), xp2 = (unsigned)(a.xpitch * 2);
+
+  // ---- staging geometry, once
+  int grow[NG], gcol[NG];
+  unsigned gcb[NG], gconst[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int v = tid + 256 * i, pix = v >> 2, cv = v & 3;
+    grow[i] = pix >> 4;
+    gcol[i] = pix & 15;
+    gcb[i] = n0 + cv * 8 < a.N ? (unsigned)(n0 + cv * 8) * 2u : WG_OOB;
+    gconst[i] = (unsigned)(grow[i] * a.OW + gcol[i]) * gp2 + gcb[i];
+  }
+  int xq[NX], xrem[NX], xlds[NX];
+  unsigned xcb[NX], xconst[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int v = tid + 256 * i, pix = v >> 2, cv = v & 3;
+    const int q = pix / WR, rem = pix - q * WR;
+    const bool live = pix < HPIX;
+    xq[i] = q;
+    xrem[i] = rem;
+    xlds[i] = live ? pix * 64 + cv * 16 : -1;
+    xcb[i] = (live && c0 + cv * 8 < a.C) ? (unsigned)(c0 + cv * 8) * 2u : WG_OOB;
+    xconst[i] = (unsigned)(q * a.PW + rem) * xp2 + xcb[i];
+  }
+
+  // ---- lane roles of the transposed reads (as conv_wgrad_kernel): this lane supplies pixel column pc(i) of the 16-pixel step
+  const int g4 = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3, h = g4 >> 1, half = g4 & 1;
+  unsigned abase[2];
+  int tkh[TPW];                                                // (scalars) tap row of slot tt, -1: no tap
+  unsigned bsel[TPW][2];                                       // this lane's halo column offset under the slot's tap column
+#pragma unroll
+  for (int i = 0; i < 2; ++i) abase[i] = (unsigned)((8 * h + 4 * i + q4) * 64 + (16 * half + 4 * p4) * 2);
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int tap = wave + 4 * tt;
+    const int kh = tap / K, kw = tap - K * kh;
+    tkh[tt] = tap < T ? kh : -1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pc = 8 * h + 4 * i + q4;
+      const int col = UPS ? ((pc + kw - 1) >> 1) + 1 : pc * S + kw;        // halo column of output column pc under tap column kw
+      bsel[tt][i] = (unsigned)(8192 + col * 64 + (16 * half + 4 * p4) * 2);
+    }
+  }
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  auto tile_of = [&](int t, int& b, int& oh0, int& ow0) {
+    unsigned u = (unsigned)t;
+    if (a.xcd) u = (u & 7u) * ((unsigned)a.ntiles >> 3) + (u >> 3);
+    unsigned txi, tyi;
+    const unsigned q1 = xpt_divmod(u, (unsigned)a.tiles_x, txi);
+    b = __builtin_amdgcn_readfirstlane((int)xpt_divmod(q1, (unsigned)a.tiles_y, tyi));
+    oh0 = __builtin_amdgcn_readfirstlane((int)tyi * 8);
+    ow0 = __builtin_amdgcn_readfirstlane((int)txi * 16);
+  };
+  u32x4 sg[NG], sx[NX];
+  auto fetch = [&](int t) {
+    int b, oh0, ow0;
+    tile_of(t, b, oh0, ow0);
+    const int plo_h = UPS ? (oh0 - 1) >> 1 : oh0 * S - a.pad_t, plo_w = UPS ? (ow0 - 1) >> 1 : ow0 * S - a.pad_l;
+    const bool g_in = oh0 + 8 <= a.OH && ow0 + 16 <= a.OW;
+    const bool x_in = plo_h >= 0 && plo_h + HR <= a.PH && plo_w >= 0 && plo_w + WR <= a.PW;      // (uniform)
+    if (g_in) {
+      const unsigned soff = (unsigned)((b * a.OH + oh0) * a.OW + ow0) * gp2;
+#pragma unroll
+      for (int i = 0; i < NG; ++i) sg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, gconst[i], soff, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        const int r = oh0 + grow[i], c = ow0 + gcol[i];
+        const unsigned off = (r < a.OH && c < a.OW) ? (unsigned)((b * a.OH + r) * a.OW + c) * gp2 + gcb[i] : WG_OOB;
+        sg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
+      }
+    }
+    if (x_in) {
+      const unsigned soff = (unsigned)((b * a.PH + plo_h) * a.PW + plo_w) * xp2;
+#pragma unroll
+      for (int i = 0; i < NX; ++i) sx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xconst[i], soff, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int pr = plo_h + xq[i], pc = plo_w + xrem[i];
+        const bool ok = (unsigned)pr < (unsigned)a.PH && (unsigned)pc < (unsigned)a.PW;
+        const unsigned off = ok ? (unsigned)((b * a.PH + pr) * a.PW + pc) * xp2 + xcb[i] : WG_OOB;
+        sx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      }
+    }
+  };
+
+  // this workgroup's tiles: split, split + nsplit, ...
+  int t = split;
+  if (t < a.ntiles) fetch(t);
+  for (; t < a.ntiles; t += a.nsplit) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NG; ++i) *(u32x4*)(gs + (tid + 256 * i) * 16) = sg[i];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+      if (xlds[i] >= 0) *(u32x4*)(xs + xlds[i]) = sx[i];
+    __syncthreads();
+    if (t + a.nsplit < a.ntiles) fetch(t + a.nsplit);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {                            // one 16-pixel reduction step per tile row
+      const bf16x8 fa = tr_pair(smem, abase[0] + rr * 1024, abase[1] + rr * 1024);
+#pragma unroll
+      for (int tt = 0; tt < TPW; ++tt) {
+        if (tkh[tt] >= 0) {                                     // (wave-uniform)
+          const int hrow = UPS ? ((rr + tkh[tt] - 1) >> 1) + 1 : rr * S + tkh[tt];      // (scalar)
+          const unsigned ro = (unsigned)(hrow * WR * 64);
+          const bf16x8 fb = tr_pair(smem, bsel[tt][0] + ro, bsel[tt][1] + ro);
+          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- this workgroup's partial: register e of tap slot tt -> output channel n0 + (e & 3) + 8 (e >> 2) + 4 h, input channel c0 + lane & 31
+  const int c = c0 + (lane & 31);
+  float* dst = a.part + (long long)split * a.N * T * a.Cr;
+#pragma unroll
+  for (int tt = 0; tt < TPW; ++tt) {
+    const int tap = wave + 4 * tt;
+    if (tap >= T) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int n = n0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (n < a.N && c < a.Cr) dst[((long long)n * T + tap) * a.Cr + c] = acc[tt][e];
+    }
+  }
+}
+
+int g_wgrad_fast = 1;            // 0: conv_wgrad_kernel for every layer
+int g_wgrad_fast_min_tiles = 1;
+
+// plan of the specialised kernel; false: the layer is outside what it serves
+bool fast_plan(int B, int C, int N, int KH, int KW, int stride, int OH, int OW, int upsample, WfArgs& a) {
+  if (!g_wgrad_fast || KH != KW || !((KH == 3 && (stride == 1 || stride == 2)) || (KH == 5 && stride == 2))) return false;
+  if (upsample && (KH != 3 || stride != 1)) return false;
+  (void)upsample;                                              // (a nearest-2x input makes OH, OW even by construction)
+  a.tiles_x = (OW + 15) / 16;
+  a.tiles_y = (OH + 7) / 8;
+  const long long nt = (long long)B * a.tiles_y * a.tiles_x;
+  if (nt < g_wgrad_fast_min_tiles || nt > 0x3fffffffLL) return false;
+  a.ntiles = (int)nt;
+  a.ct = (C + 31) / 32;
+  a.nb = (N + 31) / 32;
+  a.taps = KH * KW;
+  return true;
+}
+
 struct WgradPlan {
   int WN, WC, WT, TAPS, R, CB, nseg, nrb, units, nsplit;
   long long blocks;
@@ -226,6 +417,16 @@ struct WgradPlan {
 
 
 int g_wgrad_max_partial_mib = 12, g_wgrad_target_blocks = 512, g_wgrad_dbg = 0;
+
+// splits of the specialised kernel: three workgroups per CU over the column blocks, under the cap on partial-sum bytes
+int fast_nsplit(const WfArgs& a, int N, int C) {
+  const long long bytes = (long long)N * a.taps * C * 4;
+  long long s = (768 + a.ct * a.nb - 1) / (a.ct * a.nb);
+  const long long cap = ((long long)g_wgrad_max_partial_mib << 20) / (bytes > 0 ? bytes : 1);
+  if (s > cap) s = cap;
+  if (s > a.ntiles) s = a.ntiles;
+  return s < 1 ? 1 : (int)s;
+}
 
 
 // one candidate decomposition: sub-tiles (WN x WC), taps split WT ways; pixel units bounded by the staging registers
@@ -291,6 +492,11 @@ bool make_plan(int B, int C, int N, int KH, int KW, int stride, int OH, int OW, 
 }  // namespace
 
 extern "C" int xpt_conv2d_bwd_weight_tune(int max_partial_mib, int target_blocks) {
+  if (max_partial_mib == -1000) {      // (lab / tests: the specialised 3 x 3 kernel: 0 off, 1 on, n > 1: on from n tiles)
+    g_wgrad_fast = target_blocks != 0;
+    g_wgrad_fast_min_tiles = target_blocks > 1 ? target_blocks : 1;
+    return XPT_OK;
+  }
   if (max_partial_mib < 0) g_wgrad_dbg = -max_partial_mib;          // lab knobs, see WgradArgs::dbg
   if (max_partial_mib > 0) g_wgrad_max_partial_mib = max_partial_mib;
   if (target_blocks > 0) g_wgrad_target_blocks = target_blocks;
@@ -300,6 +506,8 @@ extern "C" int xpt_conv2d_bwd_weight_tune(int max_partial_mib, int target_blocks
 extern "C" int xpt_conv2d_bwd_weight_splits(int B, int C, int N, int KH, int KW, int stride, int OH, int OW) {
   WgradPlan p;
   if (B <= 0 || C <= 0 || N <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || OH <= 0 || OW <= 0) return XPT_ERR_SHAPE;
+  WfArgs f{};
+  if (fast_plan(B, C, N, KH, KW, stride, OH, OW, 0, f)) return fast_nsplit(f, N, C);
   if (!make_plan(B, C, N, KH, KW, stride, OH, OW, p)) return XPT_ERR_ARG;
   return p.nsplit;
 }
@@ -317,6 +525,30 @@ extern "C" int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, floa
   if (C % 8 != 0 || N % 8 != 0 || xpitch < C || xpitch % 8 != 0 || gpitch < N || gpitch % 8 != 0 ||
       ((uintptr_t)g) % 16 != 0 || ((uintptr_t)x) % 16 != 0 || stride < 1 || (upsample != 0 && upsample != 1))
     return XPT_ERR_ARG;
+  {
+    WfArgs f{};
+    if (fast_plan(B, C, N, KH, KW, stride, OH, OW, upsample, f) &&
+        (upsample ? ((long long)PH * 2 == OH && (long long)PW * 2 == OW && pad_t == 1 && pad_l == 1)
+                  : ((long long)(OH - 1) * stride - pad_t < PH && (long long)(OW - 1) * stride - pad_l < PW))) {
+      f.nsplit = fast_nsplit(f, N, C);
+      if (partial_floats < (size_t)f.nsplit * N * KH * KW * Cr) return XPT_ERR_WORKSPACE;
+      f.g = (const unsigned short*)g; f.x = (const unsigned short*)x; f.part = partials;
+      f.gpitch = gpitch; f.xpitch = xpitch;
+      f.gbytes = ((long long)B * OH * OW - 1) * gpitch * 2 + (long long)N * 2;
+      f.xbytes = ((long long)B * PH * PW - 1) * xpitch * 2 + (long long)C * 2;
+      if (f.gbytes >= (1LL << 30) || f.xbytes >= (1LL << 30)) return XPT_ERR_SHAPE;
+      f.B = B; f.PH = PH; f.PW = PW; f.OH = OH; f.OW = OW; f.C = C; f.Cr = Cr; f.N = N; f.pad_t = pad_t; f.pad_l = pad_l;
+      f.xcd = (g_xpt_xcd_affinity != 0 && f.ntiles % 8 == 0 && f.nsplit % 8 == 0 && f.ct * f.nb == 1) ? 1 : 0;
+      const dim3 grid(f.ct * f.nb * f.nsplit);
+      hipStream_t st = (hipStream_t)stream;
+      XPT_BEGIN_LAUNCH();
+      if (upsample) hipLaunchKernelGGL((conv_wgrad_fast_kernel<3, 1, true>), grid, dim3(256), 0, st, f);
+      else if (KH == 3 && stride == 1) hipLaunchKernelGGL((conv_wgrad_fast_kernel<3, 1, false>), grid, dim3(256), 0, st, f);
+      else if (KH == 3) hipLaunchKernelGGL((conv_wgrad_fast_kernel<3, 2, false>), grid, dim3(256), 0, st, f);
+      else hipLaunchKernelGGL((conv_wgrad_fast_kernel<5, 2, false>), grid, dim3(256), 0, st, f);
+      return xpt_launch_status();
+    }
+  }
   WgradPlan p;
   if (!make_plan(B, C, N, KH, KW, stride, OH, OW, p)) return XPT_ERR_ARG;
   if (partial_floats < (size_t)p.nsplit * N * KH * KW * Cr) return XPT_ERR_WORKSPACE;
