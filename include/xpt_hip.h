@@ -378,6 +378,9 @@ int xpt_conv2d_stream_serves(int B, int OH, int OW, int out_channels, int red_ch
 int xpt_conv2d_fwd_stream(const void* x, const void* w, const float* bias, void* y, int B, int PH, int PW, int C,
                           long long xpitch, int N, int pad_t, int pad_l, int OH, int OW, long long ypitch, int upsample,
                           float slope, void* stream);
+int xpt_conv2d_fwd_stream_k5s2(const void* x, const void* w, const float* bias, void* y, int B, int PH, int PW, int C,
+                               long long xpitch, int N, int pad_t, int pad_l, int OH, int OW, long long ypitch, float slope,
+                               void* stream);   /* 5 x 5 stride-2 forward (pose_net.py:60-61), served when xpt_conv2d_stream_serves says so */
 int xpt_conv2d_bwd_data_stream(const void* g, const void* wb, void* dx, int B, int OH, int OW, int Np, long long gpitch, int C,
                                int pad_t, int pad_l, int IH, int IW, long long dxpitch, int fold2x2, void* stream);
 int xpt_conv2d_bwd_weight_tune(int max_partial_mib, int target_blocks);

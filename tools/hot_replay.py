@@ -134,7 +134,7 @@ def work_of(name, a):
         B, OH, OW, Np, C, IH, IW = i(3), i(4), i(5), i(6), i(8), i(11), i(12)
         return (B * OH * OW * Np + B * IH * IW * C + Np * 9 * C) * 2, 2.0 * B * OH * OW * Np * 9 * C, f"dgrad {Np}->{C} k3 in {IH}x{IW}"
     if name == "xpt_conv2d_bwd_weight_partials":
-        pf, B, PH, PW, C, N, KH, KW, OH, OW = i(3), i(4), i(5), i(6), i(7), i(10), i(12), i(13), i(18), i(19)
+        pf, B, PH, PW, C, N, KH, KW, OH, OW = i(3), i(4), i(5), i(6), i(7), i(10), i(12), i(13), i(17), i(18)
         return (B * PH * PW * C + B * OH * OW * N) * 2 + pf * 4, 2.0 * B * OH * OW * N * KH * KW * C, f"wgrad {C}x{N} k{KH} out {OH}x{OW}"
     if name == "xpt_headconv_fwd":
         B, H, W, C = i(5), i(6), i(7), i(8)

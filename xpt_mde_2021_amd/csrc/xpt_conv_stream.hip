@@ -46,6 +46,7 @@ struct StArgs {
   int tiles_x, tiles_y, ntiles;
   int HR, WR, XP, WP;        // physical halo extent; LDS pitches in bytes per halo pixel / per weight row
   int xcd;                   // 1: tiles dealt image-major per XCD
+  int k5s2;                  // 1: 5 x 5 filter, stride 2, forward (specialised instantiation only)
 };
 
 template <int RM>
@@ -237,11 +238,13 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StArgs a) {
 template <int RM, int CC, int MODE>
 __global__ __launch_bounds__(256) void conv_stream_fast_kernel(StArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sl[];
+  // MODE 4: forward of a 5 x 5 stride-2 layer (PoseNetImproved's first two convolutions, pose_net.py:60-61)
   constexpr bool UPS = MODE == 1, QUAD = MODE == 3;
-  constexpr int SGN = MODE >= 2 ? -1 : 1, BACK = MODE >= 2 ? 2 : 0;
-  constexpr int TN = 32 * RM, Cc = 16 * CC, cvp = 2 * CC, XP = Cc * 2 + 16, WP = 9 * Cc * 2 + 16;
-  constexpr int HR = UPS ? 6 : 10, WR = UPS ? 10 : 18, HPIX = HR * WR, NV = (HPIX * cvp + 255) / 256;
-  constexpr bool AREG = RM * CC * 9 <= 18;           // the lane's weight fragments stay in registers
+  constexpr int KK = MODE == 4 ? 5 : 3, SS = MODE == 4 ? 2 : 1, TT = KK * KK;
+  constexpr int SGN = (MODE == 2 || MODE == 3) ? -1 : 1, BACK = (MODE == 2 || MODE == 3) ? 2 : 0;
+  constexpr int TN = 32 * RM, Cc = 16 * CC, cvp = 2 * CC, XP = Cc * 2 + 16, WP = TT * Cc * 2 + 16;
+  constexpr int HR = UPS ? 6 : 7 * SS + KK, WR = UPS ? 10 : 15 * SS + KK, HPIX = HR * WR, NV = (HPIX * cvp + 255) / 256;
+  constexpr bool AREG = RM * CC * TT <= 18;          // the lane's weight fragments stay in registers
   unsigned char* const lW = sl;
   unsigned char* const lX = sl + TN * WP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -253,12 +256,12 @@ __global__ __launch_bounds__(256) void conv_stream_fast_kernel(StArgs a) {
 
   // ---- the weight slab, once
   {
-    constexpr unsigned per_row = 9u * cvp, nvec = (unsigned)TN * per_row;
+    constexpr unsigned per_row = (unsigned)TT * cvp, nvec = (unsigned)TN * per_row;
     for (unsigned v = tid; v < nvec; v += 256) {
       const unsigned n = v / per_row, rest = v - n * per_row;      // (compile-time divisors)
       const unsigned tap = rest / cvp, cv = rest - tap * cvp;
       const bool ok = (int)n < a.N && (int)(cv * 8) < a.C;
-      const unsigned off = ok ? ((n * 9u + tap) * (unsigned)a.C + cv * 8) * 2u : ST_OOB;
+      const unsigned off = ok ? ((n * (unsigned)TT + tap) * (unsigned)a.C + cv * 8) * 2u : ST_OOB;
       *(u32x4*)(lW + n * WP + (tap * Cc + cv * 8) * 2) = __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0);
     }
   }
@@ -290,21 +293,21 @@ __global__ __launch_bounds__(256) void conv_stream_fast_kernel(StArgs a) {
     ty = 2 * wave + (r >> 4);
     tx = r & 15;
   }
-  unsigned bofs[3][3];
+  // nearest-2x input: nine lane constants (the source row of an output row depends on its parity); otherwise ONE lane constant,
+  // the taps are instruction immediates
+  unsigned bofs[UPS ? 3 : 1][UPS ? 3 : 1];
+  if constexpr (UPS) {
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      int prow, pcol;
-      if (UPS) {        // tiles start at even rows / columns: ((oh0 + t) >> 1) - (oh0 + off >> 1) does not depend on oh0
-        prow = ((ty + a.off_h + kh) >> 1) - (a.off_h >> 1);
-        pcol = ((tx + a.off_w + kw) >> 1) - (a.off_w >> 1);
-      } else {
-        prow = ty + SGN * kh + BACK;
-        pcol = tx + SGN * kw + BACK;
+      for (int kw = 0; kw < 3; ++kw) {
+        // tiles start at even rows / columns: ((oh0 + t) >> 1) - (oh0 + off >> 1) does not depend on oh0
+        const int prow = ((ty + a.off_h + kh) >> 1) - (a.off_h >> 1), pcol = ((tx + a.off_w + kw) >> 1) - (a.off_w >> 1);
+        bofs[kh][kw] = (unsigned)(TN * WP + (prow * WR + pcol) * XP + h * 16);
       }
-      bofs[kh][kw] = (unsigned)(TN * WP + (prow * WR + pcol) * XP + h * 16);
-    }
+  } else {
+    bofs[0][0] = (unsigned)(TN * WP + ((ty * SS + BACK) * WR + tx * SS + BACK) * XP + h * 16);
+  }
   const unsigned wofs = (unsigned)(r * WP + h * 16);
   const unsigned yp2 = (unsigned)(a.ypitch * 2);
   const unsigned yconst = QUAD ? ((unsigned)((ty >> 1) * (a.OW >> 1) + (tx >> 1)) * yp2 + 8u * h)
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(256) void conv_stream_fast_kernel(StArgs a) {
     int b, oh0, ow0;
     tile_of(t, b, oh0, ow0);
     b = __builtin_amdgcn_readfirstlane(b); oh0 = __builtin_amdgcn_readfirstlane(oh0); ow0 = __builtin_amdgcn_readfirstlane(ow0);
-    const int plo_h = (oh0 + a.off_h - BACK) >> (UPS ? 1 : 0), plo_w = (ow0 + a.off_w - BACK) >> (UPS ? 1 : 0);
+    const int plo_h = (oh0 * SS + a.off_h - BACK) >> (UPS ? 1 : 0), plo_w = (ow0 * SS + a.off_w - BACK) >> (UPS ? 1 : 0);
     const bool inside = plo_h >= 0 && plo_h + HR <= a.PH && plo_w >= 0 && plo_w + WR <= a.PW;      // (uniform)
     if (inside) {
       const unsigned soff = (unsigned)((b * a.PH + plo_h) * a.PW + plo_w) * pitch2;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_stream_fast_kernel(StArgs a) {
     }
   };
 
-  u32x4 fareg[AREG ? 9 : 1][AREG ? CC : 1][AREG ? RM : 1];
+  u32x4 fareg[AREG ? TT : 1][AREG ? CC : 1][AREG ? RM : 1];
   bool have_a = false;
   int t = (int)blockIdx.x;
   if (t < a.ntiles) fetch(t);
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void conv_stream_fast_kernel(StArgs a) {
     __syncthreads();
     if (AREG && !have_a) {                               // (the slab is in LDS behind the first barrier pair)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
+      for (int tap = 0; tap < TT; ++tap)
 #pragma unroll
         for (int k = 0; k < CC; ++k)
 #pragma unroll
@@ -382,16 +385,17 @@ __global__ __launch_bounds__(256) void conv_stream_fast_kernel(StArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int kh = 0; kh < KK; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw)
+      for (int kw = 0; kw < KK; ++kw)
 #pragma unroll
         for (int k = 0; k < CC; ++k) {
-          const u32x4 fb = *(const u32x4*)(sl + bofs[kh][kw] + 32 * k);
+          const u32x4 fb = UPS ? *(const u32x4*)(sl + bofs[UPS ? kh : 0][UPS ? kw : 0] + 32 * k)
+                               : *(const u32x4*)(sl + bofs[0][0] + (SGN * (kh * WR + kw)) * XP + 32 * k);
 #pragma unroll
           for (int i = 0; i < RM; ++i) {
-            const u32x4 fa = AREG ? fareg[AREG ? kh * 3 + kw : 0][AREG ? k : 0][AREG ? i : 0]
-                                  : *(const u32x4*)(sl + wofs + 32 * i * WP + ((kh * 3 + kw) * Cc + 16 * k) * 2);
+            const u32x4 fa = AREG ? fareg[AREG ? kh * KK + kw : 0][AREG ? k : 0][AREG ? i : 0]
+                                  : *(const u32x4*)(sl + wofs + 32 * i * WP + ((kh * KK + kw) * Cc + 16 * k) * 2);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc[i],
                                                              0, 0, 0);
           }
@@ -447,16 +451,18 @@ bool st_plan(StArgs& a, int& rm, size_t& lds) {
   a.tiles_x = (a.OW + 15) / 16;
   a.tiles_y = (a.OH + 7) / 8;
   const long long nt = (long long)a.B * a.tiles_y * a.tiles_x;
-  if (nt < g_st_min_tiles || nt > 0x3fffffffLL) return false;
+  // (the 5 x 5 stride-2 layers are served from 128 tiles on: no second tile to amortise the slab over, but 25 taps as immediates)
+  if (nt < (a.k5s2 && g_st_min_tiles > 128 ? 128 : g_st_min_tiles) || nt > 0x3fffffffLL) return false;
   a.ntiles = (int)nt;
-  const int rows = 8 + 2, cols = 16 + 2;
+  const int rows = a.k5s2 ? 7 * 2 + 5 : 8 + 2, cols = a.k5s2 ? 15 * 2 + 5 : 16 + 2;
   a.HR = a.shift ? rows / 2 + 1 : rows;
   a.WR = a.shift ? cols / 2 + 1 : cols;
   a.XP = a.Cc * 2 + 16;
-  a.WP = 9 * a.Cc * 2 + 16;
-  if (a.HR * a.WR * (a.Cc / 8) > 256 * ST_MAXV) return false;
+  a.WP = (a.k5s2 ? 25 : 9) * a.Cc * 2 + 16;
+  if (a.k5s2 && (rm != 1 || a.Cc > 32 || a.shift || a.quad || a.sgn < 0 || !g_st_fast)) return false;      // (two instantiations exist)
+  if (!a.k5s2 && a.HR * a.WR * (a.Cc / 8) > 256 * ST_MAXV) return false;
   lds = (size_t)32 * rm * a.WP + (size_t)a.HR * a.WR * a.XP;
-  if (lds > (size_t)g_st_max_lds) return false;
+  if (lds > (a.k5s2 && g_st_max_lds < 128 * 1024 ? (size_t)128 * 1024 : (size_t)g_st_max_lds)) return false;
   if (a.xbytes >= (1LL << 30) || a.wbytes >= (1LL << 30)) return false;
   return true;
 }
@@ -486,13 +492,18 @@ int launch_st(StArgs& a, int rm, size_t lds, hipStream_t s) {
   a.xcd = (g_xpt_xcd_affinity != 0 && a.ntiles % 8 == 0 && grid % 8 == 0) ? 1 : 0;
   XPT_BEGIN_LAUNCH();
   // the specialised instantiations: the decoder's half- / full-resolution layers (forward and data gradient)
-  const int mode = a.sgn > 0 ? (a.shift ? 1 : 0) : (a.quad ? 3 : 2), cc = a.Cc / 16;
+  const int mode = a.k5s2 ? 4 : (a.sgn > 0 ? (a.shift ? 1 : 0) : (a.quad ? 3 : 2)), cc = a.Cc / 16;
   const bool fast_ok = g_st_fast && a.N % 8 == 0 && a.ypitch % 4 == 0 && ((uintptr_t)a.y) % 8 == 0 && a.ybytes < (1LL << 30) &&
                        a.slope >= 0.f && a.slope <= 1.f && (!a.shift || (a.off_h == -1 && a.off_w == -1));
 #define ST_FAST(RM_, CC_, MODE_)                                                                                        \
   if (fast_ok && rm == RM_ && cc == CC_ && mode == MODE_) {                                                               \
     hipLaunchKernelGGL((conv_stream_fast_kernel<RM_, CC_, MODE_>), dim3(grid), dim3(256), lds, s, a);                      \
     return xpt_launch_status();                                                                                           \
+  }
+  if (a.k5s2) {                                                           // PoseNetImproved conv1 (15 -> 32) / conv2 (32 -> 32)
+    if (!fast_ok) return XPT_ERR_ARG;
+    ST_FAST(1, 1, 4) ST_FAST(1, 2, 4)
+    return XPT_ERR_ARG;
   }
   ST_FAST(1, 4, 1) ST_FAST(1, 5, 0) ST_FAST(1, 2, 1) ST_FAST(1, 2, 0)      // dp_up1_conv1 / conv2, dp_up0_conv1 / conv2
   ST_FAST(2, 2, 3) ST_FAST(3, 2, 2) ST_FAST(1, 1, 3) ST_FAST(1, 1, 2)      // their data gradients
@@ -522,9 +533,10 @@ extern "C" int xpt_conv2d_stream_tune(int enable, int min_tiles, int wgs_per_cu,
  * the launch enumerates -- data gradient with fold2x2: B x 2 IH x 2 IW --, out / red channels of THAT launch), else 0. */
 extern "C" int xpt_conv2d_stream_serves(int B, int OH, int OW, int out_channels, int red_channels, int KH, int KW, int stride,
                                         int upsample_or_fold) {
-  if (KH != 3 || KW != 3 || stride != 1 || B <= 0 || OH <= 0 || OW <= 0) return 0;
+  const bool k5s2 = KH == 5 && KW == 5 && stride == 2 && !upsample_or_fold;
+  if ((!(KH == 3 && KW == 3 && stride == 1) && !k5s2) || B <= 0 || OH <= 0 || OW <= 0) return 0;
   StArgs a{};
-  a.B = B; a.OH = OH; a.OW = OW; a.N = out_channels; a.C = red_channels; a.shift = 0; a.quad = 0;
+  a.B = B; a.OH = OH; a.OW = OW; a.N = out_channels; a.C = red_channels; a.shift = 0; a.quad = 0; a.sgn = 1; a.k5s2 = k5s2;
   // (forward with a nearest-2x input: smaller halo; data gradient with the fold: quad -- the worst case of the two decides)
   a.xbytes = 1; a.wbytes = 1;
   if (upsample_or_fold && ((OH | OW) & 1)) return 0;
@@ -551,6 +563,31 @@ extern "C" int xpt_conv2d_fwd_stream(const void* x, const void* w, const float* 
   a.sgn = 1; a.off_h = -pad_t; a.off_w = -pad_l;
   a.OH = OH; a.OW = OW; a.quad = 0; a.slope = slope;
   if ((long long)(OH - 1) - pad_t >= a.Hlim || (long long)(OW - 1) - pad_l >= a.Wlim) return XPT_ERR_SHAPE;
+  int rm; size_t lds;
+  if (!st_plan(a, rm, lds)) return XPT_ERR_ARG;
+  return launch_st(a, rm, lds, (hipStream_t)stream);
+}
+
+/* the same for a 5 x 5 stride-2 layer (PoseNetImproved's first two convolutions, pose_net.py:60-61); upsample must be 0 */
+extern "C" int xpt_conv2d_fwd_stream_k5s2(const void* x, const void* w, const float* bias, void* y, int B, int PH, int PW, int C,
+                                          long long xpitch, int N, int pad_t, int pad_l, int OH, int OW, long long ypitch, float slope,
+                                          void* stream) {
+  XPT_CHECK_PTR(x); XPT_CHECK_PTR(w); XPT_CHECK_PTR(y);
+  if (B <= 0 || PH <= 0 || PW <= 0 || C <= 0 || N <= 0 || OH <= 0 || OW <= 0) return XPT_ERR_SHAPE;
+  if (C % 8 != 0 || xpitch < C || xpitch % 8 != 0 || ypitch < N || ((uintptr_t)x) % 16 != 0 || ((uintptr_t)w) % 16 != 0)
+    return XPT_ERR_ARG;
+  if (pad_t < 0 || pad_l < 0) return XPT_ERR_ARG;
+  StArgs a{};
+  a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias; a.y = (unsigned short*)y;
+  a.xpitch = xpitch; a.ypitch = ypitch;
+  a.xbytes = ((long long)B * PH * PW - 1) * xpitch * 2 + (long long)C * 2;
+  a.wbytes = (long long)N * 25 * C * 2;
+  a.ybytes = ((long long)B * OH * OW - 1) * ypitch * 2 + (long long)N * 2;
+  a.B = B; a.PH = PH; a.PW = PW; a.shift = 0; a.Hlim = PH; a.Wlim = PW;
+  a.C = C; a.N = N;
+  a.sgn = 1; a.off_h = -pad_t; a.off_w = -pad_l;
+  a.OH = OH; a.OW = OW; a.quad = 0; a.slope = slope; a.k5s2 = 1;
+  if ((long long)(OH - 1) * 2 - pad_t >= PH || (long long)(OW - 1) * 2 - pad_l >= PW) return XPT_ERR_SHAPE;
   int rm; size_t lds;
   if (!st_plan(a, rm, lds)) return XPT_ERR_ARG;
   return launch_st(a, rm, lds, (hipStream_t)stream);

@@ -646,10 +646,10 @@ __device__ inline void dw_bwd_weight_body(const T* __restrict__ x, const T* __re
     for (int i = wid * RG + rg; i < GRP; i += 4 * RG) {
       const long long g = g0 + i;
       if (g >= ngrp) break;
-      const int oxg = (int)(g % OXG);
-      const long long r = g / OXG;
-      const int oy = (int)(r % d.OH);
-      const int b = (int)(r / d.OH);
+      // (ngrp < 2^31: the launchers' grids are 32-bit; three 64-bit divisions were ~360 of this loop body's ~560 instructions)
+      unsigned oxg_u, oy_u;
+      const int b = (int)xpt_divmod(xpt_divmod((unsigned)g, (unsigned)OXG, oxg_u), (unsigned)d.OH, oy_u);
+      const int oxg = (int)oxg_u, oy = (int)oy_u;
       const int ox0 = oxg * OXT;
       const int ix0 = ox0 * S - d.pad_l;
       float gy[OXT];

@@ -210,7 +210,12 @@ class _Conv2dSame(torch.autograd.Function):
                                                  y.data_ptr(), B, PH, PW, Cp, xpitch, N, KH, KW, pt, pl, OH, OW, N,
                                                  int(upsample), float(slope), ws.data_ptr(), wsf, _stream()),
                        "xpt_conv2d_fwd_splitk")
-        elif not valid and lib.xpt_conv2d_stream_serves(B, OH, OW, N, Cp, KH, KW, stride, int(upsample)):
+        elif not valid and KH == 5 and lib.xpt_conv2d_stream_serves(B, OH, OW, N, Cp, KH, KW, stride, int(upsample)):
+            # PoseNet's 5 x 5 stride-2 layers on the large maps: the same persistent kernel, specialised
+            _lib.check(lib.xpt_conv2d_fwd_stream_k5s2(x.data_ptr(), e["fwd"].data_ptr(), None if b_ is None else b_.data_ptr(),
+                                                      y.data_ptr(), B, PH, PW, Cp, xpitch, N, pt, pl, OH, OW, N, float(slope),
+                                                      _stream()), "xpt_conv2d_fwd_stream_k5s2")
+        elif not valid and KH == 3 and lib.xpt_conv2d_stream_serves(B, OH, OW, N, Cp, KH, KW, stride, int(upsample)):
             # 3 x 3 layers of the half- / full-resolution levels: persistent workgroups, weights staged once
             _lib.check(lib.xpt_conv2d_fwd_stream(x.data_ptr(), e["fwd"].data_ptr(), None if b_ is None else b_.data_ptr(),
                                                  y.data_ptr(), B, PH, PW, Cp, xpitch, N, pt, pl, OH, OW, N, int(upsample),
@@ -284,7 +289,7 @@ class _Conv2dSame(torch.autograd.Function):
                 _lib.check(lib.xpt_conv2d_bwd_data_splitk(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"],
                                                           gpitch, Cp, KH, KW, pt, pl, PH, PW, Cp, ups, ws.data_ptr(), wsf,
                                                           _stream()), "xpt_conv2d_bwd_data_splitk")
-            elif lib.xpt_conv2d_stream_serves(B, PH << ups, PW << ups, Cp, e["Np"], KH, KW, stride, ups):
+            elif KH == 3 and lib.xpt_conv2d_stream_serves(B, PH << ups, PW << ups, Cp, e["Np"], KH, KW, stride, ups):
                 _lib.check(lib.xpt_conv2d_bwd_data_stream(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"],
                                                           gpitch, Cp, pt, pl, PH, PW, Cp, ups, _stream()),
                            "xpt_conv2d_bwd_data_stream")

@@ -155,6 +155,8 @@ SIGNATURES = {
     "xpt_conv2d_stream_serves": (_i, [_i] * 9),
     "xpt_conv2d_fwd_stream": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, ctypes.c_longlong,
                                    _i, _f, _p]),
+    "xpt_conv2d_fwd_stream_k5s2": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, ctypes.c_longlong,
+                                        _f, _p]),
     "xpt_conv2d_bwd_data_stream": (_i, [_p, _p, _p, _i, _i, _i, _i, ctypes.c_longlong, _i, _i, _i, _i, _i, ctypes.c_longlong,
                                         _i, _p]),
     "xpt_conv2d_bwd_weight_tune": (_i, [_i, _i]),
