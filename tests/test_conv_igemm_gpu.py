@@ -67,7 +67,8 @@ def conv_plan():
         elif plan >= 5000:        # 5000 + n: the split-K kernels (csrc/xpt_conv_splitk.hip) with n slices on EVERY stride-1 layer
             _lib.check(lib.xpt_conv2d_tune(0), "tune")
             _lib.check(lib.xpt_conv2d_stream_tune(0, 0, 0, 0), "stream tune")
-            _lib.check(lib.xpt_conv2d_splitk_tune(1, plan - 5000, 1, 1 << 30), "splitk tune")
+            # (5100 + n: four waves per workgroup instead of eight on the 128-channel tile)
+            _lib.check(lib.xpt_conv2d_splitk_tune(4 if plan >= 5100 else 8, plan % 100, 1, 1 << 30), "splitk tune")
         else:                     # the kernels of csrc/xpt_conv.hip, one instantiation forced
             _lib.check(lib.xpt_conv2d_splitk_tune(0, 0, 0, 0), "splitk tune")
             _lib.check(lib.xpt_conv2d_stream_tune(0, 0, 0, 0), "stream tune")
@@ -76,7 +77,7 @@ def conv_plan():
     yield set_plan
     lib.xpt_conv2d_bwd_weight_tune(-1000, 1)
     lib.xpt_conv2d_tune(0)
-    lib.xpt_conv2d_splitk_tune(1, 0, 1024, 8192)
+    lib.xpt_conv2d_splitk_tune(8, 0, 1024, 8192)
     lib.xpt_conv2d_stream_tune(1, 512, 3, 80)
 
 
@@ -87,7 +88,7 @@ def conv_plan():
 # 5001 / 5002 / 5008 / 5016: the split-K tile kernels (1 / 2 / 8 / 16 slices of the reduction axis) on every stride-1 layer
 # 6001 / 6003 / 6102: the persistent weight-stationary kernels, 1 / 3 workgroups per CU (6102: generic kernel only, 2 per CU), on
 # every 3 x 3 stride-1 layer that fits
-@pytest.mark.parametrize("plan", [0, 901, 902, 110, 911, 912, 5001, 5002, 5008, 5016, 6001, 6003, 6102, 7002])
+@pytest.mark.parametrize("plan", [0, 901, 902, 110, 911, 912, 5001, 5002, 5008, 5016, 5104, 6001, 6003, 6102, 7002])
 @pytest.mark.parametrize("batch", [2])
 def test_conv_fwd_bwd_matches_fp32_reference(gpu_device, conv_plan, cin, cout, k, stride, H, W, ups, batch, plan):
     from xpt_mde_2021_amd.hip import conv as xc

@@ -109,7 +109,15 @@ for name, cin, cout, H, W, ups in LAYERS:
     for force in (() if ONE else (4, 8, 16)):                # the tile kernel alone (enable = 2: no finishing launch)
         lib.xpt_conv2d_splitk_tune(2, force, 1, 1 << 30)
         tile_only.append(f"{timeit(new_f):5.1f}/{timeit(new_d):5.1f}")
-    lib.xpt_conv2d_splitk_tune(1, 0, 1024, 8192)
+    w4 = []
+    for force in (() if ONE else (0,)):                      # four waves per workgroup (the default is eight on the 128-channel tile)
+        lib.xpt_conv2d_splitk_tune(4, force, 1, 1 << 30)
+        try:
+            w4.append(f"{timeit(new_f):5.1f}/{timeit(new_d):5.1f}")
+        except _lib.XptHipError:
+            w4.append("n/a")
+    lib.xpt_conv2d_splitk_tune(8, 0, 1024, 8192)
+    print(f"        4 waves per workgroup (auto slices): " + " | ".join(w4))
     print(f"        tile kernel alone, 4 / 8 / 16 slices: " + " | ".join(tile_only))
     if ONE:
         break

@@ -1,6 +1,7 @@
-set -e
 R=$PWD
 mkdir -p gpurun_out/final
+# (the rocprofv3 output directories are hundreds of MB: always removed, whatever fails in between -- gpurun merges back at most 64 MiB)
+trap 'rm -rf $R/gpurun_out/final/trace $R/gpurun_out/final/pmc' EXIT
 timeout -k 10 500 python bench.py > gpurun_out/final/bench_line.json 2> gpurun_out/final/bench_stderr.log
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/trace -- python $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-roofline --no-host-fed > $R/gpurun_out/final/trace.log 2>&1

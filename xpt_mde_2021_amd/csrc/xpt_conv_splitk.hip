@@ -40,16 +40,21 @@ struct SkArgs {
   int tiles_m, tiles_n;
 };
 
-// TN = 64 * WN output channels per workgroup; the four waves are (2 pixel halves) x (2 channel halves)
-template <int RN>   // 32-channel tiles per wave: 2 (TN = 128) or 1 (TN = 64)
-__global__ __launch_bounds__(256) void conv_splitk_kernel(SkArgs a) {
+// TN = 64 RN output channels per workgroup.  NW = 4 waves: (2 pixel halves) x (2 channel halves), RN 32-channel tiles per
+// wave; NW = 8 waves (TN = 128 only): (2 pixel halves) x (4 channel quarters), one tile per wave -- two waves per SIMD, so that
+// one wave's LDS / barrier / staging latencies are another wave's issue slots.
+template <int RN, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(SkArgs a) {
   constexpr int TN = 64 * RN, TP = 128, PITCH = 64 * 2 + 16;
+  constexpr int NT = 64 * NW, RPP = 8 * NW, APASS = TN / RPP, BPASS = TP / RPP;   // staging: rows per pass, passes per operand
+  constexpr int WI = NW == 4 ? RN : 1;                                            // 32-channel tiles per wave
+  static_assert(NW == 4 || (NW == 8 && RN == 2), "8 waves: the 128-channel tile only");
   __shared__ __attribute__((aligned(16))) unsigned char lds[(TN + TP) * PITCH];
   unsigned char* const lA = lds;
   unsigned char* const lB = lds + TN * PITCH;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
 
   // ---- which (split, tile) this workgroup is: workgroups are dealt round-robin over the 8 XCDs
   const unsigned bid = blockIdx.x;
@@ -99,12 +104,12 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(SkArgs a) {
   // wave against 304 MFMAs -- one wave per SIMD issues an instruction every ~4.5 cycles, the launch was bound by the address
   // arithmetic of its own staging: 26 us whatever the slice count.)
   const int sp = tid & 7, srow = tid >> 3;
-  int sb[4], base_h[4], base_w[4];
-  bool sok[4];
+  int sb[BPASS], base_h[BPASS], base_w[BPASS];
+  bool sok[BPASS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < BPASS; ++i) {
     int b, oh, ow;
-    sok[i] = decode(m0 + srow + 32 * i, b, oh, ow);
+    sok[i] = decode(m0 + srow + RPP * i, b, oh, ow);
     sb[i] = b;
     base_h[i] = oh + a.off_h;
     base_w[i] = ow + a.off_w;
@@ -114,18 +119,18 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(SkArgs a) {
   // image and a piece past the slice get an offset beyond the buffer (markers of 1 GiB each: their sums cannot wrap, the
   // launcher refuses operands of 1 GiB or more) and come back as 0 -- no masks, no selects on the loaded vectors.
   constexpr unsigned OOB = 0x40000000u;
-  unsigned wro[2 * RN];                       // byte offset of weight row n0 + srow + 32 i
+  unsigned wro[APASS];                        // byte offset of weight row n0 + srow + RPP i
 #pragma unroll
-  for (int i = 0; i < 2 * RN; ++i) {
-    const int n = n0 + srow + 32 * i;
+  for (int i = 0; i < APASS; ++i) {
+    const int n = n0 + srow + RPP * i;
     wro[i] = n < a.N ? (unsigned)n * (unsigned)(T * a.C) * 2u : OOB;
   }
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)a.wbytes, 0x00020000);
 
-  f32x16 acc[RN][2];
+  f32x16 acc[WI][2];
 #pragma unroll
-  for (int i = 0; i < RN; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -139,12 +144,12 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(SkArgs a) {
     it = (int)(((float)pcl + 0.5f) * inv_cp8);
     c0 = (pcl - it * cp8) * 8;
   }
-  unsigned xo[4];                             // byte offset of pixel row i at the current tap (channel 0), OOB outside the image
+  unsigned xo[BPASS];                         // byte offset of pixel row i at the current tap (channel 0), OOB outside the image
   auto set_tap = [&]() {
     const int kh = (int)(((float)it + 0.5f) * inv_kw);
     const int kw = it - kh * a.KW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BPASS; ++i) {
       const int th = base_h[i] + a.sgn * kh, tw = base_w[i] + a.sgn * kw;
       const bool ok = sok[i] && th >= 0 && th < a.Hlim && tw >= 0 && tw < a.Wlim;
       const int row = th >> a.shift, col = tw >> a.shift;
@@ -155,15 +160,15 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(SkArgs a) {
 
   // Two register sets: the loads of chunks ck + 1 and ck + 2 are in flight while chunk ck is multiplied.
   struct Stage {
-    u32x4 ra[2 * RN], rb[4];
+    u32x4 ra[APASS], rb[BPASS];
   };
   auto fetch = [&](Stage& st) {               // the thread's next piece
     const unsigned dead = pc < p_end ? 0u : OOB;
     const unsigned cb = (unsigned)(it * a.C + c0) * 2u + dead, xb = (unsigned)c0 * 2u + dead;
 #pragma unroll
-    for (int i = 0; i < 2 * RN; ++i) st.ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, wro[i] + cb, 0, 0);
+    for (int i = 0; i < APASS; ++i) st.ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, wro[i] + cb, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st.rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo[i] + xb, 0, 0);
+    for (int i = 0; i < BPASS; ++i) st.rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo[i] + xb, 0, 0);
     pc += 8;
     c0 += 64;
     if (c0 >= a.C) {                          // next tap (per thread: the 8 piece slots of a chunk may straddle two taps)
@@ -177,27 +182,27 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(SkArgs a) {
   };
   auto stash = [&](const Stage& st) {
 #pragma unroll
-    for (int i = 0; i < 2 * RN; ++i) *(u32x4*)(lA + (srow + 32 * i) * PITCH + sp * 16) = st.ra[i];
+    for (int i = 0; i < APASS; ++i) *(u32x4*)(lA + (srow + RPP * i) * PITCH + sp * 16) = st.ra[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *(u32x4*)(lB + (srow + 32 * i) * PITCH + sp * 16) = st.rb[i];
+    for (int i = 0; i < BPASS; ++i) *(u32x4*)(lB + (srow + RPP * i) * PITCH + sp * 16) = st.rb[i];
   };
   const unsigned char* const fB = lB + (wm * 64 + r) * PITCH + h * 16;
-  const unsigned char* const fA = lA + (wn * 32 * RN + r) * PITCH + h * 16;
+  const unsigned char* const fA = lA + (wn * 32 * WI + r) * PITCH + h * 16;
   // all 16 reduction-element steps of a chunk unconditionally (pieces past the slice were staged as zeros): straight-line
   // code, every fragment read of the chunk in flight before the first MFMA waits for its operands
   auto multiply = [&]() {
-    u32x4 fb[4][2], fa[4][RN];
+    u32x4 fb[4][2], fa[4][WI];
 #pragma unroll
     for (int k16 = 0; k16 < 4; ++k16) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) fb[k16][j] = *(const u32x4*)(fB + 32 * j * PITCH + k16 * 32);
 #pragma unroll
-      for (int i = 0; i < RN; ++i) fa[k16][i] = *(const u32x4*)(fA + 32 * i * PITCH + k16 * 32);
+      for (int i = 0; i < WI; ++i) fa[k16][i] = *(const u32x4*)(fA + 32 * i * PITCH + k16 * 32);
     }
 #pragma unroll
     for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
-      for (int i = 0; i < RN; ++i)
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[k16][i]), __builtin_bit_cast(bf16x8, fb[k16][j]),
@@ -239,10 +244,10 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(SkArgs a) {
     const long long m = m0 + 64 * wm + 32 * j + r;
     if (m >= a.M) continue;
 #pragma unroll
-    for (int i = 0; i < RN; ++i) {
+    for (int i = 0; i < WI; ++i) {
 #pragma unroll
       for (int qg = 0; qg < 4; ++qg) {
-        const int n = n0 + 32 * RN * wn + 32 * i + 8 * qg + 4 * h;
+        const int n = n0 + 32 * WI * wn + 32 * i + 8 * qg + 4 * h;
         if (n >= a.N) continue;
         float* dst = out + m * a.N + n;
         if (vec_ok) {
@@ -309,6 +314,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
 }
 
 int g_sk_skip_finish = 0;      // lab: launch the tile kernel only
+int g_sk_waves = 8;             // waves per workgroup of the 128-channel tile (4 or 8)
 int g_sk_enable = 1;            // 0: the split-K path answers "not served" for every layer
 int g_sk_force_split = 0;       // > 0: this many slices whatever the shape (lab)
 int g_sk_min_k = 1024;          // serve layers with at least this many reduction elements ...
@@ -365,8 +371,9 @@ int launch_sk(SkArgs& a, const SkPlan& p, const float* bias, unsigned short* y, 
   }
   if (blocks > 0x7fffffffLL) return XPT_ERR_SHAPE;
   XPT_BEGIN_LAUNCH();
-  if (p.rn == 2) hipLaunchKernelGGL(conv_splitk_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(conv_splitk_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  if (p.rn == 2 && g_sk_waves == 8) hipLaunchKernelGGL((conv_splitk_kernel<2, 8>), dim3((unsigned)blocks), dim3(512), 0, s, a);
+  else if (p.rn == 2) hipLaunchKernelGGL((conv_splitk_kernel<2, 4>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_splitk_kernel<1, 4>), dim3((unsigned)blocks), dim3(256), 0, s, a);
   const long long Mout = a.quad ? a.M / 4 : a.M;
   const long long threads = Mout * ((a.N + 3) / 4);
   if (g_sk_skip_finish) return xpt_launch_status();
@@ -390,6 +397,7 @@ extern "C" int xpt_conv2d_splitk_tune(int enable, int force_split, int min_k, in
   if (force_split < 0 || force_split > 16 || min_k < 0 || max_pixels < 0) return XPT_ERR_ARG;
   g_sk_enable = enable != 0;
   g_sk_skip_finish = enable == 2;      // (lab: 2 = tile kernel only, results are not finished)
+  if (enable >= 4) { g_sk_waves = enable; g_sk_enable = 1; }      // (lab: 4 / 8 = waves per workgroup of the 128-channel tile)
   g_sk_force_split = force_split;
   if (min_k > 0) g_sk_min_k = min_k;
   if (max_pixels > 0) g_sk_max_pixels = max_pixels;
