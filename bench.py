@@ -225,10 +225,19 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         sys.exit(launch_children(args))
-    # stdout carries exactly ONE line (the JSON); everything the model / loss factories print goes to stderr
+    # stdout carries exactly ONE line (the JSON); everything the model / loss factories print goes to stderr -- at the file
+    # descriptor level too: RCCL writes its version banner ("RCCL version : ...") to the C stdout when a process group starts
     import contextlib
-    with contextlib.redirect_stdout(sys.stderr):
-        result, world = run(args)
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            result, world = run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
     if result is not None:
         print(json.dumps(result), flush=True)
     if dist.is_available() and dist.is_initialized():
