@@ -71,13 +71,14 @@ __device__ inline int window_count(int y, int x, int H, int W) {
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void cell_tail_fwd_kernel(TailFwd a, T* __restrict__ out, long long out_pitch, int B, int H,
-                                                            int W, int F) {
+                                                            int W, int F, XcdSweep sw) {
   const int s = blockIdx.y;
   const int groups = F / V;
   const long long total = (long long)B * H * W * groups;
   const int nt = a.nterms[s];
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  long long idx, end;
+  if (!sw.range(blockIdx.x, total, idx, end)) return;
+  for (idx += threadIdx.x; idx < end; idx += 256) {
     unsigned c0_;
     long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
     const int c0 = (int)c0_ * V;
@@ -172,13 +173,14 @@ __device__ inline void masked_grad(const TailBwd& a, long long pix, long long ch
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void cell_tail_bwd_kernel(TailBwd a, int B, int H, int W, int F) {
+__global__ __launch_bounds__(256) void cell_tail_bwd_kernel(TailBwd a, int B, int H, int W, int F, XcdSweep sw) {
   const int job = blockIdx.y;
   const int groups = F / V;
   const long long total = (long long)B * H * W * groups;
   const long long gm_pitch = (long long)a.nslices * F;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  long long idx, end;
+  if (!sw.range(blockIdx.x, total, idx, end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (idx += threadIdx.x; idx < end; idx += 256) {
     unsigned c0_;
     long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
     const int c0 = (int)c0_ * V;
@@ -239,11 +241,12 @@ __global__ __launch_bounds__(256) void cell_tail_bwd_kernel(TailBwd a, int B, in
 // a pad backward and an accumulation in the backward.
 template <typename T, int V>
 __global__ __launch_bounds__(256) void adjust_gather_kernel(const T* __restrict__ in, long long in_pitch, T* __restrict__ out,
-                                                            int B, int H, int W, int C, int H2, int W2) {
+                                                            int B, int H, int W, int C, int H2, int W2, XcdSweep sw) {
   const int groups = C / V;
   const long long total = (long long)B * H2 * W2 * 2 * groups;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  long long idx, end;
+  if (!sw.range(blockIdx.x, total, idx, end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (idx += threadIdx.x; idx < end; idx += 256) {
     unsigned c0_;
     long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
     const int c0 = (int)c0_ * V;
@@ -266,11 +269,12 @@ __global__ __launch_bounds__(256) void adjust_gather_kernel(const T* __restrict_
 template <typename T, int V>
 __global__ __launch_bounds__(256) void adjust_scatter_kernel(const T* __restrict__ d1, long long pitch1,
                                                              const T* __restrict__ d2, long long pitch2, T* __restrict__ out,
-                                                             int B, int H, int W, int C, int H2, int W2) {
+                                                             int B, int H, int W, int C, int H2, int W2, XcdSweep sw) {
   const int groups = C / V;
   const long long total = (long long)B * H * W * groups;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  long long idx, end;
+  if (!sw.range(blockIdx.x, total, idx, end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (idx += threadIdx.x; idx < end; idx += 256) {
     unsigned c0_;
     long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
     const int c0 = (int)c0_ * V;
@@ -300,11 +304,12 @@ __global__ __launch_bounds__(256) void adjust_scatter_kernel(const T* __restrict
 template <typename T, int V>
 __global__ __launch_bounds__(256) void pool_pair_fwd_kernel(const T* __restrict__ in, long long in_pitch, T* __restrict__ mp,
                                                             T* __restrict__ ap, unsigned char* __restrict__ arg, int B, int H,
-                                                            int W, int C, int OH, int OW, int pad_t, int pad_l) {
+                                                            int W, int C, int OH, int OW, int pad_t, int pad_l, XcdSweep sw) {
   const int groups = C / V;
   const long long total = (long long)B * OH * OW * groups;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  long long idx, end;
+  if (!sw.range(blockIdx.x, total, idx, end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (idx += threadIdx.x; idx < end; idx += 256) {
     unsigned c0_;
     long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
     const int c0 = (int)c0_ * V;
@@ -344,11 +349,12 @@ __global__ __launch_bounds__(256) void pool_pair_bwd_kernel(const T* __restrict_
                                                             const T* __restrict__ gmp2, long long pitch_m2,
                                                             const T* __restrict__ gap, long long pitch_a,
                                                             const unsigned char* __restrict__ arg, T* __restrict__ dh, int B,
-                                                            int H, int W, int C, int OH, int OW, int pad_t, int pad_l) {
+                                                            int H, int W, int C, int OH, int OW, int pad_t, int pad_l, XcdSweep sw) {
   const int groups = C / V;
   const long long total = (long long)B * H * W * groups;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  long long idx, end;
+  if (!sw.range(blockIdx.x, total, idx, end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (idx += threadIdx.x; idx < end; idx += 256) {
     unsigned c0_;
     long long p = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
     const int c0 = (int)c0_ * V;
@@ -432,13 +438,12 @@ int xpt_cell_tail_fwd(int nslices, const int* nterms, const void* const* src, co
   }
   const long long total = (long long)B * H * W * (F / v);
   if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
-  long long gx = (total + 255) / 256;
-  if (gx > 4096) gx = 4096;
-  const dim3 grid((unsigned)gx, nslices);
+  const XcdSweep sw = xpt_xcd_sweep(total, 4096);
+  const dim3 grid(sw.grid, nslices);
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
 #define XPT_TAIL(T, V) \
-  hipLaunchKernelGGL((cell_tail_fwd_kernel<T, V>), grid, dim3(256), 0, st, a, (T*)out, out_pitch, B, H, W, F)
+  hipLaunchKernelGGL((cell_tail_fwd_kernel<T, V>), grid, dim3(256), 0, st, a, (T*)out, out_pitch, B, H, W, F, sw)
   if (dtype == 0) {
     if (v == 4) XPT_TAIL(float, 4);
     else if (v == 2) XPT_TAIL(float, 2);
@@ -495,12 +500,11 @@ int xpt_cell_tail_bwd(int ngrads, const void* const* grads, const long long* gpi
   }
   const long long total = (long long)B * H * W * (F / v);
   if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
-  long long gx = (total + 255) / 256;
-  if (gx > 4096) gx = 4096;
-  const dim3 grid((unsigned)gx, nslices + ndense);
+  const XcdSweep sw = xpt_xcd_sweep(total, 4096);
+  const dim3 grid(sw.grid, nslices + ndense);
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
-#define XPT_TAIL(T, V) hipLaunchKernelGGL((cell_tail_bwd_kernel<T, V>), grid, dim3(256), 0, st, a, B, H, W, F)
+#define XPT_TAIL(T, V) hipLaunchKernelGGL((cell_tail_bwd_kernel<T, V>), grid, dim3(256), 0, st, a, B, H, W, F, sw)
   if (dtype == 0) {
     if (v == 4) XPT_TAIL(float, 4);
     else if (v == 2) XPT_TAIL(float, 2);
@@ -525,12 +529,11 @@ int xpt_adjust_gather(const void* in, long long in_pitch, void* out, int B, int 
   while (v > 1 && !(C % v == 0 && aligned_for(in, in_pitch, v, esz) && aligned_for(out, C, v, esz))) v >>= 1;
   const long long total = (long long)B * H2 * W2 * 2 * (C / v);
   if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
-  long long gx = (total + 255) / 256;
-  if (gx > 8192) gx = 8192;
+  const XcdSweep sw = xpt_xcd_sweep(total, 8192);
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
 #define XPT_K(T, V) \
-  hipLaunchKernelGGL((adjust_gather_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)in, in_pitch, (T*)out, B, H, W, C, H2, W2)
+  hipLaunchKernelGGL((adjust_gather_kernel<T, V>), dim3(sw.grid), dim3(256), 0, st, (const T*)in, in_pitch, (T*)out, B, H, W, C, H2, W2, sw)
   if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
   else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
 #undef XPT_K
@@ -551,13 +554,12 @@ int xpt_adjust_scatter(const void* d1, long long pitch1, const void* d2, long lo
     v >>= 1;
   const long long total = (long long)B * H * W * (C / v);
   if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
-  long long gx = (total + 255) / 256;
-  if (gx > 8192) gx = 8192;
+  const XcdSweep sw = xpt_xcd_sweep(total, 8192);
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
 #define XPT_K(T, V)                                                                                                  \
-  hipLaunchKernelGGL((adjust_scatter_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)d1, pitch1, (const T*)d2, \
-                     pitch2, (T*)out, B, H, W, C, H2, W2)
+  hipLaunchKernelGGL((adjust_scatter_kernel<T, V>), dim3(sw.grid), dim3(256), 0, st, (const T*)d1, pitch1, (const T*)d2, \
+                     pitch2, (T*)out, B, H, W, C, H2, W2, sw)
   if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
   else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
 #undef XPT_K
@@ -578,13 +580,12 @@ int xpt_pool_pair_fwd(const void* in, long long in_pitch, void* mp, void* ap, vo
     v >>= 1;
   const long long total = (long long)B * OH * OW * (C / v);
   if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
-  long long gx = (total + 255) / 256;
-  if (gx > 8192) gx = 8192;
+  const XcdSweep sw = xpt_xcd_sweep(total, 8192);
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
 #define XPT_K(T, V)                                                                                                 \
-  hipLaunchKernelGGL((pool_pair_fwd_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)in, in_pitch, (T*)mp, \
-                     (T*)ap, (unsigned char*)arg, B, H, W, C, OH, OW, pad_t, pad_l)
+  hipLaunchKernelGGL((pool_pair_fwd_kernel<T, V>), dim3(sw.grid), dim3(256), 0, st, (const T*)in, in_pitch, (T*)mp, \
+                     (T*)ap, (unsigned char*)arg, B, H, W, C, OH, OW, pad_t, pad_l, sw)
   if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
   else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
 #undef XPT_K
@@ -613,13 +614,12 @@ int xpt_pool_pair_bwd2(const void* gmp, long long pitch_m, const void* gmp2, lon
     v >>= 1;
   const long long total = (long long)B * H * W * (C / v);
   if (total >= (1LL << 31)) return XPT_ERR_SHAPE;      // (the kernels split flat indices in 32 bits)
-  long long gx = (total + 255) / 256;
-  if (gx > 8192) gx = 8192;
+  const XcdSweep sw = xpt_xcd_sweep(total, 8192);
   hipStream_t st = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
 #define XPT_K(T, V)                                                                                                    \
-  hipLaunchKernelGGL((pool_pair_bwd_kernel<T, V>), dim3((unsigned)gx), dim3(256), 0, st, (const T*)gmp, pitch_m, (const T*)gmp2, \
-                     pitch_m2, (const T*)gap, pitch_a, (const unsigned char*)arg, (T*)dh, B, H, W, C, OH, OW, pad_t, pad_l)
+  hipLaunchKernelGGL((pool_pair_bwd_kernel<T, V>), dim3(sw.grid), dim3(256), 0, st, (const T*)gmp, pitch_m, (const T*)gmp2, \
+                     pitch_m2, (const T*)gap, pitch_a, (const unsigned char*)arg, (T*)dh, B, H, W, C, OH, OW, pad_t, pad_l, sw)
   if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
   else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
 #undef XPT_K

@@ -226,3 +226,86 @@ __device__ __forceinline__ void xpt_xcd_remap(bool on, unsigned& bx, unsigned& b
 }
 #endif
 inline bool xpt_xcd_ok(unsigned long long total) { return g_xpt_xcd_affinity != 0 && total % 8 == 0 && total >= 64; }
+
+// The same affinity for the row-sliced kernels of the encoder (pointwise / depthwise / cell kernels: activations are [M = B H W, C]
+// matrices).  A launch numbers its n units -- contiguous ranges of pixel rows, in row order -- along the FASTEST grid dimension,
+// padded to xpt_xcd_pad(n) workgroups; workgroup x of that dimension runs on XCD x % 8 (every other dimension's stride is a
+// multiple of 8) and takes unit xpt_xcd_unit(): XCD k gets the units [k n / 8, (k + 1) n / 8), i.e. the rows [k M / 8, (k + 1) M / 8)
+// -- image k of a batch of 8 -- in EVERY kernel of the chain, so what a layer wrote is still in the L2 its reader looks in.
+// Workgroups past their XCD's share return at once.  Pure renumbering: same results with the affinity off (unit = x).
+inline unsigned xpt_xcd_pad(unsigned long long n) { return (unsigned)((n + 7) & ~7ull); }
+// n / d for a divisor the host knows: m = xpt_magic(d), q = xpt_fastdiv(n, m); exact for n * d < 2^32 (workgroup decodes)
+inline unsigned xpt_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned xpt_fastdiv(unsigned n, unsigned m) { return m ? __umulhi(n, m) : n; }
+#endif
+
+// flat sweeps (element-wise kernels over pixel-major indices): workgroup x of the fastest grid dimension takes the indices
+// [u per, (u + 1) per) of its unit u instead of a grid-stride walk
+struct XcdSweep {
+  unsigned grid, units, per;      // workgroups to launch along x, units, consecutive indices per unit (a multiple of 256)
+  int on;
+#ifdef __HIPCC__
+  __device__ __forceinline__ bool range(unsigned x, long long total, long long& begin, long long& end) const;
+#endif
+};
+inline XcdSweep xpt_xcd_sweep(long long total, long long max_units, int threads = 256) {
+  XcdSweep s;
+  long long units = (total + threads - 1) / threads;
+  if (units > max_units) units = max_units;
+  if (units < 1) units = 1;
+  s.per = (unsigned)(((total + units - 1) / units + threads - 1) / threads * threads);
+  s.units = (unsigned)((total + s.per - 1) / s.per);
+  if (s.units < 1) s.units = 1;
+  s.on = g_xpt_xcd_affinity;
+  s.grid = s.on ? xpt_xcd_pad(s.units) : s.units;
+  return s;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ bool xpt_xcd_unit(bool on, unsigned x, unsigned n, unsigned& u) {
+  if (!on) {
+    u = x;
+    return x < n;
+  }
+  const unsigned k = x & 7u, q = x >> 3;
+  const unsigned lo = (k * n) >> 3, hi = ((k + 1u) * n) >> 3;
+  u = lo + q;
+  return u < hi;
+}
+// A 1-D grid of two classes of row-ordered segments (the depthwise backward launches: nA data-gradient segments of LA
+// workgroups, then nB weight-gradient segments of LB): the host launches nA * pad(LA) + nB * pad(LB) workgroups, workgroup x
+// gets the block number vb of the plain layout [segment][block] it stands for (XCD k: the k-th eighth of every segment).
+inline unsigned xpt_xcd_two_class_grid(int on, unsigned nA, unsigned LA, unsigned nB, unsigned LB) {
+  return on ? nA * xpt_xcd_pad(LA) + nB * xpt_xcd_pad(LB) : nA * LA + nB * LB;
+}
+__device__ __forceinline__ bool xpt_xcd_two_class(bool on, unsigned x, unsigned nA, unsigned LA, unsigned nB, unsigned LB,
+                                                  unsigned& vb) {
+  if (!on) {
+    vb = x;
+    return true;
+  }
+  const unsigned a8 = nA * ((LA + 7u) & ~7u);
+  const bool first = x < a8;
+  const unsigned L = first ? LA : LB, lin = first ? x : x - a8;
+  const unsigned c8 = (L + 7u) >> 3, k = lin & 7u, q = lin >> 3;
+  unsigned local;
+  const unsigned seg = xpt_divmod(q, c8, local);
+  const unsigned lo = (k * L) >> 3, hi = ((k + 1u) * L) >> 3;
+  vb = (first ? 0u : nA * LA) + seg * L + lo + local;
+  return lo + local < hi;
+}
+// the consecutive indices [begin, end) of block blk when `total` indices are dealt to nblocks blocks in multiples of 256
+__device__ __forceinline__ void xpt_chunk_range(unsigned blk, unsigned nblocks, long long total, long long& begin, long long& end) {
+  unsigned rem_;                                                 // (total < 2^31: the callers split these indices in 32 bits)
+  const unsigned per = (xpt_divmod((unsigned)total + nblocks - 1u, nblocks, rem_) + 255u) & ~255u;
+  begin = (long long)blk * per;
+  end = begin + per < total ? begin + per : total;
+}
+__device__ __forceinline__ bool XcdSweep::range(unsigned x, long long total, long long& begin, long long& end) const {
+  unsigned u;
+  if (!xpt_xcd_unit(on != 0, x, units, u)) return false;
+  begin = (long long)u * per;
+  end = begin + per < total ? begin + per : total;
+  return true;
+}
+#endif

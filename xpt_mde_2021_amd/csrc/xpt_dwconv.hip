@@ -35,11 +35,13 @@ struct DwDims {
 // y[b,oy,ox,c] = sum_{ky,kx} f(x[b, oy*S+ky-pad_t, ox*S+kx-pad_l, c]) * w[c,ky,kx],  f = relu or identity.
 template <typename T, int K, int S, int OXT>
 __device__ inline void dw_fwd_body(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
-                                   const DwDims& d, int relu_in, long long block, long long nblocks) {
+                                   const DwDims& d, int relu_in, const XcdSweep& sw, unsigned block) {
   const int OXG = (d.OW + OXT - 1) / OXT;
   const long long total = (long long)d.B * d.OH * OXG * d.C;
   constexpr int IN = (OXT - 1) * S + K;
-  for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
+  long long idx, end;
+  if (!sw.range(block, total, idx, end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (idx += threadIdx.x; idx < end; idx += 256) {
     int c, oxg, oy, b;
     xpt_split4((unsigned)idx, d.C, OXG, d.OH, c, oxg, oy, b);
     const int ox0 = oxg * OXT;
@@ -78,8 +80,8 @@ __device__ inline void dw_fwd_body(const T* __restrict__ x, const float* __restr
 
 template <typename T, int K, int S, int OXT>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y, DwDims d,
-                              int relu_in) {
-  dw_fwd_body<T, K, S, OXT>(x, w, y, d, relu_in, blockIdx.x, gridDim.x);
+                              int relu_in, XcdSweep sw) {
+  dw_fwd_body<T, K, S, OXT>(x, w, y, d, relu_in, sw, blockIdx.x);
 }
 
 // Several stride-1 depthwise layers of one shape in ONE launch (the five branch convolutions of a NASNet normal cell
@@ -93,9 +95,10 @@ struct DwMultiFwd {
 };
 
 template <typename T, int S>
-__global__ __launch_bounds__(256) void dw_multi_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, int blocks_per_job) {
+__global__ __launch_bounds__(256) void dw_multi_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, XcdSweep sw) {
   constexpr int OXT = (S == 1) ? 4 : 2;
-  const int job = blockIdx.x / blocks_per_job, blk = blockIdx.x - job * blocks_per_job;
+  const int job = blockIdx.y;
+  const unsigned blk = blockIdx.x;
   const int k = m.k[job];
   DwDims dj = d;
   dj.pad_t = m.pad_t[job];
@@ -104,11 +107,11 @@ __global__ __launch_bounds__(256) void dw_multi_fwd_kernel(DwMultiFwd m, DwDims 
   const float* w = m.w[job];
   T* y = (T*)m.y[job];
   if (k == 3)
-    dw_fwd_body<T, 3, S, OXT>(x, w, y, dj, relu_in, blk, blocks_per_job);
+    dw_fwd_body<T, 3, S, OXT>(x, w, y, dj, relu_in, sw, blk);
   else if (k == 5)
-    dw_fwd_body<T, 5, S, OXT>(x, w, y, dj, relu_in, blk, blocks_per_job);
+    dw_fwd_body<T, 5, S, OXT>(x, w, y, dj, relu_in, sw, blk);
   else
-    dw_fwd_body<T, 7, S, OXT>(x, w, y, dj, relu_in, blk, blocks_per_job);
+    dw_fwd_body<T, 7, S, OXT>(x, w, y, dj, relu_in, sw, blk);
 }
 
 // ---------------------------------------------------------------- vectorised stencil (forward, stride-1 data gradient)
@@ -275,9 +278,13 @@ __device__ inline void dw_stage_taps(float* sW, const float* __restrict__ w, int
 }
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void dw_multi_fwd_vec_kernel(DwMultiFwd m, DwDims d, int relu_in, int blocks_per_job) {
+__global__ __launch_bounds__(256) void dw_multi_fwd_vec_kernel(DwMultiFwd m, DwDims d, int relu_in, int blocks_per_job, int per,
+                                                               int xcd) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
-  const int job = blockIdx.x / blocks_per_job, blk = blockIdx.x - job * blocks_per_job;
+  // grid: x = blocks of `per` consecutive outputs (pixel-major: image-to-XCD numbering, xpt_common.h), y = job
+  const int job = blockIdx.y;
+  unsigned blk;
+  if (!xpt_xcd_unit(xcd != 0, blockIdx.x, (unsigned)blocks_per_job, blk)) return;
   const int k = m.k[job];
   dw_stage_taps(sW, m.w[job], d.C, k * k, false);
   __syncthreads();
@@ -285,7 +292,8 @@ __global__ __launch_bounds__(256) void dw_multi_fwd_vec_kernel(DwMultiFwd m, DwD
   T* y = (T*)m.y[job];
   const int CG = d.C / V, OXG = (d.OW + 1) / 2;
   const long long total = (long long)d.B * d.OH * OXG * CG;
-  for (long long idx = blk * 256LL + threadIdx.x; idx < total; idx += 256LL * blocks_per_job) {
+  const long long begin = (long long)blk * per, end = begin + per < total ? begin + per : total;
+  for (long long idx = begin + threadIdx.x; idx < end; idx += 256) {
     int c0, ox0, oy, b;
     xpt_split4((unsigned)idx, CG, OXG, d.OH, c0, ox0, oy, b);
     c0 *= V;
@@ -375,9 +383,11 @@ __device__ __forceinline__ void dw_small_stage(unsigned short* xs, float* ws, co
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void dw_small_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, int CW) {
+__global__ __launch_bounds__(256) void dw_small_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, int CW, int xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-  const int job = blockIdx.x, b = blockIdx.y, c_lo = blockIdx.z * CW;
+  unsigned b_;                                                          // grid: x = images (image-to-XCD numbering), y = job, z = chunk
+  if (!xpt_xcd_unit(xcd != 0, blockIdx.x, (unsigned)d.B, b_)) return;
+  const int job = blockIdx.y, b = (int)b_, c_lo = blockIdx.z * CW;
   const int cw = d.C - c_lo < CW ? d.C - c_lo : CW;                     // multiple of G
   const int HW = d.H * d.W, k = m.k[job], kk = k * k;
   unsigned short* xs = (unsigned short*)sm;                             // [HW][cw] bf16
@@ -410,6 +420,7 @@ struct DwTile {
   int CW, chunks;       // channels per workgroup, chunks per pixel
   int map_bytes;        // LDS bytes of one staged region (largest kernel size of the launch), multiple of 16
   int slot_bytes;       // data gradient: region + taps of one job
+  int xcd;              // image-to-XCD numbering of the workgroups (xpt_common.h)
 };
 
 // rows [y0, y0 + RH) x columns [x0, x0 + RW) of image b of src (H x W x C), channels [c_lo, c_lo + cw), zero outside the map
@@ -465,9 +476,11 @@ __device__ __forceinline__ void dw_tile_accumulate(const unsigned short* __restr
 template <int S, int G>
 __global__ __launch_bounds__(256) void dw_tile_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, DwTile t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-  const int job = blockIdx.x / t.tiles, tile = blockIdx.x - job * t.tiles;
+  unsigned u_;                                     // grid: x = (image, tile) image-major (image-to-XCD numbering), y = job, z = chunk
+  if (!xpt_xcd_unit(t.xcd != 0, blockIdx.x, (unsigned)(d.B * t.tiles), u_)) return;
+  const int job = blockIdx.y, b = (int)u_ / t.tiles, tile = (int)u_ - b * t.tiles;
   const int ty = tile / t.tiles_x, tx = tile - ty * t.tiles_x;
-  const int b = blockIdx.y, c_lo = blockIdx.z * t.CW;
+  const int c_lo = blockIdx.z * t.CW;
   const int cw = d.C - c_lo < t.CW ? d.C - c_lo : t.CW;                   // multiple of G
   const int k = m.k[job];
   const int oy0 = ty * t.TH, ox0 = tx * t.TW;
@@ -532,7 +545,9 @@ __device__ inline void dw_bwd_data_body(const T* __restrict__ x, const float* __
                                         T* __restrict__ dx, const DwDims& d, int relu_in, long long block,
                                         long long nblocks) {
   const long long total = (long long)d.B * d.H * d.W * d.C;
-  for (long long idx = block * (long long)blockDim.x + threadIdx.x; idx < total; idx += nblocks * blockDim.x) {
+  long long idx, end;
+  xpt_chunk_range((unsigned)block, (unsigned)nblocks, total, idx, end);      // consecutive (pixel-major) indices per workgroup
+  for (idx += threadIdx.x; idx < end; idx += 256) {
     int c, ix, iy, b;
     xpt_split4((unsigned)idx, d.C, d.W, d.H, c, ix, iy, b);
     float acc = dw_bwd_data_value<T, K, S>(w, dy, d, c, iy, ix, b);
@@ -543,8 +558,10 @@ __device__ inline void dw_bwd_data_body(const T* __restrict__ x, const float* __
 
 template <typename T, int K, int S>
 __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const T* __restrict__ x, const float* __restrict__ w, const T* __restrict__ dy,
-                                   T* __restrict__ dx, DwDims d, int relu_in) {
-  dw_bwd_data_body<T, K, S>(x, w, dy, dx, d, relu_in, blockIdx.x, gridDim.x);
+                                   T* __restrict__ dx, DwDims d, int relu_in, int nblocks, int xcd) {
+  unsigned blk;
+  if (!xpt_xcd_unit(xcd != 0, blockIdx.x, (unsigned)nblocks, blk)) return;
+  dw_bwd_data_body<T, K, S>(x, w, dy, dx, d, relu_in, blk, nblocks);
 }
 
 // Stride-2 data gradient with V channels per thread (the reduction cells' first layers on the 64x208 / 32x104 maps: a
@@ -714,11 +731,13 @@ template <typename T, int K, int S>
 __global__ __launch_bounds__(256) void dw_bwd_both_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                           const T* __restrict__ dy, T* __restrict__ dx,
                                                           float* __restrict__ part, DwDims d, int relu_in, int RG,
-                                                          int GRP, int data_blocks, int cchunks) {
-  if ((int)blockIdx.x < data_blocks) {
-    dw_bwd_data_body<T, K, S>(x, w, dy, dx, d, relu_in, blockIdx.x, data_blocks);
+                                                          int GRP, int data_blocks, int cchunks, int wblocks, int xcd) {
+  unsigned vb;                                  // (image-to-XCD numbering of both classes of workgroups, xpt_common.h)
+  if (!xpt_xcd_two_class(xcd != 0, blockIdx.x, 1u, (unsigned)data_blocks, 1u, (unsigned)wblocks, vb)) return;
+  if ((int)vb < data_blocks) {
+    dw_bwd_data_body<T, K, S>(x, w, dy, dx, d, relu_in, vb, data_blocks);
   } else {
-    const int t = (int)blockIdx.x - data_blocks;
+    const int t = (int)vb - data_blocks;
     dw_bwd_weight_body<T, K, S>(x, dy, part, d, relu_in, RG, GRP, t % cchunks, t / cchunks);
   }
 }
@@ -739,17 +758,22 @@ struct DwMultiBwd {
 
 template <typename T, int S>
 __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims d, int relu_in, int RG, int GRP,
-                                                           int data_blocks, int cchunks, int wblocks_per_job) {
+                                                           int data_blocks, int cchunks, int wblocks_per_job, int xcd) {
   // the weight-gradient workgroups' fold buffer, sized by the host for the largest kernel among the jobs (one static
   // buffer per kernel size added up to 63.7 KB and held the launch at two workgroups per CU)
   extern __shared__ __attribute__((aligned(16))) float sFold[];
   const int ndata = m.n_inputs * data_blocks;
-  if ((int)blockIdx.x < ndata) {
-    const int u = blockIdx.x / data_blocks, blk = blockIdx.x - u * data_blocks;
+  unsigned vb;                                  // (image-to-XCD numbering of both classes of workgroups, xpt_common.h)
+  if (!xpt_xcd_two_class(xcd != 0, blockIdx.x, (unsigned)m.n_inputs, (unsigned)data_blocks, (unsigned)m.n, (unsigned)wblocks_per_job, vb))
+    return;
+  if ((int)vb < ndata) {
+    const int u = vb / data_blocks, blk = vb - u * data_blocks;
     const T* x = (const T*)m.xin[u];
     T* dx = (T*)m.dxin[u];
     const long long total = (long long)d.B * d.H * d.W * d.C;
-    for (long long idx = blk * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)data_blocks * blockDim.x) {
+    long long idx, end;
+    xpt_chunk_range((unsigned)blk, (unsigned)data_blocks, total, idx, end);
+    for (idx += threadIdx.x; idx < end; idx += 256) {
       int c, ix, iy, b;
       xpt_split4((unsigned)idx, d.C, d.W, d.H, c, ix, iy, b);
       float acc = 0.f;
@@ -771,7 +795,7 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_kernel(DwMultiBwd m, DwDims 
     }
     return;
   }
-  const int t = (int)blockIdx.x - ndata;
+  const int t = (int)vb - ndata;
   const int job = t / wblocks_per_job, tt = t - job * wblocks_per_job;
   DwDims dj = d;
   dj.pad_t = m.pad_t[job];
@@ -891,12 +915,16 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_tile_kernel(DwMultiBwd m, Dw
                                                                 int ndata, int cchunks, int wblocks_per_job, DwTile t) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smt[];
   const int relu_in = relu_lab & 255, lab = relu_lab >> 8;
-  if (((int)blockIdx.x < ndata) ? (lab & 1) : (lab & 2)) return;
-  if ((int)blockIdx.x < ndata) {
-    dw_tile_bwd_block<S, G>(m, d, relu_in, t, blockIdx.x, smt);
+  unsigned vb;                                  // (image-to-XCD numbering of both classes of workgroups, xpt_common.h)
+  if (!xpt_xcd_two_class(t.xcd != 0, blockIdx.x, (unsigned)m.n_inputs, (unsigned)(ndata / m.n_inputs), (unsigned)m.n,
+                         (unsigned)wblocks_per_job, vb))
+    return;
+  if (((int)vb < ndata) ? (lab & 1) : (lab & 2)) return;
+  if ((int)vb < ndata) {
+    dw_tile_bwd_block<S, G>(m, d, relu_in, t, vb, smt);
     return;
   }
-  const int tt0 = (int)blockIdx.x - ndata;
+  const int tt0 = (int)vb - ndata;
   const int job = tt0 / wblocks_per_job, tt = tt0 - job * wblocks_per_job;
   DwDims dj = d;
   dj.pad_t = m.pad_t[job];
@@ -917,19 +945,22 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_tile_kernel(DwMultiBwd m, Dw
 // of conv(dy_j, w_j rotated by 180 degrees, pad' = k_j - 1 - pad_j); the rotated taps of those jobs sit in LDS.
 template <typename T, int V>
 __global__ __launch_bounds__(256, 4) void dw_multi_bwd_vec_kernel(DwMultiBwd m, DwDims d, int relu_lab, int RG, int GRP,
-                                                               int data_blocks, int cchunks, int wblocks_per_job) {
+                                                               int data_blocks, int cchunks, int wblocks_per_job, int xcd) {
   extern __shared__ __attribute__((aligned(16))) float sW[];
   const int relu_in = relu_lab & 255, lab = relu_lab >> 8;      // lab knobs (xpt_dwconv_tune(-21 / -22)): 1 no data part, 2 no weight part
   // data_blocks < 0: the small-map data gradient (whole map of an image in LDS): -data_blocks = B * C / 8 workgroups per input
   const bool small = data_blocks < 0;
   if (small) data_blocks = -data_blocks;
   const int ndata = m.n_inputs * data_blocks;
-  if (((int)blockIdx.x < ndata) ? (lab & 1) : (lab & 2)) return;
+  unsigned vb;                                  // (image-to-XCD numbering of both classes of workgroups, xpt_common.h)
+  if (!xpt_xcd_two_class(xcd != 0, blockIdx.x, (unsigned)m.n_inputs, (unsigned)data_blocks, (unsigned)m.n, (unsigned)wblocks_per_job, vb))
+    return;
+  if (((int)vb < ndata) ? (lab & 1) : (lab & 2)) return;
   if constexpr (sizeof(T) == 2 && (V == 8 || V == 4)) {
-    if (small && (int)blockIdx.x < ndata) {
+    if (small && (int)vb < ndata) {
       // workgroup = (input u, image b, V-channel group): the maps dy_j of the jobs reading u and their rotated taps go to LDS
       // in ONE burst; outputs are summed over those jobs in job order, tap by tap as the stencil path does: same bits
-      const int u = blockIdx.x / data_blocks, rest = blockIdx.x - u * data_blocks;
+      const int u = vb / data_blocks, rest = vb - u * data_blocks;
       const int g8 = d.C / V, b = rest / g8, c_lo = (rest - b * g8) * V;
       const int HW = d.OH * d.OW;                                         // stride 1: output map = input map
       unsigned char* sm = (unsigned char*)sW;
@@ -971,8 +1002,8 @@ __global__ __launch_bounds__(256, 4) void dw_multi_bwd_vec_kernel(DwMultiBwd m, 
       return;
     }
   }
-  if ((int)blockIdx.x < ndata) {
-    const int u = blockIdx.x / data_blocks, blk = blockIdx.x - u * data_blocks;
+  if ((int)vb < ndata) {
+    const int u = vb / data_blocks, blk = vb - u * data_blocks;
     int off = 0;
     for (int j = 0; j < m.n; ++j) {
       if (m.input_of[j] != u) continue;
@@ -984,7 +1015,9 @@ __global__ __launch_bounds__(256, 4) void dw_multi_bwd_vec_kernel(DwMultiBwd m, 
     T* dx = (T*)m.dxin[u];
     const int CG = d.C / V, IXG = (d.W + 1) / 2;
     const long long total = (long long)d.B * d.H * IXG * CG;
-    for (long long idx = blk * 256LL + threadIdx.x; idx < total; idx += 256LL * data_blocks) {
+    long long idx, end;
+    xpt_chunk_range((unsigned)blk, (unsigned)data_blocks, total, idx, end);
+    for (idx += threadIdx.x; idx < end; idx += 256) {
       int c0, ix0, iy, b;
       xpt_split4((unsigned)idx, CG, IXG, d.H, c0, ix0, iy, b);
       c0 *= V;
@@ -1018,7 +1051,7 @@ __global__ __launch_bounds__(256, 4) void dw_multi_bwd_vec_kernel(DwMultiBwd m, 
     }
     return;
   }
-  const int t = (int)blockIdx.x - ndata;
+  const int t = (int)vb - ndata;
   const int job = t / wblocks_per_job, tt = t - job * wblocks_per_job;
   DwDims dj = d;
   dj.pad_t = m.pad_t[job];
@@ -1120,8 +1153,8 @@ int launch_fwd(const void* x, const float* w, void* y, const DwDims& d, int relu
   }
   constexpr int OXS = OXT;
   const long long total = (long long)d.B * d.OH * ((d.OW + OXS - 1) / OXS) * d.C;
-  hipLaunchKernelGGL((dw_fwd_kernel<T, K, S, OXS>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, w, (T*)y, d,
-                     relu_in);
+  const XcdSweep sw = xpt_xcd_sweep(total, 4096);
+  hipLaunchKernelGGL((dw_fwd_kernel<T, K, S, OXS>), dim3(sw.grid), dim3(256), 0, s, (const T*)x, w, (T*)y, d, relu_in, sw);
   return xpt_launch_status();
 }
 
@@ -1161,8 +1194,9 @@ int launch_bwd_data(const void* x, const float* w, const void* dy, void* dx, con
     }
   }
   const long long total = (long long)d.B * d.H * d.W * d.C;
-  hipLaunchKernelGGL((dw_bwd_data_kernel<T, K, S>), dim3(grid_for(total)), dim3(256), 0, s, (const T*)x, w,
-                     (const T*)dy, (T*)dx, d, relu_in);
+  const int nblocks = (int)grid_for(total), xcd = g_xpt_xcd_affinity;
+  hipLaunchKernelGGL((dw_bwd_data_kernel<T, K, S>), dim3(xcd ? xpt_xcd_pad(nblocks) : nblocks), dim3(256), 0, s, (const T*)x, w,
+                     (const T*)dy, (T*)dx, d, relu_in, nblocks, xcd);
   return xpt_launch_status();
 }
 
@@ -1197,8 +1231,9 @@ int launch_bwd_both(const void* x, const float* w, const void* dy, void* dx, flo
     if (tile_bwd_launch(m, d, relu_in, RG, GRP, cchunks, cchunks * nchunk, s, S)) return xpt_launch_status();
   }
   const int data_blocks = (int)grid_for((long long)d.B * d.H * d.W * d.C);
-  hipLaunchKernelGGL((dw_bwd_both_kernel<T, K, S>), dim3(data_blocks + cchunks * nchunk), dim3(256), 0, s, (const T*)x, w,
-                     (const T*)dy, (T*)dx, ws, d, relu_in, RG, GRP, data_blocks, cchunks);
+  const int xcd = g_xpt_xcd_affinity;
+  hipLaunchKernelGGL((dw_bwd_both_kernel<T, K, S>), dim3(xpt_xcd_two_class_grid(xcd, 1, data_blocks, 1, cchunks * nchunk)), dim3(256), 0,
+                     s, (const T*)x, w, (const T*)dy, (T*)dx, ws, d, relu_in, RG, GRP, data_blocks, cchunks, cchunks * nchunk, xcd);
   return xpt_launch_status();
 }
 
@@ -1258,7 +1293,8 @@ bool tile_fwd_launch(const DwMultiFwd& m, int n, const DwDims& d, int relu_in, h
   t.map_bytes = (int)((region + 15) & ~(size_t)15);
   const size_t lds = (size_t)t.map_bytes + (size_t)kmax * kmax * t.CW * sizeof(float);
   if (lds > 64 * 1024 || (long long)n * t.tiles > 65535 * 32LL || d.B > 65535 || t.chunks > 65535) return false;
-  const dim3 grid(n * t.tiles, d.B, t.chunks);
+  t.xcd = g_xpt_xcd_affinity;
+  const dim3 grid(t.xcd ? xpt_xcd_pad((unsigned long long)d.B * t.tiles) : d.B * t.tiles, n, t.chunks);
   XPT_BEGIN_LAUNCH();
 #define XPT_TF(S_, G_) hipLaunchKernelGGL((dw_tile_fwd_kernel<S_, G_>), grid, dim3(256), lds, s, m, d, relu_in, t)
   if (stride == 2) {
@@ -1304,7 +1340,8 @@ bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, 
   if (wbpj > 0 && fold > lds) lds = fold;
   const long long ndata = (long long)m.n_inputs * d.B * t.tiles * t.chunks;
   if (lds > 64 * 1024 || ndata + (long long)m.n * wbpj > 0x7fffffffLL) return false;
-  const dim3 grid((unsigned)(ndata + (long long)m.n * wbpj));
+  t.xcd = g_xpt_xcd_affinity;
+  const dim3 grid(xpt_xcd_two_class_grid(t.xcd, m.n_inputs, (unsigned)(ndata / m.n_inputs), wbpj > 0 ? m.n : 0, wbpj > 0 ? wbpj : 0));
   XPT_BEGIN_LAUNCH();
 #define XPT_TB(S_, G_) \
   hipLaunchKernelGGL((dw_multi_bwd_tile_kernel<S_, G_>), grid, dim3(256), lds, s, m, d, relu_in | (g_dw_lab << 8), RG, GRP, (int)ndata, \
@@ -1513,11 +1550,12 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
     if (cw < G) cw = G;
     const size_t lds = (((size_t)H * W * cw * 2 + 15) & ~(size_t)15) + (size_t)kmax * kmax * cw * 4;
     if (ok && lds <= 64 * 1024) {
+      const int xcd = g_xpt_xcd_affinity;
       XPT_BEGIN_LAUNCH();
       if (G == 8)
-        hipLaunchKernelGGL(dw_small_fwd_kernel<8>, dim3(n, B, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw);
+        hipLaunchKernelGGL(dw_small_fwd_kernel<8>, dim3(xcd ? xpt_xcd_pad(B) : B, n, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw, xcd);
       else
-        hipLaunchKernelGGL(dw_small_fwd_kernel<4>, dim3(n, B, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw);
+        hipLaunchKernelGGL(dw_small_fwd_kernel<4>, dim3(xcd ? xpt_xcd_pad(B) : B, n, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw, xcd);
       return xpt_launch_status();
     }
   }
@@ -1533,10 +1571,14 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
     }
     const size_t lds = (size_t)kmax * kmax * C * sizeof(float);
     if (v > 1 && lds <= 64 * 1024) {
-      const int bpjv = (int)grid_for((long long)B * OH * ((OW + 1) / 2) * (C / v));
+      const long long totalv = (long long)B * OH * ((OW + 1) / 2) * (C / v);
+      int bpjv = (int)grid_for(totalv);
+      const int xcd = g_xpt_xcd_affinity;
+      const int per = (int)(((totalv + bpjv - 1) / bpjv + 255) / 256 * 256);     // consecutive outputs per workgroup
+      bpjv = (int)((totalv + per - 1) / per);
       XPT_BEGIN_LAUNCH();
 #define XPT_MV(T, V) \
-  hipLaunchKernelGGL((dw_multi_fwd_vec_kernel<T, V>), dim3(bpjv * n), dim3(256), lds, s, m, d, relu_in, bpjv)
+  hipLaunchKernelGGL((dw_multi_fwd_vec_kernel<T, V>), dim3(xcd ? xpt_xcd_pad(bpjv) : bpjv, n), dim3(256), lds, s, m, d, relu_in, bpjv, per, xcd)
       if (dtype == 0) { if (v == 4) XPT_MV(float, 4); else XPT_MV(float, 2); }
       else { if (v == 8) XPT_MV(__hip_bfloat16, 8); else if (v == 4) XPT_MV(__hip_bfloat16, 4); else XPT_MV(__hip_bfloat16, 2); }
 #undef XPT_MV
@@ -1544,9 +1586,9 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
     }
   }
   const int oxt = stride == 1 ? 4 : 2;
-  const int bpj = (int)grid_for((long long)B * OH * ((OW + oxt - 1) / oxt) * C);
+  const XcdSweep sw = xpt_xcd_sweep((long long)B * OH * ((OW + oxt - 1) / oxt) * C, 4096);
   XPT_BEGIN_LAUNCH();
-#define XPT_MULTI(T, S) hipLaunchKernelGGL((dw_multi_fwd_kernel<T, S>), dim3(bpj * n), dim3(256), 0, s, m, d, relu_in, bpj)
+#define XPT_MULTI(T, S) hipLaunchKernelGGL((dw_multi_fwd_kernel<T, S>), dim3(sw.grid, n), dim3(256), 0, s, m, d, relu_in, sw)
   if (dtype == 0) {
     if (stride == 1) XPT_MULTI(float, 1); else XPT_MULTI(float, 2);
   } else {
@@ -1620,10 +1662,11 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
           dbv = -(B * (C / v));
         }
       }
-      const dim3 gridv(n_inputs * (dbv < 0 ? -dbv : dbv) + n * wbpj);
+      const int xcd = g_xpt_xcd_affinity;
+      const dim3 gridv(xpt_xcd_two_class_grid(xcd, n_inputs, dbv < 0 ? -dbv : dbv, n, wbpj));
       XPT_BEGIN_LAUNCH();
 #define XPT_MV(T, V) \
-  hipLaunchKernelGGL((dw_multi_bwd_vec_kernel<T, V>), gridv, dim3(256), lds, s, m, d, relu_in | (g_dw_lab << 8), RG, GRP, dbv, cchunks, wbpj)
+  hipLaunchKernelGGL((dw_multi_bwd_vec_kernel<T, V>), gridv, dim3(256), lds, s, m, d, relu_in | (g_dw_lab << 8), RG, GRP, dbv, cchunks, wbpj, xcd)
       if (dtype == 0) { if (v == 4) XPT_MV(float, 4); else XPT_MV(float, 2); }
       else { if (v == 8) XPT_MV(__hip_bfloat16, 8); else if (v == 4) XPT_MV(__hip_bfloat16, 4); else XPT_MV(__hip_bfloat16, 2); }
 #undef XPT_MV
@@ -1631,7 +1674,8 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
     }
   }
   const int data_blocks = (int)grid_for((long long)B * H * W * C);
-  const dim3 grid(n_inputs * data_blocks + n * wbpj);
+  const int xcd = g_xpt_xcd_affinity;
+  const dim3 grid(xpt_xcd_two_class_grid(xcd, n_inputs, data_blocks, n, wbpj));
   size_t fold_bytes = 0;
   for (int j = 0; j < n; ++j) {
     const size_t f = (size_t)3 * 64 * k[j] * k[j] * sizeof(float);
@@ -1639,7 +1683,7 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
   }
   XPT_BEGIN_LAUNCH();
 #define XPT_MULTI(T, S) \
-  hipLaunchKernelGGL((dw_multi_bwd_kernel<T, S>), grid, dim3(256), fold_bytes, s, m, d, relu_in, RG, GRP, data_blocks, cchunks, wbpj)
+  hipLaunchKernelGGL((dw_multi_bwd_kernel<T, S>), grid, dim3(256), fold_bytes, s, m, d, relu_in, RG, GRP, data_blocks, cchunks, wbpj, xcd)
   if (dtype == 0) {
     if (stride == 1) XPT_MULTI(float, 1); else XPT_MULTI(float, 2);
   } else {

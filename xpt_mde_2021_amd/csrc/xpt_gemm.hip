@@ -380,6 +380,14 @@ __device__ inline void dgrad_body(const unsigned short* __restrict__ dy, long lo
   }
 }
 
+struct WgGrid {
+  unsigned tiles_ci, tiles_co;      // tiles of dW along cin / cout (= gridDim.x / gridDim.y of the 3-D grid)
+  int xcd;                          // image-to-XCD numbering of the workgroups (1-D grid)
+  unsigned inner_d, inner_w, per_job;                          // slots x ci blocks; jobs x tiles; tiles
+  unsigned m_inner_d, m_wgs_ci, m_inner_w, m_per_job, m_gx;    // xpt_magic() of the decode's divisors
+};
+__device__ __forceinline__ unsigned xpt_xcd_pad_dev(unsigned n) { return (n + 7u) & ~7u; }
+
 template <int TCO, int TCI, int VA, int VB, bool BN, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgrad_kernel(const unsigned short* __restrict__ dy_,
                                                               const unsigned short* __restrict__ x_,
@@ -387,16 +395,48 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
                                                               unsigned* __restrict__ counters, long long M, int cout,
                                                               int cin, long long pitch_dy_, long long pitch_x,
                                                               long long rows_per_block, int nsplit, int defer,
-                                                              BnFuse bn_, WgradMulti mj, DxFuse dxf) {
+                                                              BnFuse bn_, WgradMulti mj, DxFuse dxf, WgGrid wg) {
   const unsigned short* __restrict__ dy = dy_;
   const unsigned short* __restrict__ x = x_;
   float* __restrict__ partial = partial_;
   long long pitch_dy = pitch_dy_;
   BnFuse bn = bn_;
-  int split = (int)blockIdx.z - dxf.slices;                 // < 0: a data-gradient workgroup (below)
+  // Workgroup roles.  wg.xcd == 0: the 3-D grid (ci tile, co tile, z), z < dxf.slices = data-gradient workgroups numbered
+  // linearly, then job * nsplit + split.  wg.xcd != 0 (image-to-XCD numbering, xpt_common.h): a 1-D grid -- first the data-
+  // gradient part, 8 ceil(wgs_rows / 8) row blocks x (slots x ci blocks), then the weight-gradient part, 8 ceil(nsplit / 8)
+  // row splits x (jobs x tiles); XCD k (= x % 8 in both parts, their sizes are multiples of 8) owns the row blocks / splits
+  // of rows [k M / 8, (k + 1) M / 8).
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  int bz = blockIdx.z, dx_slot = -1, dx_rows = 0, dx_ci = 0, wjob = -1, wsplit = 0;
+  const unsigned gx = wg.tiles_ci;
+  if (wg.xcd) {
+    const unsigned d8 = dxf.slices ? xpt_xcd_pad_dev((unsigned)dxf.wgs_rows) * wg.inner_d : 0u;   // (short workgroups: dispatched first)
+    if (blockIdx.x < d8) {
+      const unsigned q = blockIdx.x >> 3, rl = xpt_fastdiv(q, wg.m_inner_d), in = q - rl * wg.inner_d;
+      unsigned rb;
+      if (!xpt_xcd_unit(true, (blockIdx.x & 7u) | (rl << 3), (unsigned)dxf.wgs_rows, rb)) return;
+      bz = 0;                                               // (a data-gradient workgroup: dxf.slices >= 1 here)
+      dx_slot = (int)xpt_fastdiv(in, wg.m_wgs_ci);
+      dx_ci = (int)(in - (unsigned)dx_slot * (unsigned)dxf.wgs_ci);
+      dx_rows = (int)rb;
+    } else {
+      const unsigned lin = blockIdx.x - d8;
+      const unsigned q = lin >> 3, sl = xpt_fastdiv(q, wg.m_inner_w), in = q - sl * wg.inner_w;
+      unsigned sp;
+      if (!xpt_xcd_unit(true, (lin & 7u) | (sl << 3), (unsigned)nsplit, sp)) return;
+      const unsigned job = xpt_fastdiv(in, wg.m_per_job), t = in - job * wg.per_job;
+      by = xpt_fastdiv(t, wg.m_gx);
+      bx = t - by * gx;
+      bz = dxf.slices + (int)(job * (unsigned)nsplit + sp);
+      wjob = (int)job;
+      wsplit = (int)sp;
+    }
+  }
+  int split = bz - dxf.slices;                              // < 0: a data-gradient workgroup (below)
+  if (!(BN && mj.n > 0) && wjob >= 0) split = wsplit;
   if (BN && mj.n > 0 && split >= 0) {
-    const int job = split / nsplit;
-    split -= job * nsplit;
+    const int job = wjob >= 0 ? wjob : split / nsplit;
+    split = wjob >= 0 ? wsplit : split - job * nsplit;
     dy = mj.dy[job];
     x = mj.x[job];
     partial = mj.partial[job];
@@ -413,13 +453,18 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
   constexpr int SMEM_A = STAGE_BYTES > RED_BYTES ? STAGE_BYTES : RED_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_A > DX_BYTES ? SMEM_A : DX_BYTES];
   if constexpr (VA > 1)              // (scalar staging = odd channel counts: the host never asks for a data gradient)
-  if ((int)blockIdx.z < dxf.slices) {                                    // a data-gradient workgroup (see DxFuse)
+  if (bz < dxf.slices) {                                                 // a data-gradient workgroup (see DxFuse)
     static_assert(sizeof(smem) >= 1024 + DX_KC * DX_LD * 2, "the staged W slice must fit the staging buffers");
-    const int lid = ((int)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const int per_job = dxf.wgs_rows * dxf.wgs_ci;
-    const int slot = lid / per_job;
-    if (slot >= dxf.n) return;
-    const int rem = lid - slot * per_job;
+    int slot = dx_slot;
+    if (!wg.xcd) {
+      const int lid = (bz * (int)wg.tiles_co + (int)by) * (int)gx + (int)bx;
+      const int per_job = dxf.wgs_rows * dxf.wgs_ci;
+      slot = lid / per_job;
+      if (slot >= dxf.n) return;
+      const int rem = lid - slot * per_job;
+      dx_rows = rem / dxf.wgs_ci;
+      dx_ci = rem - dx_rows * dxf.wgs_ci;
+    }
     if (BN && mj.n > 0) {
       const int job = dxf.job[slot];
       dy = mj.dy[job];
@@ -427,7 +472,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
       bn = mj.bn[job];
     }
 #define XPT_DX(EX, VW)                                                                                               \
-  dgrad_body<VA, EX, VW, NT>(dy, pitch_dy, bn, dxf.w[slot], dxf.dx[slot], M, cout, cin, rem / dxf.wgs_ci, rem % dxf.wgs_ci, \
+  dgrad_body<VA, EX, VW, NT>(dy, pitch_dy, bn, dxf.w[slot], dxf.dx[slot], M, cout, cin, dx_rows, dx_ci, \
                          dxf.row_blocks, dxf.nsub, smem)
     if (bn.n_extra > 0) {
       if (dxf.vw == 8) XPT_DX(true, 8);
@@ -453,15 +498,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
   const int r = lane & 31, h = lane >> 5;
   const int quad = wave % Q, ksub = wave / Q;
   const int qa = quad / QB, qb = quad % QB;
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-  const int co0 = blockIdx.y * TCO, ci0 = blockIdx.x * TCI;
+  const int tile = by * gx + bx;
+  const int co0 = by * TCO, ci0 = bx * TCI;
 
   const long long k_begin = (long long)split * rows_per_block;
   long long k_end = k_begin + rows_per_block;
   if (k_end > M) k_end = M;
   const int ci = ci0 + qb * 32 + r;
   const bool ci_ok = ci < cin;
-  const bool bn_tile = BN && blockIdx.x == 0;               // this workgroup also emits g and the BN partial sums
+  const bool bn_tile = BN && bx == 0;               // this workgroup also emits g and the BN partial sums
   const bool bn_sums = bn_tile && qb == 0;                  // ... summed by the waves of the first column quadrant
   float sum_dy = 0.f, sum_dyy = 0.f;
 
@@ -758,7 +803,26 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
   }
   const long long dz = dxf.slices;
   if (wz + dz > 65535) return XPT_ERR_SHAPE;
-  const dim3 grid(p.tiles_ci, p.tiles_co, (unsigned)(wz + dz));
+  WgGrid wg{};
+  wg.tiles_ci = (unsigned)p.tiles_ci;
+  wg.tiles_co = (unsigned)p.tiles_co;
+  wg.xcd = g_xpt_xcd_affinity && p.nsplit >= 8;      // (fewer row splits than XCDs: every XCD takes part, no numbering)
+  wg.per_job = wg.tiles_ci * wg.tiles_co;
+  wg.inner_w = wg.per_job * (unsigned)(multi ? multi->n : 1);
+  wg.inner_d = (unsigned)(dxf.n * dxf.wgs_ci);
+  wg.m_inner_d = xpt_magic(wg.inner_d);
+  wg.m_wgs_ci = xpt_magic((unsigned)dxf.wgs_ci);
+  wg.m_inner_w = xpt_magic(wg.inner_w);
+  wg.m_per_job = xpt_magic(wg.per_job);
+  wg.m_gx = xpt_magic(wg.tiles_ci);
+  dim3 grid(p.tiles_ci, p.tiles_co, (unsigned)(wz + dz));
+  if (wg.xcd) {
+    const unsigned long long jobs = multi ? multi->n : 1;
+    const unsigned long long total = (unsigned long long)xpt_xcd_pad(p.nsplit) * p.tiles_ci * p.tiles_co * jobs +
+                                     (dxf.slices ? (unsigned long long)xpt_xcd_pad(dxf.wgs_rows) * dxf.n * dxf.wgs_ci : 0);
+    if (total > 0x7fffffffull) return XPT_ERR_SHAPE;
+    grid = dim3((unsigned)total);
+  }
   const dim3 block(waves * 64);
   const BnFuse none{};
   XPT_BEGIN_LAUNCH();
@@ -766,10 +830,10 @@ static int wgrad_launch(const void* dy, const void* x, float* dw, float* workspa
   do {                                                                                                                \
     if (bn)                                                                                                           \
       hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, true, NWV>), grid, block, 0, s, a, b, dw, workspace,   \
-                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, *bn, mj, dxf); \
+                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, *bn, mj, dxf, wg); \
     else                                                                                                              \
       hipLaunchKernelGGL((conv1x1_wgrad_kernel<TCO, TCI, V, V, false, NWV>), grid, block, 0, s, a, b, dw, workspace,  \
-                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, none, mj, dxf); \
+                         counters, M, cout, cin, pitch_dy, pitch_x, p.rows_per_block, p.nsplit, defer, none, mj, dxf, wg); \
   } while (0)
 #define XPT_WGRAD(TCO, TCI, V)                                                                                        \
   do {                                                                                                                \

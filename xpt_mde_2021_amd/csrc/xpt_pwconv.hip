@@ -122,7 +122,7 @@ __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, 
                                           const PwBn& bn, const unsigned short* __restrict__ residual,
                                           unsigned short* __restrict__ ypre, unsigned short* __restrict__ y,
                                           const PwSibling& sib, long long M, int cin, int cout, long long pitch_x,
-                                          long long pitch_y) {
+                                          long long pitch_y, int xcd) {
   constexpr int NTH = KW == 1 ? 64 : 256;                // threads that share the store phase of one tile
   constexpr int CPR = 32 / VO, CHUNKS = 32 * CPR, ITER = (CHUNKS + NTH - 1) / NTH;
   constexpr int TILES = KW == 1 ? 4 : 1;
@@ -130,8 +130,11 @@ __device__ inline void pwconv_bn_fwd_body(const unsigned short* __restrict__ x, 
   __shared__ float s_sc[2][32], s_sh[2][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const long long m0 = (KW == 1 ? (long long)blockIdx.y * 4 + wave : (long long)blockIdx.y) * 32;
-  const int n0 = blockIdx.x * 32;
+  // grid: x = row blocks (image-to-XCD numbering, xpt_common.h), y = 32-channel tiles of the output
+  unsigned mb;
+  if (!xpt_xcd_unit(xcd != 0, blockIdx.x, (unsigned)((M + (KW == 1 ? 127 : 31)) / (KW == 1 ? 128 : 32)), mb)) return;
+  const long long m0 = (KW == 1 ? (long long)mb * 4 + wave : (long long)mb) * 32;
+  const int n0 = blockIdx.y * 32;
   const bool active = m0 < M;                            // wave-uniform (KW = 4: workgroup-uniform); no early exit: barriers below
   const long long am = m0 + r < M ? m0 + r : M - 1;      // rows past the end re-read the last row (never stored)
   const int bn_ = n0 + r;
@@ -238,9 +241,9 @@ __global__ __launch_bounds__(256) void pwconv_bn_fwd_kernel(const unsigned short
                                                              const unsigned short* __restrict__ residual,
                                                              unsigned short* __restrict__ ypre,
                                                              unsigned short* __restrict__ y, long long M, int cin,
-                                                             int cout, long long pitch_x) {
+                                                             int cout, long long pitch_x, int xcd) {
   const PwSibling none{};
-  pwconv_bn_fwd_body<V, VO, KW>(x, w, bn, residual, ypre, y, none, M, cin, cout, pitch_x, cout);
+  pwconv_bn_fwd_body<V, VO, KW>(x, w, bn, residual, ypre, y, none, M, cin, cout, pitch_x, cout, xcd);
 }
 
 // up to 6 independent layers of one shape (the branch convolutions of a cell stage): job = blockIdx.z
@@ -257,10 +260,10 @@ struct PwMulti {
 
 template <int V, int VO>
 __global__ __launch_bounds__(256) void pwconv_bn_multi_fwd_kernel(PwMulti m, long long M, int cin, int cout,
-                                                                   long long pitch_x, long long pitch_y) {
+                                                                   long long pitch_x, long long pitch_y, int xcd) {
   const int j = blockIdx.z;
   pwconv_bn_fwd_body<V, VO>(m.x[j], m.w[j], m.bn[j], m.residual[j], m.ypre[j], m.y[j], m.sib[j], M, cin, cout, pitch_x,
-                            pitch_y);
+                            pitch_y, xcd);
 }
 
 // widest vector (elements) of the output-side tensors: cout and every base must allow it
@@ -333,7 +336,8 @@ static int pwconv_multi_launch(int n, const void* const* x, const void* const* w
   pw_widths(v, vo);
   const long long mblocks = (M + 127) / 128;
   if (mblocks > 65535) return XPT_ERR_SHAPE;
-  const dim3 grid((cout + 31) / 32, (unsigned)mblocks, n);
+  const int xcd = g_xpt_xcd_affinity && mblocks >= 8;      // (fewer row blocks than XCDs: every XCD takes part, no numbering)
+  const dim3 grid(xcd ? xpt_xcd_pad(mblocks) : (unsigned)mblocks, (cout + 31) / 32, n);
   if (pitch_y != cout)                          // residuals are dense [M, cout] tensors; with a pitched y there are none
     for (int j = 0; j < n; ++j)
       if (residual[j]) return XPT_ERR_ARG;
@@ -341,7 +345,7 @@ static int pwconv_multi_launch(int n, const void* const* x, const void* const* w
   XPT_BEGIN_LAUNCH();
 #define XPT_PW_CASE(VV, VVO)                                                                                         \
   if (v == VV && vo == VVO)                                                                                          \
-    hipLaunchKernelGGL((pwconv_bn_multi_fwd_kernel<VV, VVO>), grid, dim3(256), 0, s, m, M, cin, cout, pitch_x, pitch_y);
+    hipLaunchKernelGGL((pwconv_bn_multi_fwd_kernel<VV, VVO>), grid, dim3(256), 0, s, m, M, cin, cout, pitch_x, pitch_y, xcd);
   XPT_PW_PAIRS(XPT_PW_CASE)
 #undef XPT_PW_CASE
   return xpt_launch_status();
@@ -389,26 +393,28 @@ extern "C" int xpt_pwconv_bn_fwd(const void* x, const void* w, const float* gamm
   int vo = out_width(cout, {residual, ypre, y});
   const PwBn bn{gamma, beta, mean, var, eps};
   hipStream_t s = (hipStream_t)stream;
+  int xcd = g_xpt_xcd_affinity && (M + 31) / 32 >= 8;
   // deep reduction, few tiles: the 4 waves of a workgroup split the k steps of one tile (pwconv_bn_fwd_body, KW = 4)
   const long long tiles = ((M + 31) / 32) * ((cout + 31) / 32);
   if (v == 8 && vo == 8 && cin >= g_pw_ksplit_min_cin && tiles <= g_pw_ksplit_max_tiles && (M + 31) / 32 <= 65535) {
-    const dim3 gridk((cout + 31) / 32, (unsigned)((M + 31) / 32));
+    const dim3 gridk(xcd ? xpt_xcd_pad((M + 31) / 32) : (unsigned)((M + 31) / 32), (cout + 31) / 32);
     XPT_BEGIN_LAUNCH();
     hipLaunchKernelGGL((pwconv_bn_fwd_kernel<8, 8, 4>), gridk, dim3(256), 0, s, (const unsigned short*)x,
                        (const unsigned short*)w, bn, (const unsigned short*)residual, (unsigned short*)ypre,
-                       (unsigned short*)y, M, cin, cout, pitch_x);
+                       (unsigned short*)y, M, cin, cout, pitch_x, xcd);
     return xpt_launch_status();
   }
   pw_widths(v, vo);
   const long long mblocks = (M + 127) / 128;
   if (mblocks > 65535) return XPT_ERR_SHAPE;
-  const dim3 grid((cout + 31) / 32, (unsigned)mblocks);
+  xcd = g_xpt_xcd_affinity && mblocks >= 8;
+  const dim3 grid(xcd ? xpt_xcd_pad(mblocks) : (unsigned)mblocks, (cout + 31) / 32);
   XPT_BEGIN_LAUNCH();
 #define XPT_PW_CASE(VV, VVO)                                                                                     \
   if (v == VV && vo == VVO)                                                                                      \
     hipLaunchKernelGGL((pwconv_bn_fwd_kernel<VV, VVO>), grid, dim3(256), 0, s, (const unsigned short*)x,         \
                        (const unsigned short*)w, bn, (const unsigned short*)residual, (unsigned short*)ypre,     \
-                       (unsigned short*)y, M, cin, cout, pitch_x);
+                       (unsigned short*)y, M, cin, cout, pitch_x, xcd);
   XPT_PW_PAIRS(XPT_PW_CASE)
 #undef XPT_PW_CASE
   return xpt_launch_status();

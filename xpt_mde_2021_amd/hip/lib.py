@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libxpt_hip.so")
+# (XPT_HIP_LIB: another build of the same library, e.g. the previous commit's, for same-box A/B measurements; lab use only)
+LIB_PATH = os.environ.get("XPT_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libxpt_hip.so")
 
 XPT_PHOTO_L1, XPT_PHOTO_L2, XPT_PHOTO_SSIM = 0, 1, 2
 PHOTO_METHODS = {"L1": XPT_PHOTO_L1, "L2": XPT_PHOTO_L2, "SSIM": XPT_PHOTO_SSIM}
