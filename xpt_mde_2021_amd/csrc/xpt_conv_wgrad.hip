@@ -249,7 +249,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WfArgs a) {
   char* const gs = smem;                                       // [8 x 16 px][32 ch] bf16
   char* const xs = smem + 8192;                                // [HR x WR px][32 ch] bf16
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int cblk = (int)blockIdx.x % a.ct, nblk = ((int)blockIdx.x / a.ct) % a.nb, split = (int)blockIdx.x / (a.ct * a.nb);
+  // workgroup -> (column block, row block, split).  a.xcd: the split is the fastest index (nsplit % 8 == 0: workgroup on XCD
+  // split % 8, whose tiles split, split + nsplit, ... are dealt from that XCD's image-major eighth of the tiles, tile_of())
+  int cblk, nblk, split;
+  if (a.xcd) {
+    unsigned sp_, cb_;
+    const unsigned rest = xpt_divmod(blockIdx.x, (unsigned)a.nsplit, sp_);
+    nblk = (int)xpt_divmod(rest, (unsigned)a.ct, cb_);
+    cblk = (int)cb_;
+    split = (int)sp_;
+  } else {
+    cblk = (int)blockIdx.x % a.ct;
+    nblk = ((int)blockIdx.x / a.ct) % a.nb;
+    split = (int)blockIdx.x / (a.ct * a.nb);
+  }
   const int c0 = cblk * 32, n0 = nblk * 32;
   const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)a.g, 0, (int)a.gbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.xbytes, 0x00020000);
@@ -425,6 +438,7 @@ int fast_nsplit(const WfArgs& a, int N, int C) {
   const long long cap = ((long long)g_wgrad_max_partial_mib << 20) / (bytes > 0 ? bytes : 1);
   if (s > cap) s = cap;
   if (s > a.ntiles) s = a.ntiles;
+  if (g_xpt_xcd_affinity != 0 && s >= 16) s &= ~7ll;          // image-to-XCD numbering wants whole groups of eight splits
   return s < 1 ? 1 : (int)s;
 }
 
@@ -538,7 +552,7 @@ extern "C" int xpt_conv2d_bwd_weight_partials(const void* g, const void* x, floa
       f.xbytes = ((long long)B * PH * PW - 1) * xpitch * 2 + (long long)C * 2;
       if (f.gbytes >= (1LL << 30) || f.xbytes >= (1LL << 30)) return XPT_ERR_SHAPE;
       f.B = B; f.PH = PH; f.PW = PW; f.OH = OH; f.OW = OW; f.C = C; f.Cr = Cr; f.N = N; f.pad_t = pad_t; f.pad_l = pad_l;
-      f.xcd = (g_xpt_xcd_affinity != 0 && f.ntiles % 8 == 0 && f.nsplit % 8 == 0 && f.ct * f.nb == 1) ? 1 : 0;
+      f.xcd = (g_xpt_xcd_affinity != 0 && f.ntiles % 8 == 0 && f.nsplit % 8 == 0) ? 1 : 0;
       const dim3 grid(f.ct * f.nb * f.nsplit);
       hipStream_t st = (hipStream_t)stream;
       XPT_BEGIN_LAUNCH();

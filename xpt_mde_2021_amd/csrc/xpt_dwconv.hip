@@ -383,11 +383,11 @@ __device__ __forceinline__ void dw_small_stage(unsigned short* xs, float* ws, co
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void dw_small_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, int CW, int xcd) {
+__global__ __launch_bounds__(256) void dw_small_fwd_kernel(DwMultiFwd m, DwDims d, int relu_in, int CW) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-  unsigned b_;                                                          // grid: x = images (image-to-XCD numbering), y = job, z = chunk
-  if (!xpt_xcd_unit(xcd != 0, blockIdx.x, (unsigned)d.B, b_)) return;
-  const int job = blockIdx.y, b = (int)b_, c_lo = blockIdx.z * CW;
+  // (numbering the images onto the XCDs was measured here, grid (images, jobs, chunks): 7.8 -> 8.2 us per launch -- the
+  //  workgroups that share an image's cache lines, one per 8-channel chunk, then queue on one L2 instead of eight)
+  const int job = blockIdx.x, b = blockIdx.y, c_lo = blockIdx.z * CW;
   const int cw = d.C - c_lo < CW ? d.C - c_lo : CW;                     // multiple of G
   const int HW = d.H * d.W, k = m.k[job], kk = k * k;
   unsigned short* xs = (unsigned short*)sm;                             // [HW][cw] bf16
@@ -1550,12 +1550,11 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
     if (cw < G) cw = G;
     const size_t lds = (((size_t)H * W * cw * 2 + 15) & ~(size_t)15) + (size_t)kmax * kmax * cw * 4;
     if (ok && lds <= 64 * 1024) {
-      const int xcd = g_xpt_xcd_affinity;
       XPT_BEGIN_LAUNCH();
       if (G == 8)
-        hipLaunchKernelGGL(dw_small_fwd_kernel<8>, dim3(xcd ? xpt_xcd_pad(B) : B, n, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw, xcd);
+        hipLaunchKernelGGL(dw_small_fwd_kernel<8>, dim3(n, B, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw);
       else
-        hipLaunchKernelGGL(dw_small_fwd_kernel<4>, dim3(xcd ? xpt_xcd_pad(B) : B, n, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw, xcd);
+        hipLaunchKernelGGL(dw_small_fwd_kernel<4>, dim3(n, B, (C + cw - 1) / cw), dim3(256), lds, s, m, d, relu_in, cw);
       return xpt_launch_status();
     }
   }

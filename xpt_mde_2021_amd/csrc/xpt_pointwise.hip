@@ -43,8 +43,10 @@ __device__ inline void affine_coeffs(const Affine& a, int c, float& sc, float& s
 
 template <typename T>
 __global__ void affine_act_fwd_kernel(const T* __restrict__ x, Affine a, const T* __restrict__ residual,
-                                      T* __restrict__ y, long long n, int C, float slope, int relu_in) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+                                      T* __restrict__ y, long long n, int C, float slope, int relu_in, XcdSweep sw) {
+  long long i, i_end;
+  if (!sw.range(blockIdx.x, n, i, i_end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (i += threadIdx.x; i < i_end; i += 256) {
     unsigned c_;
     (void)xpt_divmod((unsigned)i, (unsigned)C, c_);      // (n < 2^31: checked by the launcher)
     const int c = (int)c_;
@@ -101,15 +103,17 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict
                                                               T* __restrict__ dx, float* __restrict__ part,
                                                               long long rows, int C, long long rows_per_block,
                                                               float slope, int relu_in, int need_dscale,
-                                                              int final_partials) {
+                                                              int final_partials, int nblocks, int xcd) {
   __shared__ float red[2][256 * V];
+  unsigned rb;                                                // grid: x = row slices (image-to-XCD numbering), y = channel tiles
+  if (!xpt_xcd_unit(xcd != 0, blockIdx.x, (unsigned)nblocks, rb)) return;
   const int groups = C / V;                                   // V divides C
-  const int g0 = blockIdx.x * PW_MAX_GROUPS;
+  const int g0 = blockIdx.y * PW_MAX_GROUPS;
   const int gt = min(groups - g0, PW_MAX_GROUPS);             // V-groups of this channel tile
   const int slots = 256 / gt;                                 // pixel rows in flight per iteration
   const int grp = threadIdx.x % gt, slot = threadIdx.x / gt;
   const int c0 = (g0 + grp) * V;
-  const long long r_begin = (long long)blockIdx.y * rows_per_block;
+  const long long r_begin = (long long)rb * rows_per_block;
   const long long r_end = min(rows, r_begin + rows_per_block);
   float s_shift[V], s_scale[V], sc[V];
 #pragma unroll
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void affine_act_bwd_kernel(const T* __restrict
       affine_coeffs(a, c, scc, sh, rstd, mu);
       s1 = rstd * (s1 - mu * s0);
     }
-    float* p = part + (long long)blockIdx.y * 2 * C;
+    float* p = part + (long long)rb * 2 * C;
     p[c] = s0;
     p[C + c] = s1;
   }
@@ -187,11 +191,12 @@ struct SumInputs {
 };
 
 template <typename T, int V>
-__global__ __launch_bounds__(256) void sum_rows_kernel(SumInputs in, T* __restrict__ out, long long rows, int C) {
+__global__ __launch_bounds__(256) void sum_rows_kernel(SumInputs in, T* __restrict__ out, long long rows, int C, XcdSweep sw) {
   const int groups = C / V;
   const long long total = rows * groups;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  long long idx, idx_end;
+  if (!sw.range(blockIdx.x, total, idx, idx_end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (idx += threadIdx.x; idx < idx_end; idx += 256) {
     unsigned c0_;
     const long long r = (long long)xpt_divmod((unsigned)idx, (unsigned)groups, c0_);
     const int c0 = (int)c0_ * V;
@@ -254,8 +259,10 @@ struct CatInputs {
 };
 
 __global__ __launch_bounds__(256) void concat_channels_kernel(CatInputs in, unsigned short* __restrict__ out, unsigned total,
-                                                              int groups) {
-  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+                                                              int groups, XcdSweep sw) {
+  long long i64, e64;
+  if (!sw.range(blockIdx.x, (long long)total, i64, e64)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (unsigned idx = (unsigned)i64 + threadIdx.x; idx < (unsigned)e64; idx += 256u) {
     unsigned g_;
     const long long row = (long long)xpt_divmod(idx, (unsigned)groups, g_);
     const int c0 = (int)g_ * 8;
@@ -398,9 +405,12 @@ __device__ inline void up2_taps(int y, int h, int& i0, int& i1, float& l) {
 }
 
 template <typename T>
-__global__ void upsample2x_fwd_kernel(const float* __restrict__ src, T* __restrict__ out, long long total, int h, int w) {
+__global__ void upsample2x_fwd_kernel(const float* __restrict__ src, T* __restrict__ out, long long total, int h, int w,
+                                      XcdSweep sw) {
   const int H = 2 * h, W = 2 * w;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  long long i, i_end;
+  if (!sw.range(blockIdx.x, total, i, i_end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (i += threadIdx.x; i < i_end; i += 256) {
     unsigned xu, yu;                                // (total < 2^31: the launcher checks; 64-bit divisions are ~120 instructions each)
     const long long m = (long long)xpt_divmod(xpt_divmod((unsigned)i, (unsigned)W, xu), (unsigned)H, yu);
     const int x = (int)xu, y = (int)yu;
@@ -428,10 +438,11 @@ __device__ inline float up2_weight(int y, int i, int h) {
 // of an NHWC concatenation gradient is read in place)
 template <typename T>
 __global__ void upsample2x_bwd_kernel(const T* __restrict__ g, long long g_pitch, const float* __restrict__ addend,
-                                      float* __restrict__ dsrc, long long total, int h, int w) {
+                                      float* __restrict__ dsrc, long long total, int h, int w, XcdSweep sw) {
   const int W = 2 * w, H = 2 * h;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
+  long long idx, idx_end;
+  if (!sw.range(blockIdx.x, total, idx, idx_end)) return;      // (pixel-major indices: image-to-XCD numbering, xpt_common.h)
+  for (idx += threadIdx.x; idx < idx_end; idx += 256) {
     unsigned ju, iu;
     const long long m = (long long)xpt_divmod(xpt_divmod((unsigned)idx, (unsigned)w, ju), (unsigned)h, iu);
     const int j = (int)ju, i = (int)iu;
@@ -550,10 +561,11 @@ static void affine_bwd_launch_v(const void* x, const void* y, const void* dy, lo
                                 void* dx, float* part, long long rows, int C, float slope, int relu_in,
                                 int need_dscale, int final_partials, hipStream_t s) {
   const int groups = C / V;
-  const dim3 grid((groups + PW_MAX_GROUPS - 1) / PW_MAX_GROUPS, affine_bwd_blocks(rows, C));
+  const int nblocks = affine_bwd_blocks(rows, C), xcd = g_xpt_xcd_affinity && nblocks >= 8;
+  const dim3 grid(xcd ? xpt_xcd_pad(nblocks) : nblocks, (groups + PW_MAX_GROUPS - 1) / PW_MAX_GROUPS);
   hipLaunchKernelGGL((affine_act_bwd_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, (const T*)dy,
                      dy_pitch, a, (T*)dx, part, rows, C, affine_bwd_rows_per_block(rows), slope, relu_in, need_dscale,
-                     final_partials);
+                     final_partials, nblocks, xcd);
 }
 
 // dx + per-block partial sums part[blk][2][C]; final_partials: the second row holds the block's share of dgamma
@@ -609,14 +621,15 @@ int xpt_affine_act_fwd(const void* x, const float* gamma, const float* beta, con
   const long long n = rows * C;
   if (n >= (1LL << 31)) return XPT_ERR_SHAPE;            // (the kernel splits flat indices in 32 bits)
   const Affine a{gamma, beta, mean, var, eps};
+  const XcdSweep sw = xpt_xcd_sweep(n, 4096);
   XPT_BEGIN_LAUNCH();
   if (dtype == 0)
-    hipLaunchKernelGGL(affine_act_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)x, a, (const float*)residual, (float*)y, n, C, slope, relu_in);
+    hipLaunchKernelGGL(affine_act_fwd_kernel<float>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, a, (const float*)residual, (float*)y, n, C, slope, relu_in, sw);
   else
-    hipLaunchKernelGGL(affine_act_fwd_kernel<__hip_bfloat16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(affine_act_fwd_kernel<__hip_bfloat16>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
                        (const __hip_bfloat16*)x, a, (const __hip_bfloat16*)residual, (__hip_bfloat16*)y, n, C, slope,
-                       relu_in);
+                       relu_in, sw);
   return xpt_launch_status();
 }
 
@@ -730,13 +743,14 @@ int xpt_upsample2x_fwd(const float* src, void* out, long long M, int h, int w, i
   if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
   const long long total = M * 4 * h * w;
   if (total >= 0x7fffffffLL) return XPT_ERR_SHAPE;          // (32-bit index splits in the kernel)
+  const XcdSweep sw = xpt_xcd_sweep(total, 4096);
   XPT_BEGIN_LAUNCH();
   if (dtype == 0)
-    hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
-                       (float*)out, total, h, w);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream, src,
+                       (float*)out, total, h, w, sw);
   else
-    hipLaunchKernelGGL(upsample2x_fwd_kernel<__hip_bfloat16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       src, (__hip_bfloat16*)out, total, h, w);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<__hip_bfloat16>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
+                       src, (__hip_bfloat16*)out, total, h, w, sw);
   return xpt_launch_status();
 }
 
@@ -747,13 +761,14 @@ int xpt_upsample2x_bwd_add(const void* g, long long g_pitch, const float* addend
   if (dtype != 0 && dtype != 1) return XPT_ERR_ARG;
   const long long total = M * h * w;
   if (total >= 0x7fffffffLL) return XPT_ERR_SHAPE;
+  const XcdSweep sw = xpt_xcd_sweep(total, 4096);
   XPT_BEGIN_LAUNCH();
   if (dtype == 0)
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)g, g_pitch, addend, dsrc, total, h, w);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)g, g_pitch, addend, dsrc, total, h, w, sw);
   else
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<__hip_bfloat16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16*)g, g_pitch, addend, dsrc, total, h, w);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<__hip_bfloat16>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16*)g, g_pitch, addend, dsrc, total, h, w, sw);
   return xpt_launch_status();
 }
 
@@ -855,10 +870,11 @@ int xpt_sum_rows(const void* const* inputs, const long long* pitches, int n, voi
   }
   const long long total = rows * (C / v);
   if (total >= (1LL << 31)) return XPT_ERR_SHAPE;        // (the kernel splits flat indices in 32 bits)
-  const dim3 grid(grid_for(total));
+  const XcdSweep sw = xpt_xcd_sweep(total, 4096);
+  const dim3 grid(sw.grid);
   hipStream_t s = (hipStream_t)stream;
   XPT_BEGIN_LAUNCH();
-#define XPT_SUM(T, V) hipLaunchKernelGGL((sum_rows_kernel<T, V>), grid, dim3(256), 0, s, in, (T*)out, rows, C)
+#define XPT_SUM(T, V) hipLaunchKernelGGL((sum_rows_kernel<T, V>), grid, dim3(256), 0, s, in, (T*)out, rows, C, sw)
   if (dtype == 0) {
     if (v == 4) XPT_SUM(float, 4);
     else if (v == 2) XPT_SUM(float, 2);
@@ -920,8 +936,9 @@ int xpt_concat_channels(const void* const* inputs, const long long* pitches, con
   const long long total = rows * (Ct / 8);
   if (total >= (1LL << 31)) return XPT_ERR_SHAPE;
   XPT_BEGIN_LAUNCH();
-  hipLaunchKernelGGL(concat_channels_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
-                     (unsigned short*)out, (unsigned)total, Ct / 8);
+  const XcdSweep sw = xpt_xcd_sweep(total, 4096);
+  hipLaunchKernelGGL(concat_channels_kernel, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream, in,
+                     (unsigned short*)out, (unsigned)total, Ct / 8, sw);
   return xpt_launch_status();
 }
 
