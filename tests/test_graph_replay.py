@@ -71,6 +71,35 @@ def test_two_graph_step_with_cut_backward_equals_the_single_graph_step(gpu_devic
     assert ssum == dsum
 
 
+def test_posenet_on_its_side_stream_changes_nothing(gpu_device):
+    """config.NET_STREAMS (default on for the mono wrapper): PoseNet runs forward and backward on a side HIP stream next to
+    DepthNet -- a fork / join inside the captured graph, its deferred weight-gradient partials joined by the gradient sink.
+    Stream placement is no arithmetic: eight training steps with augmentation must give the SAME losses and final weights
+    as the one-stream step, captured and eager."""
+    one, osum = _loss_sequence("graph", "aug", 8, XPT_NET_STREAMS="0")
+    two, tsum = _loss_sequence("graph", "aug", 8, XPT_NET_STREAMS="1")
+    assert one == two, f"one stream  {one}\ntwo streams {two}"
+    assert osum == tsum
+    # (eager against captured without augmentation, as everywhere in this file: the two trainers draw their augmentations differently)
+    eager, esum = _loss_sequence("eager", "noaug", 6, XPT_NET_STREAMS="1")
+    graph, gsum = _loss_sequence("graph", "noaug", 6, XPT_NET_STREAMS="0")
+    assert eager == graph and esum == gsum
+
+
+def test_image_to_xcd_numbering_changes_nothing(gpu_device):
+    """xpt_set_xcd_affinity / XPT_XCD_AFFINITY: the encoder's and decoder's launches number their workgroups so that the rows
+    of image k run on XCD k in every kernel (csrc/xpt_common.h).  Renumbering only: every result keeps its value except the
+    specialised dense weight gradient's, whose splits then walk other tiles (the same tiles in total, added in another
+    grouping: last-bit differences in dW).  Six training steps: losses equal to 1e-6 relative, the final weights' checksum to
+    1e-9 relative."""
+    on, onsum = _loss_sequence("graph", "noaug", 6, XPT_XCD_AFFINITY="1")
+    off, offsum = _loss_sequence("graph", "noaug", 6, XPT_XCD_AFFINITY="0")
+    for a, b in zip(on, off):
+        assert abs(float(a) - float(b)) <= 1e-6 * abs(float(b)), f"on  {on}\noff {off}"
+    a, b = float(onsum.split()[1]), float(offsum.split()[1])
+    assert abs(a - b) <= 1e-9 * abs(b), (onsum, offsum)
+
+
 def test_one_launch_branch_stage_equals_the_two_launch_path_bit_for_bit(gpu_device):
     """csrc/xpt_sepconv.hip (ReLU -> depthwise -> pointwise -> BatchNorm [+ sibling branch / residual] of a NASNet cell
     stage in ONE launch; opt-in, XPT_FUSED_SEPCONV=1) against the separate depthwise and pointwise launches it replaces:

@@ -133,9 +133,11 @@ class VodeOptions(LossOptions):
     FRAME_PER_DRIVE = 0
     TOTAL_FRAME_LIMIT = 0
     VALIDATION_FRAMES = 500
-    # PoseNet on a side HIP stream next to DepthNet (forked / joined inside the hipGraph).  Off: on ROCm 7.0 a graph with
-    # a parallel branch replays SLOWER (20.97 vs 19.60 ms per step at batch 8; 2.9 vs 1.75 us per node in a synthetic test)
-    NET_STREAMS = False
+    # PoseNet on a side HIP stream next to DepthNet (forked / joined inside the hipGraph; the mono wrapper only).  It lost in
+    # round 2 (20.97 vs 19.60 ms per step: the parallel branch cost more per node than it overlapped); with the step at 4.2 ms
+    # it wins: 4.163 -> 4.11 ms at batch 8, 5.70 -> 5.60 at batch 16, the two-graph data-parallel step 4.45 -> 4.27; the
+    # stereo wrappers (two calls per step) measured 9.24 -> 9.33 and keep one stream.  XPT_NET_STREAMS=0 / 1 overrides.
+    NET_STREAMS = __import__("os").environ.get("XPT_NET_STREAMS", "1") == "1"
     AUGMENT_PROBS = {"CropAndResize": 0.2, "HorizontalFlip": 0.2, "ColorJitter": 0.2}
 
     # ---- training options (:216-253)

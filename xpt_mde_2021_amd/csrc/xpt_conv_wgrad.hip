@@ -438,7 +438,7 @@ int fast_nsplit(const WfArgs& a, int N, int C) {
   const long long cap = ((long long)g_wgrad_max_partial_mib << 20) / (bytes > 0 ? bytes : 1);
   if (s > cap) s = cap;
   if (s > a.ntiles) s = a.ntiles;
-  if (g_xpt_xcd_affinity != 0 && s >= 16) s &= ~7ll;          // image-to-XCD numbering wants whole groups of eight splits
+  if (s >= 16) s &= ~7ll;          // whole groups of eight splits (image-to-XCD numbering; with it off too: same partial sums)
   return s < 1 ? 1 : (int)s;
 }
 

@@ -90,7 +90,7 @@ class ModelWrapper:
             from ...hip import conv as _conv
             _conv.packer.pack()
         nets = list(self.models.values())
-        if image5d.is_cuda and len(nets) > 1 and getattr(opts, "NET_STREAMS", False):
+        if image5d.is_cuda and len(nets) > 1 and getattr(opts, "NET_STREAMS", False) and type(self) is ModelWrapper:
             # DepthNet and PoseNet are independent until the loss: the small PoseNet runs on a side HIP stream next
             # to the (launch-latency-bound) encoder, forward and -- because autograd replays every node on the stream
             # of its forward -- backward.  Inside a hipGraph capture this forks / joins the captured graph.
@@ -98,10 +98,15 @@ class ModelWrapper:
             if not hasattr(self, "_side_streams"):
                 self._side_streams = [torch.cuda.Stream() for _ in nets[1:]]
             side_out = []
+            from ...hip import ops as _ops
             for model, side in zip(nets[1:], self._side_streams):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     side_out.append(self._run(model, image5d))
+                if torch.is_grad_enabled():
+                    # the deferred parameter-gradient partials of this net are written on `side` during backward and are no
+                    # autograd outputs: the sink's finishing launch (main stream, after backward) waits for the stream itself
+                    _ops.grad_sink.join_streams.add(side)
             predictions.update(self._run(nets[0], image5d))
             for out, side in zip(side_out, self._side_streams):
                 main.wait_stream(side)
