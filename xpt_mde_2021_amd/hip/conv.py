@@ -272,14 +272,22 @@ class _Conv2dSame(torch.autograd.Function):
             # the weight gradient is off the critical path (nothing downstream of it until the step's finishing launch):
             # with a deferred destination it is forked onto a side stream BEFORE the data gradient is issued and runs next
             # to the data-gradient chain -- inside a captured step that is a fork / join of the graph
-            side = _wgrad_side_stream(g.device) if (ctx.sink_w is not None and WGRAD_SIDE_STREAM) else None
-            if side is not None:
+            if ctx.sink_w is not None and WGRAD_DEFER and getattr(weight, "defer_wgrad", False):
+                # (the DepthNet decoder: issued later, all at once, next to the encoder's backward -- _flush_deferred)
+                _deferred.append((ctx, g, gpitch, x))
+                side = None
+            else:
+                side = _wgrad_side_stream(g.device) if (ctx.sink_w is not None and WGRAD_SIDE_STREAM) else None
+            if _deferred and _deferred[-1][0] is ctx:
+                pass
+            elif side is not None:
                 side.wait_stream(torch.cuda.current_stream())
                 g.record_stream(side)
                 x.record_stream(side)
                 _ops.grad_sink.join_streams.add(side)
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                dw = _weight_grad(ctx, lib, g, gpitch, x)
+            if not (_deferred and _deferred[-1][0] is ctx):
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    dw = _weight_grad(ctx, lib, g, gpitch, x)
         if ctx.needs_input_grad[0]:
             e = packer.get(weight, need_bwd=True)
             dx = torch.empty((B, Cp, PH, PW), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
@@ -296,7 +304,38 @@ class _Conv2dSame(torch.autograd.Function):
             else:
                 _lib.check(lib.xpt_conv2d_bwd_data(g.data_ptr(), e["bwd"].data_ptr(), dx.data_ptr(), B, OH, OW, e["Np"], gpitch,
                                                    Cp, KH, KW, stride, pt, pl, PH, PW, Cp, ups, _stream()), "xpt_conv2d_bwd_data")
+        if _deferred and getattr(weight, "flush_wgrads", False):
+            _flush_deferred(True)
         return dx, dw, dbias, None, None, None, None
+
+
+# The decoder's weight gradients as ONE parallel branch of the step: a fork per layer costs more than it returns (below), so the
+# layers tagged `weight.defer_wgrad` only queue (ctx, g, x) during their backward; the layer tagged `weight.flush_wgrads` (the
+# decoder's first: its backward runs last) issues the whole queue on the side stream behind ONE fork edge, next to the encoder's
+# launch-latency-bound backward, and the gradient sink joins the stream before its finishing launch.
+# Measured (round 4, bit-identical losses): 4.11 -> 4.20 ms/step -- the persistent weight-gradient workgroups hold the CUs the
+# encoder's short launches are waiting for, the critical chain loses more than the branch saves.  Opt-in: XPT_WGRAD_DEFER=1.
+WGRAD_DEFER = __import__("os").environ.get("XPT_WGRAD_DEFER", "0") == "1"
+_deferred = []
+
+
+def _flush_deferred(to_side):
+    """Issue the queued weight-gradient launches (on the side stream, or -- the sink's safety net -- where we are)."""
+    global _deferred
+    queue, _deferred = _deferred, []
+    if not queue:
+        return
+    lib = _lib.load()
+    side = _wgrad_side_stream(queue[0][1].device) if to_side else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+        _ops.grad_sink.join_streams.add(side)
+    with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        for ctx, g, gpitch, x in queue:
+            if side is not None:
+                g.record_stream(side)
+                x.record_stream(side)
+            _weight_grad(ctx, lib, g, gpitch, x)
 
 
 # measured: the fork / join edges cost more than the overlap returns inside the captured step (10.53 -> 11.9 ms), so off
@@ -491,3 +530,6 @@ def head_conv(x, weight, bias):
 def head_usable(x, conv):
     return x.is_cuda and x.dtype == torch.bfloat16 and conv.in_channels in (16, 32, 64, 128) and conv.out_channels == 1 \
         and conv.kernel_size == (3, 3) and conv.weight.dtype == torch.float32 and conv.dilation == (1, 1) and conv.stride == (1, 1)
+
+
+_ops.grad_sink.pre_flush.append(lambda: _flush_deferred(False))

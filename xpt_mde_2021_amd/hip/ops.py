@@ -578,6 +578,7 @@ class GradSink:
         self.tables = {}         # job signature -> (table, scratch)
         self.retired = []
         self.join_streams = set()   # side streams that still produce partials of this step (hip/conv.py weight gradients)
+        self.pre_flush = []         # callables run first thing in flush()
 
     def wants(self, param):
         return self.enabled and param is not None and getattr(param, "flat_grad", None) is not None
@@ -601,6 +602,8 @@ class GradSink:
         self.pending.append((dst, src, int(offset), int(n), int(nsplit), int(stride)))
 
     def flush(self):
+        for hook in self.pre_flush:                    # (hip/conv.py: queued weight-gradient launches nobody issued)
+            hook()
         pending, self.pending = self.pending, []
         self.uses.clear()
         for side in self.join_streams:                 # partials produced off the main stream must have landed

@@ -141,6 +141,12 @@ class DepthNetPretrained(nn.Module):
         self.up1 = UpconvWithSkip(conv2d, 64, c1 + 1, 32, upsample_iterp)         # 1/2
         self.depth1 = ScaledDepthHead(conv2d, 32, pred_depth)
         self.up0 = UpconvWithSkip(conv2d, 32, 1, 16, upsample_iterp)              # 1/1: the only skip is p1 up-sampled
+        # (hip/conv.py, XPT_WGRAD_DEFER: the decoder's weight gradients as one side-stream branch, issued when up4.conv1 --
+        #  the decoder's first layer, last in the backward pass -- has sent its data gradient on to the encoder)
+        for up in (self.up4, self.up3, self.up2, self.up1, self.up0):
+            for layer in (up.conv1, up.conv2):
+                layer.conv.weight.defer_wgrad = True
+        self.up4.conv1.conv.weight.flush_wgrads = True
         self.depth0 = ScaledDepthHead(conv2d, 16, pred_depth)
         if any(sel is not None for (_, sel) in (layout[0], layout[2], layout[3], layout[4])):
             raise WrongInputException("structurally-zero channels are handled for the 1/4 tap only")
