@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--height", type=int, default=128)
     ap.add_argument("--width", type=int, default=416)
     ap.add_argument("--mode", default=None, help="eager | graph | distributed (default: graph at N=1, distributed at N>1)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--stereo", action="store_true", help="stereo feature dict + LOSS_RIGID_T2 (configs[4]-style)")
     ap.add_argument("--nets", default="rigid", choices=["rigid", "flow", "joint"],
                     help="rigid = DepthNet + PoseNet (the headline workload); flow = PWC-Net with flowL2 + flow_reg; joint = "
@@ -111,6 +111,9 @@ def launch_children(args):
 def build_step(args, world):
     from xpt_mde_2021_amd.config import opts
     opts.CONV_DTYPE = args.dtype
+    if args.dtype in ("bf16", "fp16"):      # the 16-bit format is a property of the library this process loads (hip/lib.py)
+        from xpt_mde_2021_amd.hip import lib as _xlib
+        _xlib.set_half_format(args.dtype)
     opts.PER_REPLICA_BATCH = args.batch
     opts.BATCH_SIZE = args.batch * world
     opts.IMAGE_SIZES["kitti_raw"] = (args.height, args.width)

@@ -247,6 +247,11 @@ int xpt_dwconv_tune(int wrw_groups);
 /* process-wide A/B switch (benchmarking): the kernels that number their workgroups image-major map image k of a batch of 8
  * to XCD k (each XCD's L2 keeps what it wrote across kernel boundaries); pure renumbering, same results.  Default on. */
 int xpt_set_xcd_affinity(int on);
+/* The 16-bit activation format of this build: 0 = bfloat16 (libxpt_hip.so), 1 = IEEE half (libxpt_hip_f16.so: the same sources
+ * compiled with -DXPT_HALF_F16 for BASELINE configs[4], "fp16 convs + fp32 loss accumulation").  Wherever this header says
+ * "bf16" / dtype 1 for an activation or packed-weight operand it means this format; fp32 operands, accumulators, losses and
+ * optimizer state are the same in both builds.  The reference has no counterpart (it is fp32 end to end, train_val.py:78-92). */
+int xpt_half_format(void);
 size_t xpt_dwconv_bwd_weight_workspace_floats(int B, int OH, int OW, int C, int k);
 int xpt_dwconv_bwd_weight(const void* x, const void* dy, float* dw, float* workspace, size_t workspace_floats,
                           int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int OH, int OW,

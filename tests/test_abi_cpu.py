@@ -35,6 +35,19 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert set(xl.SIGNATURES) == set(syms)
 
 
+def test_the_half_precision_build_exports_the_same_abi(lib):
+    """libxpt_hip_f16.so (the same sources with IEEE-half activations, BASELINE configs[4]) sits next to libxpt_hip.so, exports
+    every declared symbol and reports its format; the default library reports bfloat16."""
+    from xpt_mde_2021_amd.hip import lib as xl
+    assert lib.xpt_half_format() == 0
+    assert os.path.isfile(xl.LIB_PATH_F16), "csrc/build.py builds both libraries"
+    f16 = ctypes.CDLL(xl.LIB_PATH_F16)
+    for name in declared_symbols():
+        assert hasattr(f16, name), f"{name} missing from libxpt_hip_f16.so"
+    f16.xpt_half_format.restype = ctypes.c_int
+    assert f16.xpt_half_format() == 1
+
+
 def test_version_and_arch(lib):
     assert lib.xpt_abi_version() >= 1
     assert lib.xpt_build_arch() == b"gfx950"

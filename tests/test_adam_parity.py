@@ -5,6 +5,10 @@ import numpy as np
 import pytest
 import torch
 
+from xpt_mde_2021_amd.hip.lib import half as _half_dtype
+
+HALF = _half_dtype()      # 16-bit activation dtype of this process: bf16, or fp16 under XPT_HALF=fp16 (tests/test_fp16_build_gpu.py)
+
 from oracle.ref_adam import KerasAdamRef
 
 
@@ -51,7 +55,7 @@ def test_adam_kernel_matches_keras_adam(gpu_device, n, grad_scale):
     dev = gpu_device
     p, m, v = w0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
     gbuf = torch.zeros(n, device=dev)
-    shadow = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+    shadow = torch.zeros(n, dtype=HALF, device=dev)
     step = torch.zeros(1, device=dev)
     ref, w = KerasAdamRef(1e-4), w0.double().numpy()
     m_err = np.zeros(n)
@@ -74,7 +78,7 @@ def test_adam_kernel_matches_keras_adam(gpu_device, n, grad_scale):
         assert (np.abs(m.double().cpu().numpy() - ref.m) <= m_err).all()
         assert np.allclose(v.double().cpu().numpy(), ref.v, rtol=4e-6, atol=1e-30)
         assert float(gbuf.abs().max()) == 0.0                   # zero_grad happened in the same pass
-        assert torch.equal(shadow, p.to(torch.bfloat16))        # bf16 shadow = round-to-nearest-even of the updated weight
+        assert torch.equal(shadow, p.to(HALF))        # bf16 shadow = round-to-nearest-even of the updated weight
 
 
 def test_sgd_constant_host_branch():
@@ -102,7 +106,7 @@ def test_sgd_kernel(gpu_device, grad_scale):
     n = 4096 + 3
     w0, grads = make_problem(n, seed=9)
     p, gbuf = w0.clone().to(gpu_device), torch.zeros(n, device=gpu_device)
-    shadow = torch.zeros(n, dtype=torch.bfloat16, device=gpu_device)
+    shadow = torch.zeros(n, dtype=HALF, device=gpu_device)
     w = w0.clone()
     for g in grads:
         gbuf.copy_(g.to(gpu_device) / grad_scale)
@@ -112,4 +116,4 @@ def test_sgd_kernel(gpu_device, grad_scale):
         w = w - 1e-2 * ((g / grad_scale) * grad_scale)
         assert torch.allclose(p.cpu(), w, rtol=0, atol=3e-7 * float(w.abs().max()))
         assert float(gbuf.abs().max()) == 0.0
-        assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+        assert torch.equal(shadow.cpu(), p.cpu().to(HALF))

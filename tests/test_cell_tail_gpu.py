@@ -5,6 +5,10 @@ add, concatenate, Activation('relu') of tensorflow.keras.applications.nasnet's _
 (the backbone the reference instantiates at model/build_model/pretrained_nets.py:11-44)."""
 import pytest
 import torch
+
+from xpt_mde_2021_amd.hip.lib import half as _half_dtype
+
+HALF = _half_dtype()      # 16-bit activation dtype of this process: bf16, or fp16 under XPT_HALF=fp16 (tests/test_fp16_build_gpu.py)
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -27,8 +31,8 @@ def reference(spec, inputs):
 
 
 @pytest.mark.parametrize("spec,n_in", [(NORMAL, 5), (REDUCTION, 4)])
-@pytest.mark.parametrize("dtype,F_,H,W", [(torch.float32, 12, 5, 7), (torch.bfloat16, 44, 16, 52), (torch.bfloat16, 88, 8, 26),
-                                          (torch.bfloat16, 22, 9, 13), (torch.bfloat16, 11, 6, 5), (torch.float32, 6, 1, 3)])
+@pytest.mark.parametrize("dtype,F_,H,W", [(torch.float32, 12, 5, 7), (HALF, 44, 16, 52), (HALF, 88, 8, 26),
+                                          (HALF, 22, 9, 13), (HALF, 11, 6, 5), (torch.float32, 6, 1, 3)])
 def test_cell_tail_matches_composed_ops(gpu_device, spec, n_in, dtype, F_, H, W):
     from xpt_mde_2021_amd.hip import ops
     dev = gpu_device
@@ -81,8 +85,8 @@ def test_cell_tail_without_grad_and_single_alias(gpu_device):
     assert out.is_contiguous(memory_format=torch.channels_last)
 
 
-@pytest.mark.parametrize("dtype,C,H,W", [(torch.float32, 6, 6, 10), (torch.float32, 5, 7, 9), (torch.bfloat16, 32, 16, 52),
-                                         (torch.bfloat16, 44, 9, 14), (torch.bfloat16, 11, 4, 6)])
+@pytest.mark.parametrize("dtype,C,H,W", [(torch.float32, 6, 6, 10), (torch.float32, 5, 7, 9), (HALF, 32, 16, 52),
+                                         (HALF, 44, 9, 14), (HALF, 11, 4, 6)])
 def test_adjust_gather_matches_pad_crop_stride(gpu_device, dtype, C, H, W):
     """keras _adjust_block, spatial mode: p[::2, ::2] and ZeroPadding2D(((0,1),(0,1))) -> Cropping2D(((1,0),(1,0))) -> [::2, ::2]."""
     from xpt_mde_2021_amd.hip import ops
@@ -108,8 +112,8 @@ def test_adjust_gather_matches_pad_crop_stride(gpu_device, dtype, C, H, W):
     assert torch.equal(xd2.grad.float().cpu(), only1)
 
 
-@pytest.mark.parametrize("dtype,C,H,W", [(torch.float32, 6, 8, 12), (torch.float32, 5, 7, 9), (torch.bfloat16, 32, 16, 52),
-                                         (torch.bfloat16, 22, 9, 13), (torch.bfloat16, 88, 8, 26)])
+@pytest.mark.parametrize("dtype,C,H,W", [(torch.float32, 6, 8, 12), (torch.float32, 5, 7, 9), (HALF, 32, 16, 52),
+                                         (HALF, 22, 9, 13), (HALF, 88, 8, 26)])
 def test_pool_pair_matches_padded_library_pools(gpu_device, dtype, C, H, W):
     from xpt_mde_2021_amd.hip import ops
     from xpt_mde_2021_amd.model.build_model.pretrained_nets import correct_pad
@@ -133,7 +137,7 @@ def test_pool_pair_matches_padded_library_pools(gpu_device, dtype, C, H, W):
     assert (xd.grad.float().cpu() - xr.grad).abs().max().item() <= (1e-5 if dtype == torch.float32 else 1e-2) * scale
 
 
-@pytest.mark.parametrize("dtype,C,H,W", [(torch.float32, 6, 8, 12), (torch.bfloat16, 24, 9, 13), (torch.bfloat16, 88, 8, 26)])
+@pytest.mark.parametrize("dtype,C,H,W", [(torch.float32, 6, 8, 12), (HALF, 24, 9, 13), (HALF, 88, 8, 26)])
 def test_pool_pair_with_two_consumers_of_the_maximum(gpu_device, dtype, C, H, W):
     """pool_pair(split_mp=True): the max-pooled tensor as two aliases whose gradients the backward adds on load
     (xpt_pool_pair_bwd2) == one tensor with both gradients added beforehand; one consumer silent: the other alone."""

@@ -46,7 +46,10 @@ def test_mixed_shape_stereo_steps_c5(gpu_device):
     from xpt_mde_2021_amd.model import train_val as tv
     saved = (opts.PER_REPLICA_BATCH, opts.BATCH_SIZE, opts.CONV_DTYPE, dict(opts.IMAGE_SIZES), opts.STEREO)
     opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 2
-    opts.CONV_DTYPE, opts.STEREO = "bf16", True
+    # (XPT_HALF=fp16: this process runs the half-precision build -- configs[4] as written, "fp16 convs + fp32 loss
+    #  accumulation"; tests/test_fp16_build_gpu.py starts this test that way)
+    from xpt_mde_2021_amd.hip import lib as _xlib
+    opts.CONV_DTYPE, opts.STEREO = _xlib.half_format(), True
     try:
         batches, cfg = [], None
         for hw in MIXED_SHAPES:

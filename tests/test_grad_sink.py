@@ -3,6 +3,10 @@ reproduce the gradients of the immediate per-layer kernels."""
 import pytest
 import torch
 
+from xpt_mde_2021_amd.hip.lib import half as _half_dtype
+
+HALF = _half_dtype()      # 16-bit activation dtype of this process: bf16, or fp16 under XPT_HALF=fp16 (tests/test_fp16_build_gpu.py)
+
 from xpt_mde_2021_amd.config import opts
 
 pytestmark = pytest.mark.gpu
@@ -59,8 +63,11 @@ def test_reduce_partials_jobs(gpu_device):
         assert torch.allclose(d.double(), e, atol=1e-3)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "half"])
 def test_deferred_equals_immediate(gpu_device, dtype, monkeypatch):
+    if dtype == "half":                        # bf16, or fp16 in a process that runs the half-precision build (XPT_HALF=fp16)
+        from xpt_mde_2021_amd.hip import lib as _xlib
+        dtype = _xlib.half_format()
     from xpt_mde_2021_amd.hip import ops
     from xpt_mde_2021_amd.model import model_main as mm
     from xpt_mde_2021_amd.model import train_val as tv
@@ -136,10 +143,10 @@ def test_fused_conv1x1_bn_backward(gpu_device, shape, with_residual, library_for
     monkeypatch.setattr(pn, "_PWCONV_MAX_CIN", 4096)                 # exercise the kernel on the deep reductions too
     B, cin, cout, H, W = shape
     g = torch.Generator().manual_seed(cin + cout)
-    x = torch.randn(B, cin, H, W, generator=g).bfloat16()
-    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).bfloat16()
-    res = torch.randn(B, cout, H, W, generator=g).bfloat16()
-    gy = torch.randn(B, cout, H, W, generator=g).bfloat16()
+    x = torch.randn(B, cin, H, W, generator=g).to(HALF)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).to(HALF)
+    res = torch.randn(B, cout, H, W, generator=g).to(HALF)
+    gy = torch.randn(B, cout, H, W, generator=g).to(HALF)
     gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
     mean, var = torch.randn(cout, generator=g) * 0.2, torch.rand(cout, generator=g) + 0.3
     # reference: fp32 autograd; the kernel path rounds the convolution output to bf16 before the BatchNorm
@@ -160,7 +167,7 @@ def test_fused_conv1x1_bn_backward(gpu_device, shape, with_residual, library_for
     bn.bias.flat_grad = torch.zeros(cout, device=dev)
     xg = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     rg = res.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+    with torch.autocast(device_type="cuda", dtype=HALF):
         y = pn.conv1x1_bn(xg, weight, bn, rg if with_residual else None)
     assert y.grad_fn is not None and "Conv1x1Bn" in type(y.grad_fn).__name__
     y.backward(gy.to(dev))
@@ -193,10 +200,10 @@ def test_conv1x1_bn_fan_in_inside_the_backward_launch(gpu_device, shape, n_alias
     B, cin, cout, H, W = shape
     dev = gpu_device
     g = torch.Generator().manual_seed(cin * 3 + cout)
-    x = torch.randn(B, cin, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).bfloat16()
-    wide = torch.randn(B, 2 * cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
-    gys = [wide[:, cout:]] + [torch.randn(B, cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, cin, H, W, generator=g).to(HALF).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).to(HALF)
+    wide = torch.randn(B, 2 * cout, H, W, generator=g).to(HALF).to(dev).contiguous(memory_format=torch.channels_last)
+    gys = [wide[:, cout:]] + [torch.randn(B, cout, H, W, generator=g).to(HALF).to(dev).contiguous(memory_format=torch.channels_last)
                               for _ in range(n_alias - 1)]
 
     def run(fused):
@@ -211,7 +218,7 @@ def test_conv1x1_bn_fan_in_inside_the_backward_launch(gpu_device, shape, n_alias
         bn.weight.flat_grad = torch.zeros(cout, device=dev)
         bn.bias.flat_grad = torch.zeros(cout, device=dev)
         xg = x.clone().requires_grad_(True)
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        with torch.autocast(device_type="cuda", dtype=HALF):
             ys = pn.conv1x1_bn(xg, weight, bn, fan_out=n_alias)
         assert isinstance(ys, tuple) and len(ys) == n_alias
         torch.autograd.backward([ys[i] for i in live], [gys[i] for i in live])
@@ -238,9 +245,9 @@ def test_data_gradient_inside_the_weight_gradient_launch(gpu_device, shape, n_al
     B, cin, cout, H, W = shape
     dev = gpu_device
     g = torch.Generator().manual_seed(cin * 5 + cout)
-    x = torch.randn(B, cin, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).bfloat16()
-    gys = [torch.randn(B, cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, cin, H, W, generator=g).to(HALF).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).to(HALF)
+    gys = [torch.randn(B, cout, H, W, generator=g).to(HALF).to(dev).contiguous(memory_format=torch.channels_last)
            for _ in range(n_alias)]
 
     def run(fused):
@@ -255,7 +262,7 @@ def test_data_gradient_inside_the_weight_gradient_launch(gpu_device, shape, n_al
         bn.weight.flat_grad = torch.zeros(cout, device=dev)
         bn.bias.flat_grad = torch.zeros(cout, device=dev)
         xg = x.clone().requires_grad_(True)
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        with torch.autocast(device_type="cuda", dtype=HALF):
             ys = pn.conv1x1_bn(xg, weight, bn, fan_out=n_alias)
         ys = ys if isinstance(ys, tuple) else (ys,)
         torch.autograd.backward(list(ys), gys)
@@ -281,9 +288,9 @@ def test_plain_conv1x1_backward_in_one_launch(gpu_device, shape, monkeypatch):
     B, cin, cout, H, W = shape
     dev = gpu_device
     g = torch.Generator().manual_seed(cin + 7 * cout)
-    x = torch.randn(B, cin, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).bfloat16()
-    gy = torch.randn(B, cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, cin, H, W, generator=g).to(HALF).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.2).to(HALF)
+    gy = torch.randn(B, cout, H, W, generator=g).to(HALF).to(dev).contiguous(memory_format=torch.channels_last)
 
     def run(fused):
         monkeypatch.setattr(pn, "_FUSED_DGRAD", fused)
@@ -291,7 +298,7 @@ def test_plain_conv1x1_backward_in_one_launch(gpu_device, shape, monkeypatch):
         weight.shadow_bf16 = w.to(dev)
         weight.flat_grad = torch.zeros(cout, cin, 1, 1, device=dev)
         xg = x.clone().requires_grad_(True)
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        with torch.autocast(device_type="cuda", dtype=HALF):
             y = pn.conv1x1(xg, weight)
         y.backward(gy)
         ops.grad_sink.flush()
@@ -319,17 +326,17 @@ def test_depthwise_backward_in_one_launch(gpu_device, k, stride, C, relu_in):
         (pt, pb), (pl, pr) = same_pad(H, k, 2), same_pad(W, k, 2)
     else:
         pt = pb = pl = pr = k // 2
-    x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    x = torch.randn(B, C, H, W, generator=g).to(HALF).float()
     w = torch.randn(C, 1, k, k, generator=g) * 0.2
     xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
     yr = F.conv2d(F.pad(F.relu(xr) if relu_in else xr, (pl, pr, pt, pb)), wr, None, stride, 0, 1, C)
-    gy = torch.randn(yr.shape, generator=g).bfloat16().float()
+    gy = torch.randn(yr.shape, generator=g).to(HALF).float()
     yr.backward(gy)
     weight = torch.nn.Parameter(w.to(gpu_device))
     weight.flat_grad = torch.full((C, 1, k, k), float("nan"), device=gpu_device)
-    xg = x.to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xg = x.to(gpu_device, HALF).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     y = ops.depthwise_conv2d(xg, weight, stride, (pt, pb, pl, pr), relu_in)
-    y.backward(gy.to(gpu_device, torch.bfloat16))
+    y.backward(gy.to(gpu_device, HALF))
     assert weight.grad is None                                       # deferred: nothing handed to autograd
     ops.grad_sink.flush()
     torch.cuda.synchronize()
@@ -350,10 +357,10 @@ def test_multi_depthwise_matches_single_layers(gpu_device, C, deferred, stride, 
     ks = ([5, 3, 3, 5, 3] if C != 176 else [5, 7, 7, 5, 3]) if stride == 1 else [5, 7, 7, 5, 3]
     pads = [(k // 2,) * 4 for k in ks] if stride == 1 else [same_pad(H, k, 2) + same_pad(W, k, 2) for k in ks]
     OH, OW = (H, W) if stride == 1 else ((H + 1) // 2, (W + 1) // 2)
-    h = torch.randn(B, C, H, W, generator=g).to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    p = torch.randn(B, C, H, W, generator=g).to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    h = torch.randn(B, C, H, W, generator=g).to(gpu_device, HALF).contiguous(memory_format=torch.channels_last)
+    p = torch.randn(B, C, H, W, generator=g).to(gpu_device, HALF).contiguous(memory_format=torch.channels_last)
     ws = [(torch.randn(C, 1, k, k, generator=g) * 0.2).to(gpu_device) for k in ks]
-    gys = [torch.randn(B, C, OH, OW, generator=g).to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gys = [torch.randn(B, C, OH, OW, generator=g).to(gpu_device, HALF).contiguous(memory_format=torch.channels_last)
            for _ in ks]
 
     def run(multi):
@@ -376,7 +383,10 @@ def test_multi_depthwise_matches_single_layers(gpu_device, C, deferred, stride, 
     ya, gha, gpa, gwa = run(True)
     yb, ghb, gpb, gwb = run(False)
     for a, b in zip(ya, yb):
-        assert torch.equal(a, b)
+        if HALF == torch.bfloat16:
+            assert torch.equal(a, b)
+        else:       # the half-precision build: the two kernels' fp32 sums may contract differently; one ulp of half on the result
+            assert torch.allclose(a, b, rtol=2 ** -10, atol=2 ** -10 * float(b.abs().max()))
     # input gradients: one fp32 sum rounded once (multi) vs per-layer bf16 results added by autograd
     assert torch.allclose(gha, ghb, atol=3e-2 * float(ghb.abs().max()))
     assert torch.allclose(gpa, gpb, atol=3e-2 * float(gpb.abs().max()))
@@ -411,7 +421,7 @@ def test_depthwise_tiles_match_the_kernels_they_replace(gpu_device, C, ks, B, H,
         lib.xpt_dwconv_tune(-60000 - (816 if on else 0))
         lib.xpt_dwconv_tune(-70000 - (1 if on else 0))
         g = torch.Generator().manual_seed(C * 7 + H)
-        mk = lambda *s: torch.randn(*s, generator=g).to(gpu_device, torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+        mk = lambda *s: torch.randn(*s, generator=g).to(gpu_device, HALF).contiguous(memory_format=torch.channels_last)  # noqa: E731
         h, p = mk(B, C, H, W).requires_grad_(True), mk(B, C, H, W).requires_grad_(True)
         params = [torch.nn.Parameter((torch.randn(C, 1, k, k, generator=g) * 0.2).to(gpu_device)) for k in ks]
         for q in params:
@@ -468,7 +478,7 @@ def test_multi_conv1x1_bn_matches_single_layers(gpu_device):
         gg = torch.Generator().manual_seed(11)
         for _ in range(n):
             w = torch.nn.Parameter((torch.randn(C, C, 1, 1, generator=gg) * 0.2).to(dev))
-            w.shadow_bf16 = w.detach().bfloat16()
+            w.shadow_bf16 = w.detach().to(HALF)
             w.flat_grad = torch.zeros_like(w)
             bn = pn.FrozenBatchNorm(C).to(dev)
             with torch.no_grad():
@@ -479,17 +489,17 @@ def test_multi_conv1x1_bn_matches_single_layers(gpu_device):
             layers.append((w, bn))
         return layers
 
-    xs0 = [torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(n)]
-    res0 = torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    wide = torch.randn(B, 3 * C + 8, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    gys = [wide[:, :C], wide[:, C + 8:2 * C + 8], torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)]
+    xs0 = [torch.randn(B, C, H, W, generator=g).to(dev, HALF).contiguous(memory_format=torch.channels_last) for _ in range(n)]
+    res0 = torch.randn(B, C, H, W, generator=g).to(dev, HALF).contiguous(memory_format=torch.channels_last)
+    wide = torch.randn(B, 3 * C + 8, H, W, generator=g).to(dev, HALF).contiguous(memory_format=torch.channels_last)
+    gys = [wide[:, :C], wide[:, C + 8:2 * C + 8], torch.randn(B, C, H, W, generator=g).to(dev, HALF).contiguous(memory_format=torch.channels_last)]
 
     def run(multi):
         layers = make()
         xs = [x.clone().requires_grad_(True) for x in xs0]
         res = res0.clone().requires_grad_(True)
         residuals = [None, res, None]
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        with torch.autocast(device_type="cuda", dtype=HALF):
             if multi:
                 ys = pn.multi_conv1x1_bn(xs, [w for w, _ in layers], [b for _, b in layers], residuals)
                 assert "MultiConv1x1Bn" in type(ys[0].grad_fn).__name__
@@ -528,7 +538,7 @@ def test_sibling_pointwise_layers_ride_in_the_main_launch(gpu_device, C, H, W, m
         gg = torch.Generator().manual_seed(11)
         for _ in range(n):
             w = torch.nn.Parameter((torch.randn(C, C, 1, 1, generator=gg) * 0.2).to(dev))
-            w.shadow_bf16 = w.detach().bfloat16()
+            w.shadow_bf16 = w.detach().to(HALF)
             w.flat_grad = torch.zeros_like(w)
             bn = pn.FrozenBatchNorm(C).to(dev)
             with torch.no_grad():
@@ -539,7 +549,7 @@ def test_sibling_pointwise_layers_ride_in_the_main_launch(gpu_device, C, H, W, m
             layers.append((w, bn))
         return layers
 
-    rnd = lambda: torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    rnd = lambda: torch.randn(B, C, H, W, generator=g).to(dev, HALF).contiguous(memory_format=torch.channels_last)  # noqa: E731
     xs0, h0, gys = [rnd() for _ in range(n)], rnd(), [rnd() for _ in range(3)]
 
     def run(siblings):
@@ -547,7 +557,7 @@ def test_sibling_pointwise_layers_ride_in_the_main_launch(gpu_device, C, H, W, m
         xs = [x.clone().requires_grad_(True) for x in xs0]
         h = h0.clone().requires_grad_(True)
         (l1, l2, l5, r1, r2) = layers
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        with torch.autocast(device_type="cuda", dtype=HALF):
             if siblings:
                 ys = pn.multi_conv1x1_bn(xs[:3], [l1[0], l2[0], l5[0]], [l1[1], l2[1], l5[1]], [None, None, h],
                                          siblings=[(xs[3], r1[0], r1[1]), (xs[4], r2[0], r2[1]), None])
@@ -575,7 +585,7 @@ def test_sibling_pointwise_layers_ride_in_the_main_launch(gpu_device, C, H, W, m
 def _pw_layer(pn, dev, cout, cin, seed):
     gg = torch.Generator().manual_seed(seed)
     w = torch.nn.Parameter((torch.randn(cout, cin, 1, 1, generator=gg) * 0.2).to(dev))
-    w.shadow_bf16 = w.detach().bfloat16()
+    w.shadow_bf16 = w.detach().to(HALF)
     w.flat_grad = torch.zeros_like(w)
     bn = pn.FrozenBatchNorm(cout).to(dev)
     with torch.no_grad():
@@ -596,14 +606,14 @@ def test_paired_cell_heads_equal_two_separate_layers(gpu_device, cin, cout, H, W
     from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
     dev = gpu_device
     g = torch.Generator().manual_seed(cin + W)
-    rnd = lambda c: torch.randn(2, c, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)  # noqa: E731
+    rnd = lambda c: torch.randn(2, c, H, W, generator=g).to(dev, HALF).contiguous(memory_format=torch.channels_last)  # noqa: E731
     xa0, xb0 = rnd(cin), rnd(cin)
     gys = [rnd(cout) for _ in range(5)]
 
     def run(paired):
         (wa, bna), (wb, bnb) = _pw_layer(pn, dev, cout, cin, 3), _pw_layer(pn, dev, cout, cin, 4)
         xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        with torch.autocast(device_type="cuda", dtype=HALF):
             if paired:
                 assert pn.pair_conv1x1_bn_usable(xa, xb, wa, wb, bna, bnb)
                 outs = pn._PairConv1x1BnFan.apply(3, 2, pn.BN_EPS, xa, xb, wa, wb, bna.weight, bnb.weight, bna.bias, bnb.bias,
@@ -639,8 +649,8 @@ def test_fused_spatial_adjust_block_equals_the_composed_ops(gpu_device, C, F_, H
     from xpt_mde_2021_amd.model.build_model import pretrained_nets as pn
     dev = gpu_device
     g = torch.Generator().manual_seed(C + W)
-    x0 = torch.randn(2, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    gy = torch.randn(2, F_, (H + 1) // 2, (W + 1) // 2, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x0 = torch.randn(2, C, H, W, generator=g).to(dev, HALF).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(2, F_, (H + 1) // 2, (W + 1) // 2, generator=g).to(dev, HALF).contiguous(memory_format=torch.channels_last)
 
     class _Net:
         def __init__(self):
@@ -662,9 +672,9 @@ def test_fused_spatial_adjust_block_equals_the_composed_ops(gpu_device, C, F_, H
         for q in params:
             q.flat_grad = torch.zeros_like(q)
         for q in params[:2]:
-            q.shadow_bf16 = q.detach().bfloat16()
+            q.shadow_bf16 = q.detach().to(HALF)
         x = x0.clone().requires_grad_(True)
-        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        with torch.autocast(device_type="cuda", dtype=HALF):
             y = block(x, pn._Taps(set()))
             if fused:
                 assert "SpatialAdjustBn" in type(y.grad_fn).__name__

@@ -8,6 +8,10 @@ import numpy as np
 import pytest
 import torch
 
+from xpt_mde_2021_amd.hip.lib import half as _half_dtype
+
+HALF = _half_dtype()      # 16-bit activation dtype of this process: bf16, or fp16 under XPT_HALF=fp16 (tests/test_fp16_build_gpu.py)
+
 from oracle import ref_loss, ref_pose, ref_synthesize as rs
 from tests.util import flip_safe_depth, frac_close
 from xpt_mde_2021_amd.utils import synthetic_data as sd
@@ -401,17 +405,17 @@ def test_smoothness_multi_scale_equals_per_scale(ops, gpu_device, is_depth):
 
 # ------------------------------------------------------------------------------------------------ conv epilogues (a2/a3)
 @pytest.mark.parametrize("C,shape", [(44, (2, 16, 26)), (1, (2, 32, 52)), (3, (1, 5, 7)), (130, (1, 9, 11))])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, HALF])
 def test_bias_act_and_batchnorm_epilogues(ops, gpu_device, C, shape, dtype):
     import torch.nn.functional as F
     g = gen(70 + C)
     B, H, W = shape
     x = torch.randn((B, C, H, W), generator=g)
-    if dtype == torch.bfloat16:
-        x = x.bfloat16().float()
+    if dtype == HALF:
+        x = x.to(HALF).float()
     gy = torch.randn((B, C, H, W), generator=g)
-    if dtype == torch.bfloat16:
-        gy = gy.bfloat16().float()
+    if dtype == HALF:
+        gy = gy.to(HALF).float()
     bias = torch.randn(C, generator=g) * 0.3
     gamma = torch.rand(C, generator=g) + 0.5
     mean = torch.randn(C, generator=g) * 0.2
@@ -448,7 +452,7 @@ def test_bias_act_and_batchnorm_epilogues(ops, gpu_device, C, shape, dtype):
 
 
 @pytest.mark.parametrize("C,shape", [(44, (2, 16, 52)), (88, (2, 8, 26)), (11, (1, 32, 104)), (32, (1, 9, 7))])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, HALF])
 def test_batchnorm_residual_and_sliced_gradient(ops, gpu_device, C, shape, dtype):
     """The cell's branch add fused into the BatchNorm epilogue, and a dy that is a channel slice of a wider
     (concatenated) gradient read in place through its row pitch."""
@@ -458,7 +462,7 @@ def test_batchnorm_residual_and_sliced_gradient(ops, gpu_device, C, shape, dtype
 
     def rnd(*s):
         t = torch.randn(s, generator=g)
-        return t.bfloat16().float() if dtype == torch.bfloat16 else t
+        return t.to(HALF).float() if dtype == HALF else t
 
     x, res = rnd(B, C, H, W), rnd(B, C, H, W)
     gy_wide = rnd(B, 3 * C + 8, H, W)
@@ -500,7 +504,7 @@ DW_LARGE_ODD = (1, 22, 301, 330)    # V = 2 vectors, odd extents
 @pytest.mark.parametrize("k,stride,shape", [(3, 1, DW_SMALL), (5, 1, DW_SMALL), (7, 1, DW_SMALL), (3, 2, DW_SMALL),
                                             (5, 2, DW_SMALL), (7, 2, DW_SMALL), (3, 1, DW_LARGE), (5, 1, DW_LARGE),
                                             (7, 2, DW_LARGE), (3, 2, DW_LARGE), (5, 2, DW_LARGE_ODD), (7, 1, DW_LARGE_ODD)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, HALF])
 @pytest.mark.parametrize("relu_in", [False, True])
 def test_depthwise_conv_fwd_bwd(ops, gpu_device, k, stride, shape, dtype, relu_in):
     """xpt_dwconv_* against torch's fp32 grouped convolution on the CPU (TF SAME padding at stride 2)."""
@@ -514,15 +518,15 @@ def test_depthwise_conv_fwd_bwd(ops, gpu_device, k, stride, shape, dtype, relu_i
         pt = pb = pl = pr = k // 2
     x = torch.randn((B, C, H, W), generator=g)
     w = torch.randn((C, 1, k, k), generator=g) * 0.2
-    if dtype == torch.bfloat16:
-        x = x.bfloat16().float()                                   # same rounded inputs on both sides
+    if dtype == HALF:
+        x = x.to(HALF).float()                                   # same rounded inputs on both sides
     x_ref = x.clone().requires_grad_(True)
     w_ref = w.clone().requires_grad_(True)
     xin = F.relu(x_ref) if relu_in else x_ref
     y_ref = F.conv2d(F.pad(xin, (pl, pr, pt, pb)), w_ref, None, stride, 0, 1, C)
     gy = torch.randn(y_ref.shape, generator=g)
-    if dtype == torch.bfloat16:
-        gy = gy.bfloat16().float()
+    if dtype == HALF:
+        gy = gy.to(HALF).float()
     y_ref.backward(gy)
     xg = x.to(gpu_device, dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     wg = w.to(gpu_device).requires_grad_(True)
@@ -553,8 +557,8 @@ def test_depthwise_conv_fwd_bwd(ops, gpu_device, k, stride, shape, dtype, relu_i
 def test_conv1x1_weight_grad(gpu_device, M, cout, cin, pad_dy, pad_x):
     from xpt_mde_2021_amd.hip import ops
     g = torch.Generator().manual_seed(M + cout)
-    dy_full = torch.randn(M, cout + pad_dy, generator=g).to(gpu_device, torch.bfloat16)
-    x_full = torch.randn(M, cin + pad_x, generator=g).to(gpu_device, torch.bfloat16)
+    dy_full = torch.randn(M, cout + pad_dy, generator=g).to(gpu_device, HALF)
+    x_full = torch.randn(M, cin + pad_x, generator=g).to(gpu_device, HALF)
     dy2 = dy_full[:, pad_dy // 2:pad_dy // 2 + cout]
     x2 = x_full[:, pad_x // 2:pad_x // 2 + cin]
     dw = ops.conv1x1_weight_grad(dy2, x2)
@@ -586,7 +590,7 @@ def test_as_rows_views(gpu_device):
 
 
 # ------------------------------------------------------------------------------- gradient fan-in
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, HALF])
 def test_sum_rows_and_fan_out(ops, gpu_device, dtype):
     g = gen(300)
     B, C, H, W = 2, 44, 5, 7
@@ -612,18 +616,18 @@ def test_sum_rows_and_fan_out(ops, gpu_device, dtype):
 
 
 # ------------------------------------------------------------------------------- 3x3 SAME average pooling
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, HALF])
 @pytest.mark.parametrize("shape", [(2, 44, 6, 9), (1, 11, 1, 5), (2, 8, 3, 1)])
 def test_avg_pool3_same(ops, gpu_device, dtype, shape):
     import torch.nn.functional as F
     g = gen(400 + shape[1])
     B, C, H, W = shape
     x = torch.randn(shape, generator=g)
-    if dtype == torch.bfloat16:
-        x = x.bfloat16().float()
+    if dtype == HALF:
+        x = x.to(HALF).float()
     gy_wide = torch.randn((B, 2 * C + 4, H, W), generator=g)
-    if dtype == torch.bfloat16:
-        gy_wide = gy_wide.bfloat16().float()
+    if dtype == HALF:
+        gy_wide = gy_wide.to(HALF).float()
     xr = x.clone().requires_grad_(True)
     yr = F.avg_pool2d(xr, 3, 1, 1, count_include_pad=False) * 2.0
     yr.backward(gy_wide[:, 4:4 + C])
@@ -664,7 +668,7 @@ def test_inverse_sigmoid_depth(ops, gpu_device):
 
 
 @pytest.mark.parametrize("shape", [(2, 1, 16, 52), (1, 1, 1, 1), (3, 1, 5, 7), (2, 3, 4, 6)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, HALF])
 def test_upsample2x_matches_interpolate(ops, gpu_device, shape, dtype):
     """xpt_upsample2x_* (resize_image at an exact factor 2, layer_ops.py:43-50) vs F.interpolate(bilinear, half-pixel)
     forward and backward, with the gradient arriving as a channel slice of an NHWC tensor (read in place)."""
@@ -684,12 +688,12 @@ def test_upsample2x_matches_interpolate(ops, gpu_device, shape, dtype):
     wgt = torch.randn((B, 5 + C, 2 * h, 2 * w), generator=g)
     cat = torch.cat([other, y.contiguous(memory_format=torch.channels_last)], dim=1)
     (cat.float() * wgt.to(gpu_device)).sum().backward()
-    gy = wgt[:, 5:].to(dtype).double() if dtype == torch.bfloat16 else wgt[:, 5:].double()
+    gy = wgt[:, 5:].to(dtype).double() if dtype == HALF else wgt[:, 5:].double()
     yr.backward(gy)
     assert torch.allclose(xg.grad.cpu().double(), xr.grad, rtol=1e-5, atol=1e-5 if dtype == torch.float32 else 2e-2)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, HALF])
 def test_global_avg_pool(ops, gpu_device, dtype):
     """GlobalAveragePooling2D closing PoseNet (pose_net.py:45): value and gradient vs x.float().mean((2, 3))."""
     g = gen(503)
@@ -703,7 +707,7 @@ def test_global_avg_pool(ops, gpu_device, dtype):
     assert y.dtype == torch.float32
     assert torch.allclose(y.cpu().double(), x.double().mean(dim=(2, 3)), rtol=1e-6, atol=1e-6)
     assert xg.grad.dtype == dtype
-    assert torch.allclose(xg.grad.float().cpu().double(), xr.grad, rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-7)
+    assert torch.allclose(xg.grad.float().cpu().double(), xr.grad, rtol=1e-2 if dtype == HALF else 1e-6, atol=1e-7)
 
 
 def test_merge_total_matches_the_tensor_op_chain(ops, gpu_device):

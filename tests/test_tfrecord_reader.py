@@ -166,7 +166,9 @@ def test_prefetching_reader_keeps_its_descriptor_count_over_epochs(tmp_path):
     for _ in range(5):
         assert len(list(ds)) == 8
         counts.append(len(os.listdir("/proc/self/fd")))
-    assert len(set(counts)) == 1, counts
+    # (no growth: a leak adds a descriptor per shard and epoch; an earlier test's worker thread letting go of its own files
+    #  while this one runs may LOWER the count)
+    assert max(counts[1:]) <= counts[0], counts
     assert len(ds._maps) == 4
     ds.close()
     assert not ds._maps

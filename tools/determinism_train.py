@@ -29,6 +29,9 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
 use_aug = (sys.argv[2] if len(sys.argv) > 2 else "aug") == "aug"
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 opts.CONV_DTYPE = os.environ.get("XPT_DET_DTYPE", "bf16")
+if opts.CONV_DTYPE in ("bf16", "fp16"):
+    from xpt_mde_2021_amd.hip import lib as _xlib
+    _xlib.set_half_format(opts.CONV_DTYPE)
 opts.PER_REPLICA_BATCH = opts.BATCH_SIZE = 8
 opts.TRAIN_MODE = mode
 torch.manual_seed(0)

@@ -166,7 +166,12 @@ class VodeOptions(LossOptions):
     RAW_IMAGE_RES = {"kitti_raw": (375, 1242)}
 
     # ---- MI355X build switches (new; nothing to mirror in the reference)
-    CONV_DTYPE = "bf16"                       # dtype of the DepthNet / PoseNet convolutions ("bf16" | "fp32")
+    CONV_DTYPE = "bf16"                       # dtype of the DepthNet / PoseNet convolutions ("bf16" | "fp16" | "fp32")
+    # "fp16" (BASELINE configs[4]: fp16 convolutions + fp32 loss accumulation): IEEE-half activations and packed weights through
+    # libxpt_hip_f16.so, fp32 masters / losses / optimizer as always, and a STATIC loss scale -- the seed of the backward pass
+    # is LOSS_SCALE_FP16 instead of 1 (per-pixel gradients of a mean over 4e5 pixels are ~1e-7, below half's 6e-8 .. 6e-5
+    # subnormal range), taken out again by the optimizer's grad_scale (a power of two: exact)
+    LOSS_SCALE_FP16 = float(__import__("os").environ.get("XPT_LOSS_SCALE_FP16", "32768"))
     CHANNELS_LAST = True                      # NHWC activations for MIOpen
     FUSED_LOSS = True                         # fused warp+L1+SSIM march kernels when the loss set allows it
     GRAD_BUCKETS = 1                          # flat gradient buckets per all-reduce (RCCL over xGMI)

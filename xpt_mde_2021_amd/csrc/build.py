@@ -14,6 +14,9 @@ PKG = os.path.dirname(HERE)
 OUT = os.path.join(PKG, "libxpt_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
+# the same sources once more with IEEE-half activations (xpt_common.h, XPT_HALF_F16): BASELINE configs[4] "fp16 convs"
+OUT_F16 = os.path.join(PKG, "libxpt_hip_f16.so")
+OBJ_DIR_F16 = os.path.join(HERE, "build_f16")
 
 
 def sources():
@@ -24,25 +27,35 @@ def _headers():
     return glob.glob(os.path.join(HERE, "*.h")) + [os.path.join(os.path.dirname(PKG), "include", "xpt_hip.h")]
 
 
-def needs_build():
-    if not os.path.isfile(OUT):
+def needs_build(out=None):
+    out = out or OUT
+    if not os.path.isfile(out):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     return any(os.path.getmtime(d) > t for d in sources() + _headers())
 
 
 CODEGEN_FLAGS = ["-O3", "-fno-slp-vectorize", f"--offload-arch={ARCH}", "-std=c++17"]     # also used by tests/test_pipelined_isa.py
 
 
-def _object_of(src):
-    return os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+def _object_of(src, obj_dir=None):
+    return os.path.join(obj_dir or OBJ_DIR, os.path.basename(src)[:-4] + ".o")
 
 
 def build(force=False, verbose=True, extra_flags=()):
+    """Both libraries: libxpt_hip.so (bfloat16 activations) and libxpt_hip_f16.so (IEEE half)."""
+    _build_one(OUT, OBJ_DIR, force, verbose, tuple(extra_flags))
+    _build_one(OUT_F16, OBJ_DIR_F16, force, verbose, ("-DXPT_HALF_F16", *extra_flags))
+    return OUT
+
+
+def _build_one(OUT, OBJ_DIR, force, verbose, extra_flags):
+    def _object_of(src):
+        return os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libxpt_hip.so")
-    if not force and not needs_build():
+    if not force and not needs_build(OUT):
         return OUT
     os.makedirs(OBJ_DIR, exist_ok=True)
     newest_header = max(os.path.getmtime(h) for h in _headers())

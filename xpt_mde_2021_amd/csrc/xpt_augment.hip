@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void stem_input_kernel(const float* __restrict
                   a11 = q11[c] / 127.5f - 1.f;
       // at::upsample_bilinear2d: (1 - wy) * ((1 - wx) a00 + wx a01) + wy * ((1 - wx) a10 + wx a11)
       const float t = (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
-      v[c] = __builtin_bit_cast(unsigned short, (__bf16)t);
+      v[c] = xpt_f2h(t);
     }
     uint4 pk;
     pk.x = v[0] | ((unsigned)v[1] << 16); pk.y = v[2]; pk.z = 0u; pk.w = 0u;

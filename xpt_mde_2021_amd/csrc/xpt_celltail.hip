@@ -13,7 +13,6 @@
 //
 // Layout: activations are NHWC rows [M = B H W][channels] (bf16 or fp32), inputs may be channel slices (row pitch).
 // grid.y = slice (forward) / job (backward), so the term table of a workgroup is wave-uniform (SGPR loads).
-#include <hip/hip_bf16.h>
 
 #include "xpt_common.h"
 
@@ -21,19 +20,19 @@ namespace {
 
 template <typename T> __device__ inline float ldf(const T* p);
 template <> __device__ inline float ldf<float>(const float* p) { return *p; }
-template <> __device__ inline float ldf<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <> __device__ inline float ldf<xpt_half_t>(const xpt_half_t* p) { return xpt_half2float(*p); }
 template <typename T> __device__ inline void stf(T* p, float v);
 template <> __device__ inline void stf<float>(float* p, float v) { *p = v; }
-template <> __device__ inline void stf<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+template <> __device__ inline void stf<xpt_half_t>(xpt_half_t* p, float v) { *p = xpt_float2half(v); }
 
 template <typename T, int V> struct RowVec;
 template <> struct RowVec<float, 4> { typedef float4 type; };
 template <> struct RowVec<float, 2> { typedef float2 type; };
 template <> struct RowVec<float, 1> { typedef float type; };
-template <> struct RowVec<__hip_bfloat16, 8> { typedef uint4 type; };
-template <> struct RowVec<__hip_bfloat16, 4> { typedef uint2 type; };
-template <> struct RowVec<__hip_bfloat16, 2> { typedef unsigned type; };
-template <> struct RowVec<__hip_bfloat16, 1> { typedef unsigned short type; };
+template <> struct RowVec<xpt_half_t, 8> { typedef uint4 type; };
+template <> struct RowVec<xpt_half_t, 4> { typedef uint2 type; };
+template <> struct RowVec<xpt_half_t, 2> { typedef unsigned type; };
+template <> struct RowVec<xpt_half_t, 1> { typedef unsigned short type; };
 
 template <typename T, int V>
 __device__ inline void load_row(const T* p, float (&out)[V]) {
@@ -449,10 +448,10 @@ int xpt_cell_tail_fwd(int nslices, const int* nterms, const void* const* src, co
     else if (v == 2) XPT_TAIL(float, 2);
     else XPT_TAIL(float, 1);
   } else {
-    if (v == 8) XPT_TAIL(__hip_bfloat16, 8);
-    else if (v == 4) XPT_TAIL(__hip_bfloat16, 4);
-    else if (v == 2) XPT_TAIL(__hip_bfloat16, 2);
-    else XPT_TAIL(__hip_bfloat16, 1);
+    if (v == 8) XPT_TAIL(xpt_half_t, 8);
+    else if (v == 4) XPT_TAIL(xpt_half_t, 4);
+    else if (v == 2) XPT_TAIL(xpt_half_t, 2);
+    else XPT_TAIL(xpt_half_t, 1);
   }
 #undef XPT_TAIL
   return xpt_launch_status();
@@ -510,10 +509,10 @@ int xpt_cell_tail_bwd(int ngrads, const void* const* grads, const long long* gpi
     else if (v == 2) XPT_TAIL(float, 2);
     else XPT_TAIL(float, 1);
   } else {
-    if (v == 8) XPT_TAIL(__hip_bfloat16, 8);
-    else if (v == 4) XPT_TAIL(__hip_bfloat16, 4);
-    else if (v == 2) XPT_TAIL(__hip_bfloat16, 2);
-    else XPT_TAIL(__hip_bfloat16, 1);
+    if (v == 8) XPT_TAIL(xpt_half_t, 8);
+    else if (v == 4) XPT_TAIL(xpt_half_t, 4);
+    else if (v == 2) XPT_TAIL(xpt_half_t, 2);
+    else XPT_TAIL(xpt_half_t, 1);
   }
 #undef XPT_TAIL
   return xpt_launch_status();
@@ -535,7 +534,7 @@ int xpt_adjust_gather(const void* in, long long in_pitch, void* out, int B, int 
 #define XPT_K(T, V) \
   hipLaunchKernelGGL((adjust_gather_kernel<T, V>), dim3(sw.grid), dim3(256), 0, st, (const T*)in, in_pitch, (T*)out, B, H, W, C, H2, W2, sw)
   if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
-  else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
+  else { if (v == 8) XPT_K(xpt_half_t, 8); else if (v == 4) XPT_K(xpt_half_t, 4); else if (v == 2) XPT_K(xpt_half_t, 2); else XPT_K(xpt_half_t, 1); }
 #undef XPT_K
   return xpt_launch_status();
 }
@@ -561,7 +560,7 @@ int xpt_adjust_scatter(const void* d1, long long pitch1, const void* d2, long lo
   hipLaunchKernelGGL((adjust_scatter_kernel<T, V>), dim3(sw.grid), dim3(256), 0, st, (const T*)d1, pitch1, (const T*)d2, \
                      pitch2, (T*)out, B, H, W, C, H2, W2, sw)
   if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
-  else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
+  else { if (v == 8) XPT_K(xpt_half_t, 8); else if (v == 4) XPT_K(xpt_half_t, 4); else if (v == 2) XPT_K(xpt_half_t, 2); else XPT_K(xpt_half_t, 1); }
 #undef XPT_K
   return xpt_launch_status();
 }
@@ -587,7 +586,7 @@ int xpt_pool_pair_fwd(const void* in, long long in_pitch, void* mp, void* ap, vo
   hipLaunchKernelGGL((pool_pair_fwd_kernel<T, V>), dim3(sw.grid), dim3(256), 0, st, (const T*)in, in_pitch, (T*)mp, \
                      (T*)ap, (unsigned char*)arg, B, H, W, C, OH, OW, pad_t, pad_l, sw)
   if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
-  else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
+  else { if (v == 8) XPT_K(xpt_half_t, 8); else if (v == 4) XPT_K(xpt_half_t, 4); else if (v == 2) XPT_K(xpt_half_t, 2); else XPT_K(xpt_half_t, 1); }
 #undef XPT_K
   return xpt_launch_status();
 }
@@ -621,7 +620,7 @@ int xpt_pool_pair_bwd2(const void* gmp, long long pitch_m, const void* gmp2, lon
   hipLaunchKernelGGL((pool_pair_bwd_kernel<T, V>), dim3(sw.grid), dim3(256), 0, st, (const T*)gmp, pitch_m, (const T*)gmp2, \
                      pitch_m2, (const T*)gap, pitch_a, (const unsigned char*)arg, (T*)dh, B, H, W, C, OH, OW, pad_t, pad_l, sw)
   if (dtype == 0) { if (v == 4) XPT_K(float, 4); else if (v == 2) XPT_K(float, 2); else XPT_K(float, 1); }
-  else { if (v == 8) XPT_K(__hip_bfloat16, 8); else if (v == 4) XPT_K(__hip_bfloat16, 4); else if (v == 2) XPT_K(__hip_bfloat16, 2); else XPT_K(__hip_bfloat16, 1); }
+  else { if (v == 8) XPT_K(xpt_half_t, 8); else if (v == 4) XPT_K(xpt_half_t, 4); else if (v == 2) XPT_K(xpt_half_t, 2); else XPT_K(xpt_half_t, 1); }
 #undef XPT_K
   return xpt_launch_status();
 }

@@ -7,6 +7,73 @@
 
 #define XPT_WAVE 64
 
+// ---- the 16-bit activation format.  The library is built twice from these sources (csrc/build.py): libxpt_hip.so --
+// bfloat16, the benchmarked configuration -- and, with -DXPT_HALF_F16, libxpt_hip_f16.so -- IEEE half, BASELINE.json
+// configs[4] "fp16 convs + fp32 loss accumulation".  Everything that depends on the format is here: the element types, the
+// conversions (fp32 arithmetic everywhere else) and the matrix-core instruction; `dtype == 1` of the C ABI means "the 16-bit
+// format of this build".
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#ifdef XPT_HALF_F16
+typedef _Float16 xpt_h16;                 // operand element of the matrix-core builtins
+typedef __half xpt_half_t;                // element type of the templated element-wise / stencil kernels
+#define XPT_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
+typedef __bf16 xpt_h16;
+typedef __hip_bfloat16 xpt_half_t;
+#define XPT_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef xpt_h16 xpt_h16x8 __attribute__((ext_vector_type(8)));
+#ifdef __HIPCC__
+__device__ __forceinline__ float xpt_h2f(unsigned short u) {             // bits -> fp32 (exact)
+#ifdef XPT_HALF_F16
+  return (float)__builtin_bit_cast(_Float16, u);
+#else
+  return __uint_as_float(((unsigned)u) << 16);
+#endif
+}
+__device__ __forceinline__ float xpt_h2f_lo(unsigned w) {                // low / high element of a packed pair
+#ifdef XPT_HALF_F16
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+#else
+  return __uint_as_float(w << 16);
+#endif
+}
+__device__ __forceinline__ float xpt_h2f_hi(unsigned w) {
+#ifdef XPT_HALF_F16
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+#else
+  return __uint_as_float(w & 0xffff0000u);
+#endif
+}
+__device__ __forceinline__ unsigned short xpt_f2h(float f) {             // fp32 -> bits, round to nearest even (the hardware's conversion)
+  return __builtin_bit_cast(unsigned short, (xpt_h16)f);
+}
+__device__ __forceinline__ unsigned short xpt_f2h_sw(float f) {          // the pointwise kernels' integer round-to-nearest-even (bf16)
+#ifdef XPT_HALF_F16
+  return xpt_f2h(f);
+#else
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+#endif
+}
+__device__ __forceinline__ float xpt_half2float(xpt_half_t h) {
+#ifdef XPT_HALF_F16
+  return __half2float(h);
+#else
+  return __bfloat162float(h);
+#endif
+}
+__device__ __forceinline__ xpt_half_t xpt_float2half(float f) {
+#ifdef XPT_HALF_F16
+  return __float2half(f);
+#else
+  return __float2bfloat16(f);
+#endif
+}
+#endif
+
 #define XPT_CHECK_PTR(p) \
   do {                   \
     if ((p) == nullptr) return XPT_ERR_NULL; \

@@ -29,10 +29,10 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef xpt_h16x8 bf16x8;      // (8 operands of the build's 16-bit format, xpt_common.h)
 
 __device__ inline unsigned short f2bf(float f) {   // round to nearest even (inputs are finite or NaN-preserving enough here)
-  return __builtin_bit_cast(unsigned short, (__bf16)f);
+  return xpt_f2h(f);
 }
 
 struct ConvArgs {
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(NKW > 1 ? 64 * NKW : 256) void conv_igemm_kernel(Co
         for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int j = 0; j < RN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[g][i]),
-                                                                __builtin_bit_cast(bf16x8, fb[g][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = XPT_MFMA_32X32X16(__builtin_bit_cast(bf16x8, fa[g][i]),
+                                                                __builtin_bit_cast(bf16x8, fb[g][j]), acc[i][j]);
       }
     }
   }
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(256) void conv_lds_kernel(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
           const uint4 fa = *(const uint4*)(fA + 32 * i * PITCH + k16 * 32);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
-                                                           acc[i], 0, 0, 0);
+          acc[i] = XPT_MFMA_32X32X16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
+                                                           acc[i]);
         }
       }
     }
@@ -583,8 +583,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs a, HaloPlan hp)
 #pragma unroll
         for (int i = 0; i < RM; ++i) {
           const uint4 fa = *(const uint4*)(wT + 32 * i * hp.WP + k16 * 32);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
-                                                           acc[i], 0, 0, 0);
+          acc[i] = XPT_MFMA_32X32X16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
+                                                           acc[i]);
         }
       }
     };

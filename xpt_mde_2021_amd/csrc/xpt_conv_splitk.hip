@@ -19,10 +19,10 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef xpt_h16x8 bf16x8;      // (8 operands of the build's 16-bit format, xpt_common.h)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ inline unsigned short f2bf_sk(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ inline unsigned short f2bf_sk(float f) { return xpt_f2h(f); }
 
 struct SkArgs {
   const unsigned short* x;   // NHWC bf16 activations (forward: layer input; transposed: gradient at the layer output)
@@ -46,7 +46,7 @@ struct SkArgs {
 template <int RN, int NW>
 __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(SkArgs a) {
   constexpr int TN = 64 * RN, TP = 128, PITCH = 64 * 2 + 16;
-  constexpr int NT = 64 * NW, RPP = 8 * NW, APASS = TN / RPP, BPASS = TP / RPP;   // staging: rows per pass, passes per operand
+  constexpr int RPP = 8 * NW, APASS = TN / RPP, BPASS = TP / RPP;   // staging: rows per pass, passes per operand
   constexpr int WI = NW == 4 ? RN : 1;                                            // 32-channel tiles per wave
   static_assert(NW == 4 || (NW == 8 && RN == 2), "8 waves: the 128-channel tile only");
   __shared__ __attribute__((aligned(16))) unsigned char lds[(TN + TP) * PITCH];
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(SkArgs a) {
       for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[k16][i]), __builtin_bit_cast(bf16x8, fb[k16][j]),
-                                                              acc[i][j], 0, 0, 0);
+          acc[i][j] = XPT_MFMA_32X32X16(__builtin_bit_cast(bf16x8, fa[k16][i]), __builtin_bit_cast(bf16x8, fb[k16][j]),
+                                                              acc[i][j]);
   };
 
   Stage s0, s1;

@@ -24,10 +24,10 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef xpt_h16x8 bf16x8;      // (8 operands of the build's 16-bit format, xpt_common.h)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ inline unsigned short f2bf_st(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ inline unsigned short f2bf_st(float f) { return xpt_f2h(f); }
 
 constexpr int ST_MAXV = 8;                 // 16-byte halo vectors a thread stages per tile
 constexpr unsigned ST_OOB = 0x40000000u;   // offset marker beyond any operand (operands are < 1 GiB: the launcher checks)
@@ -172,8 +172,7 @@ __global__ __launch_bounds__(256) void conv_stream_kernel(StArgs a) {
 #pragma unroll
           for (int i = 0; i < RM; ++i) {
             const u32x4 fa = *(const u32x4*)(wT + 32 * i * a.WP + k16 * 32);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc[i],
-                                                             0, 0, 0);
+            acc[i] = XPT_MFMA_32X32X16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc[i]);
           }
         }
       }
@@ -396,8 +395,7 @@ __global__ __launch_bounds__(256) void conv_stream_fast_kernel(StArgs a) {
           for (int i = 0; i < RM; ++i) {
             const u32x4 fa = AREG ? fareg[AREG ? kh * KK + kw : 0][AREG ? k : 0][AREG ? i : 0]
                                   : *(const u32x4*)(sl + wofs + 32 * i * WP + ((kh * KK + kw) * Cc + 16 * k) * 2);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc[i],
-                                                             0, 0, 0);
+            acc[i] = XPT_MFMA_32X32X16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc[i]);
           }
         }
 

@@ -21,7 +21,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef xpt_h16x8 bf16x8;      // (8 operands of the build's 16-bit format, xpt_common.h)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
           for (int t = 0; t < TAPS; ++t) {
             if (tap0 + t < T) {                                // wave-uniform
               const bf16x8 fb = tr_pair(xs, b_base[0] + xa + toff[t], b_base[1] + xa + toff[t]);
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+              acc[t] = XPT_MFMA_32X32X16(fa, fb, acc[t]);
             }
           }
         }
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WfArgs a) {
           const int hrow = UPS ? ((rr + tkh[tt] - 1) >> 1) + 1 : rr * S + tkh[tt];      // (scalar)
           const unsigned ro = (unsigned)(hrow * WR * 64);
           const bf16x8 fb = tr_pair(smem, bsel[tt][0] + ro, bsel[tt][1] + ro);
-          acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[tt], 0, 0, 0);
+          acc[tt] = XPT_MFMA_32X32X16(fa, fb, acc[tt]);
         }
       }
     }

@@ -13,16 +13,15 @@
 // atomics.
 #include "xpt_common.h"
 
-#include <hip/hip_bf16.h>
 
 namespace {
 
 template <typename T> __device__ inline float cv_ld(const T* p);
 template <> __device__ inline float cv_ld<float>(const float* p) { return *p; }
-template <> __device__ inline float cv_ld<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <> __device__ inline float cv_ld<xpt_half_t>(const xpt_half_t* p) { return xpt_half2float(*p); }
 template <typename T> __device__ inline void cv_st(T* p, float v);
 template <> __device__ inline void cv_st<float>(float* p, float v) { *p = v; }
-template <> __device__ inline void cv_st<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+template <> __device__ inline void cv_st<xpt_half_t>(xpt_half_t* p, float v) { *p = xpt_float2half(v); }
 
 // 4 consecutive channels as floats (C % 4 == 0 and 4-element aligned rows are checked on the host for V == 4)
 template <typename T> __device__ inline void cv_ld4(const T* p, float (&v)[4]);
@@ -30,18 +29,18 @@ template <> __device__ inline void cv_ld4<float>(const float* p, float (&v)[4]) 
   const float4 q = *reinterpret_cast<const float4*>(p);
   v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
 }
-template <> __device__ inline void cv_ld4<__hip_bfloat16>(const __hip_bfloat16* p, float (&v)[4]) {
+template <> __device__ inline void cv_ld4<xpt_half_t>(const xpt_half_t* p, float (&v)[4]) {
   const uint2 q = *reinterpret_cast<const uint2*>(p);
-  v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
-  v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+  v[0] = xpt_h2f_lo(q.x); v[1] = xpt_h2f_hi(q.x);
+  v[2] = xpt_h2f_lo(q.y); v[3] = xpt_h2f_hi(q.y);
 }
 
 // 8 consecutive bf16 channels (16-byte load / store)
-__device__ inline void cv_ld8(const __hip_bfloat16* p, float (&v)[8]) {
+__device__ inline void cv_ld8(const xpt_half_t* p, float (&v)[8]) {
   const uint4 q = *reinterpret_cast<const uint4*>(p);
   const unsigned w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  for (int i = 0; i < 4; ++i) { v[2 * i] = xpt_h2f_lo(w[i]); v[2 * i + 1] = xpt_h2f_hi(w[i]); }
 }
 __device__ inline void cv_ld8(const float* p, float (&v)[8]) {          // (not used: fp32 rows go 4 wide)
 #pragma unroll
@@ -96,8 +95,8 @@ template <typename T> __device__ inline void cv_st4(T* p, const float (&v)[4]);
 template <> __device__ inline void cv_st4<float>(float* p, const float (&v)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
-template <> __device__ inline void cv_st4<__hip_bfloat16>(__hip_bfloat16* p, const float (&v)[4]) {
-  __hip_bfloat16 h[4] = {__float2bfloat16(v[0]), __float2bfloat16(v[1]), __float2bfloat16(v[2]), __float2bfloat16(v[3])};
+template <> __device__ inline void cv_st4<xpt_half_t>(xpt_half_t* p, const float (&v)[4]) {
+  xpt_half_t h[4] = {xpt_float2half(v[0]), xpt_float2half(v[1]), xpt_float2half(v[2]), xpt_float2half(v[3])};
   *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(h);
 }
 
@@ -202,7 +201,7 @@ int xpt_corr_cost_fwd(const void* left, const void* right, void* out, int B, int
   if (dtype == 0) {
     if (vec) XPT_CORR(float, 4); else XPT_CORR(float, 1);
   } else {
-    if (vec8) XPT_CORR(__hip_bfloat16, 8); else if (vec) XPT_CORR(__hip_bfloat16, 4); else XPT_CORR(__hip_bfloat16, 1);
+    if (vec8) XPT_CORR(xpt_half_t, 8); else if (vec) XPT_CORR(xpt_half_t, 4); else XPT_CORR(xpt_half_t, 1);
   }
 #undef XPT_CORR
   return xpt_launch_status();
@@ -232,7 +231,7 @@ int xpt_corr_cost_bwd(const void* left, const void* right, const void* gout, voi
   if (dtype == 0) {
     if (vec) XPT_CORR_BWD(float, 4); else XPT_CORR_BWD(float, 1);
   } else {
-    if (vec8) XPT_CORR_BWD(__hip_bfloat16, 8); else if (vec) XPT_CORR_BWD(__hip_bfloat16, 4); else XPT_CORR_BWD(__hip_bfloat16, 1);
+    if (vec8) XPT_CORR_BWD(xpt_half_t, 8); else if (vec) XPT_CORR_BWD(xpt_half_t, 4); else XPT_CORR_BWD(xpt_half_t, 1);
   }
 #undef XPT_CORR_BWD
   return xpt_launch_status();

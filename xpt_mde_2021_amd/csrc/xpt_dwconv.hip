@@ -12,7 +12,6 @@
 //     (and its mask into the data gradient), the zero padding of the stride-2 blocks into the bounds test;
 //   * weights / weight gradients stay fp32; activations are fp32 or bf16 with fp32 accumulation;
 //   * the weight gradient is reduced deterministically: per-workgroup partials + a fixed-order sum.
-#include <hip/hip_bf16.h>
 
 #include <initializer_list>
 
@@ -22,10 +21,10 @@ namespace {
 
 template <typename T> __device__ inline float ldf(const T* p);
 template <> __device__ inline float ldf<float>(const float* p) { return *p; }
-template <> __device__ inline float ldf<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <> __device__ inline float ldf<xpt_half_t>(const xpt_half_t* p) { return xpt_half2float(*p); }
 template <typename T> __device__ inline void stf(T* p, float v);
 template <> __device__ inline void stf<float>(float* p, float v) { *p = v; }
-template <> __device__ inline void stf<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+template <> __device__ inline void stf<xpt_half_t>(xpt_half_t* p, float v) { *p = xpt_float2half(v); }
 
 struct DwDims {
   int B, H, W, C, OH, OW, pad_t, pad_l;
@@ -125,10 +124,10 @@ __global__ __launch_bounds__(256) void dw_multi_fwd_kernel(DwMultiFwd m, DwDims 
 template <typename T, int V> struct ChanVec;
 template <> struct ChanVec<float, 4> { typedef float4 type; };
 template <> struct ChanVec<float, 2> { typedef float2 type; };
-template <> struct ChanVec<__hip_bfloat16, 8> { typedef uint4 type; };
-template <> struct ChanVec<__hip_bfloat16, 4> { typedef uint2 type; };
-template <> struct ChanVec<__hip_bfloat16, 2> { typedef unsigned type; };
-template <> struct ChanVec<__hip_bfloat16, 1> { typedef unsigned short type; };
+template <> struct ChanVec<xpt_half_t, 8> { typedef uint4 type; };
+template <> struct ChanVec<xpt_half_t, 4> { typedef uint2 type; };
+template <> struct ChanVec<xpt_half_t, 2> { typedef unsigned type; };
+template <> struct ChanVec<xpt_half_t, 1> { typedef unsigned short type; };
 
 template <typename T, int V>
 __device__ inline void load_chan(const T* p, float (&out)[V]) {
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(256) void dw_multi_fwd_vec_kernel(DwMultiFwd m, DwD
 // in the same (ky, kx) order with the same fused multiply-adds as the stencil kernels: same bits.
 //   FLIP = 0: y = conv(f(x), w);   FLIP = 1: the data gradient dx_u = [x_u > 0] * sum over the jobs reading input u of
 //   conv(dy_j, w_j rotated by 180 degrees, pad' = k_j - 1 - pad_j).
-__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return xpt_h2f(u); }
 
 template <int G> struct SmallVec;
 template <> struct SmallVec<8> { typedef uint4 type; };
@@ -403,7 +402,7 @@ __global__ __launch_bounds__(256) void dw_small_fwd_kernel(DwMultiFwd m, DwDims 
 #pragma unroll
     for (int v = 0; v < G; ++v) acc[v] = 0.f;
     dw_small_accumulate_k<G>(k, xs, ws, d.H, d.W, cw, oy, ox, c8, m.pad_t[job], m.pad_l[job], relu_in != 0, acc);
-    store_chan<__hip_bfloat16, G>((__hip_bfloat16*)m.y[job] + ((long long)b * HW + pix) * d.C + c_lo + c8, acc);
+    store_chan<xpt_half_t, G>((xpt_half_t*)m.y[job] + ((long long)b * HW + pix) * d.C + c_lo + c8, acc);
   }
 }
 
@@ -504,7 +503,7 @@ __global__ __launch_bounds__(256) void dw_tile_fwd_kernel(DwMultiFwd m, DwDims d
     if (k == 3) dw_tile_accumulate<3, S, G>(xs, ws, RW, cw, ly, lx, c8, relu_in != 0, acc);
     else if (k == 5) dw_tile_accumulate<5, S, G>(xs, ws, RW, cw, ly, lx, c8, relu_in != 0, acc);
     else dw_tile_accumulate<7, S, G>(xs, ws, RW, cw, ly, lx, c8, relu_in != 0, acc);
-    store_chan<__hip_bfloat16, G>((__hip_bfloat16*)m.y[job] + (((long long)b * d.OH + oy) * d.OW + ox) * d.C + c_lo + c8, acc);
+    store_chan<xpt_half_t, G>((xpt_half_t*)m.y[job] + (((long long)b * d.OH + oy) * d.OW + ox) * d.C + c_lo + c8, acc);
   }
 }
 
@@ -884,7 +883,7 @@ __device__ __forceinline__ void dw_tile_bwd_block(const DwMultiBwd& m, const DwD
       mk[v] = 1.f;
       acc[v] = 0.f;
     }
-    if (relu_in) load_chan<__hip_bfloat16, G>((const __hip_bfloat16*)x + o, mk);
+    if (relu_in) load_chan<xpt_half_t, G>((const xpt_half_t*)x + o, mk);
     int q = 0;
     for (int j = 0; j < m.n; ++j) {
       if (m.input_of[j] != u) continue;
@@ -905,7 +904,7 @@ __device__ __forceinline__ void dw_tile_bwd_block(const DwMultiBwd& m, const DwD
       for (int v = 0; v < G; ++v)
         if (!(mk[v] > 0.f)) acc[v] = 0.f;
     }
-    store_chan<__hip_bfloat16, G>((__hip_bfloat16*)m.dxin[u] + o, acc);
+    store_chan<xpt_half_t, G>((xpt_half_t*)m.dxin[u] + o, acc);
   }
 }
 
@@ -929,7 +928,7 @@ __global__ __launch_bounds__(256) void dw_multi_bwd_tile_kernel(DwMultiBwd m, Dw
   DwDims dj = d;
   dj.pad_t = m.pad_t[job];
   dj.pad_l = m.pad_l[job];
-  typedef __hip_bfloat16 T;
+  typedef xpt_half_t T;
   const T* x = (const T*)m.xin[m.input_of[job]];
   const T* dy = (const T*)m.dy[job];
   float* fold = (float*)smt;
@@ -1365,12 +1364,12 @@ bool tile_bwd_launch(const DwMultiBwd& m, const DwDims& d, int relu_in, int RG, 
       if (k == 5 && stride == 2) return FN<float, 5, 2>(__VA_ARGS__);          \
       if (k == 7 && stride == 2) return FN<float, 7, 2>(__VA_ARGS__);          \
     } else {                                                                   \
-      if (k == 3 && stride == 1) return FN<__hip_bfloat16, 3, 1>(__VA_ARGS__); \
-      if (k == 5 && stride == 1) return FN<__hip_bfloat16, 5, 1>(__VA_ARGS__); \
-      if (k == 7 && stride == 1) return FN<__hip_bfloat16, 7, 1>(__VA_ARGS__); \
-      if (k == 3 && stride == 2) return FN<__hip_bfloat16, 3, 2>(__VA_ARGS__); \
-      if (k == 5 && stride == 2) return FN<__hip_bfloat16, 5, 2>(__VA_ARGS__); \
-      if (k == 7 && stride == 2) return FN<__hip_bfloat16, 7, 2>(__VA_ARGS__); \
+      if (k == 3 && stride == 1) return FN<xpt_half_t, 3, 1>(__VA_ARGS__); \
+      if (k == 5 && stride == 1) return FN<xpt_half_t, 5, 1>(__VA_ARGS__); \
+      if (k == 7 && stride == 1) return FN<xpt_half_t, 7, 1>(__VA_ARGS__); \
+      if (k == 3 && stride == 2) return FN<xpt_half_t, 3, 2>(__VA_ARGS__); \
+      if (k == 5 && stride == 2) return FN<xpt_half_t, 5, 2>(__VA_ARGS__); \
+      if (k == 7 && stride == 2) return FN<xpt_half_t, 7, 2>(__VA_ARGS__); \
     }                                                                          \
     return XPT_ERR_ARG;                                                        \
   } while (0)
@@ -1579,7 +1578,7 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
 #define XPT_MV(T, V) \
   hipLaunchKernelGGL((dw_multi_fwd_vec_kernel<T, V>), dim3(xcd ? xpt_xcd_pad(bpjv) : bpjv, n), dim3(256), lds, s, m, d, relu_in, bpjv, per, xcd)
       if (dtype == 0) { if (v == 4) XPT_MV(float, 4); else XPT_MV(float, 2); }
-      else { if (v == 8) XPT_MV(__hip_bfloat16, 8); else if (v == 4) XPT_MV(__hip_bfloat16, 4); else XPT_MV(__hip_bfloat16, 2); }
+      else { if (v == 8) XPT_MV(xpt_half_t, 8); else if (v == 4) XPT_MV(xpt_half_t, 4); else XPT_MV(xpt_half_t, 2); }
 #undef XPT_MV
       return xpt_launch_status();
     }
@@ -1591,7 +1590,7 @@ int xpt_dwconv_multi_fwd(const void* const* x, const float* const* w, void* cons
   if (dtype == 0) {
     if (stride == 1) XPT_MULTI(float, 1); else XPT_MULTI(float, 2);
   } else {
-    if (stride == 1) XPT_MULTI(__hip_bfloat16, 1); else XPT_MULTI(__hip_bfloat16, 2);
+    if (stride == 1) XPT_MULTI(xpt_half_t, 1); else XPT_MULTI(xpt_half_t, 2);
   }
 #undef XPT_MULTI
   return xpt_launch_status();
@@ -1667,7 +1666,7 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
 #define XPT_MV(T, V) \
   hipLaunchKernelGGL((dw_multi_bwd_vec_kernel<T, V>), gridv, dim3(256), lds, s, m, d, relu_in | (g_dw_lab << 8), RG, GRP, dbv, cchunks, wbpj, xcd)
       if (dtype == 0) { if (v == 4) XPT_MV(float, 4); else XPT_MV(float, 2); }
-      else { if (v == 8) XPT_MV(__hip_bfloat16, 8); else if (v == 4) XPT_MV(__hip_bfloat16, 4); else XPT_MV(__hip_bfloat16, 2); }
+      else { if (v == 8) XPT_MV(xpt_half_t, 8); else if (v == 4) XPT_MV(xpt_half_t, 4); else XPT_MV(xpt_half_t, 2); }
 #undef XPT_MV
       return xpt_launch_status();
     }
@@ -1686,7 +1685,7 @@ int xpt_dwconv_multi_bwd(const void* const* xin, void* const* dxin, int n_inputs
   if (dtype == 0) {
     if (stride == 1) XPT_MULTI(float, 1); else XPT_MULTI(float, 2);
   } else {
-    if (stride == 1) XPT_MULTI(__hip_bfloat16, 1); else XPT_MULTI(__hip_bfloat16, 2);
+    if (stride == 1) XPT_MULTI(xpt_half_t, 1); else XPT_MULTI(xpt_half_t, 2);
   }
 #undef XPT_MULTI
   return xpt_launch_status();

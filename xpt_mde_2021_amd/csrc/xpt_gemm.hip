@@ -67,7 +67,7 @@ inline WgradPlan wgrad_plan(long long M, int cout, int cin, bool defer = false) 
   return p;
 }
 
-__device__ inline float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ inline float bf16_bits_to_f32(unsigned short u) { return xpt_h2f(u); }
 
 // staged vector: V consecutive bf16 of one activation row
 template <int V> struct StageVec;
@@ -128,9 +128,7 @@ struct BnFuse {
 };
 
 __device__ inline unsigned short f32_to_bf16_bits(float f) {   // round to nearest even
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  return xpt_f2h_sw(f);
 }
 
 // reg += the same elements of up to two more tensors (fp32 accumulation in source order, one bf16 rounding)
@@ -216,7 +214,7 @@ struct DxFuse {
   int vw;                                   // elements per global load of W (its rows and base are aligned to it)
 };
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef xpt_h16x8 bf16x8;      // (8 operands of the build's 16-bit format, xpt_common.h)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
@@ -365,8 +363,8 @@ __device__ inline void dgrad_body(const unsigned short* __restrict__ dy, long lo
           fa.z = a16[4] | ((unsigned)a16[5] << 16); fa.w = a16[6] | ((unsigned)a16[7] << 16);
           fb.x = b16[0] | ((unsigned)b16[1] << 16); fb.y = b16[2] | ((unsigned)b16[3] << 16);
           fb.z = b16[4] | ((unsigned)b16[5] << 16); fb.w = b16[6] | ((unsigned)b16[7] << 16);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
-                                                        acc, 0, 0, 0);
+          acc = XPT_MFMA_32X32X16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
+                                                        acc);
         }
       }
     }
@@ -586,7 +584,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 8 ? 4 : 1) void conv1x1_wgra
           sum_dyy += a_raw * bf16_bits_to_f32((unsigned short)uy[i]);
         }
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+      acc = XPT_MFMA_32X32X16(fa, fb, acc);
     }
   }
   if (BN && bn_sums) {       // fold the two row halves of the wave, park the k slice's column sums

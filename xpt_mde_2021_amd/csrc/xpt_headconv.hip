@@ -16,10 +16,10 @@
 
 namespace {
 
-__device__ inline float bf_lo(unsigned v) { return __uint_as_float(v << 16); }
-__device__ inline float bf_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ inline float bf_lo(unsigned v) { return xpt_h2f_lo(v); }
+__device__ inline float bf_hi(unsigned v) { return xpt_h2f_hi(v); }
 __device__ inline unsigned pack_bf2(float a, float b) {
-  return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)a) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+  return (unsigned)xpt_f2h(a) | ((unsigned)xpt_f2h(b) << 16);
 }
 __device__ inline void unpack8(const uint4& v, float (&f)[8]) {
   f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);

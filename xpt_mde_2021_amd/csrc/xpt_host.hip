@@ -97,6 +97,15 @@ extern "C" int xpt_graph_node_census(void* hip_graph, int* counts) {
   return census_walk((hipGraph_t)hip_graph, counts, 0);
 }
 
+/* 16-bit activation format this library was built with (xpt_common.h): 0 = bfloat16 (libxpt_hip.so), 1 = IEEE half (libxpt_hip_f16.so) */
+extern "C" int xpt_half_format(void) {
+#ifdef XPT_HALF_F16
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 /* image-to-XCD affinity of the kernels that follow the convention of xpt_common.h (xpt_xcd_remap): 0 = off */
 int g_xpt_xcd_affinity = 1;
 extern "C" int xpt_set_xcd_affinity(int on) {

@@ -4,14 +4,13 @@
 //   lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
 //   p -= lr_t * m / (sqrt(v) + eps)           with eps = 1e-7 applied to the UNcorrected sqrt(v).
 // One pass over 4 streams (p, g, m, v): 28 B / parameter, float4 accesses, HBM-bound.
-#include <hip/hip_bf16.h>
 
 #include "xpt_common.h"
 
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, const float* __restrict__ step_ptr, float lr,
                             float b1, float b2, float eps, float grad_scale, int zero_grad,
-                            __hip_bfloat16* __restrict__ shadow) {
+                            xpt_half_t* __restrict__ shadow) {
   const float t = step_ptr[0];
   const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
   const long long n4 = n >> 2;
@@ -34,7 +33,7 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
     if (zero_grad) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (shadow) {                      // bf16 copy of the updated weights for the bf16 convolutions / GEMMs
 #pragma unroll
-      for (int k = 0; k < 4; ++k) shadow[4 * i + k] = __float2bfloat16(pa[k]);
+      for (int k = 0; k < 4; ++k) shadow[4 * i + k] = xpt_float2half(pa[k]);
     }
   }
   // tail (n not a multiple of 4)
@@ -45,7 +44,7 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float*
     m[i] = mk; v[i] = vk;
     p[i] -= lr_t * mk / (sqrtf(vk) + eps);
     if (zero_grad) g[i] = 0.f;
-    if (shadow) shadow[i] = __float2bfloat16(p[i]);
+    if (shadow) shadow[i] = xpt_float2half(p[i]);
   }
 }
 
@@ -60,19 +59,19 @@ extern "C" int xpt_adam_step(float* param, float* grad, float* m, float* v, long
   if (blocks < 1) blocks = 1;
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n,
-                     step, lr, beta1, beta2, eps, grad_scale, zero_grad, (__hip_bfloat16*)shadow_bf16);
+                     step, lr, beta1, beta2, eps, grad_scale, zero_grad, (xpt_half_t*)shadow_bf16);
   return xpt_launch_status();
 }
 
 // tf.optimizers.SGD(learning_rate) (momentum 0, optimizers.py:10-11): p -= lr * g; same buffers, same bf16 shadow refresh.
 __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, long long n, float lr, float grad_scale, int zero_grad,
-                           __hip_bfloat16* __restrict__ shadow) {
+                           xpt_half_t* __restrict__ shadow) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += stride) {
     const float pk = p[i] - lr * (g[i] * grad_scale);
     p[i] = pk;
     if (zero_grad) g[i] = 0.f;
-    if (shadow) shadow[i] = __float2bfloat16(pk);
+    if (shadow) shadow[i] = xpt_float2half(pk);
   }
 }
 
@@ -84,6 +83,6 @@ extern "C" int xpt_sgd_step(float* param, float* grad, long long n, float lr, fl
   if (blocks > 4096) blocks = 4096;
   XPT_BEGIN_LAUNCH();
   hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, n, lr, grad_scale,
-                     zero_grad, (__hip_bfloat16*)shadow_bf16);
+                     zero_grad, (xpt_half_t*)shadow_bf16);
   return xpt_launch_status();
 }

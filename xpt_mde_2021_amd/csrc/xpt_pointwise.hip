@@ -6,7 +6,6 @@
 // Both are one streaming pass forward and one streaming pass backward (dx plus the per-channel parameter gradients
 // reduced deterministically: per-workgroup partials, then a fixed-order sum) instead of the 2-5 library launches per
 // layer (bias add, activation, their backward kernels and a separate reduction) of the generic framework path.
-#include <hip/hip_bf16.h>
 
 #include "xpt_common.h"
 
@@ -14,10 +13,10 @@ namespace {
 
 template <typename T> __device__ inline float ldf(const T* p);
 template <> __device__ inline float ldf<float>(const float* p) { return *p; }
-template <> __device__ inline float ldf<__hip_bfloat16>(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+template <> __device__ inline float ldf<xpt_half_t>(const xpt_half_t* p) { return xpt_half2float(*p); }
 template <typename T> __device__ inline void stf(T* p, float v);
 template <> __device__ inline void stf<float>(float* p, float v) { *p = v; }
-template <> __device__ inline void stf<__hip_bfloat16>(__hip_bfloat16* p, float v) { *p = __float2bfloat16(v); }
+template <> __device__ inline void stf<xpt_half_t>(xpt_half_t* p, float v) { *p = xpt_float2half(v); }
 
 // ---------------------------------------------------------------- y = act(f(x) * scale[c] + shift[c])
 // scale = gamma * rsqrt(var + eps), shift = beta - mean * scale (gamma == nullptr: scale = 1, shift = beta).
@@ -66,10 +65,10 @@ template <typename T, int V> struct RowVec;
 template <> struct RowVec<float, 4> { typedef float4 type; };
 template <> struct RowVec<float, 2> { typedef float2 type; };
 template <> struct RowVec<float, 1> { typedef float type; };
-template <> struct RowVec<__hip_bfloat16, 8> { typedef uint4 type; };
-template <> struct RowVec<__hip_bfloat16, 4> { typedef uint2 type; };
-template <> struct RowVec<__hip_bfloat16, 2> { typedef unsigned type; };
-template <> struct RowVec<__hip_bfloat16, 1> { typedef unsigned short type; };
+template <> struct RowVec<xpt_half_t, 8> { typedef uint4 type; };
+template <> struct RowVec<xpt_half_t, 4> { typedef uint2 type; };
+template <> struct RowVec<xpt_half_t, 2> { typedef unsigned type; };
+template <> struct RowVec<xpt_half_t, 1> { typedef unsigned short type; };
 
 template <typename T, int V>
 __device__ inline void load_row(const T* p, float (&out)[V]) {
@@ -586,10 +585,10 @@ static void affine_bwd_launch(const void* x, const void* y, const void* dy, long
     else if (v == 2) XPT_AFF(float, 2);
     else XPT_AFF(float, 1);
   } else {
-    if (v == 8) XPT_AFF(__hip_bfloat16, 8);
-    else if (v == 4) XPT_AFF(__hip_bfloat16, 4);
-    else if (v == 2) XPT_AFF(__hip_bfloat16, 2);
-    else XPT_AFF(__hip_bfloat16, 1);
+    if (v == 8) XPT_AFF(xpt_half_t, 8);
+    else if (v == 4) XPT_AFF(xpt_half_t, 4);
+    else if (v == 2) XPT_AFF(xpt_half_t, 2);
+    else XPT_AFF(xpt_half_t, 1);
   }
 #undef XPT_AFF
 }
@@ -627,8 +626,8 @@ int xpt_affine_act_fwd(const void* x, const float* gamma, const float* beta, con
     hipLaunchKernelGGL(affine_act_fwd_kernel<float>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
                        (const float*)x, a, (const float*)residual, (float*)y, n, C, slope, relu_in, sw);
   else
-    hipLaunchKernelGGL(affine_act_fwd_kernel<__hip_bfloat16>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16*)x, a, (const __hip_bfloat16*)residual, (__hip_bfloat16*)y, n, C, slope,
+    hipLaunchKernelGGL(affine_act_fwd_kernel<xpt_half_t>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
+                       (const xpt_half_t*)x, a, (const xpt_half_t*)residual, (xpt_half_t*)y, n, C, slope,
                        relu_in, sw);
   return xpt_launch_status();
 }
@@ -713,8 +712,8 @@ int xpt_global_avgpool_fwd(const void* x, float* y, int B, int HW, int C, int dt
     hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const float*)x, y, total, HW, C);
   else
-    hipLaunchKernelGGL(gap_fwd_kernel<__hip_bfloat16>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16*)x, y, total, HW, C);
+    hipLaunchKernelGGL(gap_fwd_kernel<xpt_half_t>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const xpt_half_t*)x, y, total, HW, C);
   return xpt_launch_status();
 }
 
@@ -729,8 +728,8 @@ int xpt_global_avgpool_bwd(const float* g, void* dx, int B, int HW, int C, int d
     hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g, (float*)dx,
                        total, HW, C);
   else
-    hipLaunchKernelGGL(gap_bwd_kernel<__hip_bfloat16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g,
-                       (__hip_bfloat16*)dx, total, HW, C);
+    hipLaunchKernelGGL(gap_bwd_kernel<xpt_half_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g,
+                       (xpt_half_t*)dx, total, HW, C);
   return xpt_launch_status();
 }
 
@@ -749,8 +748,8 @@ int xpt_upsample2x_fwd(const float* src, void* out, long long M, int h, int w, i
     hipLaunchKernelGGL(upsample2x_fwd_kernel<float>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream, src,
                        (float*)out, total, h, w, sw);
   else
-    hipLaunchKernelGGL(upsample2x_fwd_kernel<__hip_bfloat16>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
-                       src, (__hip_bfloat16*)out, total, h, w, sw);
+    hipLaunchKernelGGL(upsample2x_fwd_kernel<xpt_half_t>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
+                       src, (xpt_half_t*)out, total, h, w, sw);
   return xpt_launch_status();
 }
 
@@ -767,8 +766,8 @@ int xpt_upsample2x_bwd_add(const void* g, long long g_pitch, const float* addend
     hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
                        (const float*)g, g_pitch, addend, dsrc, total, h, w, sw);
   else
-    hipLaunchKernelGGL(upsample2x_bwd_kernel<__hip_bfloat16>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16*)g, g_pitch, addend, dsrc, total, h, w, sw);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel<xpt_half_t>, dim3(sw.grid), dim3(256), 0, (hipStream_t)stream,
+                       (const xpt_half_t*)g, g_pitch, addend, dsrc, total, h, w, sw);
   return xpt_launch_status();
 }
 
@@ -835,10 +834,10 @@ int xpt_avgpool3_same(const void* in, long long in_pitch, void* out, int B, int 
     else if (v == 2) XPT_POOL(float, 2);
     else XPT_POOL(float, 1);
   } else {
-    if (v == 8) XPT_POOL(__hip_bfloat16, 8);
-    else if (v == 4) XPT_POOL(__hip_bfloat16, 4);
-    else if (v == 2) XPT_POOL(__hip_bfloat16, 2);
-    else XPT_POOL(__hip_bfloat16, 1);
+    if (v == 8) XPT_POOL(xpt_half_t, 8);
+    else if (v == 4) XPT_POOL(xpt_half_t, 4);
+    else if (v == 2) XPT_POOL(xpt_half_t, 2);
+    else XPT_POOL(xpt_half_t, 1);
   }
 #undef XPT_POOL
   return xpt_launch_status();
@@ -880,10 +879,10 @@ int xpt_sum_rows(const void* const* inputs, const long long* pitches, int n, voi
     else if (v == 2) XPT_SUM(float, 2);
     else XPT_SUM(float, 1);
   } else {
-    if (v == 8) XPT_SUM(__hip_bfloat16, 8);
-    else if (v == 4) XPT_SUM(__hip_bfloat16, 4);
-    else if (v == 2) XPT_SUM(__hip_bfloat16, 2);
-    else XPT_SUM(__hip_bfloat16, 1);
+    if (v == 8) XPT_SUM(xpt_half_t, 8);
+    else if (v == 4) XPT_SUM(xpt_half_t, 4);
+    else if (v == 2) XPT_SUM(xpt_half_t, 2);
+    else XPT_SUM(xpt_half_t, 1);
   }
 #undef XPT_SUM
   return xpt_launch_status();

@@ -18,13 +18,11 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef xpt_h16x8 bf16x8;      // (8 operands of the build's 16-bit format, xpt_common.h)
 
-__device__ inline float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ inline float bf16_bits_to_f32(unsigned short u) { return xpt_h2f(u); }
 __device__ inline unsigned short f32_to_bf16_bits(float f) {   // round to nearest even
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  return xpt_f2h_sw(f);
 }
 
 // 8 consecutive bf16 of one row starting at element k (k < K); elements at or past K read as zero.  V = elements per
@@ -104,8 +102,8 @@ __device__ inline void pw_gemm_tile(f32x16& acc, const unsigned short* __restric
 #pragma unroll
     for (int g = 0; g < PW_G; ++g)
       if (s0 + g < ksteps)                               // wave-uniform
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[g]),
-                                                      __builtin_bit_cast(bf16x8, fb[g]), acc, 0, 0, 0);
+        acc = XPT_MFMA_32X32X16(__builtin_bit_cast(bf16x8, fa[g]),
+                                                      __builtin_bit_cast(bf16x8, fb[g]), acc);
   }
 }
 

@@ -19,13 +19,11 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef xpt_h16x8 bf16x8;      // (8 operands of the build's 16-bit format, xpt_common.h)
 
-__device__ inline float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ inline float bf16_bits_to_f32(unsigned short u) { return xpt_h2f(u); }
 __device__ inline unsigned short f32_to_bf16_bits(float f) {   // round to nearest even
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+  return xpt_f2h_sw(f);
 }
 
 template <int V> struct BfVec;
@@ -44,7 +42,7 @@ __device__ inline void load_bf(const unsigned short* p, float (&out)[V]) {
 
 // bf16 pairs of a loaded vector -> floats, by shifts on the 32-bit components (no pointer into the register array: an
 // address-taken local array lands in scratch memory)
-__device__ inline void unpack2(unsigned w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+__device__ inline void unpack2(unsigned w, float& lo, float& hi) { lo = xpt_h2f_lo(w); hi = xpt_h2f_hi(w); }
 __device__ inline void unpack(const uint4& r, float (&o)[8]) { unpack2(r.x, o[0], o[1]); unpack2(r.y, o[2], o[3]); unpack2(r.z, o[4], o[5]); unpack2(r.w, o[6], o[7]); }
 __device__ inline void unpack(const uint2& r, float (&o)[4]) { unpack2(r.x, o[0], o[1]); unpack2(r.y, o[2], o[3]); }
 __device__ inline void unpack(const unsigned& r, float (&o)[2]) { unpack2(r, o[0], o[1]); }
@@ -203,8 +201,8 @@ __device__ inline f32x16 pointwise_tile(const unsigned short* D, const SepBranch
     const uint4 a = *(const uint4*)(arow + k);                 // (columns C .. CP of the tile are zero)
     const uint4 bq = load_frag<V>(brow, ok ? k : 0, d.C);
     const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                  __builtin_bit_cast(bf16x8, (ok && col_ok) ? bq : zero), acc, 0, 0, 0);
+    acc = XPT_MFMA_32X32X16(__builtin_bit_cast(bf16x8, a),
+                                                  __builtin_bit_cast(bf16x8, (ok && col_ok) ? bq : zero), acc);
   }
   return acc;
 }

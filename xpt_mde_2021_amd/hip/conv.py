@@ -50,7 +50,7 @@ class ConvWeightPacker:
             if need_bwd and e["bwd"] is None:
                 if torch.cuda.is_current_stream_capturing():
                     raise _lib.XptHipError("ConvWeightPacker: new operand layout requested during graph capture")
-                e["bwd"] = torch.zeros((e["Cp"], e["T"], e["Np"]), dtype=torch.bfloat16, device=weight.device)
+                e["bwd"] = torch.zeros((e["Cp"], e["T"], e["Np"]), dtype=_lib.half(), device=weight.device)
                 self.signature = None
                 self._pack_now()
             return e
@@ -60,8 +60,8 @@ class ConvWeightPacker:
         N, C, KH, KW = weight.shape
         Cp, Np, T = round_up(C, 8), round_up(N, 8), KH * KW
         e = {"ref": weakref.ref(weight), "N": N, "C": C, "KH": KH, "KW": KW, "T": T, "Cp": Cp, "Np": Np,
-             "fwd": torch.zeros((N, T, Cp), dtype=torch.bfloat16, device=weight.device),
-             "bwd": torch.zeros((Cp, T, Np), dtype=torch.bfloat16, device=weight.device) if need_bwd else None}
+             "fwd": torch.zeros((N, T, Cp), dtype=_lib.half(), device=weight.device),
+             "bwd": torch.zeros((Cp, T, Np), dtype=_lib.half(), device=weight.device) if need_bwd else None}
         self.entries[id(weight)] = e
         self.signature = None
         self._pack_now()
@@ -156,7 +156,7 @@ def _apply_env_tuning():
 def nhwc_view(t, channels=None):
     """NCHW-indexed bf16 tensor -> (tensor, pixel pitch in elements): dense channels_last tensors and channel slices of
     them are used in place, anything else is made channels_last first."""
-    if t.dtype != torch.bfloat16 or not t.is_cuda:
+    if t.dtype != _lib.half() or not t.is_cuda:
         raise _lib.XptHipError("conv: expected a bfloat16 CUDA/HIP tensor (no CPU fallback)")
     B, C, H, W = t.shape
     sb, sc, sh, sw = t.stride()
@@ -198,7 +198,7 @@ class _Conv2dSame(torch.autograd.Function):
         else:
             (pt, _), (pl, _) = same_pad(H, KH, stride), same_pad(W, KW, stride)
             OH, OW = -(-H // stride), -(-W // stride)
-        y = torch.empty((B, N, OH, OW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        y = torch.empty((B, N, OH, OW), dtype=_lib.half(), device=x.device, memory_format=torch.channels_last)
         b_ = None if bias is None else bias.detach()
         if b_ is not None and (b_.dtype != torch.float32 or not b_.is_contiguous()):
             raise _lib.XptHipError("conv: bias must be a contiguous float32 vector")
@@ -240,10 +240,10 @@ class _Conv2dSame(torch.autograd.Function):
         weight = ctx.weight
         rows = B * OH * OW
         # ---- activation / bias backward: g = dy * act'(y) (dense bf16 [rows, N]) and the bias gradient
-        dy, dpitch = _ops._rows_with_pitch(dy_in.to(torch.bfloat16))
+        dy, dpitch = _ops._rows_with_pitch(dy_in.to(_lib.half()))
         dbias = None
         if ctx.has_bias or slope != 1.0:
-            g = torch.empty((B, N, OH, OW), dtype=torch.bfloat16, device=dy.device, memory_format=torch.channels_last)
+            g = torch.empty((B, N, OH, OW), dtype=_lib.half(), device=dy.device, memory_format=torch.channels_last)
             if ctx.sink_b is not None:
                 nblk = lib.xpt_affine_act_bwd_blocks(rows, N)
                 ws = _ops.grad_sink.partials(ctx.sink_b, "affine", nblk * 2 * N)
@@ -264,7 +264,7 @@ class _Conv2dSame(torch.autograd.Function):
                     dbias = None
             gpitch = N
         else:
-            g, gpitch = nhwc_view(dy_in.to(torch.bfloat16))
+            g, gpitch = nhwc_view(dy_in.to(_lib.half()))
         if N % 8 != 0:
             raise _lib.XptHipError(f"conv backward: {N} output channels are not a multiple of 8")
         dx = dw = None
@@ -290,7 +290,7 @@ class _Conv2dSame(torch.autograd.Function):
                     dw = _weight_grad(ctx, lib, g, gpitch, x)
         if ctx.needs_input_grad[0]:
             e = packer.get(weight, need_bwd=True)
-            dx = torch.empty((B, Cp, PH, PW), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+            dx = torch.empty((B, Cp, PH, PW), dtype=_lib.half(), device=g.device, memory_format=torch.channels_last)
             wsf = lib.xpt_conv2d_splitk_workspace_floats(B * (PH << ups) * (PW << ups), Cp, e["Np"], KH * KW, stride)
             if wsf:
                 ws = torch.empty(wsf, dtype=torch.float32, device=g.device)
@@ -386,14 +386,14 @@ def usable(x, conv, slope):
         return False
     dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else x.dtype
     k = conv.kernel_size
-    return dtype == torch.bfloat16 and k[0] == k[1] and k[0] in (1, 3, 5) and conv.out_channels % 8 == 0 \
+    return dtype == _lib.half() and k[0] == k[1] and k[0] in (1, 3, 5) and conv.out_channels % 8 == 0 \
         and conv.weight.dtype == torch.float32
 
 
 def stem_input_usable(image):
     """[B,3,H,W] float32 view of NHWC frames (channel stride 1, pixel stride 3) on the GPU under bf16 autocast."""
     if not (torch.is_tensor(image) and image.is_cuda and image.dtype == torch.float32 and image.dim() == 4
-            and image.shape[1] == 3 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            and image.shape[1] == 3 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == _lib.half()):
         return False
     sb, sc, sh, sw = image.stride()
     return sc == 1 and sw == 3 and sh == 3 * image.shape[3] and sb >= 3 * image.shape[2] * image.shape[3]
@@ -404,7 +404,7 @@ def stem_input(image):
     stem_input_kernel): [B,3,H,W] float32 (NHWC view) -> [B,8,H+2,W+2] bf16 channels_last, channels 3..7 zero."""
     lib = _lib.load()
     B, _, H, W = image.shape
-    out = torch.empty((B, 8, H + 2, W + 2), dtype=torch.bfloat16, device=image.device, memory_format=torch.channels_last)
+    out = torch.empty((B, 8, H + 2, W + 2), dtype=_lib.half(), device=image.device, memory_format=torch.channels_last)
     _lib.check(lib.xpt_stem_input(image.data_ptr(), image.stride(0), out.data_ptr(), B, H, W, _stream()), "xpt_stem_input")
     return out
 
@@ -418,7 +418,7 @@ def restack_bf16(image5d, channels_padded):
     B, S, H, W, C = image5d.shape
     if C != 3:
         raise _lib.XptHipError("restack_bf16: expected 3 channels per frame")
-    out = torch.empty((B, H, W, channels_padded), dtype=torch.bfloat16, device=image5d.device)
+    out = torch.empty((B, H, W, channels_padded), dtype=_lib.half(), device=image5d.device)
     _lib.check(lib.xpt_restack_bf16(image5d.data_ptr(), out.data_ptr(), B, S, H, W, channels_padded, _stream()),
                "xpt_restack_bf16")
     return out.permute(0, 3, 1, 2)
@@ -456,7 +456,7 @@ class _HeadConv(torch.autograd.Function):
         x, w = ctx.saved_tensors
         B, C, H, W, xpitch = ctx.geom
         g = g.contiguous().float()
-        dx = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+        dx = torch.empty((B, C, H, W), dtype=_lib.half(), device=g.device, memory_format=torch.channels_last)
         nblk = lib.xpt_headconv_bwd_blocks(B, H, W, C)
         row = 9 * C + 1
         if ctx.sink is not None:
@@ -495,8 +495,8 @@ class _HeadConvSplit(_HeadConv):
         g = g.contiguous().float()
         add, apitch = (None, 0)
         if g_x is not None:
-            add, apitch = nhwc_view(g_x.to(torch.bfloat16))
-        dx = torch.empty((B, C, H, W), dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+            add, apitch = nhwc_view(g_x.to(_lib.half()))
+        dx = torch.empty((B, C, H, W), dtype=_lib.half(), device=g.device, memory_format=torch.channels_last)
         nblk = lib.xpt_headconv_bwd_blocks(B, H, W, C)
         row = 9 * C + 1
         if ctx.sink is not None:
@@ -528,7 +528,7 @@ def head_conv(x, weight, bias):
 
 
 def head_usable(x, conv):
-    return x.is_cuda and x.dtype == torch.bfloat16 and conv.in_channels in (16, 32, 64, 128) and conv.out_channels == 1 \
+    return x.is_cuda and x.dtype == _lib.half() and conv.in_channels in (16, 32, 64, 128) and conv.out_channels == 1 \
         and conv.kernel_size == (3, 3) and conv.weight.dtype == torch.float32 and conv.dilation == (1, 1) and conv.stride == (1, 1)
 
 

@@ -10,6 +10,33 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # (XPT_HIP_LIB: another build of the same library, e.g. the previous commit's, for same-box A/B measurements; lab use only)
 LIB_PATH = os.environ.get("XPT_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "libxpt_hip.so")
+LIB_PATH_F16 = os.environ.get("XPT_HIP_LIB_F16") or os.path.join(os.path.dirname(_HERE), "libxpt_hip_f16.so")
+
+# ---- the 16-bit activation format of this PROCESS: "bf16" (libxpt_hip.so) or "fp16" (libxpt_hip_f16.so, the same sources built
+# with IEEE-half activations: BASELINE configs[4]).  Chosen before the library is first loaded -- XPT_HALF in the environment,
+# set_half_format(), or opts.CONV_DTYPE = "fp16" at model construction --; one format per process (packed weights, shadow
+# copies and captured graphs all hold 16-bit data of that format).
+_half_format = os.environ.get("XPT_HALF", "bf16")
+
+
+def set_half_format(fmt):
+    global _half_format
+    if fmt not in ("bf16", "fp16"):
+        raise XptHipError(f"unknown 16-bit format {fmt!r} (bf16 | fp16)")
+    if _lib is not None and fmt != _half_format:
+        raise XptHipError(f"the {_half_format} build of the library is already loaded in this process: {fmt} needs its own process "
+                          f"(XPT_HALF={fmt} in the environment, or set_half_format() before the first op)")
+    _half_format = fmt
+
+
+def half_format():
+    return _half_format
+
+
+def half():
+    """torch dtype of the 16-bit activations / packed weights of this process."""
+    import torch
+    return torch.float16 if _half_format == "fp16" else torch.bfloat16
 
 XPT_PHOTO_L1, XPT_PHOTO_L2, XPT_PHOTO_SSIM = 0, 1, 2
 PHOTO_METHODS = {"L1": XPT_PHOTO_L1, "L2": XPT_PHOTO_L2, "SSIM": XPT_PHOTO_SSIM}
@@ -65,6 +92,7 @@ SIGNATURES = {
                                     ctypes.c_longlong, _p]),
     "xpt_reduce_job_bytes": (_i, []),
     "xpt_reduce_partials": (_i, [_p, _p, _i, _p]),
+    "xpt_half_format": (_i, []),
     "xpt_affine_act_bwd_blocks": (_i, [ctypes.c_longlong, _i]),
     "xpt_affine_act_bwd_partials": (_i, [_p, _p, _p, ctypes.c_longlong, _p, _p, _p, _p, _f, _p, _p, _z, ctypes.c_longlong,
                                          _i, _f, _i, _i, _p]),
@@ -204,20 +232,23 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.isfile(LIB_PATH):
-        raise XptHipError(f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+    path = LIB_PATH_F16 if _half_format == "fp16" else LIB_PATH
+    if not os.path.isfile(path):
+        raise XptHipError(f"HIP extension not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; "
                           f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback for these ops.")
     # PyTorch-ROCm bundles its own libamdhip64: it must be the HIP runtime already resident when our
     # library is dlopen'ed, otherwise two runtimes coexist and launches on torch's streams fail.
     import torch  # noqa: F401
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise XptHipError(f"{LIB_PATH} does not export {name}; rebuild the extension") from e
+            raise XptHipError(f"{path} does not export {name}; rebuild the extension") from e
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.xpt_half_format() != (1 if _half_format == "fp16" else 0):
+        raise XptHipError(f"{path} was not built for {_half_format} activations; rebuild the extension (csrc/build.py)")
     variant = os.environ.get("XPT_FUSED_FWD_PIPE")
     if variant is not None:                      # A/B switch of the fused forward's row loop (default: the library's)
         lib.xpt_photo_fused_variant(int(variant))

@@ -696,7 +696,7 @@ grad_sink = GradSink()
 def _nhwc(t, name):
     if not t.is_cuda:
         raise _lib.XptHipError(f"{name}: expected a CUDA/HIP tensor (the xpt HIP ops have no CPU fallback)")
-    if t.dtype not in (torch.float32, torch.bfloat16):
+    if t.dtype not in (torch.float32, _lib.half()):
         raise _lib.XptHipError(f"{name}: expected float32 or bfloat16, got {t.dtype}")
     return t.contiguous(memory_format=torch.channels_last)
 
@@ -1029,7 +1029,7 @@ class _Upsample2x(torch.autograd.Function):
     def backward(ctx, g):
         lib = _lib.load()
         B, C, h, w = ctx.shape
-        if g.dtype not in (torch.float32, torch.bfloat16):
+        if g.dtype not in (torch.float32, _lib.half()):
             g = g.float()
         H, W = 2 * h, 2 * w
         pitch = g.stride(3)
@@ -1065,7 +1065,7 @@ class _Upsample2xSplit(torch.autograd.Function):
         if g is None:
             return g_self, None
         B, C, h, w = ctx.shape
-        if g.dtype not in (torch.float32, torch.bfloat16):
+        if g.dtype not in (torch.float32, _lib.half()):
             g = g.float()
         H, W = 2 * h, 2 * w
         pitch = g.stride(3)
@@ -1169,7 +1169,7 @@ class _AvgPool3Same(torch.autograd.Function):
 
 
 def _nhwc_any(t):
-    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
+    if not t.is_cuda or t.dtype not in (torch.float32, _lib.half()):
         raise _lib.XptHipError("avg_pool3_same: expected a float32 / bfloat16 CUDA/HIP tensor (no CPU fallback)")
     return t
 
@@ -1393,7 +1393,7 @@ class _FanOut(torch.autograd.Function):
             return None, None
         if len(live) == 1:
             return live[0], None
-        if len(live) > 8 or live[0].dim() != 4 or not live[0].is_cuda or live[0].dtype not in (torch.float32, torch.bfloat16):
+        if len(live) > 8 or live[0].dim() != 4 or not live[0].is_cuda or live[0].dtype not in (torch.float32, _lib.half()):
             total = live[0]
             for g in live[1:]:
                 total = total + g
@@ -1440,7 +1440,7 @@ def conv1x1_weight_grad(dy2, x2):
     """dW [cout, cin] float32 = dy2^T @ x2 for bf16 row matrices dy2 [M, cout], x2 [M, cin] (unit column stride, any
     row pitch): the split-K matrix-core kernel of csrc/xpt_gemm.hip."""
     lib = _lib.load()
-    if not (dy2.is_cuda and x2.is_cuda) or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16:
+    if not (dy2.is_cuda and x2.is_cuda) or dy2.dtype != _lib.half() or x2.dtype != _lib.half():
         raise _lib.XptHipError("conv1x1_weight_grad: expected bfloat16 CUDA/HIP matrices (no CPU fallback)")
     if dy2.dim() != 2 or x2.dim() != 2 or dy2.shape[0] != x2.shape[0] or dy2.stride(1) != 1 or x2.stride(1) != 1:
         raise _lib.XptHipError(f"conv1x1_weight_grad: bad operands {tuple(dy2.shape)} {dy2.stride()} / "
@@ -1463,7 +1463,7 @@ def conv1x1_weight_grad_deferred(dy2, x2, dst, w=None):
     (the weight's flat-gradient view, [cout, cin(,1,1)] contiguous).  w (the bf16 weight [cout, cin], dense): also
     returns the data gradient dx = dy2 w [M, cin] bf16, computed by extra workgroups of the same launch."""
     lib = _lib.load()
-    if not (dy2.is_cuda and x2.is_cuda) or dy2.dtype != torch.bfloat16 or x2.dtype != torch.bfloat16:
+    if not (dy2.is_cuda and x2.is_cuda) or dy2.dtype != _lib.half() or x2.dtype != _lib.half():
         raise _lib.XptHipError("conv1x1_weight_grad: expected bfloat16 CUDA/HIP matrices (no CPU fallback)")
     if dy2.dim() != 2 or x2.dim() != 2 or dy2.shape[0] != x2.shape[0] or dy2.stride(1) != 1 or x2.stride(1) != 1:
         raise _lib.XptHipError(f"conv1x1_weight_grad: bad operands {tuple(dy2.shape)} {dy2.stride()} / "
@@ -1476,7 +1476,7 @@ def conv1x1_weight_grad_deferred(dy2, x2, dst, w=None):
     ws = grad_sink.partials(dst, "conv1x1", nsplit * cout * cin)
     dx = None
     if w is not None:
-        dx = torch.empty((M, cin), dtype=torch.bfloat16, device=dy2.device)
+        dx = torch.empty((M, cin), dtype=_lib.half(), device=dy2.device)
         _lib.check(lib.xpt_conv1x1_bwd_fused(_ptr(dy2), _ptr(x2), _ptr(w), _ptr(dx), _ptr(ws), ws.numel(), M, cout, cin,
                                              pitch_dy, pitch_x, _stream()), "xpt_conv1x1_bwd_fused")
     else:
@@ -1515,7 +1515,7 @@ class _ConcatChannels(torch.autograd.Function):
         chans = [p.shape[1] for p in parts]
         total = sum(chans)
         ct = -(-total // 8) * 8
-        out = torch.empty((B, ct, H, W), dtype=torch.bfloat16, device=parts[0].device, memory_format=torch.channels_last)
+        out = torch.empty((B, ct, H, W), dtype=_lib.half(), device=parts[0].device, memory_format=torch.channels_last)
         n = len(parts)
         M = B * H * W
         P, LL, I = ctypes.c_void_p * n, ctypes.c_longlong * n, ctypes.c_int * n
@@ -1535,7 +1535,7 @@ class _ConcatChannels(torch.autograd.Function):
 
 def concat_channels(parts):
     """torch.cat(parts, dim=1) for bf16 NCHW-indexed (channels_last) tensors, zero-padded to a multiple of 8 channels."""
-    if len(parts) > 4 or any((not p.is_cuda) or p.dtype != torch.bfloat16 for p in parts):
+    if len(parts) > 4 or any((not p.is_cuda) or p.dtype != _lib.half() for p in parts):
         raise _lib.XptHipError("concat_channels: expected up to four bfloat16 CUDA/HIP tensors (no CPU fallback)")
     return _ConcatChannels.apply(*parts)
 

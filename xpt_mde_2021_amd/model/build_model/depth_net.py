@@ -3,6 +3,8 @@
 """
 import torch
 import torch.nn as nn
+from ...hip.lib import half as _half      # torch dtype of the 16-bit activations (bf16 | fp16 build of the library)
+
 import torch.nn.functional as F
 
 from ...hip import conv as _conv
@@ -48,7 +50,7 @@ class UpconvWithSkip(nn.Module):
         else:
             up = self.conv1(F.interpolate(bef_layer, scale_factor=2, mode="bilinear", align_corners=False))
         parts = [up] + [s.to(up.dtype) for s in skips]
-        if up.is_cuda and up.dtype == torch.bfloat16 and len(parts) <= 4 and _FUSED_CONCAT:
+        if up.is_cuda and up.dtype == _half() and len(parts) <= 4 and _FUSED_CONCAT:
             # the concatenation and its zero pad channels in one launch (torch.cat's batched copy ran at 0.5 - 0.8 TB/s here)
             return self.conv2(_ops.concat_channels(parts))
         if up.is_cuda:
@@ -56,7 +58,7 @@ class UpconvWithSkip(nn.Module):
             # sees mixed layouts, answers in NCHW and the convolution below pays a full re-layout copy of the concatenation
             parts = [_ChannelsLastOne.apply(p) if p.shape[1] == 1 and p.is_contiguous() else p for p in parts]
         total = sum(p.shape[1] for p in parts)
-        if up.is_cuda and up.dtype == torch.bfloat16 and total % 8:
+        if up.is_cuda and up.dtype == _half() and total % 8:
             # the matrix-core convolution reads 8-channel groups: the concatenation is built with its zero pad channels
             parts.append(self._zeros(up, -total % 8))
         return self.conv2(torch.cat(parts, dim=1))
@@ -103,12 +105,12 @@ class ScaledDepthHead(nn.Module):
             else:
                 depth, self.last_disp = self.predict_depth(conv), None
             if (_BATCHED_HEADS and conv.is_cuda and conv.dtype == torch.float32 and conv.is_contiguous()
-                    and src.dtype == torch.bfloat16 and (dst_height, dst_width) == (2 * conv.shape[2], 2 * conv.shape[3])):
+                    and src.dtype == _half() and (dst_height, dst_width) == (2 * conv.shape[2], 2 * conv.shape[3])):
                 # the exact 2x resize and the cast to the decoder's dtype in one launch (one more for the backward)
                 if _FUSED_FAN_IN and not activate and torch.is_grad_enabled() and conv.requires_grad:
-                    conv, conv_up = _ops.upsample2x_split(conv, torch.bfloat16)
+                    conv, conv_up = _ops.upsample2x_split(conv, _half())
                 else:
-                    conv_up = _ops.upsample2x(conv, torch.bfloat16)
+                    conv_up = _ops.upsample2x(conv, _half())
             else:
                 conv_up = lo.resize_image(conv, dst_height, dst_width)
         if split:

@@ -60,7 +60,11 @@ class ModelWrapper:
         self.models = models                      # {"depthnet": nn.Module, "posenet": nn.Module}
         # (BASELINE configs[4] names fp16 convolutions: this build computes them in bf16 -- same matrix-core rate on gfx950,
         #  fp32 accumulation, no loss scaling; DESIGN.md section 7 -- so "fp16" is not an accepted value)
-        self.conv_dtype = {"bf16": torch.bfloat16, "fp32": None}[opts.CONV_DTYPE]
+        if opts.CONV_DTYPE in ("bf16", "fp16"):
+            # the 16-bit format is a property of the loaded library (hip/lib.py): one per process
+            from ...hip import lib as _lib
+            _lib.set_half_format(opts.CONV_DTYPE)
+        self.conv_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[opts.CONV_DTYPE]
 
     def __call__(self, features):
         return self.predict_batch(features)

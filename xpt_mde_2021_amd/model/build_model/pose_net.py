@@ -1,6 +1,8 @@
 """PoseNetImproved / PoseNetBasic (reference: model/build_model/pose_net.py:8-91) as torch modules."""
 import torch
 import torch.nn as nn
+from ...hip.lib import half as _half      # torch dtype of the 16-bit activations (bf16 | fp16 build of the library)
+
 
 
 def restack_on_channels(image5d):
@@ -34,13 +36,13 @@ class PoseNetBasic(nn.Module):
 
     def forward(self, image5d):
         if image5d.is_cuda and image5d.dtype == torch.float32 and torch.is_autocast_enabled() \
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+                and torch.get_autocast_dtype("cuda") == _half():
             from ...hip import conv as _conv           # one launch: restack + cast + zero pad channel(s) for the MFMA conv
             x = _conv.restack_bf16(image5d, _conv.round_up(image5d.shape[1] * image5d.shape[4], 8))
         else:
             x = restack_on_channels(image5d)
         x = self.head(self.convs(x))
-        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+        if x.is_cuda and x.dtype in (torch.float32, _half()):
             from ...hip import ops as _ops
             poses = _ops.global_avg_pool(x)                    # GlobalAveragePooling2D (cast included), one launch
         else:

@@ -21,6 +21,8 @@ Bug-compatible details kept (SURVEY 7 "Hard parts" h, i):
 """
 import torch
 import torch.nn as nn
+from ...hip.lib import half as _half      # torch dtype of the 16-bit activations (bf16 | fp16 build of the library)
+
 import torch.nn.functional as F
 
 from ...hip import ops as _ops
@@ -91,7 +93,7 @@ class _Conv1x1Bf16(torch.autograd.Function):
     def backward(ctx, dy):
         x2, ws = ctx.saved_tensors
         B, cin, H, W, cout, wshape = ctx.dims
-        dy2 = _ops.as_rows(dy.to(torch.bfloat16))
+        dy2 = _ops.as_rows(dy.to(_half()))
         dx = dw = None
         if (_FUSED_DGRAD and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and ctx.sink_dst is not None
                 and ws.is_contiguous() and _ops.vector_rows(dy2, cout) and _ops.vector_rows(x2, cin)):
@@ -116,7 +118,7 @@ def conv1x1(x, weight):
     gradient one more GEMM -- no MIOpen convolution (nor its zero / cast helper launches) involved."""
     if not x.is_cuda:
         return F.conv2d(x, weight)
-    if x.dtype == torch.bfloat16 and hasattr(weight, "shadow_bf16") and torch.is_autocast_enabled():
+    if x.dtype == _half() and hasattr(weight, "shadow_bf16") and torch.is_autocast_enabled():
         return _Conv1x1Bf16.apply(x, weight)
     xv = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)            # [B,H,W,Cin] view
     y = F.linear(xv, weight.reshape(weight.shape[0], weight.shape[1]))                  # [B,H,W,Cout]
@@ -140,16 +142,16 @@ class _Conv1x1BnBf16(torch.autograd.Function):
         x2 = _ops.as_rows(x)
         M = x2.shape[0]
         pitch_x = x2.stride(0) if M > 1 else cin
-        y = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+        y = torch.empty((B, cout, H, W), dtype=_half(), device=x.device, memory_format=torch.channels_last)
         if residual is not None:
-            residual = residual.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            residual = residual.to(_half()).contiguous(memory_format=torch.channels_last)
         g_, b_ = gamma.detach(), beta.detach()
         # deep reductions on small maps (cin >= 256, few tiles) split the k loop over the 4 waves of a workgroup inside
         # the kernel (xpt_pwconv.hip, KW = 4): with that the fused launch beats GEMM + epilogue launch up to the widest
         # layer (1056 channels) too
         if not _LIBRARY_PWCONV and cin <= _PWCONV_MAX_CIN:
             # GEMM + BatchNorm (+ branch add) in one gfx950 launch (csrc/xpt_pwconv.hip)
-            ypre = torch.empty((M, cout), dtype=torch.bfloat16, device=x.device)
+            ypre = torch.empty((M, cout), dtype=_half(), device=x.device)
             _ops._lib.check(lib.xpt_pwconv_bn_fwd(x2.data_ptr(), ws.data_ptr(), g_.data_ptr(), b_.data_ptr(),
                                                   mean.data_ptr(), var.data_ptr(), float(eps), _ops._ptr(residual),
                                                   ypre.data_ptr(), y.data_ptr(), M, cin, cout, pitch_x, _ops._stream()),
@@ -189,8 +191,8 @@ def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx, ex
     lib = _ops._lib.load()
     B, cin, H, W, cout, eps = dims
     w_dst, g_dst, b_dst = dst
-    dy2 = _ops.as_rows(dy.to(torch.bfloat16))
-    more = [_ops.as_rows(e.to(torch.bfloat16)) for e in extra]
+    dy2 = _ops.as_rows(dy.to(_half()))
+    more = [_ops.as_rows(e.to(_half())) for e in extra]
     M = dy2.shape[0]
     nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
     sink = _ops.grad_sink
@@ -206,7 +208,7 @@ def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx, ex
                    and all(even(e, pitch_of(e)) for e in more))
     if _FUSED_DGRAD and ws.is_contiguous() and vector_rows:     # (odd widths: scalar staging, no data-gradient workgroups)
         # the data gradient rides in the same launch (extra workgroups of the weight-gradient kernel): no g, no GEMM launch
-        dx = torch.empty((M, cin), dtype=torch.bfloat16, device=dy.device) if need_dx else None
+        dx = torch.empty((M, cin), dtype=_half(), device=dy.device) if need_dx else None
         _ops._lib.check(lib.xpt_conv1x1_bn_bwd_fused(dy2.data_ptr(), _ops._ptr(e1), _ops._ptr(e2), ypre.data_ptr(),
                                                      x2.data_ptr(), ws.data_ptr(), gamma.data_ptr(), var.data_ptr(),
                                                      mean.data_ptr(), eps, _ops._ptr(dx), wpart.data_ptr(), wpart.numel(),
@@ -217,7 +219,7 @@ def _conv_bn_backward(x2, ws, ypre, gamma, mean, var, dims, dst, dy, need_dx, ex
         sink.add(b_dst, bpart, 0, cout, nsplit, 2 * cout)
         sink.add(g_dst, bpart, cout, cout, nsplit, 2 * cout)
         return dx.view(B, H, W, cin).permute(0, 3, 1, 2) if need_dx else None
-    g = torch.empty((M, cout), dtype=torch.bfloat16, device=dy.device)
+    g = torch.empty((M, cout), dtype=_half(), device=dy.device)
     _ops._lib.check(lib.xpt_conv1x1_bn_bwd_partials_sum(dy2.data_ptr(), _ops._ptr(e1), _ops._ptr(e2), ypre.data_ptr(),
                                                         x2.data_ptr(), gamma.data_ptr(), var.data_ptr(), mean.data_ptr(),
                                                         eps, g.data_ptr(), wpart.data_ptr(), wpart.numel(),
@@ -254,12 +256,12 @@ class _MultiConv1x1Bn(torch.autograd.Function):
         M = x2s[0].shape[0]
         pitch = x2s[0].stride(0) if M > 1 else cin
         shadows = [w.shadow_bf16.reshape(cout, cin) for w in ws_]
-        res = [None if r is None else r.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for r in rs]
+        res = [None if r is None else r.to(_half()).contiguous(memory_format=torch.channels_last) for r in rs]
         if pre is not None:                    # the fused branch-stage launch computed this stage already
             ypres, ys = list(pre[0]), list(pre[1])
         else:
-            ypres = [torch.empty((M, cout), dtype=torch.bfloat16, device=xs[0].device) for _ in range(L)]
-            ys = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=xs[0].device, memory_format=torch.channels_last)
+            ypres = [torch.empty((M, cout), dtype=_half(), device=xs[0].device) for _ in range(L)]
+            ys = [torch.empty((B, cout, H, W), dtype=_half(), device=xs[0].device, memory_format=torch.channels_last)
                   for _ in range(n)]
             P = ctypes.c_void_p * n
             ptr = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])           # noqa: E731
@@ -301,7 +303,7 @@ class _MultiConv1x1Bn(torch.autograd.Function):
         # ONE launch for the L layers: g_j = dy_j * s_j, split-K partials of dW_j / dgamma_j / dbeta_j
         lib = _ops._lib.load()
         sink = _ops.grad_sink
-        dy2s = [_ops.as_rows(d.to(torch.bfloat16)) for d in dys]
+        dy2s = [_ops.as_rows(d.to(_half())) for d in dys]
         M = dy2s[0].shape[0]
         nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
         wparts, bparts = [], []
@@ -316,7 +318,7 @@ class _MultiConv1x1Bn(torch.autograd.Function):
                        and all(x.data_ptr() % 4 == 0 for x in x2s))
         if _FUSED_DGRAD and vector_rows and all(s.is_contiguous() for s in shadows):
             # ... and the L data gradients in the same launch (extra workgroups): no g, no batched GEMM launch
-            dx_all = torch.empty((L, M, cin), dtype=torch.bfloat16, device=dys[0].device)
+            dx_all = torch.empty((L, M, cin), dtype=_half(), device=dys[0].device)
             _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_fused(
                 L, ptr(dy2s), LL(*[(d.stride(0) if M > 1 else cout) for d in dy2s]), ptr(ypres), ptr(x2s), ptr(shadows),
                 ptr(gs), ptr(vs), ptr(ms), eps, P(*[dx_all[j].data_ptr() if need[j] else None for j in range(L)]),
@@ -328,7 +330,7 @@ class _MultiConv1x1Bn(torch.autograd.Function):
                 sink.add(g_dst, bparts[j], cout, cout, nsplit, 2 * cout)
             dxs = [dx_all[j].view(B, H, W, cin).permute(0, 3, 1, 2) if need[j] else None for j in range(L)]
             return (None, None, None, *dxs, *none, *none, *none, *none, *none, *dres)
-        g_all = torch.empty((L, M, cout), dtype=torch.bfloat16, device=dys[0].device)
+        g_all = torch.empty((L, M, cout), dtype=_half(), device=dys[0].device)
         _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_partials(
             L, ptr(dy2s), LL(*[(d.stride(0) if M > 1 else cout) for d in dy2s]), ptr(ypres), ptr(x2s), ptr(gs), ptr(vs),
             ptr(ms), eps, P(*[g_all[j].data_ptr() for j in range(L)]), ptr(wparts), ptr(bparts), wparts[0].numel(),
@@ -387,7 +389,7 @@ def multi_conv1x1_bn(xs, weights, bns, residuals=None, siblings=None):
     x0, w0 = xs[0], weights[0]
     cin = w0.shape[1]
     ok = (_FUSE_CONV_BN and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD and 1 < len(all_x) <= 6 and x0.is_cuda
-          and x0.dtype == torch.bfloat16 and torch.is_autocast_enabled() and torch.is_grad_enabled()
+          and x0.dtype == _half() and torch.is_autocast_enabled() and torch.is_grad_enabled()
           and cin <= _PWCONV_MAX_CIN
           and all(x.shape == x0.shape and x.dtype == x0.dtype for x in all_x)
           and all(w.shape == w0.shape and hasattr(w, "shadow_bf16") and sink.wants(w) for w in all_w)
@@ -434,8 +436,8 @@ class _PairConv1x1BnFan(torch.autograd.Function):
         M = x2s[0].shape[0]
         pitch = x2s[0].stride(0) if M > 1 else cin
         shadows = [w.shadow_bf16.reshape(cout, cin) for w in (wa, wb)]
-        ypres = [torch.empty((M, cout), dtype=torch.bfloat16, device=xa.device) for _ in range(2)]
-        ys = [torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=xa.device, memory_format=torch.channels_last)
+        ypres = [torch.empty((M, cout), dtype=_half(), device=xa.device) for _ in range(2)]
+        ys = [torch.empty((B, cout, H, W), dtype=_half(), device=xa.device, memory_format=torch.channels_last)
               for _ in range(2)]
         P = ctypes.c_void_p * 2
         ptr = lambda ts: P(*[t.data_ptr() for t in ts])           # noqa: E731
@@ -472,7 +474,7 @@ class _PairConv1x1BnFan(torch.autograd.Function):
         rows = []
         for j in range(2):
             live = pieces[j] if len(pieces[j]) <= 3 else [_ops.sum_rows(pieces[j])]   # (the kernel adds up to three pieces)
-            rows.append([_ops.as_rows(d.to(torch.bfloat16)) for d in live])
+            rows.append([_ops.as_rows(d.to(_half())) for d in live])
         M = rows[0][0].shape[0]
         nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, cout, cin)
         wparts = [sink.partials(d[0], "conv1x1", nsplit * cout * cin) for d in ctx.dsts]
@@ -482,7 +484,7 @@ class _PairConv1x1BnFan(torch.autograd.Function):
         piece = lambda k: (P(*[(r[k].data_ptr() if len(r) > k else None) for r in rows]),      # noqa: E731
                            LL(*[(pitch_of(r[k]) if len(r) > k else 0) for r in rows]))
         pitch_x = x2s[0].stride(0) if M > 1 else cin
-        dx_all = torch.empty((2, M, cin), dtype=torch.bfloat16, device=rows[0][0].device)
+        dx_all = torch.empty((2, M, cin), dtype=_half(), device=rows[0][0].device)
         ptr = lambda ts: P(*[q.data_ptr() for q in ts])          # noqa: E731
         _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_fused_fan(
             2, *piece(0), *piece(1), *piece(2), ptr(ypres), ptr(x2s), ptr(shadows), ptr(gs), ptr(vs), ptr(ms), eps,
@@ -503,7 +505,7 @@ def pair_conv1x1_bn_usable(xa, xb, wa, wb, bna, bnb):
     sink = _ops.grad_sink
     if not (_PAIR_HEADS and _FUSE_CONV_BN and _FUSED_DGRAD and _FUSE_FAN_IN and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD):
         return False
-    if not (xa.is_cuda and xa.dtype == torch.bfloat16 and xb.dtype == torch.bfloat16 and xa.shape == xb.shape
+    if not (xa.is_cuda and xa.dtype == _half() and xb.dtype == _half() and xa.shape == xb.shape
             and torch.is_autocast_enabled() and torch.is_grad_enabled() and wa.shape == wb.shape):
         return False
     cout, cin = wa.shape[0], wa.shape[1]
@@ -533,8 +535,8 @@ class _SpatialAdjustBn(torch.autograd.Function):
         M = x2s[0].shape[0]
         pitch = x2s[0].stride(0) if M > 1 else cin
         shadows = [w.shadow_bf16.reshape(half, cin) for w in (w1, w2)]
-        y = torch.empty((B, 2 * half, H, W), dtype=torch.bfloat16, device=p1.device, memory_format=torch.channels_last)
-        ypres = [torch.empty((M, half), dtype=torch.bfloat16, device=p1.device) for _ in range(2)]
+        y = torch.empty((B, 2 * half, H, W), dtype=_half(), device=p1.device, memory_format=torch.channels_last)
+        ypres = [torch.empty((M, half), dtype=_half(), device=p1.device) for _ in range(2)]
         g_, b_ = gamma.detach(), beta.detach()
         P = ctypes.c_void_p * 2
         sl = lambda t: P(t[:half].data_ptr(), t[half:].data_ptr())       # noqa: E731
@@ -555,7 +557,7 @@ class _SpatialAdjustBn(torch.autograd.Function):
         B, cin, H, W, half, eps = ctx.dims
         lib = _ops._lib.load()
         sink = _ops.grad_sink
-        rows = _ops.as_rows(dy.to(torch.bfloat16))                        # [M, 2 half], unit channel stride
+        rows = _ops.as_rows(dy.to(_half()))                        # [M, 2 half], unit channel stride
         M = rows.shape[0]
         pitch_dy = rows.stride(0) if M > 1 else 2 * half
         nsplit = lib.xpt_conv1x1_bwd_weight_splits(M, half, cin)
@@ -564,7 +566,7 @@ class _SpatialAdjustBn(torch.autograd.Function):
         P, LL = ctypes.c_void_p * 2, ctypes.c_longlong * 2
         sl = lambda q: P(q[:half].data_ptr(), q[half:].data_ptr())       # noqa: E731
         pitch_x = x2s[0].stride(0) if M > 1 else cin
-        dx_all = torch.empty((2, M, cin), dtype=torch.bfloat16, device=dy.device)
+        dx_all = torch.empty((2, M, cin), dtype=_half(), device=dy.device)
         _ops._lib.check(lib.xpt_conv1x1_bn_multi_bwd_fused(
             2, P(rows.data_ptr(), rows.data_ptr() + 2 * half), LL(pitch_dy, pitch_dy), P(*[q.data_ptr() for q in ypres]),
             P(*[q.data_ptr() for q in x2s]), P(*[q.data_ptr() for q in shadows]), sl(gamma), sl(var), sl(mean), eps,
@@ -621,7 +623,7 @@ def conv1x1_bn(x, weight, bn, residual=None, fan_out=1):
     parameters in bf16, the two separate ops otherwise.  fan_out = n > 1 (no residual): a tuple of n aliases of the
     result, one per consumer; on the fused path their gradients are added inside the weight-gradient launch."""
     sink = _ops.grad_sink
-    if (_FUSE_CONV_BN and x.is_cuda and x.dtype == torch.bfloat16 and torch.is_autocast_enabled()
+    if (_FUSE_CONV_BN and x.is_cuda and x.dtype == _half() and torch.is_autocast_enabled()
             and torch.is_grad_enabled() and hasattr(weight, "shadow_bf16") and not _LIBRARY_WGRAD
             and sink.wants(weight) and sink.wants(bn.weight) and sink.wants(bn.bias)):
         if fan_out > 1 and residual is None and _FUSE_FAN_IN:
@@ -737,13 +739,13 @@ class AdjustBlock(nn.Module):
             return conv1x1_bn(p, self.conv.weight, self.bn, fan_out=fan_out)
         if self.mode == "spatial":
             p = shared_relu(p)
-            if p.is_cuda and _CELL_TAIL and p.dtype in (torch.float32, torch.bfloat16):
+            if p.is_cuda and _CELL_TAIL and p.dtype in (torch.float32, _half()):
                 p1, p2 = _ops.adjust_gather(p)                  # both sub-sampled copies in one launch (one scatter backward)
                 w1, w2, bn = self.conv1.weight, self.conv2.weight, self.bn
                 half, cin = w1.shape[0], w1.shape[1]
                 sink = _ops.grad_sink
                 if (_FUSED_SPATIAL_ADJUST and _FUSE_CONV_BN and _FUSED_DGRAD and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD
-                        and p.dtype == torch.bfloat16 and torch.is_autocast_enabled() and torch.is_grad_enabled()
+                        and p.dtype == _half() and torch.is_autocast_enabled() and torch.is_grad_enabled()
                         and half % 2 == 0 and cin % 2 == 0 and cin <= _PWCONV_MAX_CIN
                         and all(hasattr(w, "shadow_bf16") and sink.wants(w) and w.shadow_bf16.is_contiguous() for w in (w1, w2))
                         and sink.wants(bn.weight) and sink.wants(bn.bias)):
@@ -782,7 +784,7 @@ def _sep_stage_usable(xs, seps, bns):
     sink = _ops.grad_sink
     x0 = xs[0]
     return (_FUSED_SEP_STAGE and _FUSE_CONV_BN and _WIDE_CELL and not _LIBRARY_PWCONV and not _LIBRARY_WGRAD
-            and not _DISABLE_HIP_DWCONV and x0.is_cuda and x0.dtype == torch.bfloat16 and torch.is_autocast_enabled()
+            and not _DISABLE_HIP_DWCONV and x0.is_cuda and x0.dtype == _half() and torch.is_autocast_enabled()
             and torch.is_grad_enabled() and x0.shape[1] % 2 == 0
             and all(x.shape == x0.shape and x.dtype == x0.dtype and x.is_contiguous(memory_format=torch.channels_last) for x in xs)
             and all(sp.stride == 1 and sp.k in (3, 5, 7) and sp.pointwise.weight.shape[:2] == (x0.shape[1], x0.shape[1])
@@ -806,12 +808,12 @@ def fused_sep_stage(main, siblings=None, residuals=None):
     B, C, H, W = x0.shape
     M = B * H * W
     dev = x0.device
-    new_map = lambda: torch.empty((B, C, H, W), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)   # noqa: E731
-    new_rows = lambda: torch.empty((M, C), dtype=torch.bfloat16, device=dev)                                           # noqa: E731
+    new_map = lambda: torch.empty((B, C, H, W), dtype=_half(), device=dev, memory_format=torch.channels_last)   # noqa: E731
+    new_rows = lambda: torch.empty((M, C), dtype=_half(), device=dev)                                           # noqa: E731
     sib = [j for j in range(n) if siblings[j] is not None]
     ydw_a, ypre_a, y_a = [new_map() for _ in range(n)], [new_rows() for _ in range(n)], [new_map() for _ in range(n)]
     ydw_b, ypre_b, y_b = {j: new_map() for j in sib}, {j: new_rows() for j in sib}, {j: new_map() for j in sib}
-    res = [None if r is None else r.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for r in residuals]
+    res = [None if r is None else r.to(_half()).contiguous(memory_format=torch.channels_last) for r in residuals]
     P, I = ctypes.c_void_p * n, ctypes.c_int * n
     ptr = lambda ts: P(*[None if t is None else t.data_ptr() for t in ts])                                             # noqa: E731
 
@@ -1009,7 +1011,7 @@ class ReductionCell(nn.Module):
             h = shared_relu(ip)
         taps.offer(self.act_id, h)
         h, h_pool = conv1x1_bn(h, self.conv.weight, self.bn, fan_out=2)
-        if h.is_cuda and _CELL_TAIL and h.dtype in (torch.float32, torch.bfloat16):
+        if h.is_cuda and _CELL_TAIL and h.dtype in (torch.float32, _half()):
             # both poolings of the zero-padded h in one launch (and one backward launch)
             # (the max-pooled tensor feeds x2 and x5: two aliases, their gradients added inside the pooling backward)
             mp1, mp2, ap_h = _ops.pool_pair(h_pool, correct_pad(h.shape[2], h.shape[3], 3), split_mp=True)
@@ -1269,7 +1271,7 @@ class NASNetMobileEncoder(nn.Module):
             return self._cells(self.stem_bn(x), taps)
         x = self.preprocess(image)
         if _conv.usable(x, self.stem_conv, 1.0):          # keras Conv2D(32, 3, strides 2, padding="valid") on the matrix cores
-            x = F.pad(x.to(torch.bfloat16), (0, 0, 0, 0, 0, 5))                   # 3 -> 8 channels (16-byte pixel rows)
+            x = F.pad(x.to(_half()), (0, 0, 0, 0, 0, 5))                   # 3 -> 8 channels (16-byte pixel rows)
             x = _conv.conv2d_same(x, self.stem_conv.weight, None, 2, 1.0, valid=True)
         else:
             x = conv2d_library(x, self.stem_conv.weight, 2, (0, 0))

@@ -46,6 +46,8 @@ class TotalLoss:
         with this key suffix reads: weight of the loss type x scale weight / global batch (the coefficients __call__
         applies below), or None when they cannot be told in advance."""
         out = {"L1": [0.0] * nscales, "SSIM": [0.0] * nscales}
+        # (the fp16 configuration seeds the backward pass with its static loss scale, train_val.ModelTrainer.loss_seed)
+        seed = float(opts.LOSS_SCALE_FP16) if opts.CONV_DTYPE == "fp16" else 1.0
         try:
             for name, obj in (self.loss_objects or {}).items():
                 if type(obj) is not cls or getattr(obj, "key_suffix", "") != suffix or obj.method not in out:
@@ -54,7 +56,7 @@ class TotalLoss:
                 if len(weights) < nscales:
                     return None
                 for i in range(nscales):
-                    out[obj.method][i] += float(self.loss_weights[name]) * weights[i] / self.batch_size
+                    out[obj.method][i] += seed * float(self.loss_weights[name]) * weights[i] / self.batch_size
         except (KeyError, TypeError, ValueError):
             return None
         return out["L1"], out["SSIM"]

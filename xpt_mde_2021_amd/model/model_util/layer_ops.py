@@ -8,6 +8,8 @@ import math
 
 import torch
 import torch.nn as nn
+from ...hip.lib import half as _half      # torch dtype of the 16-bit activations (bf16 | fp16 build of the library)
+
 import torch.nn.functional as F
 
 from ...hip import conv as _conv
@@ -142,7 +144,7 @@ def unfolded_weight_grad(dy, x, weight_shape, stride, padding, dilation):
 def _low_precision_weight(weight, dtype):
     """bf16 view of the weight: the shadow copy the fused Adam kernel keeps current (no cast launch) when there is one."""
     shadow = getattr(weight, "shadow_bf16", None)
-    if shadow is not None and dtype == torch.bfloat16:
+    if shadow is not None and dtype == _half():
         return shadow
     return weight.to(dtype)
 
@@ -188,8 +190,8 @@ class Conv2DSame(nn.Module):
             # gfx950 implicit-GEMM kernels (hip/conv.py): TF-SAME padding, bias, activation (and the up-sampling) fused;
             # no library call, so nothing in a captured training step depends on MIOpen's solvers or workspaces
             cp = _conv.round_up(self.conv.in_channels, 8)
-            if x.dtype != torch.bfloat16:
-                x = x.to(torch.bfloat16)
+            if x.dtype != _half():
+                x = x.to(_half())
             if x.shape[1] < cp:
                 x = F.pad(x, (0, 0, 0, 0, 0, cp - x.shape[1]))
             return _conv.conv2d_same(x, self.conv.weight, self.conv.bias, self.s, self.slope, upsample)

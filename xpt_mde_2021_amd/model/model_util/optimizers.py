@@ -33,7 +33,7 @@ class FlatParameters:
         self.grad_views = []
         # bf16 copy of every weight, refreshed by the fused Adam kernel: the bf16 GEMMs / convolutions read it directly
         # instead of launching one fp32->bf16 cast per layer and step (and one bf16->fp32 cast per gradient)
-        self.shadow = torch.zeros(total, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
+        self.shadow = torch.zeros(total, dtype=_lib.half(), device=dev) if dev.type == "cuda" else None
         for p, off in zip(params, offsets):
             dview, gview = self._view(self.data, p, off), self._view(self.grad, p, off)
             dview.copy_(p.data)

@@ -117,12 +117,26 @@ class ModelTrainer(TrainValBase):
     def run_a_batch(self, features):
         return self.train_a_step(features)
 
+    def loss_seed(self, total_loss):
+        """Seed of the backward pass: None (= 1), or the static loss scale of the fp16 configuration (config.LOSS_SCALE_FP16;
+        a persistent tensor: no launch inside the captured step).  grad_unscale() takes it out again in the optimizer."""
+        if opts.CONV_DTYPE != "fp16" or not total_loss.is_cuda:
+            return None
+        seed = getattr(self, "_loss_seed", None)
+        if seed is None or seed.device != total_loss.device or seed.dtype != total_loss.dtype:
+            seed = self._loss_seed = torch.full_like(total_loss, float(opts.LOSS_SCALE_FP16))
+        return seed
+
+    @staticmethod
+    def grad_unscale():
+        return 1.0 / float(opts.LOSS_SCALE_FP16) if opts.CONV_DTYPE == "fp16" else 1.0
+
     def forward_backward(self, features):
         if self.augmenter is not None:
             features = self.augmenter(features)
         preds = self.model(features)
         total_loss, loss_by_type = self.loss_object(preds, features)
-        total_loss.backward()
+        total_loss.backward(gradient=self.loss_seed(total_loss))
         if total_loss.is_cuda:
             _ops.grad_sink.flush()       # one launch finishes every deferred parameter gradient into the flat buffer
         if self.optimizer is not None and getattr(self.optimizer, "flat", None) is not None:
@@ -196,7 +210,7 @@ class ModelTrainer(TrainValBase):
         """train_val.py:78-92: augment -> model -> loss -> gradients -> optimizer.apply_gradients."""
         out = self.forward_backward(features)
         self.reduce_gradients()
-        self.optimizer.apply_gradients()
+        self.optimizer.apply_gradients(grad_scale=self.grad_unscale())
         return out
 
 
@@ -479,10 +493,10 @@ class _StepGraph:
             # leaves room for a rocBLAS split-K atomic or two); fp32 steps go through MIOpen's atomically accumulating
             # solvers, whose run-to-run noise the rectified-stereo border flips can turn into
             # several-fold changes of single tiny gradients -- there only gross garbage is caught
-            rtol = 0.05 if opts.CONV_DTYPE == "bf16" else 8.0
+            rtol = 0.05 if opts.CONV_DTYPE in ("bf16", "fp16") else 8.0
         # absolute floor relative to the largest gradient of the whole model: a one-element bias whose gradient is a
         # nearly cancelling sum has no meaningful relative error under the library path's atomics
-        floor = 1e-5 if opts.CONV_DTYPE == "bf16" else 1e-3
+        floor = 1e-5 if opts.CONV_DTYPE in ("bf16", "fp16") else 1e-3
         for i, (a, b) in enumerate(zip(first, state)):
             # gradients and first moments only (indices 1, 2 of the optimizer state): Adam turns a rounding-noise
             # gradient into a +-lr step, so VALUES of parameters with a ~zero gradient legitimately differ between runs
@@ -624,7 +638,7 @@ class ModelTrainerDistrib(ModelTrainer):
             features = self.augmenter(features)
         preds = self.model(features)
         total_loss, loss_by_type = self.loss_object(preds, features)
-        total_loss.backward()
+        total_loss.backward(gradient=self.loss_seed(total_loss))
         carry = self.model.take_backward_cuts()
         if total_loss.is_cuda:
             _ops.grad_sink.flush()
@@ -675,7 +689,7 @@ class ModelTrainerDistrib(ModelTrainer):
         else:
             out = self.forward_backward(features)
         self.reduce_gradients()
-        self.optimizer.apply_gradients()
+        self.optimizer.apply_gradients(grad_scale=self.grad_unscale())
         return out
 
 
