@@ -211,7 +211,7 @@ def host_fed_leg(args, trainer, dataset, note):
                 "wait_for_reader_ms_per_step": round(1000.0 * ds.reader_seconds / max(steps + 8, 1), 4),
                 "shard_bytes": int(nbytes), "snippets": n, "decode_workers": workers, "prefetch": 3,
                 "what": "synthetic KITTI-shaped snippets written with the repo's TFRecord writer, read back (framing, masked "
-                        "CRC32C, hand-parsed tf.train.Example, uint8 -> float on the device), shuffled, batched, uploaded from "
+                        "CRC32C, tf.train.Example walked by xpt_tfrecord_decode, uint8 -> float on the device), shuffled, batched, uploaded from "
                         "pinned memory on a side stream and trained on; `value` itself is measured on HBM-resident inputs"}
     finally:
         shutil.rmtree(root, ignore_errors=True)

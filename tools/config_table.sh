@@ -10,6 +10,7 @@ run --config c5
 run --mode distributed
 XPT_DP_OVERLAP=1 run --mode distributed
 run --mode eager
+run --dtype fp16
 run --dtype fp32
 run --nets flow --width 384
 run --nets joint --width 384
