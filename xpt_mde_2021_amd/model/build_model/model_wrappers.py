@@ -106,7 +106,16 @@ class ModelWrapper:
             for model, side in zip(nets[1:], self._side_streams):
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    side_out.append(self._run(model, image5d))
+                    extra = {}
+                    if (not side_out and image5d.dtype == torch.float32 and image5d.is_contiguous() and image5d.dim() == 5
+                            and image5d.shape[-1] == 3 and image5d.shape[1] >= 2
+                            and image5d.shape[2] % 8 == 0 and image5d.shape[3] % 8 == 0):
+                        # the loss's image pyramids (dense source / target copies at 1, 1/2, 1/4, 1/8: losses.append_data) depend
+                        # on the snippets alone: issued here, next to the encoder, instead of between the nets and the march
+                        extra["image_pyramids"] = ((1, 2, 4, 8), *_ops.image_pyramids(image5d, (1, 2, 4, 8)))
+                    out = self._run(model, image5d)
+                    out.update(extra)
+                    side_out.append(out)
                 if torch.is_grad_enabled():
                     # the deferred parameter-gradient partials of this net are written on `side` during backward and are no
                     # autograd outputs: the sink's finishing launch (main stream, after backward) waits for the stream itself
@@ -116,8 +125,9 @@ class ModelWrapper:
                 main.wait_stream(side)
                 for value in out.values():
                     for t in (value if isinstance(value, (list, tuple)) else [value]):
-                        if torch.is_tensor(t):
-                            t.record_stream(main)
+                        for u in (t.values() if isinstance(t, dict) else [t]):
+                            if torch.is_tensor(u):
+                                u.record_stream(main)
                 predictions.update(out)
         else:
             for model in nets:

@@ -125,7 +125,11 @@ class TotalLoss:
         sources_ms = None
         if scales:
             # the dense copies of the source / target frames and their pyramids in one launch (xpt_image_pyramids)
-            sources, targets = _ops.image_pyramids(image5d, scales)
+            ready = predictions.get("image_pyramids" + suffix)      # (model_wrappers: issued on PoseNet's side stream)
+            if ready is not None and set(scales) <= set(ready[0]):
+                sources, targets = ready[1], ready[2]
+            else:
+                sources, targets = _ops.image_pyramids(image5d, scales)
             source_image, target_image = sources[1], targets[1]
             sources_ms, target_ms = [sources[s] for s in scales], [targets[s] for s in scales]
         else:
