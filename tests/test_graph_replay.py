@@ -86,6 +86,18 @@ def test_posenet_on_its_side_stream_changes_nothing(gpu_device):
     assert eager == graph and esum == gsum
 
 
+def test_a_scaled_backward_seed_the_loss_object_does_not_know_is_not_trusted_in_capture(gpu_device):
+    """The one-pass march announces its upstream gradients (loss weights / batch) and a captured step cannot check them on
+    the host.  A seed the loss object does not know about -- here config.LOSS_SCALE_FP16 applied in a bf16 run by hand -- is
+    seen by the eager warm-up step (a recorded miss, the two-pass path), after which captured steps take the two-pass path as
+    well: the captured run equals the eager run instead of silently using the announced gradients."""
+    eager, esum = _loss_sequence("eager", "noaug", 4, XPT_TEST_FORCE_SEED="8")
+    graph, gsum = _loss_sequence("graph", "noaug", 4, XPT_TEST_FORCE_SEED="8")
+    assert eager == graph and esum == gsum, f"eager {eager}\ngraph {graph}"
+    plain, _ = _loss_sequence("graph", "noaug", 4)
+    assert plain[0] == graph[0] and all(abs(float(a) - float(b)) < 2e-3 for a, b in zip(plain, graph))    # (a power-of-two seed, taken out again)
+
+
 def test_image_to_xcd_numbering_changes_nothing(gpu_device):
     """xpt_set_xcd_affinity / XPT_XCD_AFFINITY: the encoder's and decoder's launches number their workgroups so that the rows
     of image k run on XCD k in every kernel (csrc/xpt_common.h).  Renumbering only: every result keeps its value except the

@@ -350,12 +350,16 @@ class _PhotoFusedMS(torch.autograd.Function):
             hint, ddepths, dT = ctx.stash
             ctx.stash = None
             # the announced gradients against the ones that arrived (a device comparison + one fetch: only outside graph
-            # capture; the trainers' eager warm-up steps run it before every capture)
-            if torch.cuda.is_current_stream_capturing() or PHOTO_HINT_CHECK is False or all(
+            # capture; the trainers' eager warm-up steps run it before every capture).  A capture trusts the announcement only
+            # while no eager step of this process has seen it miss: after a miss (an upstream scaling the loss object does not
+            # know about -- backward(gradient=...), a re-weighted total) captured steps take the two-pass path below as well
+            if (torch.cuda.is_current_stream_capturing() and not PHOTO_HINT_MISSES) or PHOTO_HINT_CHECK is False or (
+                    not torch.cuda.is_current_stream_capturing()) and all(
                     (g is None and not bool(hint[i].any())) or (g is not None and torch.equal(g.reshape(-1), hint[i]))
                     for i, g in enumerate(grads)):
                 return (dT, None, None, None, *([None] * n), *ddepths, *([None] * n))
-            PHOTO_HINT_MISSES.append(tuple(None if g is None else float(g.reshape(-1)[0]) for g in grads))
+            if not torch.cuda.is_current_stream_capturing():
+                PHOTO_HINT_MISSES.append(tuple(None if g is None else float(g.reshape(-1)[0]) for g in grads))
         zero = None
         gs = []
         for g in grads:
