@@ -138,6 +138,9 @@ class VodeOptions(LossOptions):
     # it wins: 4.163 -> 4.11 ms at batch 8, 5.70 -> 5.60 at batch 16, the two-graph data-parallel step 4.45 -> 4.27; the
     # stereo wrappers (two calls per step) measured 9.24 -> 9.33 and keep one stream.  XPT_NET_STREAMS=0 / 1 overrides.
     NET_STREAMS = __import__("os").environ.get("XPT_NET_STREAMS", "1") == "1"
+    # the graph trainer updates decoder / PoseNet parameters on the side stream while the encoder's backward still runs
+    # (train_val.ModelTrainerGraph); XPT_EARLY_UPDATE=0 / 1 overrides
+    EARLY_UPDATE = __import__("os").environ.get("XPT_EARLY_UPDATE", "0") == "1"
     AUGMENT_PROBS = {"CropAndResize": 0.2, "HorizontalFlip": 0.2, "ColorJitter": 0.2}
 
     # ---- training options (:216-253)

@@ -610,8 +610,10 @@ class GradSink:
             hook()
         pending, self.pending = self.pending, []
         self.uses.clear()
+        here = torch.cuda.current_stream()
         for side in self.join_streams:                 # partials produced off the main stream must have landed
-            torch.cuda.current_stream().wait_stream(side)
+            if side != here:                           # (finishing ON the producing stream: already in order)
+                here.wait_stream(side)
         self.join_streams.clear()
         if not pending:
             return

@@ -148,21 +148,40 @@ class KerasAdam:
         self.step_count = torch.zeros(1, dtype=torch.float32, device=self.flat.data.device)
         return self.flat
 
-    def apply_gradients(self, grad_scale=1.0, zero_grad=True):
-        """optimizer.apply_gradients (train_val.py:86) on the flat buffers; hipGraph-capturable."""
-        f = self.flat
+    def begin_step(self):
+        """The step counter of a step that is applied in pieces (apply_gradients(..., lo, hi, bump=False))."""
         self.step_count += 1
+
+    def _piece(self, lo, hi):
+        f = self.flat
+        hi = f.numel if hi is None else hi
+        if not (0 <= lo < hi <= f.numel) or lo % 4:       # (the update kernels move 16-byte vectors from the piece's base)
+            raise WrongInputException(f"apply_gradients: bad range [{lo}, {hi}) of {f.numel}")
+        if (lo, hi) != (0, f.numel) and self._ranges():
+            raise WrongInputException("apply_gradients: an L2 term needs the whole buffer in one piece")
+        return lo, hi
+
+    def apply_gradients(self, grad_scale=1.0, zero_grad=True, lo=0, hi=None, bump=True):
+        """optimizer.apply_gradients (train_val.py:86) on the flat buffers; hipGraph-capturable.  [lo, hi): a piece of the
+        buffers (element-wise update: pieces are independent; the trainer that applies a step in pieces counts the step once,
+        begin_step(), and passes bump=False)."""
+        f = self.flat
+        lo, hi = self._piece(lo, hi)
+        if bump:
+            self.step_count += 1
         for a, b, coef in self._ranges():
             f.grad[a:b].add_(f.data[a:b], alpha=coef / float(grad_scale))
         if f.data.is_cuda:
             lib = _lib.load()
-            _lib.check(lib.xpt_adam_step(f.data.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                         f.numel, self.step_count.data_ptr(), self.lr, self.b1, self.b2, self.eps,
-                                         float(grad_scale), int(zero_grad),
-                                         None if f.shadow is None else f.shadow.data_ptr(),
+            _lib.check(lib.xpt_adam_step(f.data.data_ptr() + 4 * lo, f.grad.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
+                                         self.v.data_ptr() + 4 * lo, hi - lo, self.step_count.data_ptr(), self.lr, self.b1,
+                                         self.b2, self.eps, float(grad_scale), int(zero_grad),
+                                         None if f.shadow is None else f.shadow.data_ptr() + f.shadow.element_size() * lo,
                                          torch.cuda.current_stream().cuda_stream),
                        "xpt_adam_step")
             return
+        if (lo, hi) != (0, f.numel):
+            raise WrongInputException("apply_gradients: pieces are a device feature")
         # host tensors (CPU-only unit tests of the data-parallel host logic): same arithmetic with tensor ops
         with torch.no_grad():
             t = self.step_count
@@ -189,17 +208,22 @@ class KerasSGD(KerasAdam):
         self.step_count = torch.zeros(1, dtype=torch.float32, device=self.flat.data.device)
         return self.flat
 
-    def apply_gradients(self, grad_scale=1.0, zero_grad=True):
+    def apply_gradients(self, grad_scale=1.0, zero_grad=True, lo=0, hi=None, bump=True):
         f = self.flat
-        self.step_count += 1
+        lo, hi = self._piece(lo, hi)
+        if bump:
+            self.step_count += 1
         for a, b, coef in self._ranges():
             f.grad[a:b].add_(f.data[a:b], alpha=coef / float(grad_scale))
         if f.data.is_cuda:
             lib = _lib.load()
-            _lib.check(lib.xpt_sgd_step(f.data.data_ptr(), f.grad.data_ptr(), f.numel, self.lr, float(grad_scale), int(zero_grad),
-                                        None if f.shadow is None else f.shadow.data_ptr(),
+            _lib.check(lib.xpt_sgd_step(f.data.data_ptr() + 4 * lo, f.grad.data_ptr() + 4 * lo, hi - lo, self.lr, float(grad_scale),
+                                        int(zero_grad),
+                                        None if f.shadow is None else f.shadow.data_ptr() + f.shadow.element_size() * lo,
                                         torch.cuda.current_stream().cuda_stream), "xpt_sgd_step")
             return
+        if (lo, hi) != (0, f.numel):
+            raise WrongInputException("apply_gradients: pieces are a device feature")
         with torch.no_grad():
             f.data.sub_(f.grad, alpha=self.lr * float(grad_scale))
             if zero_grad:

@@ -156,6 +156,45 @@ class ModelTrainer(TrainValBase):
         # stream) alive across iterations, which breaks hipGraph capture of the next step
         return detach_tree(preds), total_loss.detach(), {k: v.detach() for k, v in loss_by_type.items()}
 
+    # ---- the backward pass in two phases (cut between the decoder and the encoder): the data-parallel trainer starts the
+    # all-reduce of the first phase's gradients between them, the graph trainer their optimizer update (ModelTrainerGraph)
+    def _find_early_bucket(self):
+        """Offset in the flat buffers where the early gradients start: the encoders' parameters (finished by the second
+        backward phase) must form the head of the buffer, everything else its tail; None when there is no such cut."""
+        flat = getattr(self.optimizer, "flat", None)
+        if flat is None or not hasattr(self.model, "set_backward_cut"):
+            return None
+        late = {id(p) for p in self.model.set_backward_cut(True)}
+        flags = [id(p) in late for p in flat.params]
+        k = sum(flags)
+        if k == 0 or k == len(flags) or not all(flags[:k]):
+            self.model.set_backward_cut(False)
+            return None
+        return flat.offsets[k]
+
+    def backward_first(self, features, finish=True):
+        """Forward pass and the backward of everything behind the encoders -> (carry for backward_second, outputs).
+        finish=False: the caller finishes the deferred gradients of this phase itself (on another stream)."""
+        if self.augmenter is not None:
+            features = self.augmenter(features)
+        preds = self.model(features)
+        total_loss, loss_by_type = self.loss_object(preds, features)
+        total_loss.backward(gradient=self.loss_seed(total_loss))
+        carry = self.model.take_backward_cuts()
+        if finish:
+            if total_loss.is_cuda:
+                _ops.grad_sink.flush()
+            self.optimizer.flat.gather_grads()
+        return carry, (detach_tree(preds), total_loss.detach(), {k: v.detach() for k, v in loss_by_type.items()})
+
+    def backward_second(self, carry):
+        """The encoders' backward, resumed from the gradients the first phase left at the cut."""
+        if carry:
+            torch.autograd.backward([t for t, _ in carry], [g for _, g in carry])
+            if carry[0][0].is_cuda:
+                _ops.grad_sink.flush()
+            self.optimizer.flat.gather_grads()
+
     def reduce_gradients(self):
         pass
 
@@ -588,9 +627,51 @@ class ModelTrainerGraph(ModelTrainer):
         weights = getattr(loss_object, "loss_weights", None) or {}
         self.trains_flow_net = ("flownet" in getattr(model, "models", {}) and any(k.startswith("flow") for k in weights)
                                 and getattr(opts, "CAPTURE_LIBRARY_STEPS", "audit") is False)
+        # Early optimizer update (config.EARLY_UPDATE): the backward pass is cut between decoder and encoder; the finishing
+        # launch of the first phase's deferred gradients (decoder, heads, PoseNet: ~60 % of the partial bytes) and the Adam
+        # update of those parameters run on the side stream while the encoder's backward occupies the main one -- 0.1 ms of
+        # memory streaming off the critical chain of the captured step.  Element-wise update, disjoint buffer pieces, the
+        # same partial sums in the same order: bit-identical to the one-piece step (tests/test_graph_replay.py).
+        self._early_start = None
+        if (getattr(opts, "EARLY_UPDATE", False) and not self.trains_flow_net and getattr(optimizer, "flat", None) is not None
+                and optimizer.flat.data.is_cuda and not getattr(optimizer, "l2_terms", None) and type(model).__name__ == "ModelWrapper"):
+            self._early_start = self._find_early_bucket()
+            if self._early_start is not None and self._early_start % 4:
+                self.model.set_backward_cut(False)
+                self._early_start = None
+        self._update_stream = None
         self._graph = _StepGraph(self.train_a_step, state=self.optimizer_state, describe=self.describe_state,
                                  segments=self.state_segments, repair=self.repair_flagged,
                                  reference=self.augmenter is None, pin=self._pin_hooks())
+
+    def train_a_step(self, features):
+        if self._early_start is None or not features["image5d"].is_cuda:
+            if self._early_start is not None:          # (host tensors: the plain step, no cut)
+                return self._plain_step_with_cut(features)
+            return super().train_a_step(features)
+        opt, scale = self.optimizer, self.grad_unscale()
+        carry, out = self.backward_first(features, finish=False)
+        opt.flat.gather_grads()                        # (gradients autograd left on parameters: copied on their own stream)
+        opt.begin_step()
+        main = torch.cuda.current_stream()
+        if self._update_stream is None:
+            streams = getattr(self.model, "_side_streams", None)
+            self._update_stream = streams[0] if streams else torch.cuda.Stream()
+        side = self._update_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _ops.grad_sink.flush()
+            opt.apply_gradients(grad_scale=scale, lo=self._early_start, hi=None, bump=False)
+        self.backward_second(carry)
+        opt.apply_gradients(grad_scale=scale, lo=0, hi=self._early_start, bump=False)
+        main.wait_stream(side)
+        return out
+
+    def _plain_step_with_cut(self, features):
+        carry, out = self.backward_first(features)
+        self.backward_second(carry)
+        self.optimizer.apply_gradients(grad_scale=self.grad_unscale())
+        return out
 
     def run_a_batch(self, features):
         if not features["image5d"].is_cuda or self.trains_flow_net:
@@ -638,41 +719,6 @@ class ModelTrainerDistrib(ModelTrainer):
         if forced is not None:
             return forced == "1"
         return self.strategy is not None and self.strategy.num_replicas_in_sync > 1 and not self.trains_flow_net
-
-    def _find_early_bucket(self):
-        """Offset in the flat buffers where the early gradients start: the encoders' parameters (finished by the second
-        backward phase) must form the head of the buffer, everything else its tail; None when there is no such cut."""
-        flat = getattr(self.optimizer, "flat", None)
-        if flat is None or not hasattr(self.model, "set_backward_cut"):
-            return None
-        late = {id(p) for p in self.model.set_backward_cut(True)}
-        flags = [id(p) in late for p in flat.params]
-        k = sum(flags)
-        if k == 0 or k == len(flags) or not all(flags[:k]):
-            self.model.set_backward_cut(False)
-            return None
-        return flat.offsets[k]
-
-    def backward_first(self, features):
-        """Forward pass and the backward of everything behind the encoders -> (carry for backward_second, outputs)."""
-        if self.augmenter is not None:
-            features = self.augmenter(features)
-        preds = self.model(features)
-        total_loss, loss_by_type = self.loss_object(preds, features)
-        total_loss.backward(gradient=self.loss_seed(total_loss))
-        carry = self.model.take_backward_cuts()
-        if total_loss.is_cuda:
-            _ops.grad_sink.flush()
-        self.optimizer.flat.gather_grads()
-        return carry, (detach_tree(preds), total_loss.detach(), {k: v.detach() for k, v in loss_by_type.items()})
-
-    def backward_second(self, carry):
-        """The encoders' backward, resumed from the gradients the first phase left at the cut."""
-        if carry:
-            torch.autograd.backward([t for t, _ in carry], [g for _, g in carry])
-            if carry[0][0].is_cuda:
-                _ops.grad_sink.flush()
-            self.optimizer.flat.gather_grads()
 
     def forward_backward(self, features):
         if self._early_start is None:
