@@ -960,11 +960,12 @@ def bias_act(x, bias, slope=1.0):
     return _AffineAct.apply(x, None, bias, None, None, 0.0, slope, False, None)
 
 
-def batchnorm_inference(x, gamma, beta, running_mean, running_var, eps, relu_in=False, residual=None):
+def batchnorm_inference(x, gamma, beta, running_mean, running_var, eps, relu_in=False, residual=None, slope=1.0):
     """keras BatchNormalization in inference mode (moving statistics, trainable gamma / beta), optionally with the
     preceding ReLU fused and with `residual` added to the result (the cell's layers.add); differentiable w.r.t. x,
-    gamma, beta and residual."""
-    return _AffineAct.apply(x, gamma, beta, running_mean, running_var, eps, 1.0, relu_in, residual)
+    gamma, beta and residual.  slope != 1: LeakyReLU_slope of the result in the same launch (0 = the Activation('relu')
+    that follows the stem's BatchNorm)."""
+    return _AffineAct.apply(x, gamma, beta, running_mean, running_var, eps, float(slope), relu_in, residual)
 
 
 # ------------------------------------------------------------------------------- depth head activation

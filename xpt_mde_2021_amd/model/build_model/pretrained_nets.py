@@ -30,6 +30,7 @@ from ...utils.util_class import WrongInputException
 from ...hip import conv as _conv
 from ..model_util.layer_ops import conv2d_library, same_pad
 
+_FUSED_STEM_RELU = __import__("os").environ.get("XPT_DEBUG_STEM_RELU", "1") == "1"         # A/B: the stem's ReLU inside its BatchNorm launch
 _LIBRARY_WGRAD = __import__("os").environ.get("XPT_DEBUG_LIBRARY_WGRAD", "0") == "1"     # A/B switch: rocBLAS weight gradient
 _DISABLE_HIP_DWCONV = bool(int(__import__("os").environ.get("XPT_DEBUG_MIOPEN_DWCONV", "0")))   # A/B debugging only
 BN_EPS = 1e-3          # keras_applications nasnet: BatchNormalization(momentum=0.9997, epsilon=1e-3)
@@ -45,14 +46,16 @@ class FrozenBatchNorm(nn.Module):
         self.register_buffer("running_mean", torch.zeros(channels))
         self.register_buffer("running_var", torch.ones(channels))
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, relu_out=False):
         """residual: added to the normalised output -- the `layers.add` that joins two branches of a NASNet cell,
-        fused into the epilogue kernel of the branch that ends in this BatchNorm."""
+        fused into the epilogue kernel of the branch that ends in this BatchNorm.  relu_out: the Activation('relu') that
+        follows rides in the same launch (forward and backward)."""
         if x.is_cuda:      # one gfx950 streaming pass (and one for dx / dgamma / dbeta in the backward)
             return _ops.batchnorm_inference(x, self.weight, self.bias, self.running_mean, self.running_var, BN_EPS,
-                                            residual=residual)
+                                            residual=residual, slope=0.0 if relu_out else 1.0)
         y = F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, False, 0.0, BN_EPS)
-        return y if residual is None else y + residual
+        y = y if residual is None else y + residual
+        return F.relu(y) if relu_out else y
 
 
 def shared_relu(x):
@@ -1268,6 +1271,14 @@ class NASNetMobileEncoder(nn.Module):
         if _conv.stem_input_usable(image) and self.stem_conv.weight.dtype == torch.float32:
             # preprocessing, resize, cast and channel padding in one launch, then the matrix-core stem convolution
             x = _conv.conv2d_same(_conv.stem_input(image), self.stem_conv.weight, None, 2, 1.0, valid=True)
+            first = self.cells[0]
+            if _FUSED_STEM_RELU and isinstance(first, ReductionCell) and first.adjust.mode == "none":
+                # the stem's BatchNorm output has ONE reader, the first cell's Activation('relu') (ReductionCell.forward,
+                # `rectified`): the ReLU rides in the BatchNorm launch, forward and backward (one aten clamp and one
+                # threshold-backward launch per step less); shared_relu() hands the tensor out as it is
+                x = self.stem_bn(x, relu_out=True)
+                x._xpt_relu_aliases = []
+                return self._cells(x, taps)
             return self._cells(self.stem_bn(x), taps)
         x = self.preprocess(image)
         if _conv.usable(x, self.stem_conv, 1.0):          # keras Conv2D(32, 3, strides 2, padding="valid") on the matrix cores
