@@ -33,10 +33,16 @@ def half_format():
     return _half_format
 
 
+_half_dtype = None
+
+
 def half():
     """torch dtype of the 16-bit activations / packed weights of this process."""
-    import torch
-    return torch.float16 if _half_format == "fp16" else torch.bfloat16
+    global _half_dtype
+    if _half_dtype is None or _half_dtype[0] != _half_format:
+        import torch
+        _half_dtype = (_half_format, torch.float16 if _half_format == "fp16" else torch.bfloat16)
+    return _half_dtype[1]
 
 XPT_PHOTO_L1, XPT_PHOTO_L2, XPT_PHOTO_SSIM = 0, 1, 2
 PHOTO_METHODS = {"L1": XPT_PHOTO_L1, "L2": XPT_PHOTO_L2, "SSIM": XPT_PHOTO_SSIM}
